@@ -1,0 +1,525 @@
+/*
+ * lpvs_oracle.c -- CPU restatement (fp64) of the LPVSpectral.jl hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (lpvspectral.jl_amd/) may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg do, and only as the checker / timed CPU baseline.
+ *
+ * Parity status:
+ *   - regressor layout, dd scaling, fourier2complex, window bookkeeping, PSD
+ *     scaling: PINNED by the reference's own known-answer tests
+ *     (test/runtests.jl:24-62, :170-173, :182-183, :186-201), reproduced in
+ *     tests/test_oracle_golden.py from tests/golden/reference_known_answers.json.
+ *   - ADMM x-update (ProximalOperators.LeastSquares/Quadratic, iterative=true ->
+ *     IterativeSolvers.cg!) and the prox operators (NormL1, NormL0, IndBallL0,
+ *     SlicedSeparableSum(NormL2)): PARITY UNPINNED.  That arithmetic lives in
+ *     the un-vendored packages ProximalOperators.jl (compat 0.10/0.15/0.16, no
+ *     Manifest) and IterativeSolvers.jl; test/test_lasso.jl holds no @test.
+ *     What follows restates their published algorithms and is anchored on the
+ *     reference call sites src/lasso.jl:51,53-55,88,98,108,119-123,151,153.
+ *
+ * All matrices are column-major (Julia layout).  Compile with
+ *   gcc -O2 -fopenmp -ffp-contract=off -fPIC -shared
+ * (-ffp-contract=off: the reference rounds every product, e.g. the phase
+ * (2pi*f)*t of src/lsfft.jl:41, so no FMA contraction is allowed).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define LPVO_OK 0
+#define LPVO_EARG (-1)     /* ArgumentError: zero frequency not first (src/lsfft.jl:22) */
+#define LPVO_EASSERT (-2)  /* AssertionError: mu outside [0,1] (src/lasso.jl:143) */
+#define LPVO_EDOMAIN (-3)  /* DomainError: noverlap >= n (DSP.arraysplit) */
+#define LPVO_ENOMEM (-4)
+
+enum { LPVO_PROX_L1 = 1, LPVO_PROX_L0 = 2, LPVO_PROX_BALL_L0 = 3, LPVO_PROX_GROUP_L2 = 4 };
+
+int lpvo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ---- src/lsfft.jl:20-24  check_freq ------------------------------------------------
+ * findfirst(iszero,f): 0 = no zero frequency, 1 = zero frequency first,
+ * LPVO_EARG when the first zero sits elsewhere. */
+int64_t lpvo_check_freq(const double *f, int64_t Nf) {
+    for (int64_t i = 0; i < Nf; ++i)
+        if (f[i] == 0.0) return i == 0 ? 1 : LPVO_EARG;
+    return 0;
+}
+
+/* ---- src/lsfft.jl:26-49  get_fourier_regressor -------------------------------------
+ * A is N x Nreg, Nreg = 2Nf (no zero freq) or 2Nf-1; A[n,fn] = cos(phi)*dd,
+ * A[n,fn+sinoffset] = -sin(phi)*dd, phi = (2pi*f[fn])*t[n], dd = 1/sqrt(2Nf). */
+int lpvo_fourier_regressor(const double *t, int64_t N, const double *f, int64_t Nf,
+                           double *A, int64_t *zerofreq_out) {
+    int64_t zf = lpvo_check_freq(f, Nf);
+    if (zf < 0) return LPVO_EARG;
+    if (zerofreq_out) *zerofreq_out = zf;
+    const double pi2 = 6.283185307179586; /* T(2pi), src/lsfft.jl:33 */
+    const double dd = 1.0 / sqrt((double)(2 * Nf)); /* src/lsfft.jl:35 */
+    const int64_t sinoffset = zf ? Nf - 1 : Nf;     /* src/lsfft.jl:32,37-39 */
+#pragma omp parallel for schedule(static)
+    for (int64_t fn = 0; fn < Nf; ++fn) {
+        const double w = pi2 * f[fn];
+        double *c = A + fn * N;
+        double *s = (zf && fn == 0) ? NULL : A + (fn + sinoffset) * N;
+        for (int64_t n = 0; n < N; ++n) {
+            const double phi = w * t[n];
+            c[n] = cos(phi) * dd;
+            if (s) s[n] = -sin(phi) * dd;
+        }
+    }
+    return LPVO_OK;
+}
+
+/* ---- src/utilities.jl:23-36  basis_activation_func ---------------------------------
+ * Centres vc = range(min V, max V, length=Nv) (or the coulomb variant), width
+ * gamma = Nv/|vc[1]-vc[end]|.  Julia's range is twice-precision; long double
+ * interpolation reproduces it to the last place.  vc must hold Nv (or 2Nv if
+ * coulomb) entries; returns the number of basis functions. */
+int64_t lpvo_basis_centers(const double *V, int64_t N, int64_t Nv, int coulomb,
+                           double *vc, double *gamma) {
+    if (!coulomb) {
+        double lo = V[0], hi = V[0];
+        for (int64_t i = 1; i < N; ++i) { if (V[i] < lo) lo = V[i]; if (V[i] > hi) hi = V[i]; }
+        for (int64_t j = 0; j < Nv; ++j)
+            vc[j] = Nv > 1 ? (double)((long double)lo + (long double)j * ((long double)hi - (long double)lo) / (long double)(Nv - 1)) : lo;
+        *gamma = (double)Nv / fabs(vc[0] - vc[Nv - 1]);
+        return Nv;
+    }
+    /* src/utilities.jl:24-29 */
+    double hi = 0;
+    for (int64_t i = 0; i < N; ++i) if (fabs(V[i]) > hi) hi = fabs(V[i]);
+    for (int64_t j = 0; j < Nv; ++j) { /* range(0,hi,length=Nv+2)[2:end-1] */
+        double c = (double)((long double)(j + 1) * (long double)hi / (long double)(Nv + 1));
+        vc[Nv + j] = c;
+        vc[Nv - 1 - j] = -c;
+    }
+    *gamma = (double)(2 * Nv) / fabs(vc[0] - vc[2 * Nv - 1]);
+    return 2 * Nv;
+}
+
+/* ---- src/lsfft.jl:195-207  _K / _K_norm / _Kcoulomb(_norm) -------------------------
+ * K[j] = exp(-gamma*(v-vc[j])^2) (x sign mask if coulomb), optionally / sum(K). */
+static inline double sgn(double x) { return (x > 0) - (x < 0); }
+void lpvo_basis_eval(double v, const double *vc, int64_t nb, double gamma, int normalize,
+                     int coulomb, double *K) {
+    double s = 0;
+    for (int64_t j = 0; j < nb; ++j) {
+        const double d = v - vc[j];
+        double k = exp(-gamma * (d * d));
+        if (coulomb) k = k * (sgn(v) == sgn(vc[j]) ? 1.0 : 0.0);
+        K[j] = k;
+        s = j == 0 ? k : s + k; /* sequential sum, as Base.sum for short vectors */
+    }
+    if (normalize) for (int64_t j = 0; j < nb; ++j) K[j] /= s;
+}
+
+/* N x nb table of activations (row n = K(V[n])), column-major. */
+int lpvo_basis_activation(const double *V, int64_t N, int64_t Nv, int normalize, int coulomb,
+                          double *Kout) {
+    const int64_t nb = coulomb ? 2 * Nv : Nv;
+    double *vc = (double *)malloc(sizeof(double) * nb);
+    double gamma;
+    lpvo_basis_centers(V, N, Nv, coulomb, vc, &gamma);
+#pragma omp parallel
+    {
+        double *K = (double *)malloc(sizeof(double) * nb);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            lpvo_basis_eval(V[n], vc, nb, gamma, normalize, coulomb, K);
+            for (int64_t j = 0; j < nb; ++j) Kout[n + j * N] = K[j];
+        }
+        free(K);
+    }
+    free(vc);
+    return LPVO_OK;
+}
+
+/* ---- src/lasso.jl:35-50 (dense twin src/lsfft.jl:240-247) --------------------------
+ * As[n, f+(v-1)Nf] = conj(exp(i*w_f*x_n)) * K_v(v_n); Phi = [Re As, Im As][:,inds],
+ * inds = reshape(1:2NfNv,Nf,:)'[:].  Written directly in permuted order:
+ *   Phi[n, f*2nb + j]      =  cos(w_f x_n) * K_j(v_n)       j <  nb
+ *   Phi[n, f*2nb + nb + j] = -(sin(w_f x_n) * K_j(v_n))
+ * permuted=0 gives the un-permuted [Re As, Im As] instead (column f+(v-1)Nf, then
+ * +Nf*nb for the imaginary half), which is what ls_spectral_lpv solves on. */
+int lpvo_lpv_regressor(const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
+                       int64_t Nv, int normalize, int coulomb, int permuted, double *Phi) {
+    const int64_t nb = coulomb ? 2 * Nv : Nv;
+    double *vc = (double *)malloc(sizeof(double) * nb);
+    double gamma;
+    lpvo_basis_centers(V, N, Nv, coulomb, vc, &gamma);
+#pragma omp parallel
+    {
+        double *K = (double *)malloc(sizeof(double) * nb);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            lpvo_basis_eval(V[n], vc, nb, gamma, normalize, coulomb, K);
+            for (int64_t f = 0; f < Nf; ++f) {
+                const double phi = w[f] * X[n];
+                const double c = cos(phi), s = sin(phi);
+                for (int64_t j = 0; j < nb; ++j) {
+                    int64_t cc, cs;
+                    if (permuted) { cc = f * 2 * nb + j; cs = cc + nb; }
+                    else { cc = f + j * Nf; cs = cc + Nf * nb; }
+                    Phi[n + cc * N] = c * K[j];
+                    Phi[n + cs * N] = -(s * K[j]);
+                }
+            }
+        }
+        free(K);
+    }
+    free(vc);
+    return LPVO_OK;
+}
+
+/* ---- prox operators (ProximalOperators.jl; call sites src/lasso.jl:53-55,88,108) ---- */
+/* NormL1(lam): soft threshold with threshold g*lam */
+void lpvo_prox_l1(double *z, const double *v, int64_t n, double lam, double g) {
+    const double gl = g * lam;
+    for (int64_t i = 0; i < n; ++i)
+        z[i] = v[i] + (v[i] <= -gl ? gl : (v[i] >= gl ? -gl : -v[i]));
+}
+/* NormL0(lam): keep |v| > sqrt(2*g*lam) */
+void lpvo_prox_l0(double *z, const double *v, int64_t n, double lam, double g) {
+    const double th = sqrt(2 * g * lam);
+    for (int64_t i = 0; i < n; ++i) z[i] = fabs(v[i]) > th ? v[i] : 0.0;
+}
+/* IndBallL0(r): keep the r largest magnitudes (ties: lowest index wins; the
+ * reference's partialsortperm leaves tie order unspecified). */
+void lpvo_prox_ball_l0(double *z, const double *v, int64_t n, int64_t r) {
+    if (r >= n) { memcpy(z, v, sizeof(double) * n); return; }
+    char *keep = (char *)calloc(n, 1);
+    for (int64_t k = 0; k < r; ++k) { /* O(n r): oracle sizes are small */
+        int64_t best = -1; double bv = -1;
+        for (int64_t i = 0; i < n; ++i)
+            if (!keep[i] && fabs(v[i]) > bv) { bv = fabs(v[i]); best = i; }
+        keep[best] = 1;
+    }
+    for (int64_t i = 0; i < n; ++i) z[i] = keep[i] ? v[i] : 0.0;
+    free(keep);
+}
+/* SlicedSeparableSum(NormL2(lam)) over contiguous groups of glen (src/lasso.jl:53-55):
+ * z_g = max(0, 1 - g*lam/||v_g||) v_g */
+void lpvo_prox_group_l2(double *z, const double *v, int64_t n, int64_t glen, double lam, double g) {
+    for (int64_t s = 0; s + glen <= n; s += glen) {
+        double ss = 0;
+        for (int64_t i = 0; i < glen; ++i) ss += v[s + i] * v[s + i];
+        const double nv = sqrt(ss);
+        double scale = 1 - lam * g / nv; /* nv==0 -> -inf -> 0 */
+        if (!(scale > 0)) scale = 0;
+        for (int64_t i = 0; i < glen; ++i) z[s + i] = scale * v[s + i];
+    }
+}
+void lpvo_prox(int kind, double *z, const double *v, int64_t n, double param, int64_t glen, double g) {
+    switch (kind) {
+    case LPVO_PROX_L1: lpvo_prox_l1(z, v, n, param, g); break;
+    case LPVO_PROX_L0: lpvo_prox_l0(z, v, n, param, g); break;
+    case LPVO_PROX_BALL_L0: lpvo_prox_ball_l0(z, v, n, (int64_t)param); break;
+    case LPVO_PROX_GROUP_L2: lpvo_prox_group_l2(z, v, n, glen, param, g); break;
+    }
+}
+
+/* ---- dense kernels used by the faithful x-update ------------------------------------ */
+static double nrm2(const double *x, int64_t n) {
+    double s = 0;
+    for (int64_t i = 0; i < n; ++i) s += x[i] * x[i];
+    return sqrt(s);
+}
+static double dot(const double *x, const double *y, int64_t n) {
+    double s = 0;
+    for (int64_t i = 0; i < n; ++i) s += x[i] * y[i];
+    return s;
+}
+/* r = A x, A is m x n column-major: parallel over row blocks */
+static void gemv_n(const double *A, int64_t m, int64_t n, const double *x, double *r) {
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+        const int nt = omp_get_num_threads(), id = omp_get_thread_num();
+#else
+        const int nt = 1, id = 0;
+#endif
+        const int64_t lo = m * id / nt, hi = m * (id + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) r[i] = 0;
+        for (int64_t j = 0; j < n; ++j) {
+            const double xj = x[j];
+            const double *a = A + j * m;
+            for (int64_t i = lo; i < hi; ++i) r[i] += a[i] * xj;
+        }
+    }
+}
+/* c = A' r: parallel over columns */
+static void gemv_t(const double *A, int64_t m, int64_t n, const double *r, double *c) {
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) c[j] = dot(A + j * m, r, m);
+}
+
+/* Operator for CG: out = (S + shift I) in, S = A'A (tall), A A' (fat) or Q (dense). */
+typedef struct {
+    int kind; /* 0: A'A, 1: A A', 2: dense symmetric Q */
+    const double *A; int64_t m, n;
+    double shift; double *work;
+} lpvo_op;
+static int64_t op_dim(const lpvo_op *o) { return o->kind == 1 ? o->m : o->n; }
+static void op_apply(const lpvo_op *o, const double *in, double *out) {
+    if (o->kind == 0) { gemv_n(o->A, o->m, o->n, in, o->work); gemv_t(o->A, o->m, o->n, o->work, out); }
+    else if (o->kind == 1) { gemv_t(o->A, o->m, o->n, in, o->work); gemv_n(o->A, o->m, o->n, o->work, out); }
+    else gemv_n(o->A, o->n, o->n, in, out);
+    const int64_t d = op_dim(o);
+    for (int64_t i = 0; i < d; ++i) out[i] += o->shift * in[i];
+}
+
+/* IterativeSolvers.cg!(x, op, b): defaults abstol=0, reltol=sqrt(eps), maxiter=dim,
+ * initial guess x (initially_zero=false); tolerance relative to the INITIAL residual.
+ * Returns the number of CG iterations. */
+static int64_t cg_solve(const lpvo_op *o, double *x, const double *b, double *r, double *u, double *c) {
+    const int64_t d = op_dim(o);
+    op_apply(o, x, c);
+    for (int64_t i = 0; i < d; ++i) { r[i] = b[i] - c[i]; u[i] = 0; }
+    double residual = nrm2(r, d), prev = 1.0;
+    const double tol = 1.4901161193847656e-08 * residual; /* sqrt(eps(Float64)) */
+    int64_t it = 0;
+    while (!(residual <= tol) && it < d) {
+        const double beta = residual * residual / (prev * prev);
+        for (int64_t i = 0; i < d; ++i) u[i] = r[i] + beta * u[i];
+        op_apply(o, u, c);
+        const double alpha = residual * residual / dot(u, c, d);
+        for (int64_t i = 0; i < d; ++i) { x[i] += alpha * u[i]; r[i] -= alpha * c[i]; }
+        prev = residual;
+        residual = nrm2(r, d);
+        ++it;
+    }
+    return it;
+}
+
+/* ---- src/lasso.jl:136-171  ADMM, with proxf = LeastSquares(A,y,iterative=true) ------
+ * (call sites src/lasso.jl:51,98) -- the FAITHFUL form: dense A in memory, lazy
+ * A'A (tall, m>=n) or A A' (fat) operator, warm-started CG, plus the extra A*x the
+ * package spends on the (discarded) objective value.  x is in/out (initial point),
+ * z,u out.  nxz_hist (may be NULL) receives ||x-z|| per iteration.
+ * Returns iterations done (<= iters); *cg_total accumulates CG iterations. */
+int64_t lpvo_admm_ls(const double *A, int64_t m, int64_t n, const double *y, double *x, double *z,
+                     double *u, int prox_kind, double prox_param, int64_t glen, int64_t iters,
+                     double tol, double mu, double *nxz_hist, int64_t *cg_total) {
+    if (!(mu >= 0 && mu <= 1)) return LPVO_EASSERT; /* src/lasso.jl:143 */
+    const int tall = m >= n;
+    const int64_t d = tall ? n : m, big = m > n ? m : n;
+    double *Aty = (double *)malloc(sizeof(double) * n), *q = (double *)malloc(sizeof(double) * n);
+    double *tmp = (double *)malloc(sizeof(double) * n);
+    double *work = (double *)malloc(sizeof(double) * big), *res = (double *)malloc(sizeof(double) * m);
+    double *res2 = (double *)calloc(m, sizeof(double));
+    double *r = (double *)malloc(sizeof(double) * d), *uu = (double *)malloc(sizeof(double) * d);
+    double *c = (double *)malloc(sizeof(double) * d);
+    gemv_t(A, m, n, y, Aty); /* lambda*A'b, lambda = 1 */
+    lpvo_op op = { tall ? 0 : 1, A, m, n, 1.0 / mu, work };
+    memcpy(z, x, sizeof(double) * n); /* src/lasso.jl:146 */
+    memset(u, 0, sizeof(double) * n); /* src/lasso.jl:147 */
+    int64_t it = 0, cgs = 0;
+    for (int64_t i = 1; i <= iters; ++i) {
+        for (int64_t k = 0; k < n; ++k) tmp[k] = z[k] - u[k];           /* :150 */
+        /* prox!(x, proxf, tmp, mu)                                        :151 */
+        for (int64_t k = 0; k < n; ++k) q[k] = Aty[k] + tmp[k] / mu;
+        if (tall) {
+            memcpy(x, tmp, sizeof(double) * n);
+            cgs += cg_solve(&op, x, q, r, uu, c);
+        } else { /* x = mu*(q - A'((AA' + I/mu) \ (A q))), CG warm-started at the last res2 */
+            gemv_n(A, m, n, q, res);
+            cgs += cg_solve(&op, res2, res, r, uu, c);
+            gemv_t(A, m, n, res2, x);
+            for (int64_t k = 0; k < n; ++k) x[k] = mu * (q[k] - x[k]);
+        }
+        gemv_n(A, m, n, x, res); /* objective value the package returns; ADMM ignores it */
+        for (int64_t k = 0; k < n; ++k) tmp[k] = x[k] + u[k];           /* :152 */
+        lpvo_prox(prox_kind, z, tmp, n, prox_param, glen, mu);          /* :153 */
+        for (int64_t k = 0; k < n; ++k) { tmp[k] = x[k] - z[k]; u[k] += tmp[k]; } /* :154-155 */
+        const double nxz = nrm2(tmp, n);                                /* :157 */
+        if (nxz_hist) nxz_hist[i - 1] = nxz;
+        it = i;
+        if (nxz < tol) break;                                           /* :164 */
+    }
+    if (cg_total) *cg_total = cgs;
+    free(Aty); free(q); free(tmp); free(work); free(res); free(res2); free(r); free(uu); free(c);
+    return it;
+}
+
+/* ---- ADMM with proxf = Quadratic(Q,q,iterative=true)  (src/lasso.jl:119-123) -------
+ * f(x) = x'Qx/2 + q'x ; prox: (Q + I/mu) x = v/mu - q, CG warm-started at v.
+ * NB the reference passes q = +A'Wy (src/lasso.jl:120), reproduced by the caller. */
+int64_t lpvo_admm_quadratic(const double *Q, int64_t n, const double *q, double *x, double *z,
+                            double *u, int prox_kind, double prox_param, int64_t glen,
+                            int64_t iters, double tol, double mu, double *nxz_hist,
+                            int64_t *cg_total) {
+    if (!(mu >= 0 && mu <= 1)) return LPVO_EASSERT;
+    double *rhs = (double *)malloc(sizeof(double) * n), *tmp = (double *)malloc(sizeof(double) * n);
+    double *r = (double *)malloc(sizeof(double) * n), *uu = (double *)malloc(sizeof(double) * n);
+    double *c = (double *)malloc(sizeof(double) * n);
+    lpvo_op op = { 2, Q, n, n, 1.0 / mu, NULL };
+    memcpy(z, x, sizeof(double) * n);
+    memset(u, 0, sizeof(double) * n);
+    int64_t it = 0, cgs = 0;
+    for (int64_t i = 1; i <= iters; ++i) {
+        for (int64_t k = 0; k < n; ++k) tmp[k] = z[k] - u[k];
+        for (int64_t k = 0; k < n; ++k) rhs[k] = tmp[k] / mu - q[k];
+        memcpy(x, tmp, sizeof(double) * n);
+        cgs += cg_solve(&op, x, rhs, r, uu, c);
+        for (int64_t k = 0; k < n; ++k) tmp[k] = x[k] + u[k];
+        lpvo_prox(prox_kind, z, tmp, n, prox_param, glen, mu);
+        for (int64_t k = 0; k < n; ++k) { tmp[k] = x[k] - z[k]; u[k] += tmp[k]; }
+        const double nxz = nrm2(tmp, n);
+        if (nxz_hist) nxz_hist[i - 1] = nxz;
+        it = i;
+        if (nxz < tol) break;
+    }
+    if (cg_total) *cg_total = cgs;
+    free(rhs); free(tmp); free(r); free(uu); free(c);
+    return it;
+}
+
+/* ---- Gram form: same iteration, x-update solved exactly (Cholesky of G + I/mu) ------
+ * Mathematically the fixed point and every iterate of lpvo_admm_ls up to the CG
+ * tolerance; this is the form the device path computes, kept here so that the
+ * two CPU forms can be compared with each other (tests/test_oracle.py). */
+/* L is stored ROW-major (L[i*n+k], k<=i) so every inner loop is contiguous. */
+static int chol_lower(double *L, int64_t n) {
+    for (int64_t j = 0; j < n; ++j) {
+        double d = L[j * n + j];
+        for (int64_t k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+        if (!(d > 0)) return -1;
+        d = sqrt(d);
+        L[j * n + j] = d;
+#pragma omp parallel for schedule(static) if (n - j > 256)
+        for (int64_t i = j + 1; i < n; ++i) {
+            double s = L[i * n + j];
+            for (int64_t k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = s / d;
+        }
+    }
+    return 0;
+}
+/* Lt is the transposed copy (Lt[i*n+k] = L[k][i]) for the contiguous back substitution */
+static void chol_solve(const double *L, const double *Lt, int64_t n, double *b) {
+    for (int64_t i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int64_t k = 0; k < i; ++k) s -= L[i * n + k] * b[k];
+        b[i] = s / L[i * n + i];
+    }
+    for (int64_t i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int64_t k = i + 1; k < n; ++k) s -= Lt[i * n + k] * b[k];
+        b[i] = s / L[i * n + i];
+    }
+}
+/* (G + I/mu) x = b + v/mu.  For the Quadratic form pass b = -q. */
+int64_t lpvo_admm_gram(const double *G, int64_t n, const double *b, double *x, double *z, double *u,
+                       int prox_kind, double prox_param, int64_t glen, int64_t iters, double tol,
+                       double mu, double *nxz_hist) {
+    if (!(mu >= 0 && mu <= 1)) return LPVO_EASSERT;
+    double *L = (double *)malloc(sizeof(double) * n * n), *tmp = (double *)malloc(sizeof(double) * n);
+    double *Lt = (double *)malloc(sizeof(double) * n * n);
+    if (!L || !Lt) return LPVO_ENOMEM;
+    memcpy(L, G, sizeof(double) * n * n); /* G symmetric: row-major == column-major */
+    for (int64_t i = 0; i < n; ++i) L[i * n + i] += 1.0 / mu;
+    if (chol_lower(L, n)) { free(L); free(Lt); free(tmp); return LPVO_EDOMAIN; }
+    for (int64_t i = 0; i < n; ++i) for (int64_t k = 0; k < n; ++k) Lt[i * n + k] = L[k * n + i];
+    memcpy(z, x, sizeof(double) * n);
+    memset(u, 0, sizeof(double) * n);
+    int64_t it = 0;
+    for (int64_t i = 1; i <= iters; ++i) {
+        for (int64_t k = 0; k < n; ++k) x[k] = b[k] + (z[k] - u[k]) / mu;
+        chol_solve(L, Lt, n, x);
+        for (int64_t k = 0; k < n; ++k) tmp[k] = x[k] + u[k];
+        lpvo_prox(prox_kind, z, tmp, n, prox_param, glen, mu);
+        for (int64_t k = 0; k < n; ++k) { tmp[k] = x[k] - z[k]; u[k] += tmp[k]; }
+        const double nxz = nrm2(tmp, n);
+        if (nxz_hist) nxz_hist[i - 1] = nxz;
+        it = i;
+        if (nxz < tol) break;
+    }
+    free(L); free(Lt); free(tmp);
+    return it;
+}
+
+/* G = A' diag(W) A (n x n, full), b = A' diag(W) y ; W may be NULL.  (src/lasso.jl:119-120) */
+int lpvo_gram(const double *A, int64_t m, int64_t n, const double *y, const double *W, double *G,
+              double *b) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t j = 0; j < n; ++j) {
+        const double *aj = A + j * m;
+        for (int64_t i = j; i < n; ++i) {
+            const double *ai = A + i * m;
+            double s = 0;
+            if (W) for (int64_t k = 0; k < m; ++k) s += ai[k] * W[k] * aj[k];
+            else for (int64_t k = 0; k < m; ++k) s += ai[k] * aj[k];
+            G[i + j * n] = s;
+            G[j + i * n] = s;
+        }
+        if (b) {
+            double s = 0;
+            if (W) for (int64_t k = 0; k < m; ++k) s += aj[k] * W[k] * y[k];
+            else for (int64_t k = 0; k < m; ++k) s += aj[k] * y[k];
+            b[j] = s;
+        }
+    }
+    return LPVO_OK;
+}
+
+/* ---- src/windows.jl:27-36 + DSP.arraysplit ------------------------------------------
+ * window i (0-based) covers samples [i*(n-noverlap), i*(n-noverlap)+n); the count is
+ * k = (L-n) div (n-noverlap) + 1 (0 if L<n); noverlap<0 => n>>1 (src/windows.jl:29). */
+int64_t lpvo_window_count(int64_t L, int64_t n, int64_t noverlap) {
+    if (noverlap < 0) noverlap = n >> 1;
+    if (noverlap >= n) return LPVO_EDOMAIN;
+    return L >= n ? (L - n) / (n - noverlap) + 1 : 0;
+}
+int64_t lpvo_window_offsets(int64_t L, int64_t n, int64_t noverlap, int64_t *offsets) {
+    if (noverlap < 0) noverlap = n >> 1;
+    const int64_t k = lpvo_window_count(L, n, noverlap);
+    for (int64_t i = 0; i < k; ++i) offsets[i] = i * (n - noverlap);
+    return k;
+}
+/* src/windows.jl:57-70  merge: overlap-average of per-window vectors (k x n, window-major) */
+int lpvo_merge(const double *yf, int64_t k, int64_t n, int64_t noverlap, int64_t L, double *ym) {
+    int64_t *counts = (int64_t *)calloc(L, sizeof(int64_t));
+    for (int64_t i = 0; i < L; ++i) ym[i] = 0;
+    int64_t lo = 0, hi = n - 1; /* inds = 1:dpw, 0-based inclusive */
+    for (int64_t w = 0; w < k; ++w) {
+        for (int64_t i = lo; i <= hi; ++i) { ym[i] += yf[w * n + (i - lo)]; counts[i] += 1; }
+        lo += n - noverlap; hi += n - noverlap;
+        if (hi > L - 1) hi = L - 1;
+    }
+    for (int64_t i = 0; i < L; ++i) ym[i] /= (double)(counts[i] > 1 ? counts[i] : 1);
+    free(counts);
+    return LPVO_OK;
+}
+
+/* ---- src/utilities.jl:62-73  fourier2complex ----------------------------------------
+ * x = [re(1..Nf); im(...)] -> (re,im) pairs of length Nf; with a zero frequency the
+ * DC term is purely real and im starts at the second frequency. */
+void lpvo_fourier2complex(const double *x, int64_t Nf, int zerofreq, double *re, double *im) {
+    if (!zerofreq) {
+        for (int64_t i = 0; i < Nf; ++i) { re[i] = x[i]; im[i] = x[Nf + i]; }
+    } else {
+        re[0] = x[0]; im[0] = 0;
+        for (int64_t i = 1; i < Nf; ++i) { re[i] = x[i]; im[i] = x[Nf + i - 1]; }
+    }
+}
+
+/* ---- src/lasso.jl:67-69  un-permute + pack ------------------------------------------
+ * z (permuted, length 2*Nf*nb) -> params[f+(v)*Nf] = z[f*2nb+v] + i z[f*2nb+nb+v] */
+void lpvo_lpv_unpermute(const double *z, int64_t Nf, int64_t nb, double *re, double *im) {
+    for (int64_t f = 0; f < Nf; ++f)
+        for (int64_t v = 0; v < nb; ++v) {
+            re[f + v * Nf] = z[f * 2 * nb + v];
+            im[f + v * Nf] = z[f * 2 * nb + nb + v];
+        }
+}

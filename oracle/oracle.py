@@ -1,0 +1,408 @@
+"""CPU oracle for the LPVSpectral.jl hot path -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of ``oracle/lpvs_oracle.c`` plus the numpy restatement of the
+host-side glue of the reference (frequency grid, dense solves, windows, PSD
+accumulation).  Function names and argument meaning follow the reference so that
+tests read like ``/root/reference/test/runtests.jl``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module; the product package must never do so.
+
+Parity status: see the header of ``lpvs_oracle.c`` -- layout / scaling / window
+bookkeeping are pinned by the reference's known-answer tests; the ADMM x-update
+and the prox operators (ProximalOperators.jl / IterativeSolvers.jl, un-vendored,
+version unpinned) are PARITY UNPINNED.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PROX_L1, PROX_L0, PROX_BALL_L0, PROX_GROUP_L2 = 1, 2, 3, 4
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc + OpenMP) next to its source."""
+    so = os.path.join(_HERE, "liblpvs_oracle.so")
+    src = os.path.join(_HERE, "lpvs_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liblpvs_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.lpvo_check_freq.restype = C.c_int64
+        _LIB.lpvo_admm_ls.restype = C.c_int64
+        _LIB.lpvo_admm_quadratic.restype = C.c_int64
+        _LIB.lpvo_admm_gram.restype = C.c_int64
+        _LIB.lpvo_window_count.restype = C.c_int64
+        _LIB.lpvo_window_offsets.restype = C.c_int64
+        _LIB.lpvo_basis_centers.restype = C.c_int64
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel())
+
+
+def num_threads() -> int:
+    return int(lib().lpvo_num_threads())
+
+
+# --------------------------------------------------------------------------- frequency grid
+def default_freqs(t_or_n, fs=None, n=None):
+    """src/lsfft.jl:3-9.  ``default_freqs(n::Int, fs)`` / ``default_freqs(t)`` /
+    ``default_freqs(t, n::Int)`` (= first n samples).  rfftfreq(n,fs) = (0:n>>1)*fs/n."""
+    if np.isscalar(t_or_n):
+        nn = int(t_or_n)
+        fs = 1.0 if fs is None else float(fs)
+    else:
+        t = np.asarray(t_or_n, dtype=np.float64)
+        if n is not None:
+            t = t[: int(n)]
+        nn = len(t)
+        if fs is None:
+            fs = 1.0 / np.mean(np.diff(t))
+    return (np.arange(nn // 2 + 1) * float(fs)) / nn
+
+
+def check_freq(f):
+    """src/lsfft.jl:20-24 -> None | 1 ; raises ValueError (ArgumentError)."""
+    f = _f64(f)
+    r = lib().lpvo_check_freq(_p(f), C.c_int64(len(f)))
+    if r < 0:
+        raise ValueError("If zero frequency is included it must be the first frequency")
+    return None if r == 0 else int(r)
+
+
+def get_fourier_regressor(t, f):
+    """src/lsfft.jl:26-49 -> (A [N x Nreg], zerofreq)."""
+    t, f = _f64(t), _f64(f)
+    zf = check_freq(f)
+    N, Nf = len(t), len(f)
+    nreg = 2 * Nf - (1 if zf else 0)
+    A = np.zeros((N, nreg), order="F")
+    zfo = C.c_int64(0)
+    rc = lib().lpvo_fourier_regressor(_p(t), C.c_int64(N), _p(f), C.c_int64(Nf), _p(A), C.byref(zfo))
+    assert rc == 0
+    return A, zf
+
+
+def get_fourier_regressor_np(t, f):
+    """Independent numpy statement of src/lsfft.jl:26-49 (cross-checks the C)."""
+    t, f = np.asarray(t, np.float64), np.asarray(f, np.float64)
+    zf = check_freq(f)
+    Nf = len(f)
+    dd = 1.0 / np.sqrt(2 * Nf)
+    phi = (6.283185307179586 * f)[None, :] * t[:, None]
+    cosp, sinp = np.cos(phi) * dd, -np.sin(phi) * dd
+    return (np.hstack([cosp, sinp[:, 1:]]) if zf else np.hstack([cosp, sinp])), zf
+
+
+# --------------------------------------------------------------------------- LPV basis
+def basis_centers(V, Nv, coulomb=False):
+    V = _f64(V)
+    vc = np.zeros(2 * Nv if coulomb else Nv)
+    g = C.c_double(0)
+    lib().lpvo_basis_centers(_p(V), C.c_int64(len(V)), C.c_int64(Nv), C.c_int(int(coulomb)), _p(vc), C.byref(g))
+    return vc, g.value
+
+
+def basis_activation(V, Nv, normalize=True, coulomb=False):
+    """src/utilities.jl:23-36 + src/lsfft.jl:195-207, evaluated at every V[n] -> N x nb."""
+    V = _f64(V)
+    nb = 2 * Nv if coulomb else Nv
+    K = np.zeros((len(V), nb), order="F")
+    lib().lpvo_basis_activation(_p(V), C.c_int64(len(V)), C.c_int64(Nv), C.c_int(int(normalize)), C.c_int(int(coulomb)), _p(K))
+    return K
+
+
+def lpv_regressor(X, V, w, Nv, normalize=True, coulomb=False, permuted=True):
+    """src/lasso.jl:35-50: Phi = [Re As, Im As][:, inds] (permuted) or [Re As, Im As]."""
+    X, V, w = _f64(X), _f64(V), _f64(w)
+    nb = 2 * Nv if coulomb else Nv
+    Phi = np.zeros((len(X), 2 * len(w) * nb), order="F")
+    lib().lpvo_lpv_regressor(_p(X), _p(V), C.c_int64(len(X)), _p(w), C.c_int64(len(w)), C.c_int64(Nv),
+                             C.c_int(int(normalize)), C.c_int(int(coulomb)), C.c_int(int(permuted)), _p(Phi))
+    return Phi
+
+
+def lpv_regressor_np(X, V, w, Nv, normalize=True):
+    """Literal numpy transcription of src/lasso.jl:35-50 (complex As, inds gather)."""
+    X, V, w = np.asarray(X, np.float64), np.asarray(V, np.float64), np.asarray(w, np.float64)
+    N, Nf = len(X), len(w)
+    vc = np.linspace(V.min(), V.max(), Nv)
+    gamma = Nv / abs(vc[0] - vc[-1])
+    As = np.zeros((N, Nf * Nv), dtype=np.complex128)
+    for n in range(N):
+        K = np.exp(-gamma * (V[n] - vc) ** 2)
+        if normalize:
+            K = K / K.sum()
+        e = np.exp(1j * w * X[n])
+        As[n, :] = np.conj(np.outer(e, K).ravel(order="F"))
+    inds = np.arange(2 * Nf * Nv).reshape((Nf, 2 * Nv), order="F").T.ravel(order="F")
+    return np.hstack([As.real, As.imag])[:, inds], inds
+
+
+# --------------------------------------------------------------------------- prox + ADMM
+class NormL1:
+    kind = PROX_L1
+    def __init__(self, lam=1.0): self.param, self.glen = float(lam), 0
+
+class NormL0:
+    kind = PROX_L0
+    def __init__(self, lam=1.0): self.param, self.glen = float(lam), 0
+
+class IndBallL0:
+    kind = PROX_BALL_L0
+    def __init__(self, r): self.param, self.glen = float(int(r)), 0
+
+class GroupL2:
+    """SlicedSeparableSum(ntuple(NormL2(lam)), contiguous groups of glen) (src/lasso.jl:53-55)."""
+    kind = PROX_GROUP_L2
+    def __init__(self, lam, glen): self.param, self.glen = float(lam), int(glen)
+
+
+def prox(g, v, gamma):
+    v = _f64(v)
+    z = np.zeros_like(v)
+    lib().lpvo_prox(C.c_int(g.kind), _p(z), _p(v), C.c_int64(len(v)), C.c_double(g.param), C.c_int64(g.glen), C.c_double(gamma))
+    return z
+
+
+def admm_ls(A, y, proxg, x0=None, iters=10000, tol=1e-5, mu=0.05, history=False):
+    """ADMM (src/lasso.jl:136-171) with proxf = LeastSquares(A,y,iterative=true): faithful form."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    y = _f64(y)
+    m, n = A.shape
+    x = np.zeros(n) if x0 is None else _f64(x0).copy()
+    z, u = np.zeros(n), np.zeros(n)
+    hist = np.zeros(iters) if history else None
+    cg = C.c_int64(0)
+    it = lib().lpvo_admm_ls(_p(A), C.c_int64(m), C.c_int64(n), _p(y), _p(x), _p(z), _p(u), C.c_int(proxg.kind),
+                            C.c_double(proxg.param), C.c_int64(proxg.glen), C.c_int64(iters), C.c_double(tol),
+                            C.c_double(mu), _p(hist) if history else None, C.byref(cg))
+    if it == -2:
+        raise AssertionError("μ should be ≤ 1")
+    return dict(x=x, z=z, u=u, iters=int(it), cg_iters=int(cg.value), nxz=hist[:it] if history else None)
+
+
+def admm_quadratic(Q, q, proxg, x0=None, iters=10000, tol=1e-5, mu=0.05, history=False):
+    """ADMM with proxf = Quadratic(Q,q,iterative=true) (src/lasso.jl:119-123)."""
+    Q = np.asfortranarray(Q, dtype=np.float64)
+    q = _f64(q)
+    n = len(q)
+    x = np.zeros(n) if x0 is None else _f64(x0).copy()
+    z, u = np.zeros(n), np.zeros(n)
+    hist = np.zeros(iters) if history else None
+    cg = C.c_int64(0)
+    it = lib().lpvo_admm_quadratic(_p(Q), C.c_int64(n), _p(q), _p(x), _p(z), _p(u), C.c_int(proxg.kind),
+                                   C.c_double(proxg.param), C.c_int64(proxg.glen), C.c_int64(iters), C.c_double(tol),
+                                   C.c_double(mu), _p(hist) if history else None, C.byref(cg))
+    if it == -2:
+        raise AssertionError("μ should be ≤ 1")
+    return dict(x=x, z=z, u=u, iters=int(it), cg_iters=int(cg.value), nxz=hist[:it] if history else None)
+
+
+def admm_gram(G, b, proxg, x0=None, iters=10000, tol=1e-5, mu=0.05, history=False):
+    """Gram form: x-update = exact solve of (G + I/mu) x = b + v/mu (Cholesky)."""
+    G = np.asfortranarray(G, dtype=np.float64)
+    b = _f64(b)
+    n = len(b)
+    x = np.zeros(n) if x0 is None else _f64(x0).copy()
+    z, u = np.zeros(n), np.zeros(n)
+    hist = np.zeros(iters) if history else None
+    it = lib().lpvo_admm_gram(_p(G), C.c_int64(n), _p(b), _p(x), _p(z), _p(u), C.c_int(proxg.kind),
+                              C.c_double(proxg.param), C.c_int64(proxg.glen), C.c_int64(iters), C.c_double(tol),
+                              C.c_double(mu), _p(hist) if history else None)
+    if it == -2:
+        raise AssertionError("μ should be ≤ 1")
+    assert it >= 0, it
+    return dict(x=x, z=z, u=u, iters=int(it), nxz=hist[:it] if history else None)
+
+
+def gram(A, y=None, W=None):
+    A = np.asfortranarray(A, dtype=np.float64)
+    m, n = A.shape
+    G = np.zeros((n, n), order="F")
+    b = np.zeros(n) if y is not None else None
+    yy = _f64(y) if y is not None else None
+    WW = _f64(W) if W is not None else None
+    lib().lpvo_gram(_p(A), C.c_int64(m), C.c_int64(n), _p(yy) if yy is not None else None,
+                    _p(WW) if WW is not None else None, _p(G), _p(b) if b is not None else None)
+    return G, b
+
+
+# --------------------------------------------------------------------------- format helpers
+def fourier2complex(x, zerofreq):
+    """src/utilities.jl:62-73."""
+    x = _f64(x)
+    Nf = (len(x) + (1 if zerofreq else 0)) // 2
+    re, im = np.zeros(Nf), np.zeros(Nf)
+    lib().lpvo_fourier2complex(_p(x), C.c_int64(Nf), C.c_int(1 if zerofreq else 0), _p(re), _p(im))
+    return re + 1j * im
+
+
+def lpv_unpermute(z, Nf, nb):
+    """src/lasso.jl:67-68: z[sortperm(inds)] -> complex params, index f+(v-1)Nf."""
+    z = _f64(z)
+    re, im = np.zeros(Nf * nb), np.zeros(Nf * nb)
+    lib().lpvo_lpv_unpermute(_p(z), C.c_int64(Nf), C.c_int64(nb), _p(re), _p(im))
+    return re + 1j * im
+
+
+def reshape_params(x, Nf):
+    """src/utilities.jl:77."""
+    return np.reshape(x, (Nf, -1), order="F")
+
+
+def psd(x, Nf):
+    """src/lsfft.jl:214-217: |sum_v x[f,v]|^2."""
+    return np.abs(reshape_params(x, Nf).sum(axis=1)) ** 2
+
+
+# --------------------------------------------------------------------------- dense estimators
+def fourier_solve(A, y, zerofreq, lam=0.0):
+    """src/utilities.jl:56-60: svd([A; lam I]) \\ [y; 0]  (minimum-norm least squares)."""
+    n = A.shape[1]
+    if lam > 0:
+        Aa = np.vstack([A, lam * np.eye(n)])
+        ya = np.concatenate([y, np.zeros(n)])
+    else:
+        Aa, ya = A, y
+    U, s, Vt = np.linalg.svd(Aa, full_matrices=False)
+    k = int(np.sum(s > np.finfo(float).eps * s[0]))  # LinearAlgebra ldiv!(::SVD) truncation
+    x = Vt[:k].T @ ((U[:, :k].T @ ya) / s[:k])
+    return fourier2complex(x, zerofreq)
+
+
+def ls_spectral(y, t, f=None, W=None, lam=1e-10):
+    """src/lsfft.jl:62-67 (3-arg, SVD) and :74-80 (weighted, normal equations)."""
+    y, t = _f64(y), _f64(t)
+    f = default_freqs(t) if f is None else _f64(f)
+    A, zf = get_fourier_regressor(t, f)
+    if W is None:
+        return fourier_solve(A, y, zf, lam), f
+    W = _f64(W)
+    x = np.linalg.solve(A.T @ (W[:, None] * A) + lam * np.eye(A.shape[1]), (A.T * W[None, :]) @ y)
+    return fourier2complex(x, zf), f
+
+
+def ls_spectral_lpv(Y, X, V, w, Nv, lam=1e-8, normalize=True, coulomb=False):
+    """src/lsfft.jl:239-259 (params only; covariance omitted): [Ar; lam I] \\ [Y; 0]."""
+    Ar = lpv_regressor(X, V, w, Nv, normalize, coulomb, permuted=False)
+    n2 = Ar.shape[1]
+    xr = np.linalg.lstsq(np.vstack([Ar, lam * np.eye(n2)]), np.concatenate([_f64(Y), np.zeros(n2)]), rcond=None)[0]
+    return xr[: n2 // 2] + 1j * xr[n2 // 2:]
+
+
+# --------------------------------------------------------------------------- sparse estimators
+def ls_sparse_spectral(y, t, f=None, W=None, lam=1.0, proxg=None, init=False, **kw):
+    """src/lasso.jl:85-102 (unweighted: LeastSquares) and :105-126 (weighted: Quadratic with
+    q = +A'Wy, sign as written in the reference)."""
+    y, t = _f64(y), _f64(t)
+    f = default_freqs(t) if f is None else _f64(f)
+    proxg = NormL1(lam) if proxg is None else proxg
+    A, zf = get_fourier_regressor(t, f)
+    x0 = None
+    if init:
+        p = fourier_solve(A, y, zf, lam)
+        x0 = np.concatenate([p.real, p.imag[1:] if zf else p.imag])
+    if W is None:
+        r = admm_ls(A, y, proxg, x0=x0, **kw)
+    else:
+        W = _f64(W)
+        Q = A.T @ (W[:, None] * A)
+        q = A.T @ (W * y)
+        r = admm_quadratic(Q, q, proxg, x0=x0, **kw)
+    return fourier2complex(r["z"], zf), f, r
+
+
+def ls_sparse_spectral_lpv(y, X, V, w, Nv, lam=1.0, normalize=True, **kw):
+    """src/lasso.jl:27-70 (coulomb=false)."""
+    w = _f64(w)
+    Phi = lpv_regressor(X, V, w, Nv, normalize, False, permuted=True)
+    r = admm_ls(Phi, y, GroupL2(lam, 2 * Nv), **kw)
+    return lpv_unpermute(r["z"], len(w), Nv), r
+
+
+# --------------------------------------------------------------------------- windows
+def window_count(L, n, noverlap):
+    k = lib().lpvo_window_count(C.c_int64(L), C.c_int64(n), C.c_int64(noverlap))
+    if k < 0:
+        raise ValueError("noverlap must be less than n")
+    return int(k)
+
+
+def rect(n):
+    return np.ones(n)
+
+
+def hanning(n):
+    """DSP.Windows.hanning (symmetric, zero end points)."""
+    return 0.5 * (1 + np.cos(2 * np.pi * np.linspace(-0.5, 0.5, n))) if n > 1 else np.ones(1)
+
+
+class Windows2:
+    """src/windows.jl:7-42."""
+    def __init__(self, y, t, n=None, noverlap=-1, window_func=rect):
+        self.y, self.t = np.asarray(y), np.asarray(t)
+        n = len(self.y) >> 3 if n is None else int(n)
+        if noverlap < 0:
+            noverlap = n >> 1
+        assert len(self.y) == len(self.t), "y and t has to be the same length"
+        self.n, self.noverlap = n, noverlap
+        self.W = np.asarray(window_func(n), dtype=np.float64)
+        k = window_count(len(self.y), n, noverlap)
+        off = np.zeros(max(k, 1), dtype=np.int64)
+        lib().lpvo_window_offsets(C.c_int64(len(self.y)), C.c_int64(n), C.c_int64(noverlap), _p(off))
+        self.offsets = off[:k]
+
+    def __len__(self):
+        return len(self.offsets)
+
+    def __iter__(self):
+        for o in self.offsets:
+            yield self.y[o:o + self.n], self.t[o:o + self.n]
+
+
+def merge(yf, w: Windows2):
+    """src/windows.jl:57-70."""
+    yfa = np.ascontiguousarray(np.asarray(yf, dtype=np.float64))
+    ym = np.zeros(len(w.y))
+    lib().lpvo_merge(_p(yfa), C.c_int64(len(w)), C.c_int64(w.n), C.c_int64(w.noverlap), C.c_int64(len(w.y)), _p(ym))
+    return ym
+
+
+def mapwindows(fn, w: Windows2):
+    """src/windows.jl:50-53."""
+    return merge([fn((yi, ti)) for yi, ti in w], w)
+
+
+def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimator=None, **kw):
+    """src/lsfft.jl:112-126.  estimator(y,t,f,W;kw...) -> (x, f, ...)."""
+    y, t = _f64(y), _f64(t)
+    n = len(y) // nw
+    if freqs is None:
+        freqs = default_freqs(t, n=n)
+    windows = Windows2(y, t, n, noverlap, window_func)
+    k = len(windows)
+    S = np.zeros(len(freqs))
+    est = estimator if estimator is not None else (lambda yi, ti, f, W, **k_: ls_spectral(yi, ti, f, W, **k_))
+    for yi, ti in windows:
+        x = est(yi, ti, freqs, windows.W, **kw)[0]
+        S += np.abs(x) ** 2
+    return S / k ** 2, freqs
