@@ -1,0 +1,155 @@
+/*
+ * lpvspectral.h -- C-ABI of the MI355X-native regression-matrix + ADMM hot path of
+ * LPVSpectral.jl.  This is the drop-in boundary: a Julia wrapper keeps the reference's
+ * function signatures and reaches these entry points through @ccall;
+ * the Python host mirror in lpvspectral.jl_amd/ reaches them through ctypes.
+ *
+ * Conventions
+ *   - every function returns an int32 status (LPVS_OK or a negative LPVS_E* code);
+ *     lpvs_last_error() gives the thread-local message of the last failure.
+ *   - sizes are int64_t (Julia Int); matrices are COLUMN-MAJOR (Julia layout).
+ *   - every array argument may be a HOST pointer or a DEVICE (HIP) pointer of the
+ *     current device; the library detects which (hipPointerGetAttributes).  The
+ *     caller owns all argument memory; it is never retained or freed here, and is
+ *     only read/written for the duration of the call.
+ *   - a handle owns one HIP stream on one device; handles are not thread-safe,
+ *     different handles may be used concurrently.
+ *   - arithmetic type: fp64 (suffix _f64), the eltype of every reference test.
+ *
+ * File:line citations are into the reference (baggepinnen/LPVSpectral.jl v0.3.4).
+ */
+#ifndef LPVSPECTRAL_H
+#define LPVSPECTRAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPVS_VERSION 100 /* 0.1.0 */
+
+/* status codes -> exception the Julia/Python wrapper raises */
+#define LPVS_OK 0
+#define LPVS_EARGUMENT (-1)    /* ArgumentError: zero frequency not first        src/lsfft.jl:22   */
+#define LPVS_EASSERT (-2)      /* AssertionError: mu outside [0,1], length mismatch src/lasso.jl:143, src/windows.jl:31 */
+#define LPVS_EDOMAIN (-3)      /* DomainError: noverlap >= n (DSP.arraysplit)    src/windows.jl:33 */
+#define LPVS_ENOMEM (-4)       /* host or device allocation failed */
+#define LPVS_EDEVICE (-5)      /* HIP runtime error / no gfx950 device */
+#define LPVS_EUNSUPPORTED (-6) /* e.g. coulomb=true in the sparse LPV path (note ++) */
+#define LPVS_ENUMERIC (-7)     /* (G + I/mu) not positive definite */
+#define LPVS_ESTATE (-8)       /* call order violated (run before init, ...) */
+
+/* prox_g kinds (ProximalOperators.jl objects at src/lasso.jl:53-55,88,108; README.md:70-83) */
+#define LPVS_PROX_L1 1       /* NormL1(lam):  soft threshold at mu*lam */
+#define LPVS_PROX_L0 2       /* NormL0(lam):  keep |v| > sqrt(2*mu*lam) */
+#define LPVS_PROX_BALL_L0 3  /* IndBallL0(r): keep the r largest |v| (param = r) */
+#define LPVS_PROX_GROUP_L2 4 /* SlicedSeparableSum(NormL2(lam)) on contiguous groups of group_len */
+
+/* linear-term convention of the x-update, lpvs_admm_init(..., linear_sign) */
+#define LPVS_LINEAR_LEAST_SQUARES (+1) /* LeastSquares(A,y): (G+I/mu)x =  b + v/mu   src/lasso.jl:51,98 */
+#define LPVS_LINEAR_QUADRATIC_AS_WRITTEN (-1) /* Quadratic(Q,q=+A'Wy): (Q+I/mu)x = -q + v/mu   src/lasso.jl:119-121 */
+
+typedef struct lpvs_problem lpvs_problem;
+
+/* ---- library ------------------------------------------------------------------------ */
+int32_t lpvs_version(void);
+int32_t lpvs_device_count(void);          /* number of visible HIP devices (0 if none) */
+const char *lpvs_last_error(void);        /* thread-local, valid until the next failing call */
+
+/* ---- a1  check_freq                                                  src/lsfft.jl:20-24
+ * *zerofreq = 0 (no zero frequency) or 1 (zero frequency is first); LPVS_EARGUMENT if a
+ * zero frequency sits elsewhere.  Host pointers only (tiny). */
+int32_t lpvs_check_freq_f64(const double *f, int64_t Nf, int64_t *zerofreq);
+
+/* ---- a2  get_fourier_regressor(t,f)                                  src/lsfft.jl:26-49
+ * A_out is N x Nreg column-major, Nreg = 2Nf - (zerofreq ? 1 : 0):
+ *   A[n,k] = cos((2pi f_k) t_n)/sqrt(2Nf);  A[n,k+sinoffset] = -sin(...)/sqrt(2Nf). */
+int32_t lpvs_fourier_regressor_f64(const double *t, int64_t N, const double *f, int64_t Nf,
+                                   double *A_out, int64_t *zerofreq);
+
+/* ---- a3  basis_activation_func evaluated on all samples   src/utilities.jl:23-36, src/lsfft.jl:195-207
+ * K_out is N x nb column-major, nb = Nv (2Nv if coulomb). */
+int32_t lpvs_basis_activation_f64(const double *V, int64_t N, int64_t Nv, int32_t normalize,
+                                  int32_t coulomb, double *K_out);
+
+/* ---- a4+a5  LPV regressor                          src/lasso.jl:35-50, src/lsfft.jl:240-247
+ * permuted != 0: Phi = [Re As, Im As][:, inds]  (N x 2*Nf*nb, each frequency's 2nb columns
+ * adjacent, the matrix ls_sparse_spectral_lpv solves on); permuted == 0: [Re As, Im As]. */
+int32_t lpvs_lpv_regressor_f64(const double *X, const double *V, int64_t N, const double *w,
+                               int64_t Nf, int64_t Nv, int32_t normalize, int32_t coulomb,
+                               int32_t permuted, double *Phi_out);
+
+/* ---- problem handles: regressor assembly + Gram on device ----------------------------
+ * Each constructor builds G (n x n) and b (n) on `device` and keeps them resident:
+ *   fourier: G = A' diag(W) A, b = A' diag(W) y  (W == NULL: identity)  src/lasso.jl:91,98 / :111,118-120
+ *   lpv:     G = Phi' Phi,     b = Phi' y   (Phi never materialised)    src/lasso.jl:35-51
+ *   gram:    G, b supplied by the caller (any Quadratic(Q,q) / LeastSquares in Gram form).
+ *   dense:   see below. */
+int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_t N, const double *f,
+                                        int64_t Nf, const double *W, int32_t device,
+                                        lpvs_problem **out);
+int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const double *V, int64_t N,
+                                    const double *w, int64_t Nf, int64_t Nv, int32_t normalize,
+                                    int32_t coulomb, int32_t device, lpvs_problem **out);
+/* dense:   A (m x n column-major) supplied by the caller: G = A' diag(W) A, b = A' diag(W) y --
+ *          the generic ADMM(x, LeastSquares(A,y,iterative=true), proxg) plugin path, src/lasso.jl:136 */
+int32_t lpvs_problem_create_dense_f64(const double *A, const double *y, int64_t m, int64_t n,
+                                      const double *W, int32_t device, lpvs_problem **out);
+int32_t lpvs_problem_create_gram_f64(const double *G, const double *b, int64_t n, int32_t device,
+                                     lpvs_problem **out);
+int32_t lpvs_problem_destroy(lpvs_problem *h);
+
+int32_t lpvs_problem_size(const lpvs_problem *h, int64_t *n);
+int32_t lpvs_problem_zerofreq(const lpvs_problem *h, int64_t *zerofreq);
+/* copy out G (n x n, full symmetric) and/or b (n); either pointer may be NULL */
+int32_t lpvs_problem_get_gram_f64(lpvs_problem *h, double *G_out, double *b_out);
+
+/* ---- dense (ridge) solve from the same Gram:  (G + ridge*I) x = b ---------------------
+ * ls_spectral weighted form (src/lsfft.jl:77, ridge = lam), fourier_solve / real_complex_bs in
+ * normal-equation form (src/utilities.jl:49-60, ridge = lam^2).  x_out has n entries in the
+ * regressor's column order. */
+int32_t lpvs_problem_solve_ridge_f64(lpvs_problem *h, double ridge, double *x_out);
+
+/* ---- ADMM                                                          src/lasso.jl:136-171
+ * set_prox: the g of z <- prox_{mu g}(x+u).  init: x <- x0 (zeros if NULL), z <- x, u <- 0,
+ * factorises (G + I/mu) once (LPVS_EASSERT unless 0 <= mu <= 1).  run: up to max_iters more
+ * iterations, stopping after the first with ||x-z||_2 < tol exactly as src/lasso.jl:164; it
+ * returns to the caller so that printing, cb(x,z) and Ctrl-C stay on the host thread
+ * (src/lasso.jl:158-163, :59-63).  *iters_done counts iterations since init. */
+int32_t lpvs_problem_set_prox(lpvs_problem *h, int32_t kind, double param, int64_t group_len);
+int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double tol,
+                           int32_t linear_sign);
+int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, double *nxz,
+                      int32_t *converged);
+/* iterates in the solver's own (regressor-column) order; any pointer may be NULL */
+int32_t lpvs_admm_get_f64(lpvs_problem *h, double *x_out, double *z_out, double *u_out);
+
+/* ---- a14 result packing ---------------------------------------------------------------
+ * fourier: fourier2complex(z, zerofreq)                         src/utilities.jl:62-73
+ * lpv:     z[sortperm(inds)] -> complex, index f+(v-1)Nf        src/lasso.jl:67-68
+ * which = 0: pack z (what the estimators return), 1: pack x.  re/im have Nf (fourier) or
+ * Nf*nb (lpv) entries. */
+int32_t lpvs_problem_get_params_f64(lpvs_problem *h, int32_t which, double *re_out, double *im_out);
+/* same packing applied to a caller-supplied coefficient vector (e.g. a ridge solution) */
+int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double *re_out,
+                                     double *im_out);
+
+/* ---- timing: HIP-event durations (ms) of the handle's phases, measured on its stream ---
+ * out[0] basis tables, out[1] Gram kernel(s), out[2] Gram reduce + rhs, out[3] factorisation,
+ * out[4] ADMM iterations (sum over lpvs_admm_run calls), out[5] number of Gram main-kernel
+ * launches, out[6] algorithmic Gram flops N*n*(n+1), out[7] ADMM iterations timed in out[4]. */
+int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out);
+
+/* ---- a15 window bookkeeping (DSP.arraysplit as used by src/windows.jl:27-36) ---------- */
+int32_t lpvs_window_count(int64_t L, int64_t n, int64_t noverlap, int64_t *count);
+int32_t lpvs_window_offsets(int64_t L, int64_t n, int64_t noverlap, int64_t *offsets /* 0-based */,
+                            int64_t capacity, int64_t *count);
+/* merge (src/windows.jl:57-70): yf is count x n (window-major, row w = window w) -> ym[L] */
+int32_t lpvs_merge_f64(const double *yf, int64_t count, int64_t n, int64_t noverlap, int64_t L,
+                       double *ym);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPVSPECTRAL_H */

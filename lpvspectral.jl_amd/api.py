@@ -1,0 +1,410 @@
+"""Host mirror of the reference's estimator API on top of the HIP library.
+
+Same names, argument order, keyword names (``λ``, ``μ``, ``proxg``, ``iters``, ``tol``,
+``printerval``, ``cb``, ``init``, ``normalize``, ``coulomb``, ``nw``, ``noverlap``,
+``window_func``, ``estimator``) and error behaviour as ``src/lsfft.jl`` / ``src/lasso.jl`` of
+LPVSpectral.jl, so the parity tests read like ``test/runtests.jl``.  All arithmetic happens in
+``liblpvspectral.so``; inputs may be numpy arrays (host) or float64 torch CUDA tensors (resident
+in HBM).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import sys
+from dataclasses import dataclass
+from typing import Any, Callable, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, check, lib, out_ptr
+from .prox import IndBallL0, LeastSquares, NormL0, NormL1, NormL2, Quadratic, SlicedSeparableSum
+from .windows import Windows2, Windows3, rect
+
+log = logging.getLogger("lpvspectral")
+
+
+# --------------------------------------------------------------------------- result type
+@dataclass
+class SpectralExt:
+    """src/LPVSpectral.jl:59-70."""
+    Y: Any
+    X: Any
+    V: Any
+    w: Any
+    Nv: int
+    λ: float
+    coulomb: bool
+    normalize: bool
+    x: Any
+    Σ: Any
+
+
+def reshape_params(x, Nf):
+    """src/utilities.jl:77: params as an [Nω × Nv] matrix."""
+    return np.reshape(np.asarray(x), (int(Nf), -1), order="F")
+
+
+def psd(se: SpectralExt):
+    """src/lsfft.jl:214-217."""
+    rp = reshape_params(np.array(se.x, copy=True), len(np.ravel(se.w)))
+    return np.abs(rp.sum(axis=1, keepdims=True)) ** 2
+
+
+# --------------------------------------------------------------------------- small host helpers
+def default_freqs(t_or_n, fs=None, n=None):
+    """src/lsfft.jl:3-9: ``default_freqs(n::Int, fs=1)``, ``default_freqs(t)``, ``default_freqs(t, n)``.
+    rfftfreq(n, fs) = (0:n÷2)·fs/n (host side, no FFTW)."""
+    if np.isscalar(t_or_n):
+        nn = int(t_or_n)
+        fs = 1.0 if fs is None else float(fs)
+    else:
+        t = _host(t_or_n)
+        if n is not None:
+            t = t[: int(n)]
+        nn = len(t)
+        if fs is None:
+            fs = 1.0 / np.mean(np.diff(t))
+    return (np.arange(nn // 2 + 1) * float(fs)) / nn
+
+
+def _host(a):
+    if _lib.is_device_array(a):
+        return a.detach().cpu().numpy().astype(np.float64, copy=False)
+    if hasattr(a, "detach") and hasattr(a, "numpy"):
+        a = a.detach().numpy()
+    return np.asarray(a, dtype=np.float64)
+
+
+def check_freq(f):
+    """src/lsfft.jl:20-24 -> ``None`` or 1; ValueError (ArgumentError) if zero is not first."""
+    fa = np.ascontiguousarray(_host(f))
+    z = C.c_int64(0)
+    check(lib().lpvs_check_freq_f64(out_ptr(fa), len(fa), C.byref(z)))
+    return None if z.value == 0 else int(z.value)
+
+
+def get_fourier_regressor(t, f):
+    """src/lsfft.jl:26-49 -> ``(A, zerofreq)`` with A an N×Nreg column-major numpy array."""
+    kt, pt, N = as_f64(t)
+    kf, pf, Nf = as_f64(f)
+    zf = check_freq(f)
+    nreg = 2 * Nf - (1 if zf else 0)
+    A = np.zeros((N, nreg), order="F")
+    z = C.c_int64(0)
+    check(lib().lpvs_fourier_regressor_f64(pt, N, pf, Nf, out_ptr(A), C.byref(z)))
+    return A, zf
+
+
+def basis_activation_func(V, Nv, normalize=True, coulomb=False):
+    """src/utilities.jl:23-36.  The reference returns a closure K(v); this mirror returns the table of
+    K evaluated at every V[n] (N × Nv, or N × 2Nv with coulomb), which is how the closure is used
+    (src/lasso.jl:42-44)."""
+    kv, pv, N = as_f64(V)
+    nb = 2 * Nv if coulomb else Nv
+    K = np.zeros((N, nb), order="F")
+    check(lib().lpvs_basis_activation_f64(pv, N, int(Nv), int(bool(normalize)), int(bool(coulomb)), out_ptr(K)))
+    return K
+
+
+def lpv_regressor(X, V, w, Nv, normalize=True, coulomb=False, permuted=True):
+    """Materialised Φ of src/lasso.jl:35-50 (tests / small problems; the solve never forms it)."""
+    kx, px, N = as_f64(X)
+    kv, pv, _ = as_f64(V)
+    kw, pw, Nf = as_f64(np.ravel(_host(w)) if not _lib.is_device_array(w) else w)
+    nb = 2 * Nv if coulomb else Nv
+    Phi = np.zeros((N, 2 * Nf * nb), order="F")
+    check(lib().lpvs_lpv_regressor_f64(px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), int(bool(permuted)), out_ptr(Phi)))
+    return Phi
+
+
+def fourier2complex(x, zerofreq):
+    """src/utilities.jl:62-73 (host formatting helper)."""
+    x = _host(x)
+    n = len(x) // 2
+    if zerofreq is None:
+        return x[:n] + 1j * x[n:]
+    out = np.empty(n + 1, dtype=np.complex128)
+    out[0] = x[0]
+    out[1:] = x[1:n + 1] + 1j * x[n + 1:]
+    return out
+
+
+# --------------------------------------------------------------------------- device problem handle
+class Problem:
+    """Owner of one ``lpvs_problem`` handle (regressor + Gram resident on one MI355X)."""
+
+    def __init__(self, handle, kind):
+        self._h = handle
+        self.kind = kind
+        n = C.c_int64(0)
+        check(lib().lpvs_problem_size(self._h, C.byref(n)))
+        self.n = int(n.value)
+
+    # constructors -----------------------------------------------------------------------
+    @classmethod
+    def fourier(cls, y, t, f, W=None, device=0):
+        ky, py, N = as_f64(y)
+        kt, pt, Nt = as_f64(t)
+        kf, pf, Nf = as_f64(f)
+        kw, pw, Nw = as_f64(W)
+        assert N == Nt, "y and t has to be the same length"
+        assert W is None or Nw == N, "W has to be the same length as y"
+        h = C.c_void_p()
+        check(lib().lpvs_problem_create_fourier_f64(py, pt, N, pf, Nf, pw, int(device), C.byref(h)))
+        p = cls(h, "fourier")
+        p.Nf = Nf
+        return p
+
+    @classmethod
+    def lpv(cls, y, X, V, w, Nv, normalize=True, coulomb=False, device=0):
+        ky, py, N = as_f64(y)
+        kx, px, Nx = as_f64(X)
+        kv, pv, Nvv = as_f64(V)
+        kw, pw, Nf = as_f64(w)
+        assert N == Nx == Nvv, "y, X and V has to be the same length"
+        h = C.c_void_p()
+        check(lib().lpvs_problem_create_lpv_f64(py, px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), int(device), C.byref(h)))
+        p = cls(h, "lpv")
+        p.Nf, p.nb = Nf, (2 * Nv if coulomb else Nv)
+        return p
+
+    @classmethod
+    def dense(cls, A, y, W=None, device=0):
+        if _lib.is_device_array(A):
+            raise TypeError("dense(): pass A as a host (numpy) column-major matrix or a transposed-contiguous device tensor via gram()")
+        Ah = np.asfortranarray(_host(A))
+        m, n = Ah.shape
+        ky, py, N = as_f64(y)
+        kw, pw, Nw = as_f64(W)
+        assert N == m
+        h = C.c_void_p()
+        check(lib().lpvs_problem_create_dense_f64(out_ptr(Ah), py, m, n, pw, int(device), C.byref(h)))
+        return cls(h, "dense")
+
+    @classmethod
+    def gram(cls, G, b, device=0):
+        kg, pg, n2 = as_f64(G)
+        kb, pb, n = as_f64(b)
+        assert n2 == n * n, "G must be n x n"
+        h = C.c_void_p()
+        check(lib().lpvs_problem_create_gram_f64(pg, pb, n, int(device), C.byref(h)))
+        return cls(h, "gram")
+
+    # housekeeping ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lpvs_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # accessors ------------------------------------------------------------------------------
+    def get_gram(self):
+        G = np.zeros((self.n, self.n), order="F")
+        b = np.zeros(self.n)
+        check(lib().lpvs_problem_get_gram_f64(self._h, out_ptr(G), out_ptr(b)))
+        return G, b
+
+    def solve_ridge(self, ridge):
+        x = np.zeros(self.n)
+        check(lib().lpvs_problem_solve_ridge_f64(self._h, float(ridge), out_ptr(x)))
+        return x
+
+    def set_prox(self, proxg):
+        if not hasattr(proxg, "device_params"):
+            raise NotImplementedError(f"proxg of type {type(proxg).__name__} has no device kernel "
+                                      "(supported: NormL1, NormL0, IndBallL0, SlicedSeparableSum(NormL2))")
+        kind, param, glen = proxg.device_params(self.n)
+        check(lib().lpvs_problem_set_prox(self._h, kind, float(param), int(glen)))
+
+    def admm_init(self, x0=None, μ=0.05, tol=1e-5, linear_sign=_lib.LINEAR_LEAST_SQUARES):
+        k0, p0, n0 = as_f64(x0)
+        assert x0 is None or n0 == self.n, "x0 has the wrong length"
+        check(lib().lpvs_admm_init_f64(self._h, p0, float(μ), float(tol), int(linear_sign)))
+
+    def admm_run(self, max_iters):
+        it, nxz, conv = C.c_int64(0), C.c_double(0), C.c_int32(0)
+        check(lib().lpvs_admm_run(self._h, int(max_iters), C.byref(it), C.byref(nxz), C.byref(conv)))
+        return int(it.value), float(nxz.value), bool(conv.value)
+
+    def admm_get(self):
+        x, z, u = np.zeros(self.n), np.zeros(self.n), np.zeros(self.n)
+        check(lib().lpvs_admm_get_f64(self._h, out_ptr(x), out_ptr(z), out_ptr(u)))
+        return x, z, u
+
+    def params(self, which=0):
+        m = self.Nf * self.nb if self.kind == "lpv" else self.Nf
+        re, im = np.zeros(m), np.zeros(m)
+        check(lib().lpvs_problem_get_params_f64(self._h, int(which), out_ptr(re), out_ptr(im)))
+        return re + 1j * im
+
+    def pack(self, coef):
+        m = self.Nf * self.nb if self.kind == "lpv" else self.Nf
+        kc, pc, _ = as_f64(coef)
+        re, im = np.zeros(m), np.zeros(m)
+        check(lib().lpvs_problem_pack_params_f64(self._h, pc, out_ptr(re), out_ptr(im)))
+        return re + 1j * im
+
+    def timing(self):
+        t = np.zeros(8)
+        check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 8))
+        return dict(basis_ms=t[0], gram_ms=t[1], reduce_rhs_ms=t[2], factor_ms=t[3], admm_ms=t[4],
+                    gram_launches=t[5], gram_flops=t[6], admm_iters=t[7])
+
+
+# --------------------------------------------------------------------------- ADMM driver
+def _admm_on_problem(prob: Problem, x0, proxg, linear_sign, iters=10000, tol=1e-5, printerval=100, cb=None, μ=0.05,
+                     out=sys.stdout):
+    """src/lasso.jl:136-171 with the iterations on device.  Control returns to the host every
+    ``printerval`` iterations, so the progress lines (:159,:165), ``cb(x,z)`` (:160-162) and
+    KeyboardInterrupt (:59-63) behave as in the reference."""
+    assert 0 <= μ <= 1, "μ should be ≤ 1"                       # src/lasso.jl:143
+    prob.set_prox(proxg)
+    prob.admm_init(x0, μ=μ, tol=tol, linear_sign=linear_sign)
+    done, conv, nxz = 0, False, 0.0
+    printerval = int(printerval) if printerval and printerval > 0 else iters
+    while done < iters and not conv:
+        chunk = min(printerval - done % printerval, iters - done)
+        done, nxz, conv = prob.admm_run(chunk)
+        if done % printerval == 0:
+            print("%d ||x-z||₂ %.10f" % (done, nxz), file=out)      # src/lasso.jl:159
+            if cb is not None:                                      # src/lasso.jl:160-162
+                x, z, _ = prob.admm_get()
+                cb(x, z)
+        if conv:
+            print("%d ||x-z||₂ %.10f" % (done, nxz), file=out)      # src/lasso.jl:165
+            log.info("||x-z||₂ ≤ tol")                              # src/lasso.jl:166
+            break
+    x, z, _ = prob.admm_get()
+    return x, z
+
+
+def ADMM(x, proxf, proxg, iters=10000, tol=1e-5, printerval=100, cb=None, μ=0.05, device=0):
+    """``ADMM(x, proxf, proxg; iters, tol, printerval, cb, μ)`` (src/lasso.jl:136-171) -> ``(x, z)``.
+
+    ``proxf`` is a :class:`LeastSquares` (dense A, b) or :class:`Quadratic` (Q, q) mirror object; its
+    Gram is formed / uploaded once and every iteration runs on the GPU."""
+    if isinstance(proxf, LeastSquares):
+        prob = Problem.dense(proxf.A, proxf.b, device=device)
+    elif isinstance(proxf, Quadratic):
+        prob = Problem.gram(proxf.Q, proxf.q, device=device)
+    else:
+        raise NotImplementedError(f"proxf of type {type(proxf).__name__} has no device path")
+    with prob:
+        return _admm_on_problem(prob, x, proxg, proxf.linear_sign, iters, tol, printerval, cb, μ)
+
+
+# --------------------------------------------------------------------------- estimators
+def ls_spectral(y, t, f=None, W=None, λ=1e-10, verbose=False, device=0):
+    """``ls_spectral(y,t,f=default_freqs(t); λ=1e-10)`` (src/lsfft.jl:62-67) and the weighted
+    ``ls_spectral(y,t,f,W; λ)`` (:74-80) -> ``(x, f)``.
+
+    Both solve the normal equations from the device Gram: the weighted form is the reference's own
+    formula ``(A'WA + λI) \\ A'Wy``; the unweighted one is the normal-equation form of
+    ``[A; λI] \\ [y; 0]`` (ridge λ²) -- identical minimiser, no SVD."""
+    f = default_freqs(t) if f is None else f
+    with Problem.fourier(y, t, f, W, device=device) as prob:
+        ridge = λ if W is not None else λ * λ
+        x = prob.solve_ridge(ridge)
+        if verbose:
+            G, _ = prob.get_gram()
+            log.info("Condition number: %s\n", round(float(np.linalg.cond(G)), 2))
+        params = prob.pack(x)
+    return params, _host(f)
+
+
+def ls_sparse_spectral(y, t, f=None, W=None, init=False, λ=1.0, proxg=None, device=0, **kwargs):
+    """``ls_sparse_spectral(y,t,f; init, λ, proxg=NormL1(λ), kwargs...)`` (src/lasso.jl:85-102) and the
+    weighted 4-argument method ``(y,t,f,W; ...)`` (:105-126) -> ``(params, f)``.
+
+    The weighted method reproduces the reference as written: ``Quadratic(Q, q=+A'Wy)``
+    (src/lasso.jl:119-121), i.e. the linear term enters with the opposite sign of least squares."""
+    f = default_freqs(t) if f is None else f
+    proxg = NormL1(λ) if proxg is None else proxg
+    with Problem.fourier(y, t, f, W, device=device) as prob:
+        x0 = None
+        if init:  # fourier_solve(A,y,zerofreq,λ), src/lasso.jl:92,112
+            zf = check_freq(f)
+            p = prob.pack(prob.solve_ridge(λ * λ))
+            x0 = np.concatenate([p.real, p.imag[1:] if zf else p.imag])  # src/lasso.jl:93-97
+        sign = _lib.LINEAR_LEAST_SQUARES if W is None else _lib.LINEAR_QUADRATIC_AS_WRITTEN
+        _admm_on_problem(prob, x0, proxg, sign, **kwargs)
+        params = prob.params(0)                                      # fourier2complex(z, zerofreq)
+    return params, _host(f)
+
+
+def ls_sparse_spectral_lpv(y, X, V, w, Nv, λ=1, coulomb=False, normalize=True, device=0, proxg=None, **kwargs):
+    """``ls_sparse_spectral_lpv(Y,X,V,w,Nv; λ, coulomb, normalize, kwargs...)`` (src/lasso.jl:27-70)
+    -> :class:`SpectralExt` with ``Σ=None``.
+
+    ``proxg=None`` gives the reference's frequency-grouped lasso (src/lasso.jl:53-55); passing another
+    prox object (e.g. ``IndBallL0(32)``) is an extension the reference does not have."""
+    if coulomb:
+        raise NotImplementedError("coulomb=true is ill-defined in the reference's sparse LPV path "
+                                  "(half of x is never written by prox!, SURVEY.md §2 ‡); use ls_spectral_lpv")
+    w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
+    Nf = len(w)
+    Nv = int(Nv)
+    with Problem.lpv(y, X, V, w, Nv, normalize, False, device=device) as prob:
+        g = SlicedSeparableSum.frequency_groups(λ, Nf, 2 * Nv) if proxg is None else proxg
+        try:
+            _admm_on_problem(prob, None, g, _lib.LINEAR_LEAST_SQUARES, **kwargs)
+            params = prob.params(0)
+        except KeyboardInterrupt:                                    # src/lasso.jl:59-63
+            log.info("Aborting")
+            params = prob.params(1)                                  # z = copy(x)
+    return SpectralExt(y, X, V, w, Nv, λ, coulomb, normalize, params, None)
+
+
+def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, device=0):
+    """``ls_spectral_lpv(Y,X,V,w,Nv; λ, coulomb, normalize)`` (src/lsfft.jl:239-259).
+
+    Ridge solve ``[Ar; λI] \\ [Y; 0]`` in normal-equation form on the device Gram (the Gram of the
+    permuted Φ; the solution is un-permuted by the same packing as the sparse path).  ``Σ`` (the
+    parameter covariance, :252-254) is not computed on device yet and is returned as ``None``."""
+    w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
+    with Problem.lpv(Y, X, V, w, int(Nv), normalize, coulomb, device=device) as prob:
+        params = prob.pack(prob.solve_ridge(λ * λ))
+    return SpectralExt(Y, X, V, w, int(Nv), λ, coulomb, normalize, params, None)
+
+
+def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimator=None, **kwargs):
+    """``ls_windowpsd(y,t,freqs; nw, noverlap, window_func, estimator=ls_spectral, kwargs...)``
+    (src/lsfft.jl:112-126) -> ``(S, freqs)``.  ``estimator`` is any callable ``(y,t,f,W; kw...) -> (x, f)``
+    (plugin boundary #1); it is always called with the window vector, as in the reference (:121)."""
+    estimator = ls_spectral if estimator is None else estimator
+    yh = y
+    n = len(yh) // nw                                               # :113
+    if freqs is None:
+        freqs = default_freqs(t, n=n)                               # :114
+    windows = Windows2(y, t, n, noverlap, window_func)              # :115
+    k = len(windows)                                                # :116
+    S = np.zeros(len(freqs))
+    for yi, ti in windows:                                          # :120
+        x = estimator(yi, ti, freqs, windows.W, **kwargs)[0]        # :121
+        S += np.abs(np.asarray(x)) ** 2                             # :122
+    return S / k ** 2, freqs                                        # :125
+
+
+def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, **kwargs):
+    """src/lsfft.jl:267-277."""
+    w = np.ravel(_host(w))
+    S = np.zeros(len(w))
+    windows = Windows3(Y, X, V, len(Y) // nw, noverlap, rect)
+    for y, x, v in windows:
+        se = ls_spectral_lpv(y, x, v, w, Nv, **kwargs)
+        rp = reshape_params(se.x, len(w))
+        S = S + np.abs(rp.sum(axis=1)) ** 2
+    return S

@@ -1,0 +1,641 @@
+// api.hip -- the C-ABI of include/lpvspectral.h on top of the gfx950 kernels.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "lpvs_internal.h"
+
+namespace lpvs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int32_t DevBuf::alloc(size_t nbytes) {
+    release();
+    if (nbytes == 0) nbytes = 16;
+    hipError_t e = hipMalloc(&p, nbytes);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu bytes) failed: %s", nbytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? LPVS_ENOMEM : LPVS_EDEVICE;
+    }
+    bytes = nbytes;
+    return LPVS_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+bool is_device_ptr(const void *p) {
+    if (p == nullptr) return false;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }  // plain (unregistered) host memory
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+int32_t copy_to_device(void *dst_dev, const void *src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return LPVS_OK;
+    LPVS_HIP(hipMemcpyAsync(dst_dev, src, bytes, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    LPVS_HIP(hipStreamSynchronize(s));  // the caller's host buffer is only valid during the call
+    return LPVS_OK;
+}
+int32_t copy_from_device(void *dst, const void *src_dev, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return LPVS_OK;
+    LPVS_HIP(hipMemcpyAsync(dst, src_dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    return LPVS_OK;
+}
+
+// A read-only argument made device-resident: aliases the caller's pointer when it already is.
+struct DevArg {
+    DevBuf own;
+    const double *p = nullptr;
+    int32_t set(const double *src, int64_t count, hipStream_t s) {
+        if (is_device_ptr(src)) { p = src; return LPVS_OK; }
+        LPVS_TRY(own.alloc(sizeof(double) * (size_t)count));
+        LPVS_TRY(copy_to_device(own.p, src, sizeof(double) * (size_t)count, s));
+        p = own.as<double>();
+        return LPVS_OK;
+    }
+};
+// An output argument: device staging buffer when the caller's pointer is host memory.
+struct DevOut {
+    DevBuf own;
+    double *p = nullptr;
+    double *user = nullptr;
+    size_t bytes = 0;
+    int32_t set(double *dst, int64_t count) {
+        user = dst; bytes = sizeof(double) * (size_t)count;
+        if (is_device_ptr(dst)) { p = dst; return LPVS_OK; }
+        LPVS_TRY(own.alloc(bytes));
+        p = own.as<double>();
+        return LPVS_OK;
+    }
+    int32_t finish(hipStream_t s) {
+        if (p != user) return copy_from_device(user, p, bytes, s);
+        LPVS_HIP(hipStreamSynchronize(s));
+        return LPVS_OK;
+    }
+};
+
+static int64_t check_freq_host(const double *f, int64_t Nf) {  // src/lsfft.jl:20-24
+    for (int64_t i = 0; i < Nf; ++i)
+        if (f[i] == 0.0) return i == 0 ? 1 : -1;
+    return 0;
+}
+static int32_t fetch_host(std::vector<double> &h, const double *src, int64_t count) {
+    h.resize((size_t)count);
+    if (count == 0) return LPVS_OK;
+    if (is_device_ptr(src)) { LPVS_HIP(hipMemcpy(h.data(), src, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost)); }
+    else memcpy(h.data(), src, sizeof(double) * (size_t)count);
+    return LPVS_OK;
+}
+
+// basis centres (src/utilities.jl:24-32); twice-precision range reproduced with long double
+static void basis_centers(double lo, double hi, double amax, int64_t Nv, int coulomb, std::vector<double> &vc, double *gamma) {
+    if (!coulomb) {
+        vc.resize((size_t)Nv);
+        for (int64_t j = 0; j < Nv; ++j)
+            vc[j] = Nv > 1 ? (double)((long double)lo + (long double)j * ((long double)hi - (long double)lo) / (long double)(Nv - 1)) : lo;
+        *gamma = (double)Nv / std::fabs(vc[0] - vc[Nv - 1]);
+    } else {
+        vc.resize((size_t)(2 * Nv));
+        for (int64_t j = 0; j < Nv; ++j) {
+            const double c = (double)((long double)(j + 1) * (long double)amax / (long double)(Nv + 1));
+            vc[Nv + j] = c;
+            vc[Nv - 1 - j] = -c;
+        }
+        *gamma = (double)(2 * Nv) / std::fabs(vc[0] - vc[2 * Nv - 1]);
+    }
+}
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    int32_t init() { LPVS_HIP(hipEventCreate(&a)); LPVS_HIP(hipEventCreate(&b)); return LPVS_OK; }
+    void destroy() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); a = b = nullptr; }
+    double ms() const { float t = 0; if (hipEventElapsedTime(&t, a, b) != hipSuccess) { (void)hipGetLastError(); return 0; } return t; }
+};
+
+}  // namespace lpvs
+
+using namespace lpvs;
+
+struct lpvs_problem {
+    int kind = 0;  // 0 fourier, 1 lpv, 2 explicit gram
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n = 0, np = 0, N = 0, Nf = 0, nb = 0, zerofreq = 0;
+    DevBuf G, b, M, x, z, u, rhs, bs, scratch, status, work, istat;
+    bool M_valid = false; double M_shift = 0;
+    int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
+    double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
+    // timing (ms) -- see lpvs_problem_get_timing
+    double t_basis = 0, t_gram = 0, t_reduce = 0, t_factor = 0, t_admm = 0, gram_launches = 0, gram_flops = 0, admm_iters_timed = 0;
+    EventPair ev[4];
+    ~lpvs_problem() {
+        for (auto &e : ev) e.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int32_t problem_begin(int32_t device, lpvs_problem **out, lpvs_problem **hp) {
+    if (out == nullptr) { set_error("out handle pointer is NULL"); return LPVS_EARGUMENT; }
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible (the gfx950 path has no CPU fallback)");
+        return LPVS_EDEVICE;
+    }
+    if (device < 0 || device >= count) { set_error("device %d out of range [0,%d)", device, count); return LPVS_EDEVICE; }
+    LPVS_HIP(hipSetDevice(device));
+    lpvs_problem *h = new (std::nothrow) lpvs_problem();
+    if (!h) return LPVS_ENOMEM;
+    h->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return LPVS_EDEVICE; }
+    for (auto &ev : h->ev) { int32_t rc = ev.init(); if (rc != LPVS_OK) { delete h; return rc; } }
+    *hp = h;
+    return LPVS_OK;
+}
+
+int32_t alloc_state(lpvs_problem *h) {
+    const size_t v = sizeof(double) * (size_t)h->np;
+    LPVS_TRY(h->x.alloc(v)); LPVS_TRY(h->z.alloc(v)); LPVS_TRY(h->u.alloc(v)); LPVS_TRY(h->rhs.alloc(v));
+    LPVS_TRY(h->bs.alloc(v)); LPVS_TRY(h->scratch.alloc(2 * v));
+    LPVS_TRY(h->status.alloc(sizeof(AdmmStatus))); LPVS_TRY(h->istat.alloc(sizeof(int)));
+    LPVS_HIP(hipMemsetAsync(h->x.p, 0, v, h->stream));
+    LPVS_HIP(hipMemsetAsync(h->status.p, 0, sizeof(AdmmStatus), h->stream));
+    return LPVS_OK;
+}
+
+// M = (G + shift I)^-1 on the padded np x np system (pad diagonal = 1), cached by shift.
+int32_t factorize(lpvs_problem *h, double shift) {
+    if (h->M_valid && h->M_shift == shift) return LPVS_OK;
+    const int64_t np = h->np, n = h->n;
+    if (!h->M.p) LPVS_TRY(h->M.alloc(sizeof(double) * (size_t)np * (size_t)np));
+    if (!h->work.p) LPVS_TRY(h->work.alloc(spd_inverse_work_bytes(np)));
+    LPVS_HIP(hipEventRecord(h->ev[3].a, h->stream));
+    LPVS_HIP(hipMemcpyAsync(h->M.p, h->G.p, sizeof(double) * (size_t)np * (size_t)np, hipMemcpyDeviceToDevice, h->stream));
+    LPVS_TRY(launch_add_diag(h->M.as<double>(), np, n, shift, h->stream));
+    LPVS_TRY(spd_inverse_inplace(h->M.as<double>(), np, h->work.as<double>(), h->istat.as<int>(), h->stream));
+    LPVS_HIP(hipEventRecord(h->ev[3].b, h->stream));
+    int st = 0;
+    LPVS_HIP(hipMemcpyAsync(&st, h->istat.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LPVS_HIP(hipStreamSynchronize(h->stream));
+    h->t_factor += h->ev[3].ms();
+    if (st != 0) {
+        h->M_valid = false;
+        set_error("(G + %.3g I) is not positive definite (non-positive pivot in the block sweep)", shift);
+        return LPVS_ENUMERIC;
+    }
+    h->M_valid = true; h->M_shift = shift;
+    return LPVS_OK;
+}
+
+}  // namespace
+
+// Common tail of the panel-form constructors: P is the k-major regressor panel [Npad][ld].
+// fill(P) must enqueue the kernel(s) that write rows [0,N) of the panel on the handle's stream.
+template <class Fill>
+static int32_t create_panel_problem(lpvs_problem *h, const double *y, const double *W, int64_t N, Fill fill) {
+    hipStream_t s = h->stream;
+    h->np = round_up(h->n, 128);
+    const GramPlan pl = make_gram_plan(h->n, N);
+    const int64_t Npad = pl.ksplit * pl.rows_per_chunk;
+    const int64_t ld = round_up(h->n, 256);
+    DevArg dy;
+    LPVS_TRY(dy.set(y, N, s));
+    LPVS_TRY(h->G.alloc(sizeof(double) * (size_t)h->np * (size_t)h->np));
+    LPVS_TRY(h->b.alloc(sizeof(double) * (size_t)h->np));
+    LPVS_HIP(hipMemsetAsync(h->G.p, 0, h->G.bytes, s));
+    LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
+    LPVS_TRY(alloc_state(h));
+
+    DevBuf P, Wp, slab, scr;
+    LPVS_TRY(P.alloc(sizeof(double) * (size_t)Npad * (size_t)ld));
+    if (Npad > N) LPVS_HIP(hipMemsetAsync(P.as<double>() + N * ld, 0, sizeof(double) * (size_t)(Npad - N) * (size_t)ld, s));
+    const double *Wdev = nullptr;
+    if (W != nullptr) {  // padded copy: pad rows carry weight 0
+        LPVS_TRY(Wp.alloc(sizeof(double) * (size_t)Npad));
+        LPVS_HIP(hipMemsetAsync(Wp.p, 0, Wp.bytes, s));
+        LPVS_TRY(copy_to_device(Wp.p, W, sizeof(double) * (size_t)N, s));
+        Wdev = Wp.as<double>();
+    }
+    LPVS_HIP(hipEventRecord(h->ev[0].a, s));
+    LPVS_TRY(fill(P.as<double>(), ld));
+    LPVS_HIP(hipEventRecord(h->ev[0].b, s));
+    LPVS_TRY(slab.alloc(pl.slab_bytes));
+    LPVS_TRY(scr.alloc(rhs_scratch_bytes(N, h->n)));
+    LPVS_HIP(hipEventRecord(h->ev[1].a, s));
+    LPVS_TRY(launch_gram_panel(pl, P.as<double>(), ld, Wdev, slab.as<double>(), s));
+    LPVS_HIP(hipEventRecord(h->ev[1].b, s));
+    LPVS_HIP(hipEventRecord(h->ev[2].a, s));
+    LPVS_TRY(launch_gram_reduce(pl, slab.as<double>(), h->G.as<double>(), h->np, s));
+    LPVS_TRY(launch_rhs_panel(P.as<double>(), ld, h->n, Wdev, dy.p, N, h->b.as<double>(), scr.as<double>(), scr.bytes, s));
+    LPVS_HIP(hipEventRecord(h->ev[2].b, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
+    h->gram_launches = 1; h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
+    return LPVS_OK;
+}
+
+extern "C" {
+
+int32_t lpvs_version(void) { return LPVS_VERSION; }
+
+int32_t lpvs_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return c;
+}
+
+const char *lpvs_last_error(void) { return g_err; }
+
+int32_t lpvs_check_freq_f64(const double *f, int64_t Nf, int64_t *zerofreq) {
+    std::vector<double> hf;
+    LPVS_TRY(fetch_host(hf, f, Nf));
+    const int64_t z = check_freq_host(hf.data(), Nf);
+    if (z < 0) { set_error("If zero frequency is included it must be the first frequency"); return LPVS_EARGUMENT; }
+    if (zerofreq) *zerofreq = z;
+    return LPVS_OK;
+}
+
+int32_t lpvs_fourier_regressor_f64(const double *t, int64_t N, const double *f, int64_t Nf, double *A_out, int64_t *zerofreq) {
+    int64_t z = 0;
+    LPVS_TRY(lpvs_check_freq_f64(f, Nf, &z));
+    if (zerofreq) *zerofreq = z;
+    if (lpvs_device_count() == 0) { set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    hipStream_t s = nullptr;
+    const int64_t nreg = z ? 2 * Nf - 1 : 2 * Nf;
+    DevArg dt, df; DevOut dA;
+    LPVS_TRY(dt.set(t, N, s)); LPVS_TRY(df.set(f, Nf, s)); LPVS_TRY(dA.set(A_out, N * nreg));
+    LPVS_TRY(launch_fourier_regressor_colmajor(dt.p, N, df.p, Nf, (int)z, dA.p, s));
+    return dA.finish(s);
+}
+
+int32_t lpvs_basis_activation_f64(const double *V, int64_t N, int64_t Nv, int32_t normalize, int32_t coulomb, double *K_out) {
+    if (lpvs_device_count() == 0) { set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    if (N <= 0 || Nv <= 0) { set_error("N and Nv must be positive"); return LPVS_EARGUMENT; }
+    hipStream_t s = nullptr;
+    const int64_t nb = coulomb ? 2 * Nv : Nv;
+    DevArg dV; LPVS_TRY(dV.set(V, N, s));
+    double lo, hi, am, gamma; std::vector<double> vc;
+    LPVS_TRY(device_minmax(dV.p, N, &lo, &hi, &am, s));
+    basis_centers(lo, hi, am, Nv, coulomb, vc, &gamma);
+    DevBuf dvc, Kt; LPVS_TRY(dvc.alloc(sizeof(double) * vc.size()));
+    LPVS_TRY(copy_to_device(dvc.p, vc.data(), sizeof(double) * vc.size(), s));
+    LPVS_TRY(Kt.alloc(sizeof(double) * (size_t)N * (size_t)nb));
+    LPVS_TRY(launch_basis_table(dV.p, N, dvc.as<double>(), nb, gamma, normalize, coulomb, Kt.as<double>(), nb, s));
+    // row-major [N][nb] -> column-major N x nb on the host side of the boundary (tiny table)
+    std::vector<double> hk((size_t)N * nb), ho((size_t)N * nb);
+    LPVS_TRY(copy_from_device(hk.data(), Kt.p, sizeof(double) * hk.size(), s));
+    for (int64_t n = 0; n < N; ++n) for (int64_t j = 0; j < nb; ++j) ho[n + j * N] = hk[n * nb + j];
+    if (is_device_ptr(K_out)) { LPVS_HIP(hipMemcpy(K_out, ho.data(), sizeof(double) * ho.size(), hipMemcpyHostToDevice)); }
+    else memcpy(K_out, ho.data(), sizeof(double) * ho.size());
+    return LPVS_OK;
+}
+
+// shared by lpvs_lpv_regressor_f64 and lpvs_problem_create_lpv_f64: T and K tables with Npad rows
+static int32_t build_lpv_tables(const double *dX, const double *dV, int64_t N, int64_t Npad, const double *dw, int64_t Nf,
+                                int64_t Nv, int normalize, int coulomb, DevBuf &T, DevBuf &K, int64_t *ldk_out, hipStream_t s) {
+    const int64_t nb = coulomb ? 2 * Nv : Nv, ldk = nb + 1;
+    double lo, hi, am, gamma; std::vector<double> vc;
+    LPVS_TRY(device_minmax(dV, N, &lo, &hi, &am, s));
+    basis_centers(lo, hi, am, Nv, coulomb, vc, &gamma);
+    DevBuf dvc; LPVS_TRY(dvc.alloc(sizeof(double) * vc.size()));
+    LPVS_TRY(copy_to_device(dvc.p, vc.data(), sizeof(double) * vc.size(), s));
+    LPVS_TRY(T.alloc(sizeof(double2) * (size_t)Npad * (size_t)Nf));
+    LPVS_TRY(K.alloc(sizeof(double) * (size_t)Npad * (size_t)ldk));
+    if (Npad > N) {  // zero pad rows: they contribute nothing to the contraction
+        LPVS_HIP(hipMemsetAsync(T.as<double2>() + N * Nf, 0, sizeof(double2) * (size_t)(Npad - N) * (size_t)Nf, s));
+        LPVS_HIP(hipMemsetAsync(K.as<double>() + N * ldk, 0, sizeof(double) * (size_t)(Npad - N) * (size_t)ldk, s));
+    }
+    LPVS_TRY(launch_trig_table(dX, N, dw, Nf, T.as<double2>(), s));
+    LPVS_TRY(launch_basis_table(dV, N, dvc.as<double>(), nb, gamma, normalize, coulomb, K.as<double>(), ldk, s));
+    LPVS_HIP(hipStreamSynchronize(s));  // dvc is released on return
+    *ldk_out = ldk;
+    return LPVS_OK;
+}
+
+int32_t lpvs_lpv_regressor_f64(const double *X, const double *V, int64_t N, const double *w, int64_t Nf, int64_t Nv,
+                               int32_t normalize, int32_t coulomb, int32_t permuted, double *Phi_out) {
+    if (lpvs_device_count() == 0) { set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    if (N <= 0 || Nf <= 0 || Nv <= 0) { set_error("N, Nf and Nv must be positive"); return LPVS_EARGUMENT; }
+    hipStream_t s = nullptr;
+    const int64_t nb = coulomb ? 2 * Nv : Nv;
+    DevArg dX, dV, dw; DevOut dP;
+    LPVS_TRY(dX.set(X, N, s)); LPVS_TRY(dV.set(V, N, s)); LPVS_TRY(dw.set(w, Nf, s));
+    LPVS_TRY(dP.set(Phi_out, N * 2 * Nf * nb));
+    DevBuf T, K; int64_t ldk;
+    LPVS_TRY(build_lpv_tables(dX.p, dV.p, N, N, dw.p, Nf, Nv, normalize, coulomb, T, K, &ldk, s));
+    LPVS_TRY(launch_lpv_regressor_colmajor(T.as<double2>(), K.as<double>(), ldk, N, Nf, nb, permuted, dP.p, s));
+    return dP.finish(s);
+}
+
+int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
+                                    int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out) {
+    if (N <= 0 || Nf <= 0 || Nv <= 0) { set_error("N, Nf and Nv must be positive"); return LPVS_EARGUMENT; }
+    lpvs_problem *h = nullptr;
+    LPVS_TRY(problem_begin(device, out, &h));
+    struct Guard { lpvs_problem *h; ~Guard() { delete h; } } guard{h};
+    hipStream_t s = h->stream;
+    const int64_t nb = coulomb ? 2 * Nv : Nv;
+    h->kind = 1; h->N = N; h->Nf = Nf; h->nb = nb; h->n = 2 * Nf * nb; h->np = round_up(h->n, 128);
+    const GramPlan pl = make_gram_plan(h->n, N);
+    const int64_t Npad = pl.ksplit * pl.rows_per_chunk;
+
+    DevArg dy, dX, dV, dw;
+    LPVS_TRY(dy.set(y, N, s)); LPVS_TRY(dX.set(X, N, s)); LPVS_TRY(dV.set(V, N, s)); LPVS_TRY(dw.set(w, Nf, s));
+    LPVS_TRY(h->G.alloc(sizeof(double) * (size_t)h->np * (size_t)h->np));
+    LPVS_TRY(h->b.alloc(sizeof(double) * (size_t)h->np));
+    LPVS_HIP(hipMemsetAsync(h->G.p, 0, h->G.bytes, s));
+    LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
+    LPVS_TRY(alloc_state(h));
+
+    DevBuf T, K, slab, scr; int64_t ldk;
+    LPVS_HIP(hipEventRecord(h->ev[0].a, s));
+    LPVS_TRY(build_lpv_tables(dX.p, dV.p, N, Npad, dw.p, Nf, Nv, normalize, coulomb, T, K, &ldk, s));
+    LPVS_HIP(hipEventRecord(h->ev[0].b, s));
+    LPVS_TRY(slab.alloc(pl.slab_bytes));
+    LPVS_TRY(scr.alloc(rhs_scratch_bytes(N, h->n)));
+    LPVS_HIP(hipEventRecord(h->ev[1].a, s));
+    LPVS_TRY(launch_gram_kr(pl, T.as<double2>(), Nf, K.as<double>(), ldk, nb, slab.as<double>(), s));
+    LPVS_HIP(hipEventRecord(h->ev[1].b, s));
+    LPVS_HIP(hipEventRecord(h->ev[2].a, s));
+    LPVS_TRY(launch_gram_reduce(pl, slab.as<double>(), h->G.as<double>(), h->np, s));
+    LPVS_TRY(launch_rhs_kr(T.as<double2>(), Nf, K.as<double>(), ldk, nb, dy.p, N, h->b.as<double>(), scr.as<double>(), scr.bytes, s));
+    LPVS_HIP(hipEventRecord(h->ev[2].b, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
+    h->gram_launches = 1; h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
+    guard.h = nullptr;
+    *out = h;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_t N, const double *f, int64_t Nf, const double *W,
+                                        int32_t device, lpvs_problem **out) {
+    if (N <= 0 || Nf <= 0) { set_error("N and Nf must be positive"); return LPVS_EARGUMENT; }
+    int64_t zf = 0;
+    LPVS_TRY(lpvs_check_freq_f64(f, Nf, &zf));
+    lpvs_problem *h = nullptr;
+    LPVS_TRY(problem_begin(device, out, &h));
+    struct Guard { lpvs_problem *h; ~Guard() { delete h; } } guard{h};
+    hipStream_t s = h->stream;
+    h->kind = 0; h->N = N; h->Nf = Nf; h->zerofreq = zf; h->n = zf ? 2 * Nf - 1 : 2 * Nf;
+    DevArg dt, df;
+    LPVS_TRY(dt.set(t, N, s)); LPVS_TRY(df.set(f, Nf, s));
+    LPVS_TRY(create_panel_problem(h, y, W, N, [&](double *P, int64_t ld) {
+        return launch_fourier_panel(dt.p, N, df.p, Nf, (int)zf, P, ld, s);
+    }));
+    guard.h = nullptr;
+    *out = h;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_create_dense_f64(const double *A, const double *y, int64_t m, int64_t n, const double *W, int32_t device,
+                                      lpvs_problem **out) {
+    if (m <= 0 || n <= 0) { set_error("m and n must be positive"); return LPVS_EARGUMENT; }
+    lpvs_problem *h = nullptr;
+    LPVS_TRY(problem_begin(device, out, &h));
+    struct Guard { lpvs_problem *h; ~Guard() { delete h; } } guard{h};
+    hipStream_t s = h->stream;
+    h->kind = 2; h->N = m; h->n = n;
+    DevArg dA;
+    LPVS_TRY(dA.set(A, m * n, s));
+    LPVS_TRY(create_panel_problem(h, y, W, m, [&](double *P, int64_t ld) {
+        return launch_transpose_to_panel(dA.p, m, n, P, ld, s);
+    }));
+    guard.h = nullptr;
+    *out = h;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_create_gram_f64(const double *G, const double *b, int64_t n, int32_t device, lpvs_problem **out) {
+    if (n <= 0) { set_error("n must be positive"); return LPVS_EARGUMENT; }
+    lpvs_problem *h = nullptr;
+    LPVS_TRY(problem_begin(device, out, &h));
+    struct Guard { lpvs_problem *h; ~Guard() { delete h; } } guard{h};
+    hipStream_t s = h->stream;
+    h->kind = 2; h->n = n; h->np = round_up(n, 128);
+    LPVS_TRY(h->G.alloc(sizeof(double) * (size_t)h->np * (size_t)h->np));
+    LPVS_TRY(h->b.alloc(sizeof(double) * (size_t)h->np));
+    LPVS_HIP(hipMemsetAsync(h->G.p, 0, h->G.bytes, s));
+    LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
+    LPVS_TRY(alloc_state(h));
+    LPVS_HIP(hipMemcpy2DAsync(h->G.p, sizeof(double) * (size_t)h->np, G, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n, (size_t)n,
+                              is_device_ptr(G) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    LPVS_TRY(copy_to_device(h->b.p, b, sizeof(double) * (size_t)n, s));
+    guard.h = nullptr;
+    *out = h;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_destroy(lpvs_problem *h) {
+    if (h == nullptr) return LPVS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    delete h;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_size(const lpvs_problem *h, int64_t *n) {
+    if (!h || !n) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    *n = h->n;
+    return LPVS_OK;
+}
+int32_t lpvs_problem_zerofreq(const lpvs_problem *h, int64_t *zerofreq) {
+    if (!h || !zerofreq) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    *zerofreq = h->zerofreq;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_get_gram_f64(lpvs_problem *h, double *G_out, double *b_out) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    if (G_out) {
+        LPVS_HIP(hipMemcpy2DAsync(G_out, sizeof(double) * (size_t)h->n, h->G.p, sizeof(double) * (size_t)h->np, sizeof(double) * (size_t)h->n,
+                                  (size_t)h->n, is_device_ptr(G_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        LPVS_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (b_out) LPVS_TRY(copy_from_device(b_out, h->b.p, sizeof(double) * (size_t)h->n, h->stream));
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_solve_ridge_f64(lpvs_problem *h, double ridge, double *x_out) {
+    if (!h || !x_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    h->inited = false;  // M is re-used
+    LPVS_TRY(factorize(h, ridge));
+    LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->b.as<double>(), h->scratch.as<double>(), h->stream));
+    return copy_from_device(x_out, h->scratch.p, sizeof(double) * (size_t)h->n, h->stream);
+}
+
+int32_t lpvs_problem_set_prox(lpvs_problem *h, int32_t kind, double param, int64_t group_len) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    if (kind < LPVS_PROX_L1 || kind > LPVS_PROX_GROUP_L2) { set_error("unknown prox kind %d", kind); return LPVS_EUNSUPPORTED; }
+    if (kind == LPVS_PROX_GROUP_L2 && group_len <= 0) { set_error("group_len must be positive"); return LPVS_EARGUMENT; }
+    h->prox_kind = kind; h->prox_param = param; h->group_len = group_len;
+    return LPVS_OK;
+}
+
+int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double tol, int32_t linear_sign) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    if (!(mu >= 0 && mu <= 1)) { set_error("μ should be ≤ 1"); return LPVS_EASSERT; }  // src/lasso.jl:143
+    if (mu == 0) { set_error("mu = 0 makes the x-update singular"); return LPVS_ENUMERIC; }
+    if (linear_sign != 1 && linear_sign != -1) { set_error("linear_sign must be +1 or -1"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    LPVS_TRY(factorize(h, 1.0 / mu));
+    h->mu = mu; h->tol = tol; h->sign = linear_sign;
+    const size_t v = sizeof(double) * (size_t)h->np;
+    if (x0) { LPVS_TRY(copy_to_device(h->x.p, x0, sizeof(double) * (size_t)h->n, s)); }
+    else LPVS_HIP(hipMemsetAsync(h->x.p, 0, v, s));
+    // signed linear term
+    std::vector<double> hb((size_t)h->np, 0.0);
+    LPVS_TRY(copy_from_device(hb.data(), h->b.p, sizeof(double) * (size_t)h->n, s));
+    if (linear_sign < 0) for (auto &q : hb) q = -q;
+    LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
+    AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
+                 h->rhs.as<double>(), mu, tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
+                 h->scratch.as<double>()};
+    LPVS_TRY(launch_admm_init(p, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    h->inited = true;
+    return LPVS_OK;
+}
+
+int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, double *nxz, int32_t *converged) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    if (!h->inited) { set_error("lpvs_admm_run before lpvs_admm_init"); return LPVS_ESTATE; }
+    LPVS_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
+                 h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
+                 h->scratch.as<double>()};
+    AdmmStatus st0{}, st{};
+    LPVS_HIP(hipMemcpyAsync(&st0, h->status.p, sizeof(st0), hipMemcpyDeviceToHost, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    if (max_iters > 0 && !st0.converged) {
+        LPVS_HIP(hipEventRecord(h->ev[0].a, s));
+        LPVS_TRY(launch_admm_iterations(p, max_iters, s));
+        LPVS_HIP(hipEventRecord(h->ev[0].b, s));
+    }
+    LPVS_HIP(hipMemcpyAsync(&st, h->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    if (max_iters > 0 && !st0.converged) { h->t_admm += h->ev[0].ms(); h->admm_iters_timed += (double)(st.iters - st0.iters); }
+    if (iters_done) *iters_done = st.iters;
+    if (nxz) *nxz = st.nxz;
+    if (converged) *converged = st.converged;
+    return LPVS_OK;
+}
+
+int32_t lpvs_admm_get_f64(lpvs_problem *h, double *x_out, double *z_out, double *u_out) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    if (!h->inited) { set_error("lpvs_admm_get before lpvs_admm_init"); return LPVS_ESTATE; }
+    LPVS_HIP(hipSetDevice(h->device));
+    const size_t v = sizeof(double) * (size_t)h->n;
+    if (x_out) LPVS_TRY(copy_from_device(x_out, h->x.p, v, h->stream));
+    if (z_out) LPVS_TRY(copy_from_device(z_out, h->z.p, v, h->stream));
+    if (u_out) LPVS_TRY(copy_from_device(u_out, h->u.p, v, h->stream));
+    return LPVS_OK;
+}
+
+static int32_t pack_host(const lpvs_problem *h, const std::vector<double> &c, double *re_out, double *im_out) {
+    const int64_t Nf = h->Nf, nb = h->nb;
+    const int64_t m = h->kind == 1 ? Nf * nb : Nf;
+    std::vector<double> re((size_t)m), im((size_t)m);
+    if (h->kind == 0) {  // fourier2complex, src/utilities.jl:62-73
+        if (!h->zerofreq) for (int64_t i = 0; i < Nf; ++i) { re[i] = c[i]; im[i] = c[Nf + i]; }
+        else { re[0] = c[0]; im[0] = 0.0; for (int64_t i = 1; i < Nf; ++i) { re[i] = c[i]; im[i] = c[Nf + i - 1]; } }
+    } else if (h->kind == 1) {  // z[sortperm(inds)] -> complex, src/lasso.jl:67-68
+        for (int64_t f = 0; f < Nf; ++f)
+            for (int64_t v = 0; v < nb; ++v) { re[f + v * Nf] = c[f * 2 * nb + v]; im[f + v * Nf] = c[f * 2 * nb + nb + v]; }
+    } else { set_error("explicit-Gram problems have no parameter packing"); return LPVS_EUNSUPPORTED; }
+    const size_t bytes = sizeof(double) * (size_t)m;
+    if (re_out) { if (is_device_ptr(re_out)) { LPVS_HIP(hipMemcpy(re_out, re.data(), bytes, hipMemcpyHostToDevice)); } else memcpy(re_out, re.data(), bytes); }
+    if (im_out) { if (is_device_ptr(im_out)) { LPVS_HIP(hipMemcpy(im_out, im.data(), bytes, hipMemcpyHostToDevice)); } else memcpy(im_out, im.data(), bytes); }
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_get_params_f64(lpvs_problem *h, int32_t which, double *re_out, double *im_out) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    if (!h->inited) { set_error("lpvs_problem_get_params before lpvs_admm_init"); return LPVS_ESTATE; }
+    LPVS_HIP(hipSetDevice(h->device));
+    std::vector<double> c((size_t)h->n);
+    LPVS_TRY(copy_from_device(c.data(), which == 1 ? h->x.p : h->z.p, sizeof(double) * (size_t)h->n, h->stream));
+    return pack_host(h, c, re_out, im_out);
+}
+
+int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double *re_out, double *im_out) {
+    if (!h || !coef) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    std::vector<double> c;
+    LPVS_TRY(fetch_host(c, coef, h->n));
+    return pack_host(h, c, re_out, im_out);
+}
+
+int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out) {
+    if (!h || !out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    const double v[8] = {h->t_basis, h->t_gram, h->t_reduce, h->t_factor, h->t_admm, h->gram_launches, h->gram_flops, h->admm_iters_timed};
+    for (int i = 0; i < n_out && i < 8; ++i) out[i] = v[i];
+    return LPVS_OK;
+}
+
+// ---- window bookkeeping (host integer arithmetic; src/windows.jl:27-36, :57-70) ----------------
+int32_t lpvs_window_count(int64_t L, int64_t n, int64_t noverlap, int64_t *count) {
+    if (!count) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (noverlap < 0) noverlap = n >> 1;  // src/windows.jl:29
+    if (n <= 0 || noverlap >= n) { set_error("noverlap must be less than n"); return LPVS_EDOMAIN; }
+    *count = L >= n ? (L - n) / (n - noverlap) + 1 : 0;
+    return LPVS_OK;
+}
+
+int32_t lpvs_window_offsets(int64_t L, int64_t n, int64_t noverlap, int64_t *offsets, int64_t capacity, int64_t *count) {
+    int64_t k = 0;
+    LPVS_TRY(lpvs_window_count(L, n, noverlap, &k));
+    if (noverlap < 0) noverlap = n >> 1;
+    if (count) *count = k;
+    if (offsets) {
+        if (capacity < k) { set_error("offsets capacity %lld < %lld windows", (long long)capacity, (long long)k); return LPVS_EARGUMENT; }
+        for (int64_t i = 0; i < k; ++i) offsets[i] = i * (n - noverlap);
+    }
+    return LPVS_OK;
+}
+
+int32_t lpvs_merge_f64(const double *yf, int64_t count, int64_t n, int64_t noverlap, int64_t L, double *ym) {
+    if (!yf || !ym) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (noverlap < 0) noverlap = n >> 1;
+    if (n <= 0 || noverlap >= n) { set_error("noverlap must be less than n"); return LPVS_EDOMAIN; }
+    std::vector<double> in, acc((size_t)L, 0.0);
+    std::vector<int64_t> cnt((size_t)L, 0);
+    LPVS_TRY(fetch_host(in, yf, count * n));
+    int64_t lo = 0, hi = n - 1;
+    for (int64_t w = 0; w < count; ++w) {
+        for (int64_t i = lo; i <= hi && i < L; ++i) { acc[i] += in[w * n + (i - lo)]; cnt[i] += 1; }
+        lo += n - noverlap; hi += n - noverlap;
+        if (hi > L - 1) hi = L - 1;
+    }
+    for (int64_t i = 0; i < L; ++i) acc[i] /= (double)(cnt[i] > 1 ? cnt[i] : 1);
+    if (is_device_ptr(ym)) { LPVS_HIP(hipMemcpy(ym, acc.data(), sizeof(double) * (size_t)L, hipMemcpyHostToDevice)); }
+    else memcpy(ym, acc.data(), sizeof(double) * (size_t)L);
+    return LPVS_OK;
+}
+
+}  // extern "C"

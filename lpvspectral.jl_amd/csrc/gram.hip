@@ -1,0 +1,420 @@
+// gram.hip -- G = Phi' Phi (and b = Phi' y) as tall-skinny f64 MFMA contractions on gfx950.
+//
+// The N x n regressor Phi is never read from HBM for the solve.  Two operand generators feed
+// one MFMA core (v_mfma_f64_16x16x4_f64):
+//   KR    (LPV, src/lasso.jl:35-50): Phi[k][f*2nb+c] = T[k][f][c>=nb] * K[k][c mod nb] -- the
+//         Khatri-Rao structure is expanded IN REGISTERS: per 4-sample k-step a lane reads one
+//         trig value and one activation from LDS and multiplies them into its MFMA operand, so
+//         a 128x256 output tile stages only (24 freqs x 16 B + 9 x 8 B) per sample instead of
+//         384 x 8 B.
+//   PANEL (Fourier, src/lsfft.jl:26-49): Phi[k][c] = P[k][c], a k-major panel staged as is,
+//         with the optional row weight of A' diag(W) A (src/lasso.jl:119) applied to the A operand.
+// Staging is LDS-DMA (global_load_lds_dwordx4, dense lane-linear LDS images, two buffers, one
+// barrier per 32-sample stage).  Work items are (lower-triangle 128x256 tile) x (sample chunk);
+// each writes its partial tile to a slab and a second kernel sums the chunks in fixed order, so
+// the result is bit-reproducible (no float atomics).
+//
+// Roofline: MFMA-bound.  Algorithmic work N*n*(n+1) flop; the kernel issues
+// tiles*128*256*2*N flop (97 % useful at n = 8192: diagonal tiles are computed whole).
+#include "lpvs_internal.h"
+
+#include <vector>
+
+namespace lpvs {
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 128;     // tile extent along a (rows of G)
+constexpr int TN = 256;     // tile extent along b (cols of G)
+constexpr int BK = 32;      // samples per stage
+constexpr int NTHREADS = 512;  // 8 waves: 2 (a) x 4 (b), 64x64 outputs each
+
+struct GramArgs {
+    // common
+    int64_t n;             // valid columns
+    int64_t rows_per_chunk;  // multiple of BK
+    int ksplit;
+    int ntiles;
+    const int2 *tiles;     // (ti, tj) of every lower-triangle tile
+    double *slab;          // [tile][chunk][TM][TN]
+    // KR
+    const double2 *T;      // [Npad][Nf]
+    const double *K;       // [Npad][ldk], K[.][nb..ldk) == 0
+    int Nf, nb, ldk;
+    // PANEL
+    const double *P;       // [Npad][ld]
+    const double *W;       // [Npad] or nullptr
+    int64_t ld;
+};
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+    // 64 lanes x 16 B -> LDS at (wave-uniform base) + lane*16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int MODE>  // 0 = KR, 1 = PANEL
+__global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 2, wb = wave & 3;  // wave's 64x64 block inside the 128x256 tile
+    const int item = blockIdx.x;
+    const int tile = item / a.ksplit, chunk = item - tile * a.ksplit;
+    const int2 tt = a.tiles[tile];
+    const int64_t a0 = (int64_t)tt.x * TM, b0 = (int64_t)tt.y * TN;
+    const int64_t r_begin = (int64_t)chunk * a.rows_per_chunk;
+    const int nstages = (int)(a.rows_per_chunk / BK);
+
+    // ---- per-tile LDS image geometry -----------------------------------------------------
+    // KR:    stage image = [BK][nfTot] double2 trig values, then [BK][ldk] activations
+    // PANEL: stage image = [BK][TM+TN] panel values, then [BK] weights
+    int nfI = 0, nfJ = 0, fI0 = 0, fJ0 = 0, nfTot = 0;
+    int img_doubles;      // doubles per stage image (first part)
+    int aux_doubles;      // doubles of the second part
+    if (MODE == 0) {
+        const int g2 = 2 * a.nb;
+        const int64_t alast = (a0 + TM - 1 < a.n - 1 ? a0 + TM - 1 : a.n - 1);
+        const int64_t blast = (b0 + TN - 1 < a.n - 1 ? b0 + TN - 1 : a.n - 1);
+        fI0 = (int)(a0 / g2); nfI = (int)(alast / g2) - fI0 + 1;
+        fJ0 = (int)(b0 / g2); nfJ = (int)(blast / g2) - fJ0 + 1;
+        nfTot = nfI + nfJ;
+        img_doubles = BK * nfTot * 2;
+        aux_doubles = BK * a.ldk;
+    } else {
+        img_doubles = BK * (TM + TN);
+        aux_doubles = BK;
+    }
+    // both parts rounded up to whole 1 KiB DMA pieces so that buffers stay 16-B aligned
+    const int img_pad = (img_doubles + 127) & ~127, aux_pad = (aux_doubles + 127) & ~127;
+    const int stage_doubles = img_pad + aux_pad;
+    double *buf0 = lds, *buf1 = lds + stage_doubles;
+
+    // ---- per-lane operand addressing (fixed for the whole K loop) --------------------------
+    // MFMA operand lane map: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
+    const int li = lane & 15, lk = lane >> 4;
+    int offA[4], offB[4];      // offset (doubles) of the lane's value inside a k-row of the image
+    int offKA[4], offKB[4];    // KR: offset of the activation inside a k-row of the K image
+    int rowT, rowK;            // k-row strides (doubles)
+    if (MODE == 0) {
+        const int g2 = 2 * a.nb;
+        rowT = nfTot * 2; rowK = a.ldk;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            {
+                const int64_t col = a0 + wa * 64 + t * 16 + li;
+                const bool ok = col < a.n;
+                const int f = ok ? (int)(col / g2) : fI0;
+                const int c = ok ? (int)(col - (int64_t)f * g2) : 0;
+                const int cs = c >= a.nb;
+                offA[t] = (f - fI0) * 2 + cs;
+                offKA[t] = ok ? c - cs * a.nb : a.nb;  // K[.][nb] == 0 masks columns >= n
+            }
+            {
+                const int64_t col = b0 + wb * 64 + t * 16 + li;
+                const bool ok = col < a.n;
+                const int f = ok ? (int)(col / g2) : fJ0;
+                const int c = ok ? (int)(col - (int64_t)f * g2) : 0;
+                const int cs = c >= a.nb;
+                offB[t] = (nfI + f - fJ0) * 2 + cs;
+                offKB[t] = ok ? c - cs * a.nb : a.nb;
+            }
+        }
+    } else {
+        rowT = TM + TN; rowK = 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            offA[t] = wa * 64 + t * 16 + li;
+            offB[t] = TM + wb * 64 + t * 16 + li;
+            offKA[t] = offKB[t] = 0;
+        }
+    }
+
+    // ---- stage loader: every wave copies whole 1 KiB pieces, lane-linear -------------------
+    auto stage_load = [&](double *buf, int64_t r0) {
+        if (MODE == 0) {
+            const int total = BK * nfTot;  // double2 elements
+            for (int p = wave; p * 64 < total; p += NTHREADS / 64) {
+                const int e = p * 64 + lane;
+                if (e < total) {
+                    const int k = e / nfTot, q = e - k * nfTot;
+                    const int f = q < nfI ? fI0 + q : fJ0 + (q - nfI);
+                    glds16(a.T + (r0 + k) * a.Nf + f, buf + p * 128);
+                }
+            }
+            const int totalk = BK * a.ldk / 2;  // 16-B elements; rows r0..r0+BK are contiguous
+            const double *ksrc = a.K + r0 * a.ldk;
+            for (int p = wave; p * 64 < totalk; p += NTHREADS / 64) {
+                const int e = p * 64 + lane;
+                if (e < totalk) glds16(ksrc + 2 * e, buf + img_pad + p * 128);
+            }
+        } else {
+            // piece p = (k, part): part 0 -> I columns [a0,a0+128), parts 1,2 -> J columns
+            for (int p = wave; p < BK * 3; p += NTHREADS / 64) {
+                const int k = p / 3, part = p - k * 3;
+                const int64_t col = part == 0 ? a0 : b0 + (part - 1) * 128;
+                glds16(a.P + (r0 + k) * a.ld + col + 2 * lane, buf + p * 128);
+            }
+            if (a.W != nullptr && wave == 0 && lane < BK / 2)
+                glds16(a.W + r0 + 2 * lane, buf + img_pad);
+        }
+    };
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+    stage_load(buf0, r_begin);
+    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the image
+
+    const bool weighted = (MODE == 1) && a.W != nullptr;
+    for (int s = 0; s < nstages; ++s) {
+        double *cur = (s & 1) ? buf1 : buf0;
+        double *nxt = (s & 1) ? buf0 : buf1;
+        if (s + 1 < nstages) stage_load(nxt, r_begin + (int64_t)(s + 1) * BK);
+
+        const double *img = cur, *aux = cur + img_pad;
+#pragma unroll 2
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int row = kk * 4 + lk;
+            double opA[4], opB[4];
+            if (MODE == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    opA[t] = img[row * rowT + offA[t]] * aux[row * rowK + offKA[t]];
+                    opB[t] = img[row * rowT + offB[t]] * aux[row * rowK + offKB[t]];
+                }
+            } else {
+                const double wv = weighted ? aux[row] : 1.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double av = img[row * rowT + offA[t]];
+                    opA[t] = weighted ? av * wv : av;
+                    opB[t] = img[row * rowT + offB[t]];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // next image landed (vmcnt(0)) and everyone is done with `cur`
+    }
+
+    // ---- epilogue: partial tile -> slab[tile][chunk][TM][TN] -------------------------------
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+    double *out = a.slab + ((int64_t)tile * a.ksplit + chunk) * (TM * TN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = wa * 64 + i * 16 + lk + 4 * r;
+                const int jl = wb * 64 + j * 16 + li;
+                out[il * TN + jl] = acc[i][j][r];
+            }
+}
+
+// G[a][b] = G[b][a] = sum_chunk slab[tile(a,b)][chunk][a%128][b%256], a >= b, fixed chunk order.
+__global__ void __launch_bounds__(256)
+gram_reduce_kernel(const double *__restrict__ slab, const int2 *__restrict__ tiles, int ksplit, int64_t n,
+                   double *__restrict__ G, int64_t ldg) {
+    const int tile = blockIdx.x;
+    const int2 tt = tiles[tile];
+    const int64_t a0 = (int64_t)tt.x * TM, b0 = (int64_t)tt.y * TN;
+    const double *base = slab + (int64_t)tile * ksplit * (TM * TN);
+    for (int e = threadIdx.x; e < TM * TN; e += 256) {
+        const int il = e / TN, jl = e - il * TN;
+        const int64_t ga = a0 + il, gb = b0 + jl;
+        if (ga >= n || gb > ga) continue;
+        double s = base[e];
+        for (int c = 1; c < ksplit; ++c) s += base[(int64_t)c * (TM * TN) + e];
+        G[ga * ldg + gb] = s;
+        G[gb * ldg + ga] = s;
+    }
+}
+
+// ---- right-hand side b = Phi' (W .* y) -----------------------------------------------------
+constexpr int RHS_ROWS = 2048;  // samples per partial
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+rhs_kernel(const double2 *__restrict__ T, int Nf, const double *__restrict__ K, int ldk, int nb,
+           const double *__restrict__ P, int64_t ld, const double *__restrict__ W,
+           const double *__restrict__ y, int64_t N, int64_t ncol, double *__restrict__ part) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * RHS_ROWS;
+    const int64_t r1 = r0 + RHS_ROWS < N ? r0 + RHS_ROWS : N;
+    if (col >= ncol) return;
+    double s = 0;
+    if (MODE == 0) {
+        const int g2 = 2 * nb;
+        const int f = (int)(col / g2), c = (int)(col - (int64_t)f * g2);
+        const int cs = c >= nb, j = c - cs * nb;
+        const double *Td = reinterpret_cast<const double *>(T);
+        for (int64_t r = r0; r < r1; ++r)
+            s = fma(Td[(r * Nf + f) * 2 + cs] * K[r * ldk + j], y[r], s);
+    } else {
+        for (int64_t r = r0; r < r1; ++r) {
+            const double yy = W ? W[r] * y[r] : y[r];
+            s = fma(P[r * ld + col], yy, s);
+        }
+    }
+    part[(int64_t)blockIdx.y * ncol + col] = s;
+}
+
+__global__ void __launch_bounds__(256)
+rhs_reduce_kernel(const double *__restrict__ part, int nparts, int64_t ncol, double *__restrict__ b) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncol) return;
+    double s = 0;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * ncol + col];
+    b[col] = s;
+}
+
+struct TileList {
+    std::vector<int2> host;
+};
+TileList make_tiles(int64_t n) {
+    TileList tl;
+    const int64_t nti = ceil_div(n, TM);
+    for (int64_t ti = 0; ti < nti; ++ti)
+        for (int64_t tj = 0; tj <= ti / 2; ++tj) tl.host.push_back(make_int2((int)ti, (int)tj));
+    return tl;
+}
+
+}  // namespace
+
+GramPlan make_gram_plan(int64_t n, int64_t N) {
+    GramPlan pl;
+    pl.n = n; pl.N = N;
+    pl.tiles = (int64_t)make_tiles(n).host.size();
+    // split the samples so that (tiles x chunks) fills the 256 CUs in whole rounds
+    const int64_t nstage = ceil_div(N, BK);
+    const int64_t max_split = nstage / 16 > 0 ? nstage / 16 : 1;  // >= 512 samples per chunk
+    int64_t want = ceil_div(256 * 16, pl.tiles);
+    if (want > max_split) want = max_split;
+    int64_t best = 1; double best_eff = -1;
+    for (int64_t ks = want / 2 > 0 ? want / 2 : 1; ks <= want * 2 && ks <= max_split; ++ks) {
+        const int64_t items = pl.tiles * ks;
+        const double eff = (double)items / (double)(ceil_div(items, 256) * 256);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
+    }
+    pl.ksplit = best;
+    pl.rows_per_chunk = round_up(ceil_div(N, pl.ksplit), BK);
+    pl.slab_bytes = sizeof(double) * (size_t)pl.tiles * (size_t)pl.ksplit * TM * TN;
+    return pl;
+}
+
+// Device copy of the tile list, cached per n on the calling thread.
+static int32_t get_tiles(int64_t n, hipStream_t s, const int2 **out, int *count) {
+    thread_local int64_t cached_n = -1;
+    thread_local DevBuf cached;
+    thread_local int cached_count = 0;
+    thread_local int cached_dev = -1;
+    int dev = 0;
+    LPVS_HIP(hipGetDevice(&dev));
+    if (cached_n != n || cached_dev != dev) {
+        TileList tl = make_tiles(n);
+        cached.release();
+        LPVS_TRY(cached.alloc(sizeof(int2) * tl.host.size()));
+        LPVS_HIP(hipMemcpyAsync(cached.p, tl.host.data(), sizeof(int2) * tl.host.size(), hipMemcpyHostToDevice, s));
+        LPVS_HIP(hipStreamSynchronize(s));
+        cached_n = n; cached_count = (int)tl.host.size(); cached_dev = dev;
+    }
+    *out = cached.as<int2>();
+    *count = cached_count;
+    return LPVS_OK;
+}
+
+static size_t gram_lds_bytes(int mode, int64_t nb, int64_t ldk) {
+    int img, aux;
+    if (mode == 0) {
+        const int g2 = (int)(2 * nb);
+        const int nfI = (TM + g2 - 2) / g2 + 1, nfJ = (TN + g2 - 2) / g2 + 1;  // upper bounds
+        img = BK * (nfI + nfJ) * 2;
+        aux = (int)(BK * ldk);
+    } else {
+        img = BK * (TM + TN);
+        aux = BK;
+    }
+    const int img_pad = (img + 127) & ~127, aux_pad = (aux + 127) & ~127;
+    return sizeof(double) * 2 * (size_t)(img_pad + aux_pad);
+}
+
+int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const double *K, int64_t ldk,
+                       int64_t nb, double *slab, hipStream_t s) {
+    GramArgs a{};
+    a.n = pl.n; a.rows_per_chunk = pl.rows_per_chunk; a.ksplit = (int)pl.ksplit;
+    LPVS_TRY(get_tiles(pl.n, s, &a.tiles, &a.ntiles));
+    a.slab = slab; a.T = T; a.K = K; a.Nf = (int)Nf; a.nb = (int)nb; a.ldk = (int)ldk;
+    const size_t lds = gram_lds_bytes(0, nb, ldk);
+    if (lds > 160 * 1024) {
+        set_error("gram_kr: LDS image of %zu bytes exceeds 160 KiB (nb=%lld)", lds, (long long)nb);
+        return LPVS_EUNSUPPORTED;
+    }
+    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<0>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gram_kernel<0>, dim3((unsigned)(pl.tiles * pl.ksplit)), dim3(NTHREADS), lds, s, a);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_gram_panel(const GramPlan &pl, const double *P, int64_t ld, const double *W, double *slab,
+                          hipStream_t s) {
+    GramArgs a{};
+    a.n = pl.n; a.rows_per_chunk = pl.rows_per_chunk; a.ksplit = (int)pl.ksplit;
+    LPVS_TRY(get_tiles(pl.n, s, &a.tiles, &a.ntiles));
+    a.slab = slab; a.P = P; a.W = W; a.ld = ld;
+    const size_t lds = gram_lds_bytes(1, 0, 0);
+    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gram_kernel<1>, dim3((unsigned)(pl.tiles * pl.ksplit)), dim3(NTHREADS), lds, s, a);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_gram_reduce(const GramPlan &pl, const double *slab, double *G, int64_t ldg, hipStream_t s) {
+    const int2 *tiles; int nt;
+    LPVS_TRY(get_tiles(pl.n, s, &tiles, &nt));
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)nt), dim3(256), 0, s, slab, tiles, (int)pl.ksplit, pl.n, G, ldg);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+size_t rhs_scratch_bytes(int64_t N, int64_t n) { return sizeof(double) * (size_t)ceil_div(N, RHS_ROWS) * (size_t)n; }
+
+int32_t launch_rhs_kr(const double2 *T, int64_t Nf, const double *K, int64_t ldk, int64_t nb, const double *y,
+                      int64_t N, double *b, double *scratch, size_t scratch_bytes, hipStream_t s) {
+    const int64_t n = 2 * Nf * nb;
+    const int64_t parts = ceil_div(N, RHS_ROWS);
+    if (scratch_bytes < rhs_scratch_bytes(N, n)) { set_error("rhs scratch too small"); return LPVS_ESTATE; }
+    dim3 grid((unsigned)ceil_div(n, 256), (unsigned)parts);
+    hipLaunchKernelGGL(rhs_kernel<0>, grid, dim3(256), 0, s, T, (int)Nf, K, (int)ldk, (int)nb, (const double *)nullptr,
+                       (int64_t)0, (const double *)nullptr, y, N, n, scratch);
+    LPVS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rhs_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, scratch, (int)parts, n, b);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_rhs_panel(const double *P, int64_t ld, int64_t ncol, const double *W, const double *y, int64_t N,
+                         double *b, double *scratch, size_t scratch_bytes, hipStream_t s) {
+    const int64_t parts = ceil_div(N, RHS_ROWS);
+    if (scratch_bytes < rhs_scratch_bytes(N, ncol)) { set_error("rhs scratch too small"); return LPVS_ESTATE; }
+    dim3 grid((unsigned)ceil_div(ncol, 256), (unsigned)parts);
+    hipLaunchKernelGGL(rhs_kernel<1>, grid, dim3(256), 0, s, (const double2 *)nullptr, 0, (const double *)nullptr, 0, 0, P,
+                       ld, W, y, N, ncol, scratch);
+    LPVS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rhs_reduce_kernel, dim3((unsigned)ceil_div(ncol, 256)), dim3(256), 0, s, scratch, (int)parts, ncol, b);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+}  // namespace lpvs

@@ -1,0 +1,208 @@
+// linalg.hip -- dense SPD inverse on device: M = (G + I/mu)^-1, the factor-once replacement of
+// the reference's per-iteration CG solve (ProximalOperators LeastSquares/Quadratic iterative=true,
+// call sites src/lasso.jl:51,98,121,151).
+//
+// Blocked symmetric sweep (Gauss-Jordan without pivoting, valid for SPD): for every 64-wide pivot
+// block k:  P = A_kk^-1;  B = A[:,k] (block k zeroed);  C = B P;  A -= C B' (all blocks != k);
+// A[:,k] = C, A[k,:] = C', A_kk = -P.  After all sweeps A = -A0^-1.  The rank-64 trailing update
+// is an f64 MFMA contraction over the lower triangle (n^3 flop in total), mirrored on store so
+// the result stays exactly symmetric.
+#include "lpvs_internal.h"
+
+namespace lpvs {
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int NB = 64;
+
+// P = inv(A_kk) by in-LDS Gauss-Jordan; status[0] |= 1 on a non-positive pivot.
+__global__ void __launch_bounds__(256)
+diag_inverse_kernel(const double *__restrict__ A, int64_t np, int k, double *__restrict__ P, int *status) {
+    __shared__ double S[NB][NB + 1];
+    __shared__ double colp[NB], rowp[NB];
+    const double *blk = A + (int64_t)k * NB * np + (int64_t)k * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) S[e / NB][e % NB] = blk[(int64_t)(e / NB) * np + (e % NB)];
+    __syncthreads();
+    for (int p = 0; p < NB; ++p) {
+        const double d = S[p][p];
+        if (threadIdx.x < NB) { colp[threadIdx.x] = S[threadIdx.x][p]; rowp[threadIdx.x] = S[p][threadIdx.x]; }
+        if (threadIdx.x == 0 && !(d > 0)) atomicOr(status, 1);
+        __syncthreads();
+        const double inv = 1.0 / d;
+        for (int e = threadIdx.x; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            double v;
+            if (i == p && j == p) v = inv;
+            else if (i == p) v = rowp[j] * inv;
+            else if (j == p) v = -colp[i] * inv;
+            else v = S[i][j] - colp[i] * (rowp[j] * inv);
+            S[i][j] = v;
+        }
+        __syncthreads();
+    }
+    // symmetrise (P is symmetric up to rounding) so that C = B P and the mirrored stores agree
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        P[e] = 0.5 * (S[i][j] + S[j][i]);
+    }
+}
+
+// One workgroup per 64-row block i: B_i = A[i,k] (zero for i == k), C_i = B_i P; panels are stored
+// column-major np x 64 (element (r,c) at r + c*np), the MFMA operand layout of the update kernel.
+// Writes A[i,k] = C_i, A[k,i] = C_i', A[k,k] = -P.
+__global__ void __launch_bounds__(256)
+panel_kernel(double *__restrict__ A, int64_t np, int k, const double *__restrict__ P,
+             double *__restrict__ Bp, double *__restrict__ Cp) {
+    __shared__ double sB[NB][NB + 1], sP[NB][NB + 1];
+    const int i = blockIdx.x;
+    const int64_t r0 = (int64_t)i * NB, k0 = (int64_t)k * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        sB[r][c] = (i == k) ? 0.0 : A[(r0 + r) * np + k0 + c];
+        sP[r][c] = P[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e % NB, c = e / NB;  // r fastest: coalesced panel stores
+        double s = 0;
+        for (int q = 0; q < NB; ++q) s = fma(sB[r][q], sP[q][c], s);
+        Bp[(r0 + r) + (int64_t)c * np] = sB[r][c];
+        Cp[(r0 + r) + (int64_t)c * np] = s;
+        if (i != k) {
+            A[(r0 + r) * np + k0 + c] = s;
+            A[(k0 + c) * np + r0 + r] = s;
+        } else {
+            A[(r0 + r) * np + k0 + c] = -sP[r][c];
+        }
+    }
+}
+
+// A[i,j] -= C_i B_j' for 64-blocks i >= j, i != k, j != k; result mirrored to A[j,i].
+// Workgroup = 4 waves on a 128x128 tile of the lower triangle; wave (wi,wj) owns one 64x64 block.
+__global__ void __launch_bounds__(256)
+sweep_update_kernel(double *__restrict__ A, int64_t np, int k, const double *__restrict__ Bp,
+                    const double *__restrict__ Cp) {
+    // linear lower-triangle tile index -> (ti, tj), ti >= tj
+    const int t = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bi = ti * 2 + (wave >> 1), bj = tj * 2 + (wave & 1);
+    if (bi < bj || bi == k || bj == k) return;
+    const int li = lane & 15, lk = lane >> 4;
+    const double *cbase = Cp + (int64_t)bi * NB + li;
+    const double *bbase = Bp + (int64_t)bj * NB + li;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const int64_t koff = (int64_t)(kk * 4 + lk) * np;
+        double opA[4], opB[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { opA[q] = cbase[koff + q * 16]; opB[q] = bbase[koff + q * 16]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+    }
+    const int64_t r0 = (int64_t)bi * NB, c0 = (int64_t)bj * NB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r0 + i * 16 + lk + 4 * r, col = c0 + j * 16 + li;
+                if (bi == bj && col > row) continue;  // diagonal block: lower part is the master
+                const double v = A[row * np + col] - acc[i][j][r];
+                A[row * np + col] = v;
+                if (row != col) A[col * np + row] = v;
+            }
+}
+
+// diag(M) += shift on the valid part; the pad block becomes the identity
+__global__ void __launch_bounds__(256) add_diag_kernel(double *__restrict__ M, int64_t np, int64_t n, double shift) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < np) M[i * np + i] = i < n ? M[i * np + i] + shift : 1.0;
+}
+
+__global__ void __launch_bounds__(256) negate_kernel(double *__restrict__ A, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) A[i] = -A[i];
+}
+
+// C = A * B, all np x np, A and B symmetric (so row-major == column-major); diagnostics only.
+__global__ void __launch_bounds__(256)
+symm_matmul_kernel(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C, int64_t np) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.y * 2 + (wave >> 1)) * 64, c0 = ((int64_t)blockIdx.x * 2 + (wave & 1)) * 64;
+    const int li = lane & 15, lk = lane >> 4;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int64_t kk = 0; kk < np; kk += 4) {
+        double opA[4], opB[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            opA[q] = A[(kk + lk) * np + r0 + q * 16 + li];  // A[r][k] = A[k][r]
+            opB[q] = B[(kk + lk) * np + c0 + q * 16 + li];  // B[k][c]
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                C[(r0 + i * 16 + lk + 4 * r) * np + c0 + j * 16 + li] = acc[i][j][r];
+}
+
+}  // namespace
+
+size_t spd_inverse_work_bytes(int64_t np) { return sizeof(double) * (size_t)(2 * np * NB + NB * NB); }
+
+int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s) {
+    if (np % 128 != 0) { set_error("spd_inverse: np=%lld not a multiple of 128", (long long)np); return LPVS_ESTATE; }
+    double *Bp = work, *Cp = work + np * NB, *P = work + 2 * np * NB;
+    const int nblk = (int)(np / NB);
+    const int nt = (int)(np / 128);
+    const unsigned ntiles = (unsigned)(nt * (nt + 1) / 2);
+    LPVS_HIP(hipMemsetAsync(status_dev, 0, sizeof(int), s));
+    for (int k = 0; k < nblk; ++k) {
+        hipLaunchKernelGGL(diag_inverse_kernel, dim3(1), dim3(256), 0, s, A, np, k, P, status_dev);
+        hipLaunchKernelGGL(panel_kernel, dim3((unsigned)nblk), dim3(256), 0, s, A, np, k, P, Bp, Cp);
+        hipLaunchKernelGGL(sweep_update_kernel, dim3(ntiles), dim3(256), 0, s, A, np, k, Bp, Cp);
+    }
+    LPVS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(negate_kernel, dim3(2048), dim3(256), 0, s, A, np * np);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_add_diag(double *M, int64_t np, int64_t n, double shift, hipStream_t s) {
+    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, s, M, np, n, shift);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_symm_matmul(const double *A, const double *B, double *C, int64_t np, hipStream_t s) {
+    if (np % 128 != 0) return LPVS_ESTATE;
+    hipLaunchKernelGGL(symm_matmul_kernel, dim3((unsigned)(np / 128), (unsigned)(np / 128)), dim3(256), 0, s, A, B, C, np);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+}  // namespace lpvs

@@ -1,0 +1,135 @@
+// lpvs_internal.h -- shared declarations of the gfx950 implementation behind include/lpvspectral.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/lpvspectral.h"
+
+namespace lpvs {
+
+// ---- error plumbing ---------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define LPVS_HIP(call)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            lpvs::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                            __LINE__);                                                       \
+            return e_ == hipErrorOutOfMemory ? LPVS_ENOMEM : LPVS_EDEVICE;                   \
+        }                                                                                    \
+    } while (0)
+#define LPVS_TRY(call)                \
+    do {                              \
+        int32_t rc_ = (call);         \
+        if (rc_ != LPVS_OK) return rc_; \
+    } while (0)
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device buffers ---------------------------------------------------------------------
+// RAII device allocation; copy_in accepts a host or a device source pointer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int32_t alloc(size_t nbytes);
+    void release();
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+bool is_device_ptr(const void *p);
+// dst device <- src (host or device); dst (host or device) <- src device
+int32_t copy_to_device(void *dst_dev, const void *src, size_t bytes, hipStream_t s);
+int32_t copy_from_device(void *dst, const void *src_dev, size_t bytes, hipStream_t s);
+
+// ---- basis tables (basis.hip) -----------------------------------------------------------
+// Fourier regressor, column-major N x Nreg (reference layout)          src/lsfft.jl:26-49
+int32_t launch_fourier_regressor_colmajor(const double *t, int64_t N, const double *f, int64_t Nf,
+                                          int zerofreq, double *A, hipStream_t s);
+// Fourier regressor as a row-major panel P[n][ld] (k-major operand of the Gram kernel);
+// columns >= Nreg up to ld are zero-filled.
+int32_t launch_fourier_panel(const double *t, int64_t N, const double *f, int64_t Nf, int zerofreq,
+                             double *P, int64_t ld, hipStream_t s);
+// trig table T[n][f] = (cos(w_f x_n), -sin(w_f x_n))                   src/lasso.jl:39
+int32_t launch_trig_table(const double *X, int64_t N, const double *w, int64_t Nf, double2 *T,
+                          hipStream_t s);
+// activation table K[n][ldk] (row-major, nb valid entries per row)     src/lsfft.jl:195-207
+int32_t launch_basis_table(const double *V, int64_t N, const double *vc, int64_t nb, double gamma,
+                           int normalize, int coulomb, double *K, int64_t ldk, hipStream_t s);
+// min / max / max|.| of V (device), results to host
+int32_t device_minmax(const double *V, int64_t N, double *lo, double *hi, double *amax,
+                      hipStream_t s);
+// materialised LPV regressor, column-major N x 2*Nf*nb                 src/lasso.jl:35-50
+int32_t launch_lpv_regressor_colmajor(const double2 *T, const double *K, int64_t ldk, int64_t N,
+                                      int64_t Nf, int64_t nb, int permuted, double *Phi,
+                                      hipStream_t s);
+// column-major m x n -> k-major panel P[m][ld], pad columns zero-filled
+int32_t launch_transpose_to_panel(const double *A, int64_t m, int64_t n, double *P, int64_t ld,
+                                  hipStream_t s);
+
+// ---- Gram (gram.hip) --------------------------------------------------------------------
+struct GramPlan {
+    int64_t n = 0;       // unknowns (valid columns)
+    int64_t N = 0;       // samples
+    int64_t tiles = 0;   // lower-triangle 128x256 tiles
+    int64_t ksplit = 0;  // sample chunks
+    int64_t rows_per_chunk = 0;
+    size_t slab_bytes = 0;
+};
+GramPlan make_gram_plan(int64_t n, int64_t N);
+// Khatri-Rao form: Phi[k][f*2nb + c] = T[k][f][c>=nb] * K[k][c mod nb]
+int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const double *K,
+                       int64_t ldk, int64_t nb, double *slab, hipStream_t s);
+// panel form: Phi[k][c] = P[k*ld + c], optional row weights W (applied once: G = P' diag(W) P)
+int32_t launch_gram_panel(const GramPlan &pl, const double *P, int64_t ld, const double *W,
+                          double *slab, hipStream_t s);
+// G[a][b] (ldg x ldg, symmetric, full) = sum over chunks of the slabs
+int32_t launch_gram_reduce(const GramPlan &pl, const double *slab, double *G, int64_t ldg,
+                           hipStream_t s);
+// b = Phi' (W .* y)
+int32_t launch_rhs_kr(const double2 *T, int64_t Nf, const double *K, int64_t ldk, int64_t nb,
+                      const double *y, int64_t N, double *b, double *scratch, size_t scratch_bytes,
+                      hipStream_t s);
+int32_t launch_rhs_panel(const double *P, int64_t ld, int64_t ncol, const double *W, const double *y,
+                         int64_t N, double *b, double *scratch, size_t scratch_bytes, hipStream_t s);
+size_t rhs_scratch_bytes(int64_t N, int64_t n);
+
+// ---- dense symmetric inverse (linalg.hip) ------------------------------------------------
+// In-place inverse of the SPD matrix A (np x np, np % 64 == 0, full symmetric storage) by
+// blocked symmetric sweeps; work holds 2 panels of np x 64 + one 64 x 64 block.
+size_t spd_inverse_work_bytes(int64_t np);
+int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s);
+int32_t launch_add_diag(double *M, int64_t np, int64_t n, double shift, hipStream_t s);
+// C (m x m, ld) = A * B for symmetric np x np operands (test/diagnostic helper)
+int32_t launch_symm_matmul(const double *A, const double *B, double *C, int64_t np, hipStream_t s);
+
+// ---- ADMM (admm.hip) --------------------------------------------------------------------
+struct AdmmStatus {  // lives in device memory, copied back after each run
+    long long iters;
+    int converged;
+    int pad;
+    double nxz;
+};
+struct AdmmParams {
+    const double *M;   // (G + I/mu)^-1, np x np
+    int64_t np;        // padded size (multiple of 64)
+    int64_t n;         // valid size
+    const double *b;   // linear term (already signed)
+    double *x, *z, *u, *rhs;
+    double mu, tol;
+    int prox_kind;
+    double prox_param;
+    int64_t group_len;
+    AdmmStatus *status;
+    double *scratch;   // >= 2*np doubles (top-r selection keys)
+};
+int32_t launch_admm_init(const AdmmParams &p, hipStream_t s);              // z=x, u=0, rhs, status=0
+int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s);
+// x = Minv * rhs_in (one GEMV; ridge solves)
+int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s);
+
+}  // namespace lpvs

@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import lpvspectral_jl_amd as L
+        from lpvspectral_jl_amd._lib import lib
+        return lib().lpvs_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def L():
+    """The product package (loads liblpvspectral.so; ImportError if it was not built)."""
+    import lpvspectral_jl_amd as L
+    return L
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.lib()
+    return o
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

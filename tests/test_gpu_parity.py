@@ -1,0 +1,322 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+inputs, at sizes the oracle finishes in seconds.
+
+Tolerances (fp64 path):
+  * regressor / basis tables: |dev - oracle| <= 4e-16 * scale (device sincos/exp vs glibc: <= 2 ulp)
+  * Gram G, b: relative 1e-12 of max|G| (different summation order over N)
+  * ADMM iterates at equal iteration count vs the Gram-form oracle: rel-L2 <= 1e-9, identical support,
+    identical iteration count at tol > 0; vs the faithful CG oracle: rel-L2 <= 1e-6
+  * index / window bookkeeping, iteration counts at tol = 0: bit-exact
+"""
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def lpv_signal(N, seed, xmax=10.0):
+    rng = np.random.default_rng(seed)
+    X = np.sort(xmax * rng.random(N))
+    V = np.linspace(0, 1, N)
+    fd = [lambda v: 2 * v ** 2, lambda v: 2 / (5 * v + 1), lambda v: 3 * np.exp(-10 * (v - 0.5) ** 2)]
+    w = 2 * np.pi * np.array([2.0, 10.0, 20.0])
+    dep = np.stack([fd[i](V) for i in range(3)], 1)
+    Y = (dep * np.cos(w[None, :] * X[:, None] - 0.5 * dep)).sum(1) + 0.1 * rng.standard_normal(N)
+    return Y, X, V
+
+
+def sines(N, seed, nonuniform=True):
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.random(N)) * N if nonuniform else np.arange(N, dtype=float)
+    f = np.arange(1, 65) / 128.0
+    y = sum(a * np.sin(2 * np.pi * f[i] * t + p) for a, i, p in [(2, 5, 0.3), (1, 20, 1.1), (0.5, 40, 2.0)])
+    return y + 0.1 * rng.standard_normal(N), t, f
+
+
+# ------------------------------------------------------------------ a2: Fourier regressor
+@pytest.mark.parametrize("zero", [False, True])
+def test_fourier_regressor(L, oracle, zero):
+    rng = np.random.default_rng(0)
+    t = np.sort(rng.random(777)) * 3e5           # phases up to ~1e6 rad: exercises the large-argument path
+    f = np.arange(0 if zero else 1, 40) / 80.0
+    A, zf = L.get_fourier_regressor(t, f)
+    Ao, zo = oracle.get_fourier_regressor(t, f)
+    assert zf == zo and A.shape == Ao.shape
+    assert np.abs(A - Ao).max() <= 4e-16 / np.sqrt(2 * len(f)) * 4
+
+
+def test_fourier_regressor_device_resident_inputs(L, oracle):
+    import torch
+    t = np.arange(500) * 0.1
+    f = L.default_freqs(t)
+    A, zf = L.get_fourier_regressor(torch.tensor(t, device="cuda"), torch.tensor(f, device="cuda"))
+    Ao, _ = oracle.get_fourier_regressor(t, f)
+    assert A.shape == (500, 2 * len(f) - 1) and np.abs(A - Ao).max() < 1e-15
+
+
+def test_zero_frequency_must_be_first(L):
+    with pytest.raises(ValueError):
+        L.get_fourier_regressor(np.arange(10.0), np.array([1.0, 0.0, 2.0]))
+    with pytest.raises(ValueError):
+        L.ls_sparse_spectral(np.ones(10), np.arange(10.0), np.array([1.0, 0.0, 2.0]), iters=1)
+
+
+# ------------------------------------------------------------------ a3-a5: LPV basis + regressor
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("coulomb", [False, True])
+def test_basis_activation(L, oracle, normalize, coulomb):
+    rng = np.random.default_rng(2)
+    V = rng.standard_normal(333)
+    K = L.basis_activation_func(V, 7, normalize, coulomb)
+    Ko = oracle.basis_activation(V, 7, normalize, coulomb)
+    assert K.shape == Ko.shape and np.abs(K - Ko).max() <= 1e-15
+
+
+@pytest.mark.parametrize("permuted", [True, False])
+@pytest.mark.parametrize("Nv", [3, 8])
+def test_lpv_regressor(L, oracle, permuted, Nv):
+    Y, X, V = lpv_signal(201, 4, xmax=3e4)
+    w = 2 * np.pi * np.arange(2, 16, 2.0)
+    Phi = L.lpv_regressor(X, V, w, Nv, True, False, permuted)
+    Po = oracle.lpv_regressor(X, V, w, Nv, True, False, permuted)
+    assert Phi.shape == Po.shape and np.abs(Phi - Po).max() <= 2e-15
+
+
+# ------------------------------------------------------------------ Gram (a6/a8 setup)
+@pytest.mark.parametrize("N,Nf,Nv", [(500, 12, 50), (1000, 40, 8), (4099, 24, 8), (300, 7, 3), (2500, 70, 1)])
+def test_gram_lpv(L, oracle, N, Nf, Nv):
+    Y, X, V = lpv_signal(N, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) * 25 / Nf
+    with L.Problem.lpv(Y, X, V, w, Nv) as p:
+        G, b = p.get_gram()
+    Phi = oracle.lpv_regressor(X, V, w, Nv)
+    Go, bo = Phi.T @ Phi, Phi.T @ Y
+    assert G.shape == Go.shape
+    assert np.abs(G - Go).max() <= 1e-12 * np.abs(Go).max()
+    assert np.abs(b - bo).max() <= 1e-12 * np.abs(bo).max()
+    assert np.array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("N,zero,weighted", [(1000, True, False), (1000, False, True), (3001, True, True), (130, False, False)])
+def test_gram_fourier(L, oracle, N, zero, weighted):
+    y, t, f = sines(N, N)
+    if zero:
+        f = np.concatenate([[0.0], f])
+    W = np.random.default_rng(9).random(N) + 0.5 if weighted else None
+    with L.Problem.fourier(y, t, f, W) as p:
+        G, b = p.get_gram()
+    A, _ = oracle.get_fourier_regressor(t, f)
+    Go = A.T @ ((W[:, None] if weighted else 1.0) * A)
+    bo = A.T @ ((W if weighted else 1.0) * y)
+    assert np.abs(G - Go).max() <= 1e-12 * np.abs(Go).max()
+    assert np.abs(b - bo).max() <= 1e-12 * np.abs(bo).max()
+
+
+def test_gram_dense_and_explicit(L):
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((700, 150)); y = rng.standard_normal(700)
+    with L.Problem.dense(A, y) as p:
+        G, b = p.get_gram()
+    assert np.abs(G - A.T @ A).max() <= 1e-12 * np.abs(A.T @ A).max()
+    assert np.abs(b - A.T @ y).max() <= 1e-12 * np.abs(A.T @ y).max()
+    with L.Problem.gram(A.T @ A, A.T @ y) as p:
+        G2, b2 = p.get_gram()
+    assert np.array_equal(G2, A.T @ A) and np.array_equal(b2, A.T @ y)
+
+
+# ------------------------------------------------------------------ x-update solver
+@pytest.mark.parametrize("n", [64, 200, 513])
+def test_ridge_solve_matches_numpy(L, n):
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((3 * n, n)) * rng.random(n)[None, :]
+    y = rng.standard_normal(3 * n)
+    G, b = A.T @ A, A.T @ y
+    with L.Problem.gram(G, b) as p:
+        x = p.solve_ridge(20.0)
+    xo = np.linalg.solve(G + 20.0 * np.eye(n), b)
+    assert rel(x, xo) <= 1e-11
+
+
+def test_not_positive_definite_is_reported(L):
+    G = -np.eye(8)
+    with L.Problem.gram(G, np.ones(8)) as p:
+        with pytest.raises(L.NumericError):
+            p.solve_ridge(0.5)
+
+
+# ------------------------------------------------------------------ ADMM (a6-a13)
+def _device_admm(L, prob, proxg, sign=1, **kw):
+    prob.set_prox(proxg)
+    prob.admm_init(None, μ=kw.get("μ", 0.05), tol=kw.get("tol", 1e-5), linear_sign=sign)
+    it, nxz, conv = prob.admm_run(kw.get("iters", 100))
+    x, z, u = prob.admm_get()
+    return dict(x=x, z=z, u=u, iters=it, nxz=nxz, conv=conv)
+
+
+PROXES = [("l1", 0.02), ("l0", 0.002), ("ball", 6), ("group", 0.5)]
+
+
+@pytest.mark.parametrize("kind,param", PROXES)
+def test_admm_fourier_matches_gram_oracle(L, oracle, kind, param):
+    y, t, f = sines(600, 11)
+    A, _ = oracle.get_fourier_regressor(t, f)
+    Go, bo = oracle.gram(A, y)
+    mk = {"l1": (L.NormL1, oracle.NormL1), "l0": (L.NormL0, oracle.NormL0), "ball": (L.IndBallL0, oracle.IndBallL0)}
+    if kind == "group":
+        gd = L.SlicedSeparableSum.frequency_groups(param, len(f), 2)
+        go = oracle.GroupL2(param, 2)
+    else:
+        gd, go = mk[kind][0](param), mk[kind][1](param)
+    ro = oracle.admm_gram(Go, bo, go, iters=300, tol=0.0, mu=0.05, history=True)
+    with L.Problem.fourier(y, t, f) as p:
+        rd = _device_admm(L, p, gd, iters=300, tol=0.0, μ=0.05)
+    assert rd["iters"] == ro["iters"] == 300 and not rd["conv"]
+    assert rel(rd["z"], ro["z"]) <= 1e-9 and rel(rd["x"], ro["x"]) <= 1e-9 and rel(rd["u"], ro["u"]) <= 1e-9
+    assert np.array_equal(rd["z"] != 0, ro["z"] != 0)
+    assert abs(rd["nxz"] - ro["nxz"][-1]) <= 1e-9 * max(ro["nxz"][-1], 1e-12)
+    assert np.count_nonzero(ro["z"]) > 0
+
+
+def test_admm_stops_at_reference_iteration(L, oracle):
+    y, t, f = sines(500, 12)
+    A, _ = oracle.get_fourier_regressor(t, f)
+    Go, bo = oracle.gram(A, y)
+    ro = oracle.admm_gram(Go, bo, oracle.NormL1(0.05), iters=5000, tol=1e-6, mu=0.05, history=True)
+    assert 10 < ro["iters"] < 5000
+    with L.Problem.fourier(y, t, f) as p:
+        p.set_prox(L.NormL1(0.05)); p.admm_init(None, μ=0.05, tol=1e-6)
+        it1, _, c1 = p.admm_run(7)                     # chunked like the host wrapper
+        it, nxz, conv = p.admm_run(5000)
+        x, z, u = p.admm_get()
+        it2, _, _ = p.admm_run(50)                     # no-op after convergence
+    assert it1 == 7 and not c1
+    assert conv and it == ro["iters"] and it2 == it
+    assert rel(z, ro["z"]) <= 1e-9
+
+
+def test_admm_vs_faithful_cg_oracle_lpv(L, oracle):
+    """Headline path at test size (the reference's own test problem, test/test_lasso.jl:17-32)."""
+    Y, X, V = lpv_signal(500, 0)
+    w_test = 2 * np.pi * np.arange(2, 26, 2.0)
+    Nv = 50
+    po, ro = oracle.ls_sparse_spectral_lpv(Y, X, V, w_test, Nv, lam=5, tol=1e-8, iters=2000)
+    buf = io.StringIO()
+    import lpvspectral_jl_amd.api as api
+    with L.Problem.lpv(Y, X, V, w_test, Nv) as p:
+        g = L.SlicedSeparableSum.frequency_groups(5, len(w_test), 2 * Nv)
+        x, z = api._admm_on_problem(p, None, g, 1, iters=2000, tol=1e-8, printerval=100, μ=0.05, out=buf)
+        params = p.params(0)
+    lines = buf.getvalue().strip().splitlines()
+    assert lines[0].startswith("100 ||x-z||₂ ")
+    assert lines[-1].startswith("%d ||x-z||₂ " % ro["iters"])         # same stopping iteration
+    assert rel(z, ro["z"]) <= 1e-6
+    assert rel(params, po) <= 1e-6
+    assert np.array_equal(z != 0, ro["z"] != 0)
+    assert set(np.argsort(-oracle.psd(params, len(w_test)))[:3] + 1) == {1, 5, 10}
+
+
+def test_ls_sparse_spectral_lpv_api(L, oracle):
+    Y, X, V = lpv_signal(400, 7)
+    w = 2 * np.pi * np.arange(2, 26, 2.0)
+    se = L.ls_sparse_spectral_lpv(Y, X, V, w, 8, λ=5, iters=300, tol=0, printerval=1000)
+    po, ro = oracle.ls_sparse_spectral_lpv(Y, X, V, w, 8, lam=5, iters=300, tol=0)
+    assert isinstance(se, L.SpectralExt) and se.Σ is None and se.x.shape == (len(w) * 8,)
+    assert rel(se.x, po) <= 1e-6
+    G, bo = oracle.gram(oracle.lpv_regressor(X, V, w, 8), Y)
+    rg = oracle.admm_gram(G, bo, oracle.GroupL2(5, 16), iters=300, tol=0)
+    assert rel(se.x, oracle.lpv_unpermute(rg["z"], len(w), 8)) <= 1e-9
+    assert np.allclose(L.psd(se).ravel(), oracle.psd(se.x, len(w)))
+    with pytest.raises(NotImplementedError):
+        L.ls_sparse_spectral_lpv(Y, X, V, w, 8, coulomb=True)
+    with pytest.raises(AssertionError):
+        L.ls_sparse_spectral_lpv(Y, X, V, w, 8, μ=1.5)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("zero", [False, True])
+def test_ls_sparse_spectral_api(L, oracle, weighted, zero):
+    y, t, f = sines(700, 21)
+    if zero:
+        f = np.concatenate([[0.0], f]); y = y + 0.7
+    W = np.ones(700) if weighted else None
+    x, fr = L.ls_sparse_spectral(y, t, f, W, λ=0.05, iters=400, tol=0, μ=0.05, printerval=1000)
+    xo, _, ro = oracle.ls_sparse_spectral(y, t, f, W, lam=0.05, iters=400, tol=0, mu=0.05)
+    assert x.shape == (len(f),) and np.array_equal(fr, f)
+    assert rel(x, xo) <= 1e-6
+    assert np.array_equal(x != 0, xo != 0) and np.count_nonzero(x) >= 3
+    if zero:
+        assert x[0].imag == 0
+
+
+def test_admm_plugin_boundary_generic_objects(L, oracle):
+    """ADMM(x, proxf, proxg) on caller-supplied LeastSquares / Quadratic objects (src/lasso.jl:136)."""
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((400, 90)); xs = np.zeros(90); xs[[3, 40, 77]] = [2, -1, 3]
+    y = A @ xs + 0.01 * rng.standard_normal(400)
+    x, z = L.ADMM(np.zeros(90), L.LeastSquares(A, y, iterative=True), L.NormL1(5.0), iters=500, tol=1e-9, printerval=10000)
+    ro = oracle.admm_ls(A, y, oracle.NormL1(5.0), iters=500, tol=1e-9)
+    assert rel(z, ro["z"]) <= 1e-6 and set(np.nonzero(z)[0]) == {3, 40, 77}
+    Q, q = A.T @ A, -(A.T @ y)
+    x2, z2 = L.ADMM(np.zeros(90), L.Quadratic(Q, q, iterative=True), L.NormL1(5.0), iters=500, tol=1e-9, printerval=10000)
+    assert rel(z2, z) <= 1e-9
+    with pytest.raises(NotImplementedError):
+        L.ADMM(np.zeros(90), L.LeastSquares(A, y), object(), iters=1)
+
+
+def test_callback_and_printing(L):
+    y, t, f = sines(300, 2)
+    calls = []
+    L.ls_sparse_spectral(y, t, f, λ=0.05, iters=250, tol=0, printerval=100, cb=lambda x, z: calls.append((x.copy(), z.copy())))
+    assert len(calls) == 2 and calls[0][0].shape == (2 * len(f),)
+
+
+# ------------------------------------------------------------------ dense estimators + windows (a16, a18)
+def test_ls_spectral_known_answers_on_device(L):
+    """test/runtests.jl:185-195 through the device path (weighted form; the 3-arg form needs N >= Nreg)."""
+    t = np.arange(1000) * 0.1
+    y = np.sin(2 * np.pi * t)
+    f = L.default_freqs(t)
+    x, _ = L.ls_spectral(y, t, f, np.ones(len(y)))
+    p = np.abs(x) ** 2
+    assert abs(p.max() - 2.0 * len(f)) < 1e-4 and p.argmax() + 1 == 101
+    f2 = f[:-1]                                   # drop Nyquist: tall, full-rank system
+    x2, _ = L.ls_spectral(y, t, f2)
+    p2 = np.abs(x2) ** 2
+    assert abs(p2.max() - 2.0 * len(f2)) < 1e-4 and p2.argmax() + 1 == 101
+
+
+def test_ls_windowpsd_known_answers_on_device(L, oracle):
+    t = np.arange(1000) * 0.1
+    y = np.sin(2 * np.pi * t)
+    S, fr = L.ls_windowpsd(y, t, noverlap=0)
+    assert S.argmax() + 1 == 13 and len(fr) == 63
+    S16, _ = L.ls_windowpsd(y, t, nw=16, noverlap=0)
+    assert np.abs(S16).argmax() + 1 == 7
+    So, _ = oracle.ls_windowpsd(y, t, noverlap=0)
+    assert rel(S, So) <= 1e-6
+
+
+def test_ls_windowpsd_sparse_estimator(L, oracle):
+    Y, X, V = lpv_signal(500, 0)
+    fr = np.arange(1, 22.01, 0.5)
+    S, _ = L.ls_windowpsd(Y, X, fr, nw=2, estimator=L.ls_sparse_spectral, λ=0.2, tol=1e-10, printerval=10000, iters=3000, μ=0.0001)
+    So, _ = oracle.ls_windowpsd(Y, X, fr, nw=2, estimator=lambda y, t, f, W, **k: oracle.ls_sparse_spectral(y, t, f, W, **k),
+                                lam=0.2, tol=1e-10, iters=3000, mu=0.0001)
+    assert rel(S, So) <= 1e-6
+
+
+def test_ls_spectral_lpv_top3(L, oracle):
+    Y, X, V = lpv_signal(500, 0)
+    w_test = 2 * np.pi * np.arange(2, 26, 2.0)
+    se = L.ls_spectral_lpv(Y, X, V, w_test, 50, λ=0.02)
+    assert set(np.argsort(-L.psd(se).ravel())[:3] + 1) == {1, 5, 10}
+    xo = oracle.ls_spectral_lpv(Y, X, V, w_test, 50, lam=0.02)
+    assert rel(se.x, xo) <= 1e-6
+    Sw = L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02)
+    assert set(np.argsort(-Sw)[:3] + 1) == {1, 5, 10}

@@ -1,0 +1,147 @@
+"""Pins the CPU oracle against the reference's own known answers (test/runtests.jl) and
+cross-checks the C restatement against independent numpy statements.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+def _t():
+    g = GOLD["default_freqs"]["t"]
+    return np.arange(1000) * g["step"] + g["start"]
+
+
+@pytest.mark.parametrize("case", GOLD["windows2"])
+def test_windows2(oracle, case):
+    y = np.arange(1, case["L"] + 1)
+    W = oracle.Windows2(y, y, case["n"], case["noverlap"])
+    assert len(W) == case["count"]
+    ws = list(W)
+    assert np.array_equal(ws[0][0], np.arange(case["first"][0], case["first"][1] + 1))
+    if "second" in case:
+        assert np.array_equal(ws[1][0], np.arange(case["second"][0], case["second"][1] + 1))
+        assert np.array_equal(ws[1][1], ws[1][0])
+    res = oracle.mapwindows(lambda yt: -yt[0], W)
+    assert np.array_equal(res, -np.arange(1, case["L"] + 1))
+
+
+def test_default_freqs_and_check_freq(oracle):
+    g = GOLD["default_freqs"]
+    f = oracle.default_freqs(_t())
+    assert f[0] == g["first"] and f[-1] == g["last"] and len(f) == g["length"]
+    assert oracle.check_freq(f) == GOLD["check_freq"]["ok_returns"]
+    with pytest.raises(ValueError):
+        oracle.check_freq(GOLD["check_freq"]["throws_ArgumentError_for"])
+
+
+def test_regressor_size_and_numpy_crosscheck(oracle):
+    t = _t()
+    f = oracle.default_freqs(t)
+    A, z = oracle.get_fourier_regressor(t, f)
+    assert list(A.shape) == GOLD["regressor_size"]["size"] and z == 1
+    A2, _ = oracle.get_fourier_regressor_np(t, f)
+    assert np.abs(A - A2).max() < 1e-15
+    f2 = f[1:]
+    A3, z3 = oracle.get_fourier_regressor(t, f2)
+    A4, _ = oracle.get_fourier_regressor_np(t, f2)
+    assert z3 is None and A3.shape == (1000, 1000) and np.abs(A3 - A4).max() < 1e-15
+
+
+def test_ls_spectral_known_answer(oracle):
+    g = GOLD["ls_spectral_sine"]
+    t = _t()
+    y = np.sin(2 * np.pi * t)
+    x, f = oracle.ls_spectral(y, t)
+    p = np.abs(x) ** 2
+    assert abs(p.max() - g["findmax_abs2"][0]) < g["atol"] and p.argmax() + 1 == g["findmax_abs2"][1]
+    x, _ = oracle.ls_spectral(y, t, f, np.ones(len(y)))
+    p = np.abs(x) ** 2
+    assert abs(p.max() - g["findmax_abs2"][0]) < g["atol"] and p.argmax() + 1 == g["findmax_abs2"][1]
+
+
+@pytest.mark.parametrize("case", GOLD["ls_windowpsd"])
+def test_ls_windowpsd_known_answer(oracle, case):
+    t = _t()
+    y = np.sin(2 * np.pi * t)
+    S, _ = oracle.ls_windowpsd(y, t, nw=case["nw"], noverlap=case["noverlap"])
+    assert np.abs(S).argmax() + 1 == case["argmax"]
+
+
+def _lpv_signal(N, seed):
+    rng = np.random.default_rng(seed)
+    X = np.sort(10 * rng.random(N))
+    V = np.linspace(0, 1, N)
+    fd = [lambda v: 2 * v ** 2, lambda v: 2 / (5 * v + 1), lambda v: 3 * np.exp(-10 * (v - 0.5) ** 2)]
+    w = 2 * np.pi * np.array([2.0, 10.0, 20.0])
+    dep = np.stack([fd[i](V) for i in range(3)], 1)
+    Y = (dep * np.cos(w[None, :] * X[:, None] - 0.5 * dep)).sum(1) + 0.1 * rng.standard_normal(N)
+    return Y, X, V
+
+
+def test_lpv_regressor_matches_literal_transcription(oracle):
+    Y, X, V = _lpv_signal(60, 3)
+    w = 2 * np.pi * np.arange(2, 12, 2.0)
+    Phi = oracle.lpv_regressor(X, V, w, 4)
+    Phi2, inds = oracle.lpv_regressor_np(X, V, w, 4)
+    assert np.abs(Phi - Phi2).max() < 1e-15
+    # inds layout of src/lasso.jl:47 (verified table: Nf=3, Nv=2 -> [1,4,7,10, 2,5,8,11, 3,6,9,12])
+    i32 = np.arange(12).reshape((3, 4), order="F").T.ravel(order="F") + 1
+    assert list(i32) == [1, 4, 7, 10, 2, 5, 8, 11, 3, 6, 9, 12]
+
+
+def test_lpv_top3_known_answer(oracle):
+    g = GOLD["lpv_top3"]
+    Y, X, V = _lpv_signal(g["N"], 0)
+    w_test = 2 * np.pi * np.array(g["w_test_hz"], dtype=float)
+    x = oracle.ls_spectral_lpv(Y, X, V, w_test, g["Nv"], lam=g["lambda"])
+    top = set(np.argsort(-oracle.psd(x, len(w_test)))[:3] + 1)
+    assert top == set(g["top3_psd_indices"])
+    p, r = oracle.ls_sparse_spectral_lpv(Y, X, V, w_test, g["Nv"], lam=5, tol=1e-8, iters=2000)
+    assert set(np.argsort(-oracle.psd(p, len(w_test)))[:3] + 1) == set(g["top3_psd_indices"])
+
+
+def test_faithful_cg_form_equals_gram_form(oracle):
+    """The reference's x-update (warm-started CG, reltol sqrt(eps)) and the exact Gram-form solve walk
+    the same trajectory: equal iteration counts, z equal to ~1e-9 (tall and fat cases)."""
+    Y, X, V = _lpv_signal(300, 1)
+    w_test = 2 * np.pi * np.arange(2, 26, 2.0)
+    for Nv in (4, 20):  # tall (96 < 300) and fat (480 > 300)
+        Phi = oracle.lpv_regressor(X, V, w_test, Nv)
+        r1 = oracle.admm_ls(Phi, Y, oracle.GroupL2(5, 2 * Nv), iters=400, tol=1e-9, history=True)
+        G, b = oracle.gram(Phi, Y)
+        r2 = oracle.admm_gram(G, b, oracle.GroupL2(5, 2 * Nv), iters=400, tol=1e-9, history=True)
+        assert r1["iters"] == r2["iters"]
+        assert np.linalg.norm(r1["z"] - r2["z"]) <= 1e-8 * max(np.linalg.norm(r2["z"]), 1e-30)
+        assert np.array_equal(r1["z"] != 0, r2["z"] != 0)
+
+
+def test_quadratic_as_written_sign(oracle):
+    """src/lasso.jl:119-121 passes q=+A'Wy to Quadratic: coefficients come out negated relative to the
+    least-squares path; abs2 (the PSD) is unaffected."""
+    rng = np.random.default_rng(5)
+    t = np.sort(rng.random(200)) * 20
+    f = np.arange(1, 21) / 10.0
+    y = np.sin(2 * np.pi * 0.7 * t) + 0.05 * rng.standard_normal(200)
+    W = np.ones(200)
+    xu, _, _ = oracle.ls_sparse_spectral(y, t, f, lam=0.05, iters=500, tol=0, mu=0.05)
+    xw, _, _ = oracle.ls_sparse_spectral(y, t, f, W, lam=0.05, iters=500, tol=0, mu=0.05)
+    assert np.linalg.norm(xu + xw) < 1e-6 * np.linalg.norm(xu)
+
+
+def test_prox_operators(oracle):
+    v = np.array([3.0, -0.2, 0.5, -4.0, 0.0, 1.0])
+    assert np.allclose(oracle.prox(oracle.NormL1(2.0), v, 0.25), [2.5, 0, 0, -3.5, 0, 0.5])
+    assert np.allclose(oracle.prox(oracle.NormL0(2.0), v, 0.25), [3.0, 0, 0, -4.0, 0, 0])  # thr = 1: strict >
+    assert np.allclose(oracle.prox(oracle.IndBallL0(2), v, 0.25), [3.0, 0, 0, -4.0, 0, 0])
+    z = oracle.prox(oracle.GroupL2(2.0, 3), v, 0.25)
+    n1, n2 = np.linalg.norm(v[:3]), np.linalg.norm(v[3:])
+    assert np.allclose(z[:3], (1 - 0.5 / n1) * v[:3]) and np.allclose(z[3:], (1 - 0.5 / n2) * v[3:])
+    assert np.all(oracle.prox(oracle.GroupL2(100.0, 3), v, 0.25) == 0)
+
+
+def test_admm_mu_assert(oracle):
+    with pytest.raises(AssertionError):
+        oracle.admm_gram(np.eye(3), np.ones(3), oracle.NormL1(1.0), mu=1.5)
