@@ -78,6 +78,14 @@ def lib():
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C lpvspectral.jl_amd/csrc). "
                 "There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  If torch is going
+        # to be used in this process (tests, bench: device tensors, torch.distributed) it must be loaded
+        # first, so that this library binds to the same runtime through the matching SONAME; two copies
+        # of the runtime cannot both own the GPU.  Without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError here == header/library mismatch

@@ -28,7 +28,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 128;     // tile extent along a (rows of G)
 constexpr int TN = 256;     // tile extent along b (cols of G)
-constexpr int BK = 32;      // samples per stage
+constexpr int BK_ALIGN = 32;  // sample chunks are multiples of this (every stage depth divides it)
 constexpr int NTHREADS = 512;  // 8 waves: 2 (a) x 4 (b), 64x64 outputs each
 
 struct GramArgs {
@@ -55,11 +55,12 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MODE>  // 0 = KR, 1 = PANEL
+template <int MODE, int BK>  // MODE 0 = KR, 1 = PANEL; BK = samples per stage
 __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS-DMA bases derive from it
     const int wa = wave >> 2, wb = wave & 3;  // wave's 64x64 block inside the 128x256 tile
     const int item = blockIdx.x;
     const int tile = item / a.ksplit, chunk = item - tile * a.ksplit;
@@ -296,7 +297,7 @@ GramPlan make_gram_plan(int64_t n, int64_t N) {
     pl.n = n; pl.N = N;
     pl.tiles = (int64_t)make_tiles(n).host.size();
     // split the samples so that (tiles x chunks) fills the 256 CUs in whole rounds
-    const int64_t nstage = ceil_div(N, BK);
+    const int64_t nstage = ceil_div(N, BK_ALIGN);
     const int64_t max_split = nstage / 16 > 0 ? nstage / 16 : 1;  // >= 512 samples per chunk
     int64_t want = ceil_div(256 * 16, pl.tiles);
     if (want > max_split) want = max_split;
@@ -307,7 +308,7 @@ GramPlan make_gram_plan(int64_t n, int64_t N) {
         if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
     }
     pl.ksplit = best;
-    pl.rows_per_chunk = round_up(ceil_div(N, pl.ksplit), BK);
+    pl.rows_per_chunk = round_up(ceil_div(N, pl.ksplit), BK_ALIGN);
     pl.slab_bytes = sizeof(double) * (size_t)pl.tiles * (size_t)pl.ksplit * TM * TN;
     return pl;
 }
@@ -333,7 +334,7 @@ static int32_t get_tiles(int64_t n, hipStream_t s, const int2 **out, int *count)
     return LPVS_OK;
 }
 
-static size_t gram_lds_bytes(int mode, int64_t nb, int64_t ldk) {
+static size_t gram_lds_bytes(int mode, int BK, int64_t nb, int64_t ldk) {
     int img, aux;
     if (mode == 0) {
         const int g2 = (int)(2 * nb);
@@ -348,22 +349,30 @@ static size_t gram_lds_bytes(int mode, int64_t nb, int64_t ldk) {
     return sizeof(double) * 2 * (size_t)(img_pad + aux_pad);
 }
 
+template <int MODE, int BK>
+static int32_t launch_gram_t(const GramArgs &a, unsigned grid, size_t lds, hipStream_t s) {
+    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<MODE, BK>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gram_kernel<MODE, BK>), dim3(grid), dim3(NTHREADS), lds, s, a);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+constexpr size_t kLdsBudget = 160 * 1024;
+
 int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const double *K, int64_t ldk,
                        int64_t nb, double *slab, hipStream_t s) {
     GramArgs a{};
     a.n = pl.n; a.rows_per_chunk = pl.rows_per_chunk; a.ksplit = (int)pl.ksplit;
     LPVS_TRY(get_tiles(pl.n, s, &a.tiles, &a.ntiles));
     a.slab = slab; a.T = T; a.K = K; a.Nf = (int)Nf; a.nb = (int)nb; a.ldk = (int)ldk;
-    const size_t lds = gram_lds_bytes(0, nb, ldk);
-    if (lds > 160 * 1024) {
-        set_error("gram_kr: LDS image of %zu bytes exceeds 160 KiB (nb=%lld)", lds, (long long)nb);
-        return LPVS_EUNSUPPORTED;
-    }
-    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<0>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(gram_kernel<0>, dim3((unsigned)(pl.tiles * pl.ksplit)), dim3(NTHREADS), lds, s, a);
-    LPVS_HIP(hipGetLastError());
-    return LPVS_OK;
+    const unsigned grid = (unsigned)(pl.tiles * pl.ksplit);
+    // deepest stage whose two LDS images fit (few basis functions -> many frequencies per tile)
+    if (gram_lds_bytes(0, 32, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 32>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
+    if (gram_lds_bytes(0, 16, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 16>(a, grid, gram_lds_bytes(0, 16, nb, ldk), s);
+    if (gram_lds_bytes(0, 8, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 8>(a, grid, gram_lds_bytes(0, 8, nb, ldk), s);
+    set_error("gram_kr: LDS image exceeds 160 KiB even at 8 samples per stage (nb=%lld)", (long long)nb);
+    return LPVS_EUNSUPPORTED;
 }
 
 int32_t launch_gram_panel(const GramPlan &pl, const double *P, int64_t ld, const double *W, double *slab,
@@ -372,12 +381,7 @@ int32_t launch_gram_panel(const GramPlan &pl, const double *P, int64_t ld, const
     a.n = pl.n; a.rows_per_chunk = pl.rows_per_chunk; a.ksplit = (int)pl.ksplit;
     LPVS_TRY(get_tiles(pl.n, s, &a.tiles, &a.ntiles));
     a.slab = slab; a.P = P; a.W = W; a.ld = ld;
-    const size_t lds = gram_lds_bytes(1, 0, 0);
-    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<1>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(gram_kernel<1>, dim3((unsigned)(pl.tiles * pl.ksplit)), dim3(NTHREADS), lds, s, a);
-    LPVS_HIP(hipGetLastError());
-    return LPVS_OK;
+    return launch_gram_t<1, 16>(a, (unsigned)(pl.tiles * pl.ksplit), gram_lds_bytes(1, 16, 0, 0), s);  // 2 x 48 KiB
 }
 
 int32_t launch_gram_reduce(const GramPlan &pl, const double *slab, double *G, int64_t ldg, hipStream_t s) {

@@ -16,6 +16,7 @@ void set_error(const char *fmt, ...);
         if (e_ != hipSuccess) {                                                              \
             lpvs::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
                             __LINE__);                                                       \
+            (void)hipGetLastError(); /* clear the sticky error state */                      \
             return e_ == hipErrorOutOfMemory ? LPVS_ENOMEM : LPVS_EDEVICE;                   \
         }                                                                                    \
     } while (0)

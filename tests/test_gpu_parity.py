@@ -89,7 +89,7 @@ def test_lpv_regressor(L, oracle, permuted, Nv):
 
 
 # ------------------------------------------------------------------ Gram (a6/a8 setup)
-@pytest.mark.parametrize("N,Nf,Nv", [(500, 12, 50), (1000, 40, 8), (4099, 24, 8), (300, 7, 3), (2500, 70, 1)])
+@pytest.mark.parametrize("N,Nf,Nv", [(500, 12, 50), (1000, 40, 8), (4099, 24, 8), (300, 7, 3), (2500, 70, 2)])
 def test_gram_lpv(L, oracle, N, Nf, Nv):
     Y, X, V = lpv_signal(N, N)
     w = 2 * np.pi * (np.arange(Nf) + 1.0) * 25 / Nf
@@ -159,7 +159,7 @@ def _device_admm(L, prob, proxg, sign=1, **kw):
     return dict(x=x, z=z, u=u, iters=it, nxz=nxz, conv=conv)
 
 
-PROXES = [("l1", 0.02), ("l0", 0.002), ("ball", 6), ("group", 0.5)]
+PROXES = [("l1", 1.0), ("l0", 5.0), ("ball", 6), ("group", 2.0)]
 
 
 @pytest.mark.parametrize("kind,param", PROXES)
@@ -173,24 +173,24 @@ def test_admm_fourier_matches_gram_oracle(L, oracle, kind, param):
         go = oracle.GroupL2(param, 2)
     else:
         gd, go = mk[kind][0](param), mk[kind][1](param)
-    ro = oracle.admm_gram(Go, bo, go, iters=300, tol=0.0, mu=0.05, history=True)
+    ro = oracle.admm_gram(Go, bo, go, iters=60, tol=0.0, mu=0.05, history=True)
     with L.Problem.fourier(y, t, f) as p:
-        rd = _device_admm(L, p, gd, iters=300, tol=0.0, μ=0.05)
-    assert rd["iters"] == ro["iters"] == 300 and not rd["conv"]
+        rd = _device_admm(L, p, gd, iters=60, tol=0.0, μ=0.05)
+    assert rd["iters"] == ro["iters"] == 60 and not rd["conv"]
     assert rel(rd["z"], ro["z"]) <= 1e-9 and rel(rd["x"], ro["x"]) <= 1e-9 and rel(rd["u"], ro["u"]) <= 1e-9
     assert np.array_equal(rd["z"] != 0, ro["z"] != 0)
-    assert abs(rd["nxz"] - ro["nxz"][-1]) <= 1e-9 * max(ro["nxz"][-1], 1e-12)
-    assert np.count_nonzero(ro["z"]) > 0
+    assert abs(rd["nxz"] - ro["nxz"][-1]) <= 1e-7 * ro["nxz"][-1] + 1e-12 * np.linalg.norm(ro["x"])
+    assert 0 < np.count_nonzero(ro["z"]) <= 12
 
 
 def test_admm_stops_at_reference_iteration(L, oracle):
     y, t, f = sines(500, 12)
     A, _ = oracle.get_fourier_regressor(t, f)
     Go, bo = oracle.gram(A, y)
-    ro = oracle.admm_gram(Go, bo, oracle.NormL1(0.05), iters=5000, tol=1e-6, mu=0.05, history=True)
-    assert 10 < ro["iters"] < 5000
+    ro = oracle.admm_gram(Go, bo, oracle.NormL1(1.0), iters=5000, tol=1e-9, mu=0.05, history=True)
+    assert 50 < ro["iters"] < 5000
     with L.Problem.fourier(y, t, f) as p:
-        p.set_prox(L.NormL1(0.05)); p.admm_init(None, μ=0.05, tol=1e-6)
+        p.set_prox(L.NormL1(1.0)); p.admm_init(None, μ=0.05, tol=1e-9)
         it1, _, c1 = p.admm_run(7)                     # chunked like the host wrapper
         it, nxz, conv = p.admm_run(5000)
         x, z, u = p.admm_get()
@@ -245,11 +245,11 @@ def test_ls_sparse_spectral_api(L, oracle, weighted, zero):
     if zero:
         f = np.concatenate([[0.0], f]); y = y + 0.7
     W = np.ones(700) if weighted else None
-    x, fr = L.ls_sparse_spectral(y, t, f, W, λ=0.05, iters=400, tol=0, μ=0.05, printerval=1000)
-    xo, _, ro = oracle.ls_sparse_spectral(y, t, f, W, lam=0.05, iters=400, tol=0, mu=0.05)
+    x, fr = L.ls_sparse_spectral(y, t, f, W, λ=1.0, iters=100, tol=0, μ=0.05, printerval=1000)
+    xo, _, ro = oracle.ls_sparse_spectral(y, t, f, W, lam=1.0, iters=100, tol=0, mu=0.05)
     assert x.shape == (len(f),) and np.array_equal(fr, f)
     assert rel(x, xo) <= 1e-6
-    assert np.array_equal(x != 0, xo != 0) and np.count_nonzero(x) >= 3
+    assert np.array_equal(x != 0, xo != 0) and 3 <= np.count_nonzero(x) <= 8
     if zero:
         assert x[0].imag == 0
 
