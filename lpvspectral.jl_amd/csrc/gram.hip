@@ -18,6 +18,7 @@
 // tiles*128*256*2*N flop (97 % useful at n = 8192: diagonal tiles are computed whole).
 #include "lpvs_internal.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace lpvs {
@@ -28,7 +29,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 128;     // tile extent along a (rows of G)
 constexpr int TN = 256;     // tile extent along b (cols of G)
-constexpr int BK_ALIGN = 32;  // sample chunks are multiples of this (every stage depth divides it)
+constexpr int BK_ALIGN = 64;  // sample chunks are multiples of this (every stage depth divides it)
 constexpr int NTHREADS = 512;  // 8 waves: 2 (a) x 4 (b), 64x64 outputs each
 
 struct GramArgs {
@@ -55,7 +56,7 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MODE, int BK>  // MODE 0 = KR, 1 = PANEL; BK = samples per stage
+template <int MODE, int BK, int VAR>  // MODE 0 = KR, 1 = PANEL; BK = samples per stage; VAR = k-loop schedule
 __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
 
@@ -173,36 +174,95 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
     __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the image
 
     const bool weighted = (MODE == 1) && a.W != nullptr;
+    // KR with 2*nb == 16: every 16-wide MFMA tile is one frequency, so all eight tiles of a lane use the
+    // same activation K[k][lane & 7] -> one LDS read per k-step instead of eight.
+    const bool one_k = (MODE == 0) && (2 * a.nb == 16) && (a.n % 16 == 0);
+
+    // raw operand fetch for k-step kk of the image `img`: the two LDS values each operand is built from
+    double rT[8], rK[8];
+    auto fetch = [&](const double *img, const double *aux, int kk) {
+        const int row = kk * 4 + lk;
+        if (MODE == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                rT[t] = img[row * rowT + offA[t]];
+                rT[4 + t] = img[row * rowT + offB[t]];
+            }
+            if (one_k) {
+                rK[0] = aux[row * rowK + offKA[0]];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    rK[t] = aux[row * rowK + offKA[t]];
+                    rK[4 + t] = aux[row * rowK + offKB[t]];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                rT[t] = img[row * rowT + offA[t]];
+                rT[4 + t] = img[row * rowT + offB[t]];
+            }
+            if (weighted) rK[0] = aux[row];
+        }
+    };
+
     for (int s = 0; s < nstages; ++s) {
         double *cur = (s & 1) ? buf1 : buf0;
         double *nxt = (s & 1) ? buf0 : buf1;
         if (s + 1 < nstages) stage_load(nxt, r_begin + (int64_t)(s + 1) * BK);
 
         const double *img = cur, *aux = cur + img_pad;
+        if (VAR == 0) {
 #pragma unroll 2
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const int row = kk * 4 + lk;
-            double opA[4], opB[4];
-            if (MODE == 0) {
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                fetch(img, aux, kk);
+                double opA[4], opB[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    opA[t] = img[row * rowT + offA[t]] * aux[row * rowK + offKA[t]];
-                    opB[t] = img[row * rowT + offB[t]] * aux[row * rowK + offKB[t]];
+                    if (MODE == 0) {
+                        opA[t] = rT[t] * (one_k ? rK[0] : rK[t]);
+                        opB[t] = rT[4 + t] * (one_k ? rK[0] : rK[4 + t]);
+                    } else {
+                        opA[t] = weighted ? rT[t] * rK[0] : rT[t];
+                        opB[t] = rT[4 + t];
+                    }
                 }
-            } else {
-                const double wv = weighted ? aux[row] : 1.0;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const double av = img[row * rowT + offA[t]];
-                    opA[t] = weighted ? av * wv : av;
-                    opB[t] = img[row * rowT + offB[t]];
-                }
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
             }
+        } else {
+            // software pipeline: the LDS reads of k-step kk+1 are issued before the 16 MFMAs of k-step kk
+            // and land while the matrix pipe works (sched_barrier pins that order)
+            fetch(img, aux, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double opA[4], opB[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) {
+                    if (MODE == 0) {
+                        opA[t] = rT[t] * (one_k ? rK[0] : rK[t]);
+                        opB[t] = rT[4 + t] * (one_k ? rK[0] : rK[4 + t]);
+                    } else {
+                        opA[t] = weighted ? rT[t] * rK[0] : rT[t];
+                        opB[t] = rT[4 + t];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < BK / 4) fetch(img, aux, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+                if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();  // next image landed (vmcnt(0)) and everyone is done with `cur`
     }
@@ -349,13 +409,19 @@ static size_t gram_lds_bytes(int mode, int BK, int64_t nb, int64_t ldk) {
     return sizeof(double) * 2 * (size_t)(img_pad + aux_pad);
 }
 
-template <int MODE, int BK>
+template <int MODE, int BK, int VAR = 1>
 static int32_t launch_gram_t(const GramArgs &a, unsigned grid, size_t lds, hipStream_t s) {
-    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<MODE, BK>),
+    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<MODE, BK, VAR>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gram_kernel<MODE, BK>), dim3(grid), dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL((gram_kernel<MODE, BK, VAR>), dim3(grid), dim3(NTHREADS), lds, s, a);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
+}
+
+// development knob (A/B runs of k-loop schedules in one process): LPVS_GRAM_VARIANT=<bk><var>, e.g. 320, 321, 641
+static int gram_variant() {
+    const char *e = getenv("LPVS_GRAM_VARIANT");
+    return e ? atoi(e) : -1;
 }
 
 constexpr size_t kLdsBudget = 160 * 1024;
@@ -368,6 +434,15 @@ int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const d
     a.slab = slab; a.T = T; a.K = K; a.Nf = (int)Nf; a.nb = (int)nb; a.ldk = (int)ldk;
     const unsigned grid = (unsigned)(pl.tiles * pl.ksplit);
     // deepest stage whose two LDS images fit (few basis functions -> many frequencies per tile)
+    switch (gram_variant()) {
+    case 320: return launch_gram_t<0, 32, 0>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
+    case 321: return launch_gram_t<0, 32, 1>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
+    case 322: return launch_gram_t<0, 32, 2>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
+    case 640: return launch_gram_t<0, 64, 0>(a, grid, gram_lds_bytes(0, 64, nb, ldk), s);
+    case 641: return launch_gram_t<0, 64, 1>(a, grid, gram_lds_bytes(0, 64, nb, ldk), s);
+    case 642: return launch_gram_t<0, 64, 2>(a, grid, gram_lds_bytes(0, 64, nb, ldk), s);
+    default: break;
+    }
     if (gram_lds_bytes(0, 32, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 32>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
     if (gram_lds_bytes(0, 16, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 16>(a, grid, gram_lds_bytes(0, 16, nb, ldk), s);
     if (gram_lds_bytes(0, 8, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 8>(a, grid, gram_lds_bytes(0, 8, nb, ldk), s);

@@ -14,8 +14,10 @@ struct Stamp { unsigned long long cyc, rt; };
 template <int NACC, int MODE>  // MODE 0: mfma f64, 1: mfma f32, 2: v_fma_f64
 __global__ void __launch_bounds__(256) kern(double *out, Stamp *st, int iters, double a0, double b0) {
     double a = a0 + threadIdx.x * 1e-3, b = b0 - threadIdx.x * 1e-3;
-    f64x4 acc[NACC]; f32x4 accf[NACC]; double accv[NACC * 4];
-    for (int i = 0; i < NACC; ++i) { acc[i] = (f64x4){0, 0, 0, 0}; accf[i] = (f32x4){0, 0, 0, 0}; for (int j = 0; j < 4; ++j) accv[4*i+j] = i + j; }
+    f64x4 acc[MODE == 0 ? NACC : 1]; f32x4 accf[MODE == 1 ? NACC : 1]; double accv[MODE == 2 ? NACC * 4 : 1];
+    for (int i = 0; i < (MODE == 0 ? NACC : 1); ++i) acc[i] = (f64x4){0, 0, 0, 0};
+    for (int i = 0; i < (MODE == 1 ? NACC : 1); ++i) accf[i] = (f32x4){0, 0, 0, 0};
+    for (int i = 0; i < (MODE == 2 ? NACC * 4 : 1); ++i) accv[i] = i;
     float af = (float)a, bf = (float)b;
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
@@ -23,14 +25,16 @@ __global__ void __launch_bounds__(256) kern(double *out, Stamp *st, int iters, d
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int i = 0; i < NACC; ++i) {
-                if (MODE == 0) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-                else if (MODE == 1) accf[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, accf[i], 0, 0, 0);
+                if constexpr (MODE == 0) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+                else if constexpr (MODE == 1) accf[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, accf[i], 0, 0, 0);
                 else { for (int j = 0; j < 4; ++j) accv[4*i+j] = fma(a, accv[4*i+j], b); }
             }
     }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0;
-    for (int i = 0; i < NACC; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j] + accf[i][j] + accv[4*i+j];
+    for (int i = 0; i < (MODE == 0 ? NACC : 1); ++i) for (int j = 0; j < 4; ++j) s += acc[i][j];
+    for (int i = 0; i < (MODE == 1 ? NACC : 1); ++i) for (int j = 0; j < 4; ++j) s += accf[i][j];
+    for (int i = 0; i < (MODE == 2 ? NACC * 4 : 1); ++i) s += accv[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) { st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c1 - c0, r1 - r0}; }
 }
@@ -59,14 +63,14 @@ void run(const char *name, int wg_per_cu, int iters, double *o, Stamp *st) {
 int main() {
     double *o; Stamp *st;
     (void)hipMalloc(&o, 8 * 256 * 4096); (void)hipMalloc(&st, sizeof(Stamp) * 4096 * 4);
-    for (int w = 1; w <= 2; ++w) {
+    for (int w = 1; w <= 4; ++w) {
+        run<1, 0>("mfma_f64", w, 8000, o, st);
+        run<2, 0>("mfma_f64", w, 8000, o, st);
         run<4, 0>("mfma_f64", w, 4000, o, st);
         run<8, 0>("mfma_f64", w, 2000, o, st);
-        run<16, 0>("mfma_f64", w, 1000, o, st);
+        if (w <= 2) run<16, 0>("mfma_f64", w, 1000, o, st);
         run<4, 1>("mfma_f32", w, 4000, o, st);
-        run<8, 1>("mfma_f32", w, 2000, o, st);
         run<4, 2>("v_fma_f64", w, 4000, o, st);
     }
-    run<4, 2>("v_fma_f64", 4, 4000, o, st);
     return 0;
 }
