@@ -118,91 +118,129 @@ __device__ void topr_threshold(const double *v, int64_t n, int64_t r, unsigned l
     *keep_equal = remaining;
 }
 
+// Elements are processed in coalesced passes of 1024 threads x EPT elements: all loads of a pass are
+// issued before any store (no aliasing-serialised round trips); group norms go through LDS.
+constexpr int EPT = 8;                 // elements per thread per pass
+constexpr int PASS = 1024 * EPT;       // 8192 elements per pass
+
 __global__ void __launch_bounds__(1024)
 admm_prox_kernel(AdmmParams p) {
     __shared__ double sh[16];
     __shared__ unsigned int hist[256];
     __shared__ long long shll[2];
     __shared__ int scan[1024];
+    __shared__ double sq[PASS];        // v^2 of the current pass (group prox)
+    __shared__ double gscale[PASS];    // per-group scale of the current pass
     if (p.status->converged) return;
     const int64_t n = p.n;
     const double mu = p.mu;
+    const double *__restrict__ X = p.x;
+    const double *__restrict__ B = p.b;
+    double *__restrict__ Z = p.z;
+    double *__restrict__ U = p.u;
+    double *__restrict__ R = p.rhs;
     double ss = 0;  // sum (x-z)^2 over this thread's elements
 
-    auto finish = [&](int64_t i, double xi, double ui, double zi) {
+    auto finish = [&](int64_t i, double xi, double ui, double bi, double zi) {
         const double d = xi - zi;              // tmp = x - z            src/lasso.jl:154
         const double un = ui + d;              // u += tmp               src/lasso.jl:155
-        p.z[i] = zi; p.u[i] = un;
-        p.rhs[i] = p.b[i] + (zi - un) / mu;    // next x-update: b + (z-u)/mu
+        Z[i] = zi; U[i] = un;
+        R[i] = bi + (zi - un) / mu;            // next x-update: b + (z-u)/mu
         ss = fma(d, d, ss);
     };
 
-    if (p.prox_kind == LPVS_PROX_L1) {
-        const double gl = mu * p.prox_param;
-        for (int64_t i = threadIdx.x; i < n; i += 1024) {
-            const double xi = p.x[i], ui = p.u[i], v = xi + ui;
-            const double zi = v + (v <= -gl ? gl : (v >= gl ? -gl : -v));
-            finish(i, xi, ui, zi);
-        }
-    } else if (p.prox_kind == LPVS_PROX_L0) {
-        const double th = sqrt(2.0 * mu * p.prox_param);
-        for (int64_t i = threadIdx.x; i < n; i += 1024) {
-            const double xi = p.x[i], ui = p.u[i], v = xi + ui;
-            finish(i, xi, ui, fabs(v) > th ? v : 0.0);
-        }
-    } else if (p.prox_kind == LPVS_PROX_GROUP_L2) {
+    const int kind = p.prox_kind;
+    double thr_l1 = mu * p.prox_param, thr_l0 = sqrt(2.0 * mu * p.prox_param);
+    unsigned long long ball_thr = 0; long long ball_keep_eq = 0, ball_r = (long long)p.prox_param;
+    double *vbuf = p.scratch;
+    if (kind == LPVS_PROX_BALL_L0 && ball_r > 0 && ball_r < n) {
+        for (int64_t i = threadIdx.x; i < n; i += 1024) vbuf[i] = X[i] + U[i];
+        __syncthreads();
+        topr_threshold(vbuf, n, ball_r, &ball_thr, &ball_keep_eq, hist, shll);
+    }
+    long long eq_seen = 0;  // equal-key elements at lower indices (uniform across threads)
+
+    if (kind == LPVS_PROX_GROUP_L2) {
         const int64_t gl = p.group_len, ng = n / gl;
         const double lm = p.prox_param * mu;
-        for (int64_t g = threadIdx.x; g < ng; g += 1024) {
-            double s2 = 0;
-            for (int64_t q = 0; q < gl; ++q) { const double v = p.x[g * gl + q] + p.u[g * gl + q]; s2 += v * v; }
-            double scale = 1.0 - lm / sqrt(s2);   // s2 == 0 -> -inf -> 0
-            if (!(scale > 0)) scale = 0.0;
-            for (int64_t q = 0; q < gl; ++q) {
-                const int64_t i = g * gl + q;
-                const double xi = p.x[i], ui = p.u[i];
-                finish(i, xi, ui, scale * (xi + ui));
+        const int64_t gpp = PASS / gl;                         // whole groups per pass
+        for (int64_t g0 = 0; g0 < ng; g0 += gpp) {
+            const int64_t gcount = (ng - g0 < gpp) ? ng - g0 : gpp;
+            const int64_t c0 = g0 * gl, cnt = gcount * gl;
+            double xv[EPT], uv[EPT], bv[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int64_t e = threadIdx.x + 1024 * k;
+                const bool ok = e < cnt;
+                xv[k] = ok ? X[c0 + e] : 0.0; uv[k] = ok ? U[c0 + e] : 0.0; bv[k] = ok ? B[c0 + e] : 0.0;
             }
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int64_t e = threadIdx.x + 1024 * k;
+                const double v = xv[k] + uv[k];
+                if (e < cnt) sq[e] = v * v;
+            }
+            __syncthreads();
+            for (int64_t g = threadIdx.x; g < gcount; g += 1024) {
+                double s2 = 0;
+                for (int64_t q = 0; q < gl; ++q) s2 += sq[g * gl + q];   // sequential, as norm() on a short slice
+                double scale = 1.0 - lm / sqrt(s2);                    // s2 == 0 -> -inf -> 0
+                if (!(scale > 0)) scale = 0.0;
+                gscale[g] = scale;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int64_t e = threadIdx.x + 1024 * k;
+                if (e < cnt) finish(c0 + e, xv[k], uv[k], bv[k], gscale[e / gl] * (xv[k] + uv[k]));
+            }
+            __syncthreads();
         }
-        for (int64_t i = ng * gl + threadIdx.x; i < n; i += 1024) {  // entries outside every slice: prox leaves z
-            const double xi = p.x[i], ui = p.u[i];
-            finish(i, xi, ui, p.z[i]);
-        }
-    } else {  // LPVS_PROX_BALL_L0
-        double *v = p.scratch;
-        for (int64_t i = threadIdx.x; i < n; i += 1024) v[i] = p.x[i] + p.u[i];
-        __syncthreads();
-        long long r = (long long)p.prox_param;
-        if (r >= n) {
-            for (int64_t i = threadIdx.x; i < n; i += 1024) finish(i, p.x[i], p.u[i], v[i]);
-        } else if (r <= 0) {
-            for (int64_t i = threadIdx.x; i < n; i += 1024) finish(i, p.x[i], p.u[i], 0.0);
-        } else {
-            unsigned long long thr; long long keep_eq;
-            topr_threshold(v, n, r, &thr, &keep_eq, hist, shll);
-            long long eq_seen = 0;  // equal-key elements at lower indices (uniform across threads)
-            for (int64_t base = 0; base < n; base += 1024) {
-                const int64_t i = base + threadIdx.x;
-                const bool in = i < n;
-                const unsigned long long k = in ? abs_key(v[i]) : 0ull;
-                const int iseq = in && k == thr;
-                // inclusive block scan of iseq (Hillis-Steele in LDS; n/1024 rounds only)
-                scan[threadIdx.x] = iseq;
-                __syncthreads();
-                for (int o = 1; o < 1024; o <<= 1) {
-                    const int t = threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+        for (int64_t i = ng * gl + threadIdx.x; i < n; i += 1024)  // entries outside every slice: prox! leaves z
+            finish(i, X[i], U[i], B[i], Z[i]);
+    } else {
+        for (int64_t c0 = 0; c0 < n; c0 += PASS) {
+            double xv[EPT], uv[EPT], bv[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int64_t i = c0 + threadIdx.x + 1024 * k;
+                const bool ok = i < n;
+                xv[k] = ok ? X[i] : 0.0; uv[k] = ok ? U[i] : 0.0; bv[k] = ok ? B[i] : 0.0;
+            }
+            if (kind == LPVS_PROX_L1 || kind == LPVS_PROX_L0 || ball_r <= 0 || ball_r >= n) {
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    const int64_t i = c0 + threadIdx.x + 1024 * k;
+                    if (i >= n) continue;
+                    const double v = xv[k] + uv[k];
+                    double zi;
+                    if (kind == LPVS_PROX_L1) zi = v + (v <= -thr_l1 ? thr_l1 : (v >= thr_l1 ? -thr_l1 : -v));
+                    else if (kind == LPVS_PROX_L0) zi = fabs(v) > thr_l0 ? v : 0.0;
+                    else zi = ball_r >= n ? v : 0.0;
+                    finish(i, xv[k], uv[k], bv[k], zi);
+                }
+            } else {  // IndBallL0: keys > threshold, plus the first keep_eq equal keys in index order
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    const int64_t i = c0 + threadIdx.x + 1024 * k;
+                    const bool in = i < n;
+                    const double v = xv[k] + uv[k];
+                    const unsigned long long key = in ? abs_key(v) : 0ull;
+                    const int iseq = in && key == ball_thr;
+                    scan[threadIdx.x] = iseq;
                     __syncthreads();
-                    scan[threadIdx.x] += t;
+                    for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan
+                        const int t = (int)threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+                        __syncthreads();
+                        scan[threadIdx.x] += t;
+                        __syncthreads();
+                    }
+                    const long long rank_eq = eq_seen + scan[threadIdx.x];
+                    const long long tot = scan[1023];
+                    if (in) finish(i, xv[k], uv[k], bv[k], (key > ball_thr || (iseq && rank_eq <= ball_keep_eq)) ? v : 0.0);
+                    eq_seen += tot;
                     __syncthreads();
                 }
-                const long long rank_eq = eq_seen + scan[threadIdx.x];  // 1-based rank among equals
-                const long long tot = scan[1023];
-                if (in) {
-                    const bool keep = k > thr || (iseq && rank_eq <= keep_eq);
-                    finish(i, p.x[i], p.u[i], keep ? v[i] : 0.0);
-                }
-                eq_seen += tot;
-                __syncthreads();
             }
         }
     }
@@ -216,12 +254,240 @@ admm_prox_kernel(AdmmParams p) {
     }
 }
 
+// ---- symmetric mat-vec on the lower-triangle 128x128 tiles of M (np^2*4 bytes instead of np^2*8) -------
+// M is re-stored tile-packed: Mp[t][128][128], t = I(I+1)/2 + J, I >= J, so a workgroup streams one
+// contiguous 128 KiB tile.  Per tile:  part1[t][i] = sum_j T[i][j] r[J*128+j]      (rows)
+//                                      part2[t][j] = sum_i T[i][j] r[I*128+i]      (transpose, I != J)
+// Each wave holds 32 rows (16 B per lane per row, all 32 loads in flight); the 32 row sums are reduced
+// across the 64 lanes by a halving butterfly (32 shuffles per wave instead of 32*6).
+constexpr int TS = 128;
+
+__device__ __forceinline__ void tile_index(int t, int &I, int &J) {
+    I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    while (I * (I + 1) / 2 > t) --I;
+    J = t - I * (I + 1) / 2;
+}
+
+__global__ void __launch_bounds__(256)
+pack_tiles_kernel(const double *__restrict__ M, int64_t np, double *__restrict__ Mp) {
+    int I, J;
+    tile_index(blockIdx.x, I, J);
+    const double2 *src = reinterpret_cast<const double2 *>(M + (int64_t)I * TS * np + (int64_t)J * TS);
+    double2 *dst = reinterpret_cast<double2 *>(Mp + (int64_t)blockIdx.x * TS * TS);
+    for (int e = threadIdx.x; e < TS * TS / 2; e += 256) {
+        const int r = e / (TS / 2), c = e % (TS / 2);
+        dst[e] = src[(int64_t)r * (np / 2) + c];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+symv_tile_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs, double *__restrict__ part1,
+                 double *__restrict__ part2, const AdmmStatus *status) {
+    if (status != nullptr && status->converged) return;
+    __shared__ double sI[TS], sJ[TS], sT[4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double2 *base = reinterpret_cast<const double2 *>(Mp + (int64_t)t * TS * TS + wave * 32 * TS) + lane;
+    double2 m[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) m[r] = base[r * (TS / 2)];
+    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+    __syncthreads();
+    const double rj0 = sJ[2 * lane], rj1 = sJ[2 * lane + 1];
+    double t0 = 0, t1 = 0, v[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const double ri = sI[wave * 32 + r];
+        t0 = fma(m[r].x, ri, t0);
+        t1 = fma(m[r].y, ri, t1);
+        v[r] = fma(m[r].x, rj0, m[r].y * rj1);
+    }
+    // halving butterfly: after the step with mask w a lane keeps the rows whose bit matches its own
+#pragma unroll
+    for (int w = 32, cnt = 16; w >= 2; w >>= 1, cnt >>= 1) {
+        const bool hi = (lane & w) != 0;
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const double send = hi ? v[k] : v[k + cnt];
+            const double keep = hi ? v[k + cnt] : v[k];
+            v[k] = keep + __shfl_xor(send, w, 64);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1, 64);
+    if ((lane & 1) == 0) {
+        const int row = ((lane & 32) ? 16 : 0) + ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
+        part1[(int64_t)t * TS + wave * 32 + row] = v[0];
+    }
+    if (I != J) {
+        sT[wave][2 * lane] = t0; sT[wave][2 * lane + 1] = t1;
+        __syncthreads();
+        if (threadIdx.x < TS)
+            part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+    }
+}
+
+// x[I*128+i] = sum_{J<=I} part1[(I,J)][i] + sum_{K>I} part2[(K,I)][i]; both sums in fixed order.
+// 256 threads: 0..127 walk part1, 128..255 walk part2, 8 independent loads in flight each.
+__device__ __forceinline__ double gather_x(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, int I,
+                                           double *sh /*[128]*/) {
+    const int i = threadIdx.x & 127, half = threadIdx.x >> 7;
+    double s = 0;
+    if (half == 0) {
+        const double *p = part1 + ((int64_t)I * (I + 1) / 2) * TS + i;
+        int J = 0;
+        for (; J + 8 <= I + 1; J += 8) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = p[(int64_t)(J + q) * TS];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += a[q];
+        }
+        for (; J <= I; ++J) s += p[(int64_t)J * TS];
+    } else {
+        int K = I + 1;
+        for (; K + 8 <= nblk; K += 8) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = part2[((int64_t)(K + q) * (K + q + 1) / 2 + I) * TS + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += a[q];
+        }
+        for (; K < nblk; ++K) s += part2[((int64_t)K * (K + 1) / 2 + I) * TS + i];
+        sh[i] = s;
+    }
+    __syncthreads();
+    return half == 0 ? s + sh[i] : 0.0;
+}
+
+__global__ void __launch_bounds__(256)
+symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, double *__restrict__ x,
+                   const AdmmStatus *status) {
+    if (status != nullptr && status->converged) return;
+    __shared__ double sh[TS];
+    const double s = gather_x(part1, part2, nblk, blockIdx.x, sh);
+    if (threadIdx.x < TS) x[(int64_t)blockIdx.x * TS + threadIdx.x] = s;
+}
+
+// ---- fused: gather x from the tile partials + prox_g + dual update + next rhs, one workgroup per
+// 128-row block; ||x-z||^2 is combined by the last-arriving workgroup in fixed block order (deterministic).
+// Valid for element-wise prox (L1, L0) and for group prox with 128 % group_len == 0, n % group_len == 0.
+__global__ void __launch_bounds__(256)
+admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1, const double *__restrict__ part2, int nblk,
+                         double *__restrict__ blocknorm, unsigned int *__restrict__ ticket) {
+    if (p.status->converged) return;
+    __shared__ double sh[TS], sq[TS], gs[TS];
+    __shared__ int last;
+    const int I = blockIdx.x, i = threadIdx.x & 127;
+    const int64_t gi = (int64_t)I * TS + i;
+    const double xs = gather_x(part1, part2, nblk, I, sh);
+    const bool row = threadIdx.x < TS, ok = row && gi < p.n;
+    const double xi = xs, ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;
+    const double v = xi + ui;
+    double zi = 0.0, d2 = 0.0;
+    if (p.prox_kind == LPVS_PROX_L1) {
+        const double gl = p.mu * p.prox_param;
+        zi = v + (v <= -gl ? gl : (v >= gl ? -gl : -v));
+    } else if (p.prox_kind == LPVS_PROX_L0) {
+        zi = fabs(v) > sqrt(2.0 * p.mu * p.prox_param) ? v : 0.0;
+    } else {  // group: block soft-threshold, norms through LDS
+        const int gl = (int)p.group_len;
+        if (row) sq[i] = v * v;
+        __syncthreads();
+        if (threadIdx.x < TS / gl) {
+            double s2 = 0;
+            for (int q = 0; q < gl; ++q) s2 += sq[threadIdx.x * gl + q];   // sequential, as norm() on the slice
+            double scale = 1.0 - p.prox_param * p.mu / sqrt(s2);           // s2 == 0 -> -inf -> 0
+            if (!(scale > 0)) scale = 0.0;
+            gs[threadIdx.x] = scale;
+        }
+        __syncthreads();
+        if (row) zi = gs[i / gl] * v;
+    }
+    if (row) {
+        if (!ok) zi = 0.0;
+        const double d = xi - zi, un = ui + d;     // src/lasso.jl:154-155
+        p.x[gi] = xi; p.z[gi] = zi; p.u[gi] = un;
+        p.rhs[gi] = ok ? bi + (zi - un) / p.mu : 0.0;
+        d2 = ok ? d * d : 0.0;
+    }
+    // block sum of d2: the two row waves reduce by shuffles (fixed pattern -> reproducible)
+    const double wsum = wave_sum(d2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&blocknorm[I], sh[0] + sh[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (tk == (unsigned)nblk - 1);
+    }
+    __syncthreads();
+    if (last) {  // every other workgroup has published its block norm
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        double part = 0;  // thread q sums blocks q, q+256, ... ; then a fixed-order combine
+        for (int q = threadIdx.x; q < nblk; q += 256) part += __hip_atomic_load(&blocknorm[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double w = wave_sum(part);
+        if ((threadIdx.x & 63) == 0) sq[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double nxz = sqrt(((sq[0] + sq[1]) + sq[2]) + sq[3]);   // norm(tmp)   src/lasso.jl:157
+            p.status->iters += 1;
+            p.status->nxz = nxz;
+            if (nxz < p.tol) p.status->converged = 1;                     //             src/lasso.jl:164
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 }  // namespace
 
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s) {
     hipLaunchKernelGGL(admm_init_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
+}
+
+size_t symv_part_doubles(int64_t np) {
+    const int64_t nblk = np / TS;
+    return (size_t)(nblk * (nblk + 1) / 2) * TS * 2 + (size_t)nblk + 16;   // part1, part2, block norms, ticket
+}
+size_t symv_packed_doubles(int64_t np) {
+    const int64_t nblk = np / TS;
+    return (size_t)(nblk * (nblk + 1) / 2) * TS * TS;
+}
+
+int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s) {
+    const int nblk = (int)(np / TS);
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, M, np, Mp);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+static bool fused_ok(const AdmmParams &p) {
+    if (p.prox_kind == LPVS_PROX_L1 || p.prox_kind == LPVS_PROX_L0) return true;
+    return p.prox_kind == LPVS_PROX_GROUP_L2 && p.group_len <= TS && TS % p.group_len == 0 && p.n % p.group_len == 0;
+}
+
+// one ADMM iteration on the packed symmetric form
+static void launch_iteration_sym(const AdmmParams &p, hipStream_t s) {
+    const int nblk = (int)(p.np / TS);
+    const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
+    double *part1 = p.part, *part2 = p.part + (size_t)ntiles * TS;
+    double *blocknorm = part2 + (size_t)ntiles * TS;
+    unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + nblk);
+    hipLaunchKernelGGL(symv_tile_kernel, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, part1, part2, p.status);
+    if (fused_ok(p)) {
+        hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p, part1, part2, nblk, blocknorm, ticket);
+    } else {
+        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, s, part1, part2, nblk, p.x, p.status);
+        hipLaunchKernelGGL(admm_prox_kernel, dim3(1), dim3(1024), 0, s, p);
+    }
 }
 
 static void launch_symv_raw(const double *M, int64_t np, const double *rhs, double *x, const AdmmStatus *st,
@@ -239,9 +505,14 @@ int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, h
 }
 
 int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s) {
+    const bool sym = p.part != nullptr && p.Mp != nullptr;
     for (int64_t i = 0; i < iters; ++i) {
-        launch_symv_raw(p.M, p.np, p.rhs, p.x, p.status, s);
-        hipLaunchKernelGGL(admm_prox_kernel, dim3(1), dim3(1024), 0, s, p);
+        if (sym) {
+            launch_iteration_sym(p, s);
+        } else {
+            launch_symv_raw(p.M, p.np, p.rhs, p.x, p.status, s);
+            hipLaunchKernelGGL(admm_prox_kernel, dim3(1), dim3(1024), 0, s, p);
+        }
     }
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;

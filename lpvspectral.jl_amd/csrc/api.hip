@@ -137,7 +137,7 @@ struct lpvs_problem {
     int device = 0;
     hipStream_t stream = nullptr;
     int64_t n = 0, np = 0, N = 0, Nf = 0, nb = 0, zerofreq = 0;
-    DevBuf G, b, M, x, z, u, rhs, bs, scratch, status, work, istat;
+    DevBuf G, b, M, x, z, u, rhs, bs, scratch, status, work, istat, part, Mp;
     bool M_valid = false; double M_shift = 0;
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
@@ -178,6 +178,7 @@ int32_t alloc_state(lpvs_problem *h) {
     LPVS_TRY(h->x.alloc(v)); LPVS_TRY(h->z.alloc(v)); LPVS_TRY(h->u.alloc(v)); LPVS_TRY(h->rhs.alloc(v));
     LPVS_TRY(h->bs.alloc(v)); LPVS_TRY(h->scratch.alloc(2 * v));
     LPVS_TRY(h->status.alloc(sizeof(AdmmStatus))); LPVS_TRY(h->istat.alloc(sizeof(int)));
+    LPVS_TRY(h->part.alloc(sizeof(double) * symv_part_doubles(h->np)));
     LPVS_HIP(hipMemsetAsync(h->x.p, 0, v, h->stream));
     LPVS_HIP(hipMemsetAsync(h->status.p, 0, sizeof(AdmmStatus), h->stream));
     return LPVS_OK;
@@ -491,6 +492,7 @@ int32_t lpvs_problem_set_prox(lpvs_problem *h, int32_t kind, double param, int64
     if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
     if (kind < LPVS_PROX_L1 || kind > LPVS_PROX_GROUP_L2) { set_error("unknown prox kind %d", kind); return LPVS_EUNSUPPORTED; }
     if (kind == LPVS_PROX_GROUP_L2 && group_len <= 0) { set_error("group_len must be positive"); return LPVS_EARGUMENT; }
+    if (kind == LPVS_PROX_GROUP_L2 && group_len > 8192) { set_error("group_len > 8192 is not supported by the device prox"); return LPVS_EUNSUPPORTED; }
     h->prox_kind = kind; h->prox_param = param; h->group_len = group_len;
     return LPVS_OK;
 }
@@ -502,7 +504,13 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     if (linear_sign != 1 && linear_sign != -1) { set_error("linear_sign must be +1 or -1"); return LPVS_EARGUMENT; }
     LPVS_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
+    const bool had_M = h->M_valid && h->M_shift == 1.0 / mu && h->Mp.p != nullptr;
     LPVS_TRY(factorize(h, 1.0 / mu));
+    if (h->np >= kSymmetricMinNp && !had_M) {   // tile-packed lower triangle for the half-traffic mat-vec
+        if (!h->Mp.p) LPVS_TRY(h->Mp.alloc(sizeof(double) * symv_packed_doubles(h->np)));
+        LPVS_TRY(launch_pack_tiles(h->M.as<double>(), h->np, h->Mp.as<double>(), s));
+    }
+    LPVS_HIP(hipMemsetAsync(h->part.p, 0, h->part.bytes, s));   // zero the ticket / block norms
     h->mu = mu; h->tol = tol; h->sign = linear_sign;
     const size_t v = sizeof(double) * (size_t)h->np;
     if (x0) { LPVS_TRY(copy_to_device(h->x.p, x0, sizeof(double) * (size_t)h->n, s)); }
@@ -514,7 +522,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
     AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
                  h->rhs.as<double>(), mu, tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
-                 h->scratch.as<double>()};
+                 h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr};
     LPVS_TRY(launch_admm_init(p, s));
     LPVS_HIP(hipStreamSynchronize(s));
     h->inited = true;
@@ -528,7 +536,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     hipStream_t s = h->stream;
     AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
                  h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
-                 h->scratch.as<double>()};
+                 h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr};
     AdmmStatus st0{}, st{};
     LPVS_HIP(hipMemcpyAsync(&st0, h->status.p, sizeof(st0), hipMemcpyDeviceToHost, s));
     LPVS_HIP(hipStreamSynchronize(s));

@@ -127,7 +127,13 @@ struct AdmmParams {
     int64_t group_len;
     AdmmStatus *status;
     double *scratch;   // >= 2*np doubles (top-r selection keys)
+    double *part;      // symv_part_doubles(np) doubles of tile partials, or nullptr (full mat-vec)
+    const double *Mp;  // tile-packed lower triangle of M (symv_packed_doubles(np)), or nullptr
 };
+size_t symv_part_doubles(int64_t np);
+size_t symv_packed_doubles(int64_t np);
+int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s);
+constexpr int64_t kSymmetricMinNp = 2048;  // below this the iteration is launch-latency bound: plain mat-vec
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s);              // z=x, u=0, rhs, status=0
 int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s);
 // x = Minv * rhs_in (one GEMV; ridge solves)
