@@ -357,7 +357,8 @@ int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const doub
     hipStream_t s = h->stream;
     const int64_t nb = coulomb ? 2 * Nv : Nv;
     h->kind = 1; h->N = N; h->Nf = Nf; h->nb = nb; h->n = 2 * Nf * nb; h->np = round_up(h->n, 128);
-    const GramPlan pl = make_gram_plan(h->n, N);
+    const bool krs = gram_krs_fits(nb);   // symmetric-pair form unless the pair table does not fit LDS
+    const GramPlan pl = krs ? make_gram_plan_pairs(Nf, nb, N) : make_gram_plan(h->n, N);
     const int64_t Npad = pl.ksplit * pl.rows_per_chunk;
 
     DevArg dy, dX, dV, dw;
@@ -368,17 +369,24 @@ int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const doub
     LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
     LPVS_TRY(alloc_state(h));
 
-    DevBuf T, K, slab, scr; int64_t ldk;
+    DevBuf T, K, KK, G3, slab, scr; int64_t ldk;
     LPVS_HIP(hipEventRecord(h->ev[0].a, s));
     LPVS_TRY(build_lpv_tables(dX.p, dV.p, N, Npad, dw.p, Nf, Nv, normalize, coulomb, T, K, &ldk, s));
+    if (krs) {
+        LPVS_TRY(KK.alloc(sizeof(double) * (size_t)Npad * (size_t)pl.pairs));
+        LPVS_TRY(launch_pair_table(K.as<double>(), ldk, nb, Npad, KK.as<double>(), s));
+    }
     LPVS_HIP(hipEventRecord(h->ev[0].b, s));
     LPVS_TRY(slab.alloc(pl.slab_bytes));
     LPVS_TRY(scr.alloc(rhs_scratch_bytes(N, h->n)));
+    if (krs) LPVS_TRY(G3.alloc(sizeof(double) * (size_t)pl.np2 * (size_t)(pl.np2 * pl.pairs)));
     LPVS_HIP(hipEventRecord(h->ev[1].a, s));
-    LPVS_TRY(launch_gram_kr(pl, T.as<double2>(), Nf, K.as<double>(), ldk, nb, slab.as<double>(), s));
+    if (krs) LPVS_TRY(launch_gram_krs(pl, T.as<double2>(), Nf, KK.as<double>(), nb, slab.as<double>(), s));
+    else LPVS_TRY(launch_gram_kr(pl, T.as<double2>(), Nf, K.as<double>(), ldk, nb, slab.as<double>(), s));
     LPVS_HIP(hipEventRecord(h->ev[1].b, s));
     LPVS_HIP(hipEventRecord(h->ev[2].a, s));
-    LPVS_TRY(launch_gram_reduce(pl, slab.as<double>(), h->G.as<double>(), h->np, s));
+    if (krs) LPVS_TRY(launch_gram_reduce_krs(pl, slab.as<double>(), nb, G3.as<double>(), h->G.as<double>(), h->np, s));
+    else LPVS_TRY(launch_gram_reduce(pl, slab.as<double>(), h->G.as<double>(), h->np, s));
     LPVS_TRY(launch_rhs_kr(T.as<double2>(), Nf, K.as<double>(), ldk, nb, dy.p, N, h->b.as<double>(), scr.as<double>(), scr.bytes, s));
     LPVS_HIP(hipEventRecord(h->ev[2].b, s));
     LPVS_HIP(hipStreamSynchronize(s));

@@ -7,6 +7,12 @@
 //         trig value and one activation from LDS and multiplies them into its MFMA operand, so
 //         a 128x256 output tile stages only (24 freqs x 16 B + 9 x 8 B) per sample instead of
 //         384 x 8 B.
+//   KRS   (LPV, symmetric-pair form): K_j K_j' is symmetric in (j,j'), so
+//         G[(f,c,j),(f',c',j')] = sum_k T[k][p] * (T[k][p'] * KK[k][{j,j'}]),  p=(f,c), KK = nb(nb+1)/2 pair
+//         products.  Rows of the contraction are the 2Nf trig columns, columns are (p', pair) -> the same
+//         MFMA core computes G3[p][p'*P+pair] for p' <= p with 2nb/(nb+1) (1.78x at nb=8) fewer flops than
+//         the n x n lower triangle; an expansion kernel scatters G3 into G.  Rounding differs from KR only
+//         in the grouping of each 4-factor product (<= 3 ulp per term).
 //   PANEL (Fourier, src/lsfft.jl:26-49): Phi[k][c] = P[k][c], a k-major panel staged as is,
 //         with the optional row weight of A' diag(W) A (src/lasso.jl:119) applied to the A operand.
 // Staging is LDS-DMA (global_load_lds_dwordx4, dense lane-linear LDS images, two buffers, one
@@ -42,8 +48,10 @@ struct GramArgs {
     double *slab;          // [tile][chunk][TM][TN]
     // KR
     const double2 *T;      // [Npad][Nf]
-    const double *K;       // [Npad][ldk], K[.][nb..ldk) == 0
+    const double *K;       // KR: [Npad][ldk], K[.][nb..ldk) == 0;  KRS: pair products KK[Npad][ldk], ldk = P
     int Nf, nb, ldk;
+    int npair;             // KRS: nb(nb+1)/2 activation pairs
+    int64_t nq;            // KRS: valid columns 2Nf*P (rows are the 2Nf trig columns)
     // PANEL
     const double *P;       // [Npad][ld]
     const double *W;       // [Npad] or nullptr
@@ -82,6 +90,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
         const int64_t blast = (b0 + TN - 1 < a.n - 1 ? b0 + TN - 1 : a.n - 1);
         fI0 = (int)(a0 / g2); nfI = (int)(alast / g2) - fI0 + 1;
         fJ0 = (int)(b0 / g2); nfJ = (int)(blast / g2) - fJ0 + 1;
+        nfTot = nfI + nfJ;
+        img_doubles = BK * nfTot * 2;
+        aux_doubles = BK * a.ldk;
+    } else if (MODE == 2) {
+        const int64_t np2 = 2 * (int64_t)a.Nf;
+        const int64_t alast = (a0 + TM - 1 < np2 - 1 ? a0 + TM - 1 : np2 - 1);
+        const int64_t blast = (b0 + TN - 1 < a.nq - 1 ? b0 + TN - 1 : a.nq - 1);
+        fI0 = (int)(a0 / 2); nfI = (int)(alast / 2) - fI0 + 1;
+        fJ0 = (int)((b0 / a.npair) / 2); nfJ = (int)((blast / a.npair) / 2) - fJ0 + 1;
         nfTot = nfI + nfJ;
         img_doubles = BK * nfTot * 2;
         aux_doubles = BK * a.ldk;
@@ -124,6 +141,22 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
                 offKB[t] = ok ? c - cs * a.nb : a.nb;
             }
         }
+    } else if (MODE == 2) {
+        // rows/columns beyond the valid range are clamped, not masked: those G3 entries are never read
+        rowT = nfTot * 2; rowK = a.ldk;
+        const int64_t np2 = 2 * (int64_t)a.Nf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int64_t pr = a0 + wa * 64 + t * 16 + li;
+            if (pr > np2 - 1) pr = np2 - 1;
+            offA[t] = (int)(pr - 2 * (int64_t)fI0);           // (f - fI0)*2 + c
+            offKA[t] = 0;                                      // A operand is the trig value alone
+            int64_t q = b0 + wb * 64 + t * 16 + li;
+            if (q > a.nq - 1) q = a.nq - 1;
+            const int64_t pc = q / a.npair;
+            offB[t] = nfI * 2 + (int)(pc - 2 * (int64_t)fJ0);
+            offKB[t] = (int)(q - pc * a.npair);                // pair index
+        }
     } else {
         rowT = TM + TN; rowK = 1;
 #pragma unroll
@@ -136,7 +169,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
 
     // ---- stage loader: every wave copies whole 1 KiB pieces, lane-linear -------------------
     auto stage_load = [&](double *buf, int64_t r0) {
-        if (MODE == 0) {
+        if (MODE != 1) {
             const int total = BK * nfTot;  // double2 elements
             for (int p = wave; p * 64 < total; p += NTHREADS / 64) {
                 const int e = p * 64 + lane;
@@ -177,12 +210,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
     // KR with 2*nb == 16: every 16-wide MFMA tile is one frequency, so all eight tiles of a lane use the
     // same activation K[k][lane & 7] -> one LDS read per k-step instead of eight.
     const bool one_k = (MODE == 0) && (2 * a.nb == 16) && (a.n % 16 == 0);
+    (void)offKA;
 
     // raw operand fetch for k-step kk of the image `img`: the two LDS values each operand is built from
     double rT[8], rK[8];
     auto fetch = [&](const double *img, const double *aux, int kk) {
         const int row = kk * 4 + lk;
-        if (MODE == 0) {
+        if (MODE == 2) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                rT[t] = img[row * rowT + offA[t]];
+                rT[4 + t] = img[row * rowT + offB[t]];
+                rK[4 + t] = aux[row * rowK + offKB[t]];
+            }
+        } else if (MODE == 0) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 rT[t] = img[row * rowT + offA[t]];
@@ -220,7 +261,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
                 double opA[4], opB[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (MODE == 0) {
+                    if (MODE == 2) {
+                        opA[t] = rT[t];
+                        opB[t] = rT[4 + t] * rK[4 + t];
+                    } else if (MODE == 0) {
                         opA[t] = rT[t] * (one_k ? rK[0] : rK[t]);
                         opB[t] = rT[4 + t] * (one_k ? rK[0] : rK[4 + t]);
                     } else {
@@ -243,7 +287,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
                 double opA[4], opB[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (MODE == 0) {
+                    if (MODE == 2) {
+                        opA[t] = rT[t];
+                        opB[t] = rT[4 + t] * rK[4 + t];
+                    } else if (MODE == 0) {
                         opA[t] = rT[t] * (one_k ? rK[0] : rK[t]);
                         opB[t] = rT[4 + t] * (one_k ? rK[0] : rK[4 + t]);
                     } else {
@@ -301,6 +348,50 @@ gram_reduce_kernel(const double *__restrict__ slab, const int2 *__restrict__ til
     }
 }
 
+// KRS: G3[p][q] = sum_chunk slab[tile][chunk][p%128][q%256] for the valid part of every tile (coalesced)
+__global__ void __launch_bounds__(256)
+gram_reduce3_kernel(const double *__restrict__ slab, const int2 *__restrict__ tiles, int ksplit, int64_t np2, int64_t nq,
+                    double *__restrict__ G3) {
+    const int tile = blockIdx.x;
+    const int2 tt = tiles[tile];
+    const int64_t a0 = (int64_t)tt.x * TM, b0 = (int64_t)tt.y * TN;
+    const double *base = slab + (int64_t)tile * ksplit * (TM * TN);
+    for (int e = threadIdx.x; e < TM * TN; e += 256) {
+        const int il = e / TN, jl = e - il * TN;
+        const int64_t gp = a0 + il, gq = b0 + jl;
+        if (gp >= np2 || gq >= nq) continue;
+        double s = base[e];
+        for (int c = 1; c < ksplit; ++c) s += base[(int64_t)c * (TM * TN) + e];
+        G3[gp * nq + gq] = s;
+    }
+}
+
+// KRS: G[a][b] = G[b][a] = G3[p(a)][p(b)*P + pair(j(a), j(b))] for a >= b, a = f*2nb + c*nb + j, p = 2f + c
+__global__ void __launch_bounds__(256)
+gram_expand_kernel(const double *__restrict__ G3, int64_t nq, int nb, int P, int64_t n, double *__restrict__ G, int64_t ldg) {
+    const int64_t ga = blockIdx.y;
+    const int64_t gb = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gb > ga || ga >= n) return;
+    const int64_t pa = ga / nb, pb = gb / nb;
+    int ja = (int)(ga - pa * nb), jb = (int)(gb - pb * nb);
+    if (ja > jb) { const int t = ja; ja = jb; jb = t; }
+    const int pair = ja * nb - ja * (ja - 1) / 2 + (jb - ja);
+    const double v = G3[pa * nq + pb * P + pair];
+    G[ga * ldg + gb] = v;
+    G[gb * ldg + ga] = v;
+}
+
+// KK[n][pair(j,j')] = K[n][j] * K[n][j'], j <= j'
+__global__ void __launch_bounds__(256)
+pair_table_kernel(const double *__restrict__ K, int64_t ldk, int nb, int64_t Npad, double *__restrict__ KK, int P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Npad * P) return;
+    const int64_t r = idx / P;
+    int pair = (int)(idx - r * P), j = 0;
+    while (pair >= nb - j) { pair -= nb - j; ++j; }
+    KK[idx] = K[r * ldk + j] * K[r * ldk + j + pair];
+}
+
 // ---- right-hand side b = Phi' (W .* y) -----------------------------------------------------
 constexpr int RHS_ROWS = 2048;  // samples per partial
 
@@ -350,12 +441,54 @@ TileList make_tiles(int64_t n) {
     return tl;
 }
 
+// KRS tiles: rows p in [0,2Nf), columns q = p'*P + pair; tile needed when its first column's p' <= its last row
+TileList make_tiles_pairs(int64_t np2, int64_t P) {
+    TileList tl;
+    const int64_t nti = ceil_div(np2, TM), ntj = ceil_div(np2 * P, TN);
+    for (int64_t ti = 0; ti < nti; ++ti) {
+        const int64_t plast = (ti * TM + TM - 1 < np2 - 1) ? ti * TM + TM - 1 : np2 - 1;
+        for (int64_t tj = 0; tj < ntj; ++tj)
+            if ((tj * TN) / P <= plast) tl.host.push_back(make_int2((int)ti, (int)tj));
+    }
+    return tl;
+}
+
+static void choose_split(GramPlan &pl, int64_t N) {
+    // split the samples so that (tiles x chunks) fills the 256 CUs in whole rounds
+    const int64_t nstage = ceil_div(N, BK_ALIGN);
+    const int64_t max_split = nstage / 8 > 0 ? nstage / 8 : 1;  // >= 512 samples per chunk
+    int64_t want = ceil_div(256 * 16, pl.tiles);
+    if (want > max_split) want = max_split;
+    int64_t best = 1; double best_eff = -1;
+    for (int64_t ks = want / 2 > 0 ? want / 2 : 1; ks <= want * 2 && ks <= max_split; ++ks) {
+        const int64_t items = pl.tiles * ks;
+        const double eff = (double)items / (double)(ceil_div(items, 256) * 256);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
+    }
+    pl.ksplit = best;
+    pl.rows_per_chunk = round_up(ceil_div(N, pl.ksplit), BK_ALIGN);
+    pl.slab_bytes = sizeof(double) * (size_t)pl.tiles * (size_t)pl.ksplit * TM * TN;
+}
+
 }  // namespace
+
+GramPlan make_gram_plan_pairs(int64_t Nf, int64_t nb, int64_t N) {
+    GramPlan pl;
+    pl.n = 2 * Nf * nb; pl.N = N; pl.pairs = nb * (nb + 1) / 2; pl.np2 = 2 * Nf;
+    pl.tiles = (int64_t)make_tiles_pairs(pl.np2, pl.pairs).host.size();
+    choose_split(pl, N);
+    return pl;
+}
 
 GramPlan make_gram_plan(int64_t n, int64_t N) {
     GramPlan pl;
     pl.n = n; pl.N = N;
     pl.tiles = (int64_t)make_tiles(n).host.size();
+    choose_split(pl, N);
+    return pl;
+}
+
+#if 0
     // split the samples so that (tiles x chunks) fills the 256 CUs in whole rounds
     const int64_t nstage = ceil_div(N, BK_ALIGN);
     const int64_t max_split = nstage / 16 > 0 ? nstage / 16 : 1;  // >= 512 samples per chunk
@@ -372,22 +505,23 @@ GramPlan make_gram_plan(int64_t n, int64_t N) {
     pl.slab_bytes = sizeof(double) * (size_t)pl.tiles * (size_t)pl.ksplit * TM * TN;
     return pl;
 }
+#endif
 
-// Device copy of the tile list, cached per n on the calling thread.
-static int32_t get_tiles(int64_t n, hipStream_t s, const int2 **out, int *count) {
-    thread_local int64_t cached_n = -1;
+// Device copy of the tile list, cached per (n, pairs) on the calling thread.
+static int32_t get_tiles(int64_t n, int64_t pairs, hipStream_t s, const int2 **out, int *count) {
+    thread_local int64_t cached_n = -1, cached_pairs = -1;
     thread_local DevBuf cached;
     thread_local int cached_count = 0;
     thread_local int cached_dev = -1;
     int dev = 0;
     LPVS_HIP(hipGetDevice(&dev));
-    if (cached_n != n || cached_dev != dev) {
-        TileList tl = make_tiles(n);
+    if (cached_n != n || cached_pairs != pairs || cached_dev != dev) {
+        TileList tl = pairs > 0 ? make_tiles_pairs(n, pairs) : make_tiles(n);
         cached.release();
         LPVS_TRY(cached.alloc(sizeof(int2) * tl.host.size()));
         LPVS_HIP(hipMemcpyAsync(cached.p, tl.host.data(), sizeof(int2) * tl.host.size(), hipMemcpyHostToDevice, s));
         LPVS_HIP(hipStreamSynchronize(s));
-        cached_n = n; cached_count = (int)tl.host.size(); cached_dev = dev;
+        cached_n = n; cached_pairs = pairs; cached_count = (int)tl.host.size(); cached_dev = dev;
     }
     *out = cached.as<int2>();
     *count = cached_count;
@@ -399,6 +533,11 @@ static size_t gram_lds_bytes(int mode, int BK, int64_t nb, int64_t ldk) {
     if (mode == 0) {
         const int g2 = (int)(2 * nb);
         const int nfI = (TM + g2 - 2) / g2 + 1, nfJ = (TN + g2 - 2) / g2 + 1;  // upper bounds
+        img = BK * (nfI + nfJ) * 2;
+        aux = (int)(BK * ldk);
+    } else if (mode == 2) {
+        const int P = (int)(nb * (nb + 1) / 2);
+        const int nfI = TM / 2 + 1, nfJ = ((TN + P - 2) / P + 1) / 2 + 2;     // upper bounds
         img = BK * (nfI + nfJ) * 2;
         aux = (int)(BK * ldk);
     } else {
@@ -430,7 +569,7 @@ int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const d
                        int64_t nb, double *slab, hipStream_t s) {
     GramArgs a{};
     a.n = pl.n; a.rows_per_chunk = pl.rows_per_chunk; a.ksplit = (int)pl.ksplit;
-    LPVS_TRY(get_tiles(pl.n, s, &a.tiles, &a.ntiles));
+    LPVS_TRY(get_tiles(pl.n, 0, s, &a.tiles, &a.ntiles));
     a.slab = slab; a.T = T; a.K = K; a.Nf = (int)Nf; a.nb = (int)nb; a.ldk = (int)ldk;
     const unsigned grid = (unsigned)(pl.tiles * pl.ksplit);
     // deepest stage whose two LDS images fit (few basis functions -> many frequencies per tile)
@@ -450,18 +589,60 @@ int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const d
     return LPVS_EUNSUPPORTED;
 }
 
+int32_t launch_gram_krs(const GramPlan &pl, const double2 *T, int64_t Nf, const double *KK, int64_t nb, double *slab,
+                        hipStream_t s) {
+    GramArgs a{};
+    a.n = pl.n; a.rows_per_chunk = pl.rows_per_chunk; a.ksplit = (int)pl.ksplit;
+    LPVS_TRY(get_tiles(pl.np2, pl.pairs, s, &a.tiles, &a.ntiles));
+    a.slab = slab; a.T = T; a.K = KK; a.Nf = (int)Nf; a.nb = (int)nb; a.ldk = (int)pl.pairs; a.npair = (int)pl.pairs;
+    a.nq = pl.np2 * pl.pairs;
+    const unsigned grid = (unsigned)(pl.tiles * pl.ksplit);
+    if (gram_lds_bytes(2, 32, nb, pl.pairs) <= kLdsBudget) return launch_gram_t<2, 32>(a, grid, gram_lds_bytes(2, 32, nb, pl.pairs), s);
+    if (gram_lds_bytes(2, 16, nb, pl.pairs) <= kLdsBudget) return launch_gram_t<2, 16>(a, grid, gram_lds_bytes(2, 16, nb, pl.pairs), s);
+    set_error("gram_krs: LDS image exceeds 160 KiB (nb=%lld)", (long long)nb);
+    return LPVS_EUNSUPPORTED;
+}
+
+bool gram_krs_fits(int64_t nb) {
+    const int64_t P = nb * (nb + 1) / 2;
+    const char *e = getenv("LPVS_GRAM_FORM");   // development knob: "kr" forces the n x n lower-triangle form
+    if (e && e[0] == 'k' && e[1] == 'r' && e[2] == 0) return false;
+    return nb >= 2 && gram_lds_bytes(2, 16, nb, P) <= kLdsBudget;
+}
+
+int32_t launch_pair_table(const double *K, int64_t ldk, int64_t nb, int64_t Npad, double *KK, hipStream_t s) {
+    const int P = (int)(nb * (nb + 1) / 2);
+    hipLaunchKernelGGL(pair_table_kernel, dim3((unsigned)ceil_div(Npad * P, 256)), dim3(256), 0, s, K, ldk, (int)nb, Npad, KK, P);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+// slab -> G3 (2Nf x 2Nf*P) -> G (n x n, ldg), both symmetric halves written
+int32_t launch_gram_reduce_krs(const GramPlan &pl, const double *slab, int64_t nb, double *G3, double *G, int64_t ldg,
+                               hipStream_t s) {
+    const int2 *tiles; int nt;
+    LPVS_TRY(get_tiles(pl.np2, pl.pairs, s, &tiles, &nt));
+    const int64_t nq = pl.np2 * pl.pairs;
+    hipLaunchKernelGGL(gram_reduce3_kernel, dim3((unsigned)nt), dim3(256), 0, s, slab, tiles, (int)pl.ksplit, pl.np2, nq, G3);
+    LPVS_HIP(hipGetLastError());
+    dim3 grid((unsigned)ceil_div(pl.n, 256), (unsigned)pl.n);
+    hipLaunchKernelGGL(gram_expand_kernel, grid, dim3(256), 0, s, G3, nq, (int)nb, (int)pl.pairs, pl.n, G, ldg);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_gram_panel(const GramPlan &pl, const double *P, int64_t ld, const double *W, double *slab,
                           hipStream_t s) {
     GramArgs a{};
     a.n = pl.n; a.rows_per_chunk = pl.rows_per_chunk; a.ksplit = (int)pl.ksplit;
-    LPVS_TRY(get_tiles(pl.n, s, &a.tiles, &a.ntiles));
+    LPVS_TRY(get_tiles(pl.n, 0, s, &a.tiles, &a.ntiles));
     a.slab = slab; a.P = P; a.W = W; a.ld = ld;
     return launch_gram_t<1, 16>(a, (unsigned)(pl.tiles * pl.ksplit), gram_lds_bytes(1, 16, 0, 0), s);  // 2 x 48 KiB
 }
 
 int32_t launch_gram_reduce(const GramPlan &pl, const double *slab, double *G, int64_t ldg, hipStream_t s) {
     const int2 *tiles; int nt;
-    LPVS_TRY(get_tiles(pl.n, s, &tiles, &nt));
+    LPVS_TRY(get_tiles(pl.n, 0, s, &tiles, &nt));
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)nt), dim3(256), 0, s, slab, tiles, (int)pl.ksplit, pl.n, G, ldg);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;

@@ -80,8 +80,18 @@ struct GramPlan {
     int64_t ksplit = 0;  // sample chunks
     int64_t rows_per_chunk = 0;
     size_t slab_bytes = 0;
+    int64_t pairs = 0;   // KRS: nb(nb+1)/2, else 0
+    int64_t np2 = 0;     // KRS: row space 2Nf
 };
 GramPlan make_gram_plan(int64_t n, int64_t N);
+GramPlan make_gram_plan_pairs(int64_t Nf, int64_t nb, int64_t N);
+bool gram_krs_fits(int64_t nb);   // does the symmetric-pair form fit LDS for this many basis functions?
+// symmetric-pair form of the LPV Gram (see gram.hip): KK = pair products of the activation table
+int32_t launch_pair_table(const double *K, int64_t ldk, int64_t nb, int64_t Npad, double *KK, hipStream_t s);
+int32_t launch_gram_krs(const GramPlan &pl, const double2 *T, int64_t Nf, const double *KK, int64_t nb,
+                        double *slab, hipStream_t s);
+int32_t launch_gram_reduce_krs(const GramPlan &pl, const double *slab, int64_t nb, double *G3, double *G,
+                               int64_t ldg, hipStream_t s);
 // Khatri-Rao form: Phi[k][f*2nb + c] = T[k][f][c>=nb] * K[k][c mod nb]
 int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const double *K,
                        int64_t ldk, int64_t nb, double *slab, hipStream_t s);

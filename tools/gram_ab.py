@@ -6,7 +6,7 @@ import numpy as np, torch
 import lpvspectral_jl_amd as L
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-variants = sys.argv[3:] or ["320", "321", "322", "640", "641", "642"]
+variants = sys.argv[3:] or ["kr", "krs"]
 N, Nf, Nv = 1 << lg, 512, 8
 g = torch.Generator(device="cuda").manual_seed(0)
 X = torch.sort(torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * (10.0 * N / 500)).values
@@ -17,7 +17,7 @@ res = {v: [] for v in variants}
 ref = None
 for r in range(rounds):
     for v in variants:
-        os.environ["LPVS_GRAM_VARIANT"] = v
+        os.environ["LPVS_GRAM_FORM"] = v
         with L.Problem.lpv(y, X, V, w, Nv) as p:
             tm = p.timing()
             if r == 0:
