@@ -137,8 +137,9 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
 
 /* ---- timing: HIP-event durations (ms) of the handle's phases, measured on its stream ---
  * out[0] basis tables, out[1] Gram kernel(s), out[2] Gram reduce + rhs, out[3] factorisation,
- * out[4] ADMM iterations (sum over lpvs_admm_run calls), out[5] number of Gram main-kernel
- * launches, out[6] algorithmic Gram flops N*n*(n+1), out[7] ADMM iterations timed in out[4]. */
+ * out[4] ADMM iterations (sum over lpvs_admm_run calls), out[5] flops the Gram kernel's MFMA core
+ * actually issues (tiles*128*256*2*Npad), out[6] algorithmic Gram flops N*n*(n+1), out[7] ADMM
+ * iterations timed in out[4]. */
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out);
 
 /* ---- a15 window bookkeeping (DSP.arraysplit as used by src/windows.jl:27-36) ---------- */

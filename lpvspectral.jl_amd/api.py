@@ -261,7 +261,7 @@ class Problem:
         t = np.zeros(8)
         check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 8))
         return dict(basis_ms=t[0], gram_ms=t[1], reduce_rhs_ms=t[2], factor_ms=t[3], admm_ms=t[4],
-                    gram_launches=t[5], gram_flops=t[6], admm_iters=t[7])
+                    gram_issued_flops=t[5], gram_flops=t[6], admm_iters=t[7])
 
 
 # --------------------------------------------------------------------------- ADMM driver

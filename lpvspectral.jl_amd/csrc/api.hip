@@ -251,7 +251,8 @@ static int32_t create_panel_problem(lpvs_problem *h, const double *y, const doub
     LPVS_HIP(hipEventRecord(h->ev[2].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
-    h->gram_launches = 1; h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
+    h->gram_launches = (double)pl.tiles * 128.0 * 256.0 * 2.0 * (double)(pl.ksplit * pl.rows_per_chunk);   // flops the MFMA core issues
+    h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
     return LPVS_OK;
 }
 
