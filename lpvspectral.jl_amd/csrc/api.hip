@@ -392,7 +392,7 @@ int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const doub
     LPVS_HIP(hipEventRecord(h->ev[2].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
-    h->gram_launches = 1; h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
+    h->gram_launches = (double)pl.tiles * 128.0 * 256.0 * 2.0 * (double)(pl.ksplit * pl.rows_per_chunk); h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
     guard.h = nullptr;
     *out = h;
     return LPVS_OK;
