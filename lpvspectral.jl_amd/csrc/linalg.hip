@@ -5,8 +5,9 @@
 // Blocked symmetric sweep (Gauss-Jordan without pivoting, valid for SPD): for every 64-wide pivot
 // block k:  P = A_kk^-1;  B = A[:,k] (block k zeroed);  C = B P;  A -= C B' (all blocks != k);
 // A[:,k] = C, A[k,:] = C', A_kk = -P.  After all sweeps A = -A0^-1.  The rank-64 trailing update
-// is an f64 MFMA contraction over the lower triangle (n^3 flop in total), mirrored on store so
-// the result stays exactly symmetric.
+// is an f64 MFMA contraction over the lower triangle (n^3 flop in total).  Only the lower triangle is
+// kept current during the sweeps (row panels are read transposed from it); one pass at the end
+// negates and mirrors it, so the result is exactly symmetric.
 #include "lpvs_internal.h"
 
 namespace lpvs {
@@ -22,7 +23,10 @@ diag_inverse_kernel(const double *__restrict__ A, int64_t np, int k, double *__r
     __shared__ double S[NB][NB + 1];
     __shared__ double colp[NB], rowp[NB];
     const double *blk = A + (int64_t)k * NB * np + (int64_t)k * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) S[e / NB][e % NB] = blk[(int64_t)(e / NB) * np + (e % NB)];
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {  // only the lower triangle of A is current
+        const int i = e / NB, j = e % NB;
+        S[i][j] = j <= i ? blk[(int64_t)i * np + j] : blk[(int64_t)j * np + i];
+    }
     __syncthreads();
     for (int p = 0; p < NB; ++p) {
         const double d = S[p][p];
@@ -48,9 +52,9 @@ diag_inverse_kernel(const double *__restrict__ A, int64_t np, int k, double *__r
     }
 }
 
-// One workgroup per 64-row block i: B_i = A[i,k] (zero for i == k), C_i = B_i P; panels are stored
-// column-major np x 64 (element (r,c) at r + c*np), the MFMA operand layout of the update kernel.
-// Writes A[i,k] = C_i, A[k,i] = C_i', A[k,k] = -P.
+// One workgroup per 64-row block i: B_i = A[i,k] (taken from the lower triangle: A[k,i]' for i < k; zero for
+// i == k), C_i = B_i P; panels are stored column-major np x 64 (element (r,c) at r + c*np), the MFMA operand
+// layout of the update kernel.  Writes back C_i into the lower triangle (A[i,k] or A[k,i]') and A[k,k] = -P.
 __global__ void __launch_bounds__(256)
 panel_kernel(double *__restrict__ A, int64_t np, int k, const double *__restrict__ P,
              double *__restrict__ Bp, double *__restrict__ Cp) {
@@ -58,23 +62,37 @@ panel_kernel(double *__restrict__ A, int64_t np, int k, const double *__restrict
     const int i = blockIdx.x;
     const int64_t r0 = (int64_t)i * NB, k0 = (int64_t)k * NB;
     for (int e = threadIdx.x; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e % NB;
-        sB[r][c] = (i == k) ? 0.0 : A[(r0 + r) * np + k0 + c];
+        const int r = e / NB, c = e % NB;       // c fastest: coalesced reads of either orientation
+        double v = 0.0;
+        if (i > k) v = A[(r0 + r) * np + k0 + c];
+        if (i > k) sB[r][c] = v;
+        if (i < k) sB[c][r] = A[(k0 + r) * np + r0 + c];   // B_i[c][r] = A[k0+r][r0+c]
+        if (i == k) sB[r][c] = 0.0;
         sP[r][c] = P[e];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    double res[NB * NB / 256];
+#pragma unroll
+    for (int u = 0; u < NB * NB / 256; ++u) {
+        const int e = threadIdx.x + 256 * u;
         const int r = e % NB, c = e / NB;  // r fastest: coalesced panel stores
         double s = 0;
         for (int q = 0; q < NB; ++q) s = fma(sB[r][q], sP[q][c], s);
         Bp[(r0 + r) + (int64_t)c * np] = sB[r][c];
         Cp[(r0 + r) + (int64_t)c * np] = s;
-        if (i != k) {
-            A[(r0 + r) * np + k0 + c] = s;
-            A[(k0 + c) * np + r0 + r] = s;
-        } else {
-            A[(r0 + r) * np + k0 + c] = -sP[r][c];
-        }
+        res[u] = (i == k) ? -sP[r][c] : s;
+    }
+    __syncthreads();                       // every product has consumed sB before it is overwritten
+#pragma unroll
+    for (int u = 0; u < NB * NB / 256; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        sB[e % NB][e / NB] = res[u];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;       // c fastest: coalesced stores
+        if (i >= k) A[(r0 + r) * np + k0 + c] = sB[r][c];
+        else A[(k0 + r) * np + r0 + c] = sB[c][r];
     }
 }
 
@@ -120,10 +138,8 @@ sweep_update_kernel(double *__restrict__ A, int64_t np, int k, const double *__r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = r0 + i * 16 + lk + 4 * r, col = c0 + j * 16 + li;
-                if (bi == bj && col > row) continue;  // diagonal block: lower part is the master
-                const double v = A[row * np + col] - acc[i][j][r];
-                A[row * np + col] = v;
-                if (row != col) A[col * np + row] = v;
+                if (bi == bj && col > row) continue;  // only the lower triangle is maintained
+                A[row * np + col] -= acc[i][j][r];
             }
 }
 
@@ -133,8 +149,21 @@ __global__ void __launch_bounds__(256) add_diag_kernel(double *__restrict__ M, i
     if (i < np) M[i * np + i] = i < n ? M[i * np + i] + shift : 1.0;
 }
 
-__global__ void __launch_bounds__(256) negate_kernel(double *__restrict__ A, int64_t count) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) A[i] = -A[i];
+// A <- -A on the lower triangle, mirrored into the upper one (32x32 LDS-transposed tiles, both sides coalesced)
+__global__ void __launch_bounds__(256) negate_mirror_kernel(double *__restrict__ A, int64_t np) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)bi * 32, c0 = (int64_t)bj * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const double v = -A[(r0 + r) * np + c0 + tx];
+        tile[r][tx] = v;
+        if (bi != bj || tx <= r) A[(r0 + r) * np + c0 + tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)   // upper block (bj, bi): element (c0+r, r0+tx) = tile[tx][r]
+        if (bi != bj || tx > r) A[(c0 + r) * np + r0 + tx] = tile[tx][r];
 }
 
 // C = A * B, all np x np, A and B symmetric (so row-major == column-major); diagnostics only.
@@ -187,7 +216,7 @@ int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev
         hipLaunchKernelGGL(sweep_update_kernel, dim3(ntiles), dim3(256), 0, s, A, np, k, Bp, Cp);
     }
     LPVS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(negate_kernel, dim3(2048), dim3(256), 0, s, A, np * np);
+    hipLaunchKernelGGL(negate_mirror_kernel, dim3((unsigned)(np / 32), (unsigned)(np / 32)), dim3(256), 0, s, A, np);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

@@ -240,21 +240,43 @@ static double dot(const double *x, const double *y, int64_t n) {
     for (int64_t i = 0; i < n; ++i) s += x[i] * y[i];
     return s;
 }
-/* r = A x, A is m x n column-major: parallel over row blocks */
+/* r = A x, A is m x n column-major.  Each thread streams a contiguous block of whole columns into a
+ * private accumulator (long unit-stride runs on many-core hosts), then the accumulators are summed in
+ * thread order. */
 static void gemv_n(const double *A, int64_t m, int64_t n, const double *x, double *r) {
-#pragma omp parallel
+    static double *priv = NULL;
+    static int64_t priv_len = 0;
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+#endif
+    if (nt > n) nt = (int)n;
+    if (priv_len < (int64_t)nt * m) {
+        free(priv);
+        priv = (double *)malloc(sizeof(double) * (size_t)nt * (size_t)m);
+        priv_len = (int64_t)nt * m;
+    }
+#pragma omp parallel num_threads(nt)
     {
 #ifdef _OPENMP
-        const int nt = omp_get_num_threads(), id = omp_get_thread_num();
+        const int id = omp_get_thread_num();
 #else
-        const int nt = 1, id = 0;
+        const int id = 0;
 #endif
-        const int64_t lo = m * id / nt, hi = m * (id + 1) / nt;
-        for (int64_t i = lo; i < hi; ++i) r[i] = 0;
-        for (int64_t j = 0; j < n; ++j) {
+        double *acc = priv + (int64_t)id * m;
+        const int64_t c0 = n * id / nt, c1 = n * (id + 1) / nt;
+        for (int64_t i = 0; i < m; ++i) acc[i] = 0;
+        for (int64_t j = c0; j < c1; ++j) {
             const double xj = x[j];
             const double *a = A + j * m;
-            for (int64_t i = lo; i < hi; ++i) r[i] += a[i] * xj;
+            for (int64_t i = 0; i < m; ++i) acc[i] += a[i] * xj;
+        }
+#pragma omp barrier
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < m; ++i) {
+            double s = 0;
+            for (int t = 0; t < nt; ++t) s += priv[(int64_t)t * m + i];
+            r[i] = s;
         }
     }
 }
