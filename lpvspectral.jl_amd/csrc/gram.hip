@@ -71,8 +71,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS-DMA bases derive from it
     const int wa = wave >> 2, wb = wave & 3;  // wave's 64x64 block inside the 128x256 tile
-    const int item = blockIdx.x;
-    const int tile = item / a.ksplit, chunk = item - tile * a.ksplit;
+    // XCD-aware order: blocks are dealt round-robin to the 8 XCDs, so blocks b, b+8, b+16, ... share an L2.
+    // Give each XCD a contiguous run of the (chunk, tile)-sorted work list: the tiles of one row panel
+    // over one sample chunk then stream the same trig rows through the same L2 at about the same time.
+    const int total = a.ntiles * a.ksplit;
+    const int bq = total / 8, br = total % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;   // bijective for any total
+    const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
+    const int chunk = item / a.ntiles, tile = item - chunk * a.ntiles;
     const int2 tt = a.tiles[tile];
     const int64_t a0 = (int64_t)tt.x * TM, b0 = (int64_t)tt.y * TN;
     const int64_t r_begin = (int64_t)chunk * a.rows_per_chunk;

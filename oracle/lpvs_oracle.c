@@ -251,6 +251,7 @@ static void gemv_n(const double *A, int64_t m, int64_t n, const double *x, doubl
     nt = omp_get_max_threads();
 #endif
     if (nt > n) nt = (int)n;
+    if (m * n < (int64_t)1 << 20) nt = 1;   /* small operands: fork/join costs more than the product */
     if (priv_len < (int64_t)nt * m) {
         free(priv);
         priv = (double *)malloc(sizeof(double) * (size_t)nt * (size_t)m);
@@ -282,7 +283,7 @@ static void gemv_n(const double *A, int64_t m, int64_t n, const double *x, doubl
 }
 /* c = A' r: parallel over columns */
 static void gemv_t(const double *A, int64_t m, int64_t n, const double *r, double *c) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m * n >= (int64_t)1 << 20)
     for (int64_t j = 0; j < n; ++j) c[j] = dot(A + j * m, r, m);
 }
 
