@@ -150,6 +150,23 @@ int32_t lpvs_window_offsets(int64_t L, int64_t n, int64_t noverlap, int64_t *off
 int32_t lpvs_merge_f64(const double *yf, int64_t count, int64_t n, int64_t noverlap, int64_t L,
                        double *ym);
 
+/* ---- batched windows: ls_windowpsd(y,t,freqs; estimator = ls_sparse_spectral)  ----------------------
+ * src/lsfft.jl:112-126 driving src/lasso.jl:105-126 for every window of src/windows.jl:27-36, all windows
+ * [win_lo, win_hi) (0-based, of the k = (L-n) div (n-noverlap) + 1 windows) solved together on `device`:
+ * one batch of regressor panels, Gram matrices, factorisations and ADMM iterations per launch instead of a
+ * sequential loop.  Windows are independent, so ranks of a multi-GPU job take disjoint [win_lo, win_hi).
+ *   W          n window weights (NULL = rect/ones); the estimator is always the weighted 4-argument method
+ *   linear_sign LPVS_LINEAR_QUADRATIC_AS_WRITTEN reproduces Quadratic(Q, q=+A'Wy) of src/lasso.jl:119-121
+ *   prox_kind  L1, L0 or GROUP_L2 (IndBallL0 is not batched)
+ *   x_re,x_im  (win_hi-win_lo) x Nf, window-major: fourier2complex(z) of each window
+ *   S_out      Nf: sum over these windows, in window order, of |x|^2 (NOT yet divided by k^2); may be NULL
+ *   iters_out  per-window iteration count (stops per window at ||x-z|| < tol); may be NULL */
+int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, int64_t n, int64_t noverlap,
+                                  const double *W, const double *freqs, int64_t Nf, int32_t prox_kind,
+                                  double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
+                                  int32_t linear_sign, int64_t win_lo, int64_t win_hi, int32_t device,
+                                  double *x_re, double *x_im, double *S_out, int64_t *iters_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,8 @@ SIGNATURES = {
     "lpvs_problem_get_params_f64": (_I32, [_P, _I32, _P, _P]),
     "lpvs_problem_pack_params_f64": (_I32, [_P, _P, _P, _P]),
     "lpvs_problem_get_timing": (_I32, [_P, _P, _I32]),
+    "lpvs_windowpsd_sparse_f64": (_I32, [_P, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I64, _F64, _F64, _I64, _I32, _I64, _I64,
+                                         _I32, _P, _P, _P, _P]),
     "lpvs_window_count": (_I32, [_I64, _I64, _I64, _PI64]),
     "lpvs_window_offsets": (_I32, [_I64, _I64, _I64, _P, _I64, _PI64]),
     "lpvs_merge_f64": (_I32, [_P, _I64, _I64, _I64, _I64, _P]),

@@ -380,10 +380,41 @@ def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, devi
     return SpectralExt(Y, X, V, w, int(Nv), λ, coulomb, normalize, params, None)
 
 
-def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimator=None, **kwargs):
+def windowpsd_sparse_batched(y, t, freqs, n, noverlap=-1, W=None, proxg=None, λ=1.0, μ=0.05, tol=1e-5, iters=10000,
+                             win_lo=0, win_hi=None, device=0, as_written=True):
+    """All windows ``[win_lo, win_hi)`` of ``Windows2(y,t,n,noverlap)`` solved together on one GPU with the weighted
+    ``ls_sparse_spectral(y,t,f,W)`` estimator (src/lasso.jl:105-126): one batch of panels / Gram matrices /
+    factorisations / ADMM iterations per launch.  Returns ``(x [nwin x Nf complex], S_partial [Nf], iters [nwin])``
+    where ``S_partial = Σ_i |x_i|²`` in window order (not yet divided by k²)."""
+    ky, py, Ly = as_f64(y)
+    kt, pt, Lt = as_f64(t)
+    kf, pf, Nf = as_f64(freqs)
+    kw, pw, nW = as_f64(W)
+    assert Ly == Lt, "y and t has to be the same length"
+    assert W is None or nW == n, "W must have one weight per window sample"
+    k = C.c_int64(0)
+    check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
+    win_hi = int(k.value) if win_hi is None else int(win_hi)
+    nwin = win_hi - int(win_lo)
+    proxg = NormL1(λ) if proxg is None else proxg
+    kind, param, glen = proxg.device_params(2 * Nf)
+    xre, xim = np.zeros((max(nwin, 1), Nf)), np.zeros((max(nwin, 1), Nf))
+    S, its = np.zeros(Nf), np.zeros(max(nwin, 1), dtype=np.int64)
+    sign = _lib.LINEAR_QUADRATIC_AS_WRITTEN if as_written else _lib.LINEAR_LEAST_SQUARES
+    check(lib().lpvs_windowpsd_sparse_f64(py, pt, Ly, int(n), int(noverlap), pw, pf, Nf, int(kind), float(param), int(glen),
+                                          float(μ), float(tol), int(iters), int(sign), int(win_lo), win_hi, int(device),
+                                          out_ptr(xre), out_ptr(xim), out_ptr(S), out_ptr(its)))
+    return (xre + 1j * xim)[:nwin], S, its[:nwin]
+
+
+def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimator=None, batched=True, **kwargs):
     """``ls_windowpsd(y,t,freqs; nw, noverlap, window_func, estimator=ls_spectral, kwargs...)``
     (src/lsfft.jl:112-126) -> ``(S, freqs)``.  ``estimator`` is any callable ``(y,t,f,W; kw...) -> (x, f)``
-    (plugin boundary #1); it is always called with the window vector, as in the reference (:121)."""
+    (plugin boundary #1); it is always called with the window vector, as in the reference (:121).
+
+    With ``estimator=ls_sparse_spectral`` (this package's) and no per-iteration callback the windows are solved
+    as ONE device batch (``windowpsd_sparse_batched``; per-iteration progress lines are not printed);
+    ``batched=False`` forces the reference's sequential loop."""
     estimator = ls_spectral if estimator is None else estimator
     yh = y
     n = len(yh) // nw                                               # :113
@@ -391,6 +422,13 @@ def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimato
         freqs = default_freqs(t, n=n)                               # :114
     windows = Windows2(y, t, n, noverlap, window_func)              # :115
     k = len(windows)                                                # :116
+    pg = kwargs.get("proxg")
+    if (batched and estimator is ls_sparse_spectral and k > 0 and kwargs.get("cb") is None and not kwargs.get("init", False)
+            and (pg is None or (hasattr(pg, "device_params") and not isinstance(pg, IndBallL0)))):
+        kw = {a: kwargs[a] for a in ("λ", "proxg", "μ", "tol", "iters") if a in kwargs}
+        kw.setdefault("tol", 1e-5); kw.setdefault("iters", 10000); kw.setdefault("μ", 0.05)
+        _, S, _ = windowpsd_sparse_batched(y, t, freqs, n, windows.noverlap, windows.W, device=kwargs.get("device", 0), **kw)
+        return S / k ** 2, freqs                                    # :125
     S = np.zeros(len(freqs))
     for yi, ti in windows:                                          # :120
         x = estimator(yi, ti, freqs, windows.W, **kwargs)[0]        # :121

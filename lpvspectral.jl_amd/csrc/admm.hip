@@ -445,7 +445,110 @@ admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1, const d
     }
 }
 
+// ---- batch of independent small problems (windows of ls_windowpsd): problem q = blockIdx.y ----------------
+__global__ void __launch_bounds__(256)
+admm_batch_init_kernel(AdmmBatch p) {
+    const int q = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < p.np) {
+        const int64_t o = (int64_t)q * p.np + i;
+        p.x[o] = 0.0; p.z[o] = 0.0; p.u[o] = 0.0;
+        p.rhs[o] = i < p.n ? p.b[o] : 0.0;         // b + (z-u)/mu with z = u = 0
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { p.status[q].iters = 0; p.status[q].converged = 0; p.status[q].nxz = 0.0; }
+}
+
+__global__ void __launch_bounds__(256)
+symv_batch_kernel(AdmmBatch p) {
+    const int q = blockIdx.y;
+    if (p.status[q].converged) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= p.np) return;
+    const double2 *m2 = reinterpret_cast<const double2 *>(p.M + ((int64_t)q * p.np + row) * p.np);
+    const double2 *r2 = reinterpret_cast<const double2 *>(p.rhs + (int64_t)q * p.np);
+    double acc = 0;
+    const int64_t nv = p.np / 2;
+#pragma unroll 4
+    for (int64_t j = lane; j < nv; j += 64) {
+        const double2 m = m2[j], v = r2[j];
+        acc = fma(m.x, v.x, acc);
+        acc = fma(m.y, v.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) p.x[(int64_t)q * p.np + row] = acc;
+}
+
+// one workgroup per problem: prox_g + dual update + ||x-z|| + next rhs + that problem's convergence flag
+__global__ void __launch_bounds__(256)
+admm_batch_prox_kernel(AdmmBatch p) {
+    __shared__ double sh[4];
+    const int q = blockIdx.x;
+    if (p.status[q].converged) return;
+    const int64_t o = (int64_t)q * p.np, n = p.n;
+    const double mu = p.mu;
+    const double *__restrict__ X = p.x + o;
+    const double *__restrict__ B = p.b + o;
+    double *__restrict__ Z = p.z + o;
+    double *__restrict__ U = p.u + o;
+    double *__restrict__ R = p.rhs + o;
+    double ss = 0;
+    auto finish = [&](int64_t i, double xi, double ui, double zi) {
+        const double d = xi - zi, un = ui + d;
+        Z[i] = zi; U[i] = un;
+        R[i] = B[i] + (zi - un) / mu;
+        ss = fma(d, d, ss);
+    };
+    if (p.prox_kind == LPVS_PROX_GROUP_L2) {
+        const int64_t gl = p.group_len, ng = n / gl;
+        const double lm = p.prox_param * mu;
+        for (int64_t g = threadIdx.x; g < ng; g += 256) {
+            double s2 = 0;
+            for (int64_t k = 0; k < gl; ++k) { const double v = X[g * gl + k] + U[g * gl + k]; s2 += v * v; }
+            double scale = 1.0 - lm / sqrt(s2);
+            if (!(scale > 0)) scale = 0.0;
+            for (int64_t k = 0; k < gl; ++k) {
+                const int64_t i = g * gl + k;
+                const double xi = X[i], ui = U[i];
+                finish(i, xi, ui, scale * (xi + ui));
+            }
+        }
+        for (int64_t i = ng * gl + threadIdx.x; i < n; i += 256) finish(i, X[i], U[i], Z[i]);
+    } else {
+        const double gl1 = mu * p.prox_param, th0 = sqrt(2.0 * mu * p.prox_param);
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const double xi = X[i], ui = U[i], v = xi + ui;
+            const double zi = p.prox_kind == LPVS_PROX_L1 ? v + (v <= -gl1 ? gl1 : (v >= gl1 ? -gl1 : -v)) : (fabs(v) > th0 ? v : 0.0);
+            finish(i, xi, ui, zi);
+        }
+    }
+    const double w = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double nxz = sqrt(((sh[0] + sh[1]) + sh[2]) + sh[3]);
+        p.status[q].iters += 1;
+        p.status[q].nxz = nxz;
+        if (nxz < p.tol) p.status[q].converged = 1;
+    }
+}
+
 }  // namespace
+
+int32_t launch_admm_batch_init(const AdmmBatch &p, hipStream_t s) {
+    hipLaunchKernelGGL(admm_batch_init_kernel, dim3((unsigned)ceil_div(p.np, 256), (unsigned)p.nbatch), dim3(256), 0, s, p);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s) {
+    for (int64_t i = 0; i < iters; ++i) {
+        hipLaunchKernelGGL(symv_batch_kernel, dim3((unsigned)ceil_div(p.np, 4), (unsigned)p.nbatch), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(admm_batch_prox_kernel, dim3((unsigned)p.nbatch), dim3(256), 0, s, p);
+    }
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
 
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s) {
     hipLaunchKernelGGL(admm_init_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p);

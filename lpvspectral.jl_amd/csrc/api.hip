@@ -615,6 +615,134 @@ int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out) {
     return LPVS_OK;
 }
 
+// ---- batched windows ------------------------------------------------------------------------------------
+int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,
+                                  const double *freqs, int64_t Nf, int32_t prox_kind, double prox_param, int64_t group_len,
+                                  double mu, double tol, int64_t iters, int32_t linear_sign, int64_t win_lo, int64_t win_hi,
+                                  int32_t device, double *x_re, double *x_im, double *S_out, int64_t *iters_out) {
+    int64_t k = 0;
+    LPVS_TRY(lpvs_window_count(L, n, noverlap, &k));
+    if (noverlap < 0) noverlap = n >> 1;
+    if (win_lo < 0 || win_hi > k || win_lo > win_hi) { set_error("window range [%lld,%lld) outside [0,%lld)", (long long)win_lo, (long long)win_hi, (long long)k); return LPVS_EARGUMENT; }
+    if (!(mu >= 0 && mu <= 1)) { set_error("μ should be ≤ 1"); return LPVS_EASSERT; }
+    if (mu == 0) { set_error("mu = 0 makes the x-update singular"); return LPVS_ENUMERIC; }
+    if (prox_kind != LPVS_PROX_L1 && prox_kind != LPVS_PROX_L0 && prox_kind != LPVS_PROX_GROUP_L2) { set_error("prox kind %d is not batched", prox_kind); return LPVS_EUNSUPPORTED; }
+    if (prox_kind == LPVS_PROX_GROUP_L2 && group_len <= 0) { set_error("group_len must be positive"); return LPVS_EARGUMENT; }
+    if (linear_sign != 1 && linear_sign != -1) { set_error("linear_sign must be +1 or -1"); return LPVS_EARGUMENT; }
+    int64_t zf = 0;
+    LPVS_TRY(lpvs_check_freq_f64(freqs, Nf, &zf));
+    const int64_t nwin = win_hi - win_lo;
+    if (nwin == 0) return LPVS_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    if (device < 0 || device >= count) { set_error("device %d out of range", device); return LPVS_EDEVICE; }
+    LPVS_HIP(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    struct StreamGuard { hipStream_t s = nullptr; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } sg;
+    LPVS_HIP(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    s = sg.s;
+
+    const int64_t nreg = zf ? 2 * Nf - 1 : 2 * Nf, np = round_up(nreg, 128), ld = round_up(nreg, 256);
+    const GramPlan pl = make_gram_plan(nreg, n);
+    const int64_t nrows = pl.ksplit * pl.rows_per_chunk;
+    // sub-batch: keep the panels of one pass under ~12 GiB
+    const size_t panel_bytes = sizeof(double) * (size_t)nrows * (size_t)ld;
+    int64_t bw = (int64_t)(((size_t)12 << 30) / panel_bytes);
+    if (bw < 1) bw = 1;
+    if (bw > nwin) bw = nwin;
+    if (bw > 16384) bw = 16384;
+
+    // the part of y, t this call touches
+    const int64_t step = n - noverlap, s0 = win_lo * step, s1 = (win_hi - 1) * step + n;
+    DevArg dy, dt, df;
+    LPVS_TRY(dy.set(y, L, s)); LPVS_TRY(dt.set(t, L, s)); LPVS_TRY(df.set(freqs, Nf, s));
+    (void)s0; (void)s1;
+    DevBuf Wp;
+    const double *Wdev = nullptr;
+    if (W != nullptr) {
+        LPVS_TRY(Wp.alloc(sizeof(double) * (size_t)nrows));
+        LPVS_HIP(hipMemsetAsync(Wp.p, 0, Wp.bytes, s));
+        LPVS_TRY(copy_to_device(Wp.p, W, sizeof(double) * (size_t)n, s));
+        Wdev = Wp.as<double>();
+    }
+    DevBuf P, slab, M, bvec, x, z, u, rhs, status, work, istat, offs, scr;
+    LPVS_TRY(P.alloc(panel_bytes * (size_t)bw));
+    LPVS_TRY(slab.alloc(pl.slab_bytes * (size_t)bw));
+    LPVS_TRY(M.alloc(sizeof(double) * (size_t)np * (size_t)np * (size_t)bw));
+    const size_t vb = sizeof(double) * (size_t)np * (size_t)bw;
+    LPVS_TRY(bvec.alloc(vb)); LPVS_TRY(x.alloc(vb)); LPVS_TRY(z.alloc(vb)); LPVS_TRY(u.alloc(vb)); LPVS_TRY(rhs.alloc(vb));
+    LPVS_TRY(status.alloc(sizeof(AdmmStatus) * (size_t)bw)); LPVS_TRY(istat.alloc(sizeof(int) * (size_t)bw));
+    LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)bw));
+    LPVS_TRY(offs.alloc(sizeof(int64_t) * (size_t)bw));
+    LPVS_TRY(scr.alloc(rhs_scratch_bytes(n, nreg) * (size_t)bw));
+
+    std::vector<double> S((size_t)Nf, 0.0), zh((size_t)np * (size_t)bw), re((size_t)Nf), im((size_t)Nf);
+    std::vector<int64_t> hoff((size_t)bw);
+    std::vector<AdmmStatus> hst((size_t)bw);
+    std::vector<int> hist_((size_t)bw);
+    std::vector<double> xre_h, xim_h;
+    const bool out_dev_re = is_device_ptr(x_re), out_dev_im = is_device_ptr(x_im);
+    if (out_dev_re || out_dev_im) { xre_h.resize((size_t)nwin * Nf); xim_h.resize((size_t)nwin * Nf); }
+
+    for (int64_t w0 = 0; w0 < nwin; w0 += bw) {
+        const int nb_ = (int)((nwin - w0 < bw) ? nwin - w0 : bw);
+        for (int q = 0; q < nb_; ++q) hoff[q] = (win_lo + w0 + q) * step;           // arraysplit offsets, src/windows.jl:33
+        LPVS_HIP(hipMemcpyAsync(offs.p, hoff.data(), sizeof(int64_t) * (size_t)nb_, hipMemcpyHostToDevice, s));
+        LPVS_TRY(launch_window_panels(dt.p, offs.as<int64_t>(), nb_, n, nrows, df.p, Nf, (int)zf, P.as<double>(), ld, s));
+        LPVS_TRY(launch_gram_panel_batch(pl, nb_, P.as<double>(), nrows * ld, ld, Wdev, slab.as<double>(), s));
+        LPVS_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
+        LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
+        LPVS_TRY(launch_gram_reduce_batch(pl, nb_, slab.as<double>(), M.as<double>(), np, s));     // Q = A'WA   src/lasso.jl:119
+        LPVS_TRY(launch_rhs_panel_batch(nb_, P.as<double>(), nrows * ld, ld, nreg, Wdev, dy.p, offs.as<int64_t>(), n, bvec.as<double>(), np,
+                                        scr.as<double>(), scr.bytes, s));                          // q = A'Wy   src/lasso.jl:120
+        if (linear_sign < 0) {  // Quadratic(Q, +q): the x-update's linear term is -q
+            LPVS_HIP(hipMemcpyAsync(zh.data(), bvec.p, sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyDeviceToHost, s));
+            LPVS_HIP(hipStreamSynchronize(s));
+            for (size_t i = 0; i < (size_t)np * (size_t)nb_; ++i) zh[i] = -zh[i];
+            LPVS_HIP(hipMemcpyAsync(bvec.p, zh.data(), sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyHostToDevice, s));
+            LPVS_HIP(hipStreamSynchronize(s));
+        }
+        LPVS_TRY(launch_add_diag_batch(M.as<double>(), np, nreg, 1.0 / mu, nb_, s));
+        LPVS_TRY(spd_inverse_inplace_batch(M.as<double>(), np, nb_, work.as<double>(), istat.as<int>(), s));
+        LPVS_HIP(hipMemcpyAsync(hist_.data(), istat.p, sizeof(int) * (size_t)nb_, hipMemcpyDeviceToHost, s));
+        LPVS_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < nb_; ++q)
+            if (hist_[q] != 0) { set_error("window %lld: (Q + I/mu) is not positive definite", (long long)(win_lo + w0 + q)); return LPVS_ENUMERIC; }
+        AdmmBatch ab{M.as<double>(), np, nreg, nb_, bvec.as<double>(), x.as<double>(), z.as<double>(), u.as<double>(), rhs.as<double>(),
+                     mu, tol, prox_kind, prox_param, group_len, status.as<AdmmStatus>()};
+        LPVS_TRY(launch_admm_batch_init(ab, s));
+        for (int64_t done = 0; done < iters;) {   // chunks: stop early once every window of the batch has converged
+            const int64_t chunk = iters - done < 256 ? iters - done : 256;
+            LPVS_TRY(launch_admm_batch_iterations(ab, chunk, s));
+            done += chunk;
+            LPVS_HIP(hipMemcpyAsync(hst.data(), status.p, sizeof(AdmmStatus) * (size_t)nb_, hipMemcpyDeviceToHost, s));
+            LPVS_HIP(hipStreamSynchronize(s));
+            bool all = true;
+            for (int q = 0; q < nb_; ++q) all = all && hst[q].converged;
+            if (all) break;
+        }
+        LPVS_HIP(hipMemcpyAsync(zh.data(), z.p, sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyDeviceToHost, s));
+        LPVS_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < nb_; ++q) {
+            const double *c = zh.data() + (size_t)q * (size_t)np;           // fourier2complex, src/utilities.jl:62-73
+            if (!zf) for (int64_t i = 0; i < Nf; ++i) { re[i] = c[i]; im[i] = c[Nf + i]; }
+            else { re[0] = c[0]; im[0] = 0.0; for (int64_t i = 1; i < Nf; ++i) { re[i] = c[i]; im[i] = c[Nf + i - 1]; } }
+            for (int64_t i = 0; i < Nf; ++i) S[i] += re[i] * re[i] + im[i] * im[i];   // S .+= abs2.(x), window order   src/lsfft.jl:122
+            double *dre = out_dev_re ? xre_h.data() : x_re, *dim_ = out_dev_im ? xim_h.data() : x_im;
+            if (dre) memcpy(dre + (size_t)(w0 + q) * Nf, re.data(), sizeof(double) * (size_t)Nf);
+            if (dim_) memcpy(dim_ + (size_t)(w0 + q) * Nf, im.data(), sizeof(double) * (size_t)Nf);
+            if (iters_out) iters_out[w0 + q] = hst[q].iters;
+        }
+    }
+    if (out_dev_re && x_re) LPVS_HIP(hipMemcpy(x_re, xre_h.data(), sizeof(double) * xre_h.size(), hipMemcpyHostToDevice));
+    if (out_dev_im && x_im) LPVS_HIP(hipMemcpy(x_im, xim_h.data(), sizeof(double) * xim_h.size(), hipMemcpyHostToDevice));
+    if (S_out) {
+        if (is_device_ptr(S_out)) { LPVS_HIP(hipMemcpy(S_out, S.data(), sizeof(double) * (size_t)Nf, hipMemcpyHostToDevice)); }
+        else memcpy(S_out, S.data(), sizeof(double) * (size_t)Nf);
+    }
+    return LPVS_OK;
+}
+
 // ---- window bookkeeping (host integer arithmetic; src/windows.jl:27-36, :57-70) ----------------
 int32_t lpvs_window_count(int64_t L, int64_t n, int64_t noverlap, int64_t *count) {
     if (!count) { set_error("NULL argument"); return LPVS_EARGUMENT; }

@@ -49,6 +49,30 @@ fourier_panel_kernel(const double *__restrict__ t, int64_t N, const double *__re
     for (int64_t cpad = nreg + fn; cpad < ld; cpad += Nf) row[cpad] = 0.0;  // zero the pad columns
 }
 
+// ---- batch of windows: P[q][r][ld], window q covers samples toff[q] .. toff[q]+n (src/windows.jl:33-34) -----
+// rows r >= n (up to nrows) and columns >= Nreg are zero-filled
+__global__ void __launch_bounds__(256)
+window_panel_kernel(const double *__restrict__ t, const int64_t *__restrict__ toff, int64_t n, int64_t nrows,
+                    const double *__restrict__ f, int64_t Nf, int zerofreq, double *__restrict__ P, int64_t ld) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nrows * Nf) return;
+    const int64_t r = idx / Nf, fn = idx - r * Nf;
+    const int q = blockIdx.y;
+    const double dd = 1.0 / sqrt((double)(2 * Nf));
+    const int64_t sinoffset = zerofreq ? Nf - 1 : Nf;
+    const int64_t nreg = zerofreq ? 2 * Nf - 1 : 2 * Nf;
+    double *row = P + ((int64_t)q * nrows + r) * ld;
+    double s = 0, c = 0;
+    if (r < n) {
+        const double phi = (kTwoPi * f[fn]) * t[toff[q] + r];
+        sincos(phi, &s, &c);
+        c = c * dd; s = -s * dd;
+    }
+    row[fn] = c;
+    if (!(zerofreq && fn == 0)) row[fn + sinoffset] = s;
+    for (int64_t cpad = nreg + fn; cpad < ld; cpad += Nf) row[cpad] = 0.0;
+}
+
 // ---- a4: trig table T[n][f] = (cos(w_f x_n), -sin(w_f x_n)) --------------------------------
 // conj(exp(i w x)) of src/lasso.jl:39; the minus sign is exact, so T.y * K == -(sin * K).
 __global__ void __launch_bounds__(256)
@@ -185,6 +209,14 @@ int32_t launch_fourier_panel(const double *t, int64_t N, const double *f, int64_
     if (N == 0 || Nf == 0) return LPVS_OK;
     hipLaunchKernelGGL(fourier_panel_kernel, dim3((unsigned)ceil_div(N * Nf, 256)), dim3(256), 0, s, t, N, f,
                        Nf, zerofreq, P, ld);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_window_panels(const double *t, const int64_t *toff_dev, int nbatch, int64_t n, int64_t nrows, const double *f,
+                             int64_t Nf, int zerofreq, double *P, int64_t ld, hipStream_t s) {
+    dim3 grid((unsigned)ceil_div(nrows * Nf, 256), (unsigned)nbatch);
+    hipLaunchKernelGGL(window_panel_kernel, grid, dim3(256), 0, s, t, toff_dev, n, nrows, f, Nf, zerofreq, P, ld);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

@@ -54,8 +54,11 @@ struct GramArgs {
     int64_t nq;            // KRS: valid columns 2Nf*P (rows are the 2Nf trig columns)
     // PANEL
     const double *P;       // [Npad][ld]
-    const double *W;       // [Npad] or nullptr
+    const double *W;       // [Npad] or nullptr (shared by every problem of a batch)
     int64_t ld;
+    // batch of independent PANEL problems (windows): problem q uses P + q*batch_stride_P, slab + q*items*TM*TN
+    int nbatch;            // 0 or 1: single problem
+    int64_t batch_stride_P;
 };
 
 __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
@@ -74,9 +77,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
     // XCD-aware order: blocks are dealt round-robin to the 8 XCDs, so blocks b, b+8, b+16, ... share an L2.
     // Give each XCD a contiguous run of the (chunk, tile)-sorted work list: the tiles of one row panel
     // over one sample chunk then stream the same trig rows through the same L2 at about the same time.
-    const int total = a.ntiles * a.ksplit;
+    const int per_problem = a.ntiles * a.ksplit;
+    const int total = per_problem * (a.nbatch > 1 ? a.nbatch : 1);
     const int bq = total / 8, br = total % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;   // bijective for any total
-    const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
+    const int item_all = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
+    const int prob = item_all / per_problem, item = item_all - prob * per_problem;
     const int chunk = item / a.ntiles, tile = item - chunk * a.ntiles;
     const int2 tt = a.tiles[tile];
     const int64_t a0 = (int64_t)tt.x * TM, b0 = (int64_t)tt.y * TN;
@@ -195,7 +200,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
             for (int p = wave; p < BK * 3; p += NTHREADS / 64) {
                 const int k = p / 3, part = p - k * 3;
                 const int64_t col = part == 0 ? a0 : b0 + (part - 1) * 128;
-                glds16(a.P + (r0 + k) * a.ld + col + 2 * lane, buf + p * 128);
+                glds16(a.P + (int64_t)prob * a.batch_stride_P + (r0 + k) * a.ld + col + 2 * lane, buf + p * 128);
             }
             if (a.W != nullptr && wave == 0 && lane < BK / 2)
                 glds16(a.W + r0 + 2 * lane, buf + img_pad);
@@ -321,7 +326,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
 
     // ---- epilogue: partial tile -> slab[tile][chunk][TM][TN] -------------------------------
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
-    double *out = a.slab + ((int64_t)tile * a.ksplit + chunk) * (TM * TN);
+    double *out = a.slab + (((int64_t)prob * a.ntiles + tile) * a.ksplit + chunk) * (TM * TN);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -337,11 +342,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
 // G[a][b] = G[b][a] = sum_chunk slab[tile(a,b)][chunk][a%128][b%256], a >= b, fixed chunk order.
 __global__ void __launch_bounds__(256)
 gram_reduce_kernel(const double *__restrict__ slab, const int2 *__restrict__ tiles, int ksplit, int64_t n,
-                   double *__restrict__ G, int64_t ldg) {
-    const int tile = blockIdx.x;
+                   double *__restrict__ Gall, int64_t ldg) {
+    const int tile = blockIdx.x;                      // blockIdx.y = problem of a batch
     const int2 tt = tiles[tile];
     const int64_t a0 = (int64_t)tt.x * TM, b0 = (int64_t)tt.y * TN;
-    const double *base = slab + (int64_t)tile * ksplit * (TM * TN);
+    const double *base = slab + ((int64_t)blockIdx.y * gridDim.x + tile) * ksplit * (TM * TN);
+    double *G = Gall + (int64_t)blockIdx.y * ldg * ldg;
     for (int e = threadIdx.x; e < TM * TN; e += 256) {
         const int il = e / TN, jl = e - il * TN;
         const int64_t ga = a0 + il, gb = b0 + jl;
@@ -424,6 +430,34 @@ rhs_kernel(const double2 *__restrict__ T, int Nf, const double *__restrict__ K, 
         }
     }
     part[(int64_t)blockIdx.y * ncol + col] = s;
+}
+
+// batch of windows: problem q = blockIdx.z reads P + q*strideP and y + yoff[q]; partials [q][part][ncol]
+__global__ void __launch_bounds__(256)
+rhs_panel_batch_kernel(const double *__restrict__ Pall, int64_t strideP, int64_t ld, const double *__restrict__ W,
+                       const double *__restrict__ yall, const int64_t *__restrict__ yoff, int64_t N, int64_t ncol,
+                       double *__restrict__ partall) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * RHS_ROWS;
+    const int64_t r1 = r0 + RHS_ROWS < N ? r0 + RHS_ROWS : N;
+    if (col >= ncol) return;
+    const double *P = Pall + (int64_t)blockIdx.z * strideP;
+    const double *y = yall + yoff[blockIdx.z];
+    double s = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const double yy = W ? W[r] * y[r] : y[r];
+        s = fma(P[r * ld + col], yy, s);
+    }
+    partall[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * ncol + col] = s;
+}
+
+__global__ void __launch_bounds__(256)
+rhs_reduce_batch_kernel(const double *__restrict__ part, int nparts, int64_t ncol, double *__restrict__ b, int64_t ldb) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncol) return;
+    double s = 0;
+    for (int p = 0; p < nparts; ++p) s += part[((int64_t)blockIdx.y * nparts + p) * ncol + col];
+    b[(int64_t)blockIdx.y * ldb + col] = s;
 }
 
 __global__ void __launch_bounds__(256)
@@ -645,6 +679,24 @@ int32_t launch_gram_panel(const GramPlan &pl, const double *P, int64_t ld, const
     return launch_gram_t<1, 16>(a, (unsigned)(pl.tiles * pl.ksplit), gram_lds_bytes(1, 16, 0, 0), s);  // 2 x 48 KiB
 }
 
+// batch of nbatch independent panel problems of identical shape (windows of ls_windowpsd)
+int32_t launch_gram_panel_batch(const GramPlan &pl, int nbatch, const double *P, int64_t batch_stride_P, int64_t ld,
+                                const double *W, double *slab, hipStream_t s) {
+    GramArgs a{};
+    a.n = pl.n; a.rows_per_chunk = pl.rows_per_chunk; a.ksplit = (int)pl.ksplit;
+    LPVS_TRY(get_tiles(pl.n, 0, s, &a.tiles, &a.ntiles));
+    a.slab = slab; a.P = P; a.W = W; a.ld = ld; a.nbatch = nbatch; a.batch_stride_P = batch_stride_P;
+    return launch_gram_t<1, 16>(a, (unsigned)(pl.tiles * pl.ksplit * nbatch), gram_lds_bytes(1, 16, 0, 0), s);
+}
+
+int32_t launch_gram_reduce_batch(const GramPlan &pl, int nbatch, const double *slab, double *G, int64_t ldg, hipStream_t s) {
+    const int2 *tiles; int nt;
+    LPVS_TRY(get_tiles(pl.n, 0, s, &tiles, &nt));
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)nt, (unsigned)nbatch), dim3(256), 0, s, slab, tiles, (int)pl.ksplit, pl.n, G, ldg);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_gram_reduce(const GramPlan &pl, const double *slab, double *G, int64_t ldg, hipStream_t s) {
     const int2 *tiles; int nt;
     LPVS_TRY(get_tiles(pl.n, 0, s, &tiles, &nt));
@@ -665,6 +717,20 @@ int32_t launch_rhs_kr(const double2 *T, int64_t Nf, const double *K, int64_t ldk
                        (int64_t)0, (const double *)nullptr, y, N, n, scratch);
     LPVS_HIP(hipGetLastError());
     hipLaunchKernelGGL(rhs_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, scratch, (int)parts, n, b);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_rhs_panel_batch(int nbatch, const double *P, int64_t strideP, int64_t ld, int64_t ncol, const double *W,
+                               const double *y, const int64_t *yoff_dev, int64_t N, double *b, int64_t ldb, double *scratch,
+                               size_t scratch_bytes, hipStream_t s) {
+    const int64_t parts = ceil_div(N, RHS_ROWS);
+    if (scratch_bytes < rhs_scratch_bytes(N, ncol) * (size_t)nbatch) { set_error("rhs scratch too small"); return LPVS_ESTATE; }
+    dim3 grid((unsigned)ceil_div(ncol, 256), (unsigned)parts, (unsigned)nbatch);
+    hipLaunchKernelGGL(rhs_panel_batch_kernel, grid, dim3(256), 0, s, P, strideP, ld, W, y, yoff_dev, N, ncol, scratch);
+    LPVS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rhs_reduce_batch_kernel, dim3((unsigned)ceil_div(ncol, 256), (unsigned)nbatch), dim3(256), 0, s, scratch,
+                       (int)parts, ncol, b, ldb);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

@@ -19,9 +19,12 @@ constexpr int NB = 64;
 
 // P = inv(A_kk) by in-LDS Gauss-Jordan; status[0] |= 1 on a non-positive pivot.
 __global__ void __launch_bounds__(256)
-diag_inverse_kernel(const double *__restrict__ A, int64_t np, int k, double *__restrict__ P, int *status) {
+diag_inverse_kernel(const double *__restrict__ Aall, int64_t np, int k, double *__restrict__ Pall, int *status,
+                    int64_t strideA, int64_t strideW) {
     __shared__ double S[NB][NB + 1];
     __shared__ double colp[NB], rowp[NB];
+    const double *A = Aall + (int64_t)blockIdx.x * strideA;     // blockIdx.x = problem of a batch
+    double *P = Pall + (int64_t)blockIdx.x * strideW;
     const double *blk = A + (int64_t)k * NB * np + (int64_t)k * NB;
     for (int e = threadIdx.x; e < NB * NB; e += 256) {  // only the lower triangle of A is current
         const int i = e / NB, j = e % NB;
@@ -31,7 +34,7 @@ diag_inverse_kernel(const double *__restrict__ A, int64_t np, int k, double *__r
     for (int p = 0; p < NB; ++p) {
         const double d = S[p][p];
         if (threadIdx.x < NB) { colp[threadIdx.x] = S[threadIdx.x][p]; rowp[threadIdx.x] = S[p][threadIdx.x]; }
-        if (threadIdx.x == 0 && !(d > 0)) atomicOr(status, 1);
+        if (threadIdx.x == 0 && !(d > 0)) atomicOr(status + blockIdx.x, 1);
         __syncthreads();
         const double inv = 1.0 / d;
         for (int e = threadIdx.x; e < NB * NB; e += 256) {
@@ -56,9 +59,12 @@ diag_inverse_kernel(const double *__restrict__ A, int64_t np, int k, double *__r
 // i == k), C_i = B_i P; panels are stored column-major np x 64 (element (r,c) at r + c*np), the MFMA operand
 // layout of the update kernel.  Writes back C_i into the lower triangle (A[i,k] or A[k,i]') and A[k,k] = -P.
 __global__ void __launch_bounds__(256)
-panel_kernel(double *__restrict__ A, int64_t np, int k, const double *__restrict__ P,
-             double *__restrict__ Bp, double *__restrict__ Cp) {
+panel_kernel(double *__restrict__ Aall, int64_t np, int k, const double *__restrict__ Pall,
+             double *__restrict__ Bpall, double *__restrict__ Cpall, int64_t strideA, int64_t strideW) {
     __shared__ double sB[NB][NB + 1], sP[NB][NB + 1];
+    double *A = Aall + (int64_t)blockIdx.y * strideA;
+    const double *P = Pall + (int64_t)blockIdx.y * strideW;
+    double *Bp = Bpall + (int64_t)blockIdx.y * strideW, *Cp = Cpall + (int64_t)blockIdx.y * strideW;
     const int i = blockIdx.x;
     const int64_t r0 = (int64_t)i * NB, k0 = (int64_t)k * NB;
     for (int e = threadIdx.x; e < NB * NB; e += 256) {
@@ -99,8 +105,10 @@ panel_kernel(double *__restrict__ A, int64_t np, int k, const double *__restrict
 // A[i,j] -= C_i B_j' for 64-blocks i >= j, i != k, j != k; result mirrored to A[j,i].
 // Workgroup = 4 waves on a 128x128 tile of the lower triangle; wave (wi,wj) owns one 64x64 block.
 __global__ void __launch_bounds__(256)
-sweep_update_kernel(double *__restrict__ A, int64_t np, int k, const double *__restrict__ Bp,
-                    const double *__restrict__ Cp) {
+sweep_update_kernel(double *__restrict__ Aall, int64_t np, int k, const double *__restrict__ Bpall,
+                    const double *__restrict__ Cpall, int64_t strideA, int64_t strideW) {
+    double *A = Aall + (int64_t)blockIdx.y * strideA;
+    const double *Bp = Bpall + (int64_t)blockIdx.y * strideW, *Cp = Cpall + (int64_t)blockIdx.y * strideW;
     // linear lower-triangle tile index -> (ti, tj), ti >= tj
     const int t = blockIdx.x;
     int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
@@ -144,14 +152,16 @@ sweep_update_kernel(double *__restrict__ A, int64_t np, int k, const double *__r
 }
 
 // diag(M) += shift on the valid part; the pad block becomes the identity
-__global__ void __launch_bounds__(256) add_diag_kernel(double *__restrict__ M, int64_t np, int64_t n, double shift) {
+__global__ void __launch_bounds__(256) add_diag_kernel(double *__restrict__ Mall, int64_t np, int64_t n, double shift) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double *M = Mall + (int64_t)blockIdx.y * np * np;
     if (i < np) M[i * np + i] = i < n ? M[i * np + i] + shift : 1.0;
 }
 
 // A <- -A on the lower triangle, mirrored into the upper one (32x32 LDS-transposed tiles, both sides coalesced)
-__global__ void __launch_bounds__(256) negate_mirror_kernel(double *__restrict__ A, int64_t np) {
+__global__ void __launch_bounds__(256) negate_mirror_kernel(double *__restrict__ Aall, int64_t np) {
     __shared__ double tile[32][33];
+    double *A = Aall + (int64_t)blockIdx.z * np * np;
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj > bi) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -203,20 +213,32 @@ symm_matmul_kernel(const double *__restrict__ A, const double *__restrict__ B, d
 
 size_t spd_inverse_work_bytes(int64_t np) { return sizeof(double) * (size_t)(2 * np * NB + NB * NB); }
 
-int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s) {
+// nbatch independent matrices A + q*np*np; work holds nbatch * spd_inverse_work_bytes(np); status_dev nbatch ints
+int32_t spd_inverse_inplace_batch(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s) {
     if (np % 128 != 0) { set_error("spd_inverse: np=%lld not a multiple of 128", (long long)np); return LPVS_ESTATE; }
+    const int64_t strideW = (int64_t)(2 * np * NB + NB * NB), strideA = np * np;
     double *Bp = work, *Cp = work + np * NB, *P = work + 2 * np * NB;
     const int nblk = (int)(np / NB);
     const int nt = (int)(np / 128);
     const unsigned ntiles = (unsigned)(nt * (nt + 1) / 2);
-    LPVS_HIP(hipMemsetAsync(status_dev, 0, sizeof(int), s));
+    LPVS_HIP(hipMemsetAsync(status_dev, 0, sizeof(int) * (size_t)nbatch, s));
     for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(diag_inverse_kernel, dim3(1), dim3(256), 0, s, A, np, k, P, status_dev);
-        hipLaunchKernelGGL(panel_kernel, dim3((unsigned)nblk), dim3(256), 0, s, A, np, k, P, Bp, Cp);
-        hipLaunchKernelGGL(sweep_update_kernel, dim3(ntiles), dim3(256), 0, s, A, np, k, Bp, Cp);
+        hipLaunchKernelGGL(diag_inverse_kernel, dim3((unsigned)nbatch), dim3(256), 0, s, A, np, k, P, status_dev, strideA, strideW);
+        hipLaunchKernelGGL(panel_kernel, dim3((unsigned)nblk, (unsigned)nbatch), dim3(256), 0, s, A, np, k, P, Bp, Cp, strideA, strideW);
+        hipLaunchKernelGGL(sweep_update_kernel, dim3(ntiles, (unsigned)nbatch), dim3(256), 0, s, A, np, k, Bp, Cp, strideA, strideW);
     }
     LPVS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(negate_mirror_kernel, dim3((unsigned)(np / 32), (unsigned)(np / 32)), dim3(256), 0, s, A, np);
+    hipLaunchKernelGGL(negate_mirror_kernel, dim3((unsigned)(np / 32), (unsigned)(np / 32), (unsigned)nbatch), dim3(256), 0, s, A, np);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s) {
+    return spd_inverse_inplace_batch(A, np, 1, work, status_dev, s);
+}
+
+int32_t launch_add_diag_batch(double *M, int64_t np, int64_t n, double shift, int nbatch, hipStream_t s) {
+    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)ceil_div(np, 256), (unsigned)nbatch), dim3(256), 0, s, M, np, n, shift);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

@@ -55,6 +55,9 @@ int32_t launch_fourier_regressor_colmajor(const double *t, int64_t N, const doub
 // columns >= Nreg up to ld are zero-filled.
 int32_t launch_fourier_panel(const double *t, int64_t N, const double *f, int64_t Nf, int zerofreq,
                              double *P, int64_t ld, hipStream_t s);
+// batch of window panels P[q][nrows][ld] (window q starts at sample toff[q], n samples, zero pad rows)
+int32_t launch_window_panels(const double *t, const int64_t *toff_dev, int nbatch, int64_t n, int64_t nrows, const double *f,
+                             int64_t Nf, int zerofreq, double *P, int64_t ld, hipStream_t s);
 // trig table T[n][f] = (cos(w_f x_n), -sin(w_f x_n))                   src/lasso.jl:39
 int32_t launch_trig_table(const double *X, int64_t N, const double *w, int64_t Nf, double2 *T,
                           hipStream_t s);
@@ -98,6 +101,9 @@ int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const d
 // panel form: Phi[k][c] = P[k*ld + c], optional row weights W (applied once: G = P' diag(W) P)
 int32_t launch_gram_panel(const GramPlan &pl, const double *P, int64_t ld, const double *W,
                           double *slab, hipStream_t s);
+int32_t launch_gram_panel_batch(const GramPlan &pl, int nbatch, const double *P, int64_t batch_stride_P, int64_t ld,
+                                const double *W, double *slab, hipStream_t s);
+int32_t launch_gram_reduce_batch(const GramPlan &pl, int nbatch, const double *slab, double *G, int64_t ldg, hipStream_t s);
 // G[a][b] (ldg x ldg, symmetric, full) = sum over chunks of the slabs
 int32_t launch_gram_reduce(const GramPlan &pl, const double *slab, double *G, int64_t ldg,
                            hipStream_t s);
@@ -108,6 +114,9 @@ int32_t launch_rhs_kr(const double2 *T, int64_t Nf, const double *K, int64_t ldk
 int32_t launch_rhs_panel(const double *P, int64_t ld, int64_t ncol, const double *W, const double *y,
                          int64_t N, double *b, double *scratch, size_t scratch_bytes, hipStream_t s);
 size_t rhs_scratch_bytes(int64_t N, int64_t n);
+int32_t launch_rhs_panel_batch(int nbatch, const double *P, int64_t strideP, int64_t ld, int64_t ncol, const double *W,
+                               const double *y, const int64_t *yoff_dev, int64_t N, double *b, int64_t ldb, double *scratch,
+                               size_t scratch_bytes, hipStream_t s);
 
 // ---- dense symmetric inverse (linalg.hip) ------------------------------------------------
 // In-place inverse of the SPD matrix A (np x np, np % 64 == 0, full symmetric storage) by
@@ -115,6 +124,8 @@ size_t rhs_scratch_bytes(int64_t N, int64_t n);
 size_t spd_inverse_work_bytes(int64_t np);
 int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s);
 int32_t launch_add_diag(double *M, int64_t np, int64_t n, double shift, hipStream_t s);
+int32_t launch_add_diag_batch(double *M, int64_t np, int64_t n, double shift, int nbatch, hipStream_t s);
+int32_t spd_inverse_inplace_batch(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s);
 // C (m x m, ld) = A * B for symmetric np x np operands (test/diagnostic helper)
 int32_t launch_symm_matmul(const double *A, const double *B, double *C, int64_t np, hipStream_t s);
 
@@ -144,6 +155,21 @@ size_t symv_part_doubles(int64_t np);
 size_t symv_packed_doubles(int64_t np);
 int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s);
 constexpr int64_t kSymmetricMinNp = 2048;  // below this the iteration is launch-latency bound: plain mat-vec
+// batch of nbatch independent problems of one shape: arrays are [nbatch][np] (matrices [nbatch][np][np])
+struct AdmmBatch {
+    const double *M;
+    int64_t np, n;
+    int nbatch;
+    const double *b;
+    double *x, *z, *u, *rhs;
+    double mu, tol;
+    int prox_kind;
+    double prox_param;
+    int64_t group_len;
+    AdmmStatus *status;   // [nbatch]
+};
+int32_t launch_admm_batch_init(const AdmmBatch &p, hipStream_t s);
+int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s);
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s);              // z=x, u=0, rhs, status=0
 int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s);
 // x = Minv * rhs_in (one GEMV; ridge solves)
