@@ -56,6 +56,8 @@ typedef struct lpvs_problem lpvs_problem;
 int32_t lpvs_version(void);
 int32_t lpvs_device_count(void);          /* number of visible HIP devices (0 if none) */
 const char *lpvs_last_error(void);        /* thread-local, valid until the next failing call */
+/* work buffers are cached per device between calls (cap: LPVS_POOL_GIB, default 128); this returns them to the driver */
+int32_t lpvs_release_cached_memory(void);
 
 /* ---- a1  check_freq                                                  src/lsfft.jl:20-24
  * *zerofreq = 0 (no zero frequency) or 1 (zero frequency is first); LPVS_EARGUMENT if a

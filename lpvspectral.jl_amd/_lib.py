@@ -41,6 +41,7 @@ SIGNATURES = {
     "lpvs_version": (_I32, []),
     "lpvs_device_count": (_I32, []),
     "lpvs_last_error": (C.c_char_p, []),
+    "lpvs_release_cached_memory": (_I32, []),
     "lpvs_check_freq_f64": (_I32, [_P, _I64, _PI64]),
     "lpvs_fourier_regressor_f64": (_I32, [_P, _I64, _P, _I64, _P, _PI64]),
     "lpvs_basis_activation_f64": (_I32, [_P, _I64, _I64, _I32, _I32, _P]),

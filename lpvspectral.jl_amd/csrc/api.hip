@@ -2,7 +2,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "lpvs_internal.h"
@@ -18,10 +22,75 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- caching device allocator -----------------------------------------------------------------------------
+// Work buffers of a solve are tens of GiB (trig table, slabs, panels); hipMalloc/hipFree of that size costs
+// milliseconds to seconds and synchronises the device.  Freed blocks are kept per device and handed out
+// again (best fit within 25 % slack); the cache is capped (LPVS_POOL_GIB, default 128) and can be emptied
+// with lpvs_release_cached_memory().  Every user synchronises its stream before releasing a buffer, so a
+// cached block is idle by construction.
+namespace {
+struct Pool {
+    std::mutex m;
+    std::multimap<size_t, void *> free_[16];
+    size_t cached[16] = {0};
+    size_t cap() {
+        static size_t c = [] { const char *e = getenv("LPVS_POOL_GIB"); const long g = e ? atol(e) : 128; return (size_t)(g < 0 ? 0 : g) << 30; }();
+        return c;
+    }
+    void give(int dev, size_t n, void *p) {
+        std::lock_guard<std::mutex> lk(m);
+        if (n > cap()) { (void)hipFree(p); return; }
+        free_[dev].emplace(n, p);
+        cached[dev] += n;
+        while (cached[dev] > cap() && !free_[dev].empty()) {   // evict the largest blocks first
+            auto it = std::prev(free_[dev].end());
+            cached[dev] -= it->first;
+            (void)hipFree(it->second);
+            free_[dev].erase(it);
+        }
+    }
+    void flush() {
+        std::lock_guard<std::mutex> lk(m);
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (int d = 0; d < 16; ++d) {
+            if (free_[d].empty()) continue;
+            (void)hipSetDevice(d);
+            for (auto &kv : free_[d]) (void)hipFree(kv.second);
+            free_[d].clear();
+            cached[d] = 0;
+        }
+        (void)hipSetDevice(cur);
+    }
+};
+Pool &pool() { static Pool p; return p; }
+}  // namespace
+
 int32_t DevBuf::alloc(size_t nbytes) {
     release();
     if (nbytes == 0) nbytes = 16;
+    nbytes = (nbytes + 255) & ~(size_t)255;
+    int d = 0;
+    (void)hipGetDevice(&d);
+    dev = d;
+    // the cache keys blocks by their true size, so a reused block may be up to 25 % larger than asked for
+    if (d >= 0 && d < 16) {
+        std::lock_guard<std::mutex> lk(pool().m);
+        auto &fl = pool().free_[d];
+        auto it = fl.lower_bound(nbytes);
+        if (it != fl.end() && it->first <= nbytes + nbytes / 4 + (1 << 20)) {
+            p = it->second; bytes = it->first;
+            pool().cached[d] -= it->first;
+            fl.erase(it);
+            return LPVS_OK;
+        }
+    }
     hipError_t e = hipMalloc(&p, nbytes);
+    if (e == hipErrorOutOfMemory) {   // give the cache back to the driver and retry once
+        (void)hipGetLastError();
+        pool().flush();
+        e = hipMalloc(&p, nbytes);
+    }
     if (e != hipSuccess) {
         p = nullptr;
         set_error("hipMalloc(%zu bytes) failed: %s", nbytes, hipGetErrorString(e));
@@ -32,7 +101,10 @@ int32_t DevBuf::alloc(size_t nbytes) {
     return LPVS_OK;
 }
 void DevBuf::release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+        if (dev >= 0 && dev < 16) pool().give(dev, bytes, p);
+        else (void)hipFree(p);
+    }
     p = nullptr;
     bytes = 0;
 }
@@ -267,6 +339,11 @@ int32_t lpvs_device_count(void) {
 }
 
 const char *lpvs_last_error(void) { return g_err; }
+
+int32_t lpvs_release_cached_memory(void) {
+    pool().flush();
+    return LPVS_OK;
+}
 
 int32_t lpvs_check_freq_f64(const double *f, int64_t Nf, int64_t *zerofreq) {
     std::vector<double> hf;
@@ -615,6 +692,20 @@ int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out) {
     return LPVS_OK;
 }
 
+// development aid: LPVS_TRACE=1 prints host wall-clock per phase of the batched path (with stream syncs)
+struct PhaseTrace {
+    bool on; hipStream_t s; double t0;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    PhaseTrace(hipStream_t s_) : on(getenv("LPVS_TRACE") != nullptr), s(s_), t0(now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const double t = now();
+        fprintf(stderr, "[lpvs trace] %-28s %9.3f ms\n", what, (t - t0) * 1e3);
+        t0 = t;
+    }
+};
+
 // ---- batched windows ------------------------------------------------------------------------------------
 int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,
                                   const double *freqs, int64_t Nf, int32_t prox_kind, double prox_param, int64_t group_len,
@@ -643,14 +734,17 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
     s = sg.s;
 
     const int64_t nreg = zf ? 2 * Nf - 1 : 2 * Nf, np = round_up(nreg, 128), ld = round_up(nreg, 256);
-    const GramPlan pl = make_gram_plan(nreg, n);
-    const int64_t nrows = pl.ksplit * pl.rows_per_chunk;
-    // sub-batch: keep the panels of one pass under ~12 GiB
-    const size_t panel_bytes = sizeof(double) * (size_t)nrows * (size_t)ld;
-    int64_t bw = (int64_t)(((size_t)12 << 30) / panel_bytes);
+    // sub-batch: the k-major regressor panels of one pass stay under a budget (default 48 GiB of the 288 GB)
+    size_t budget = (size_t)48 << 30;
+    if (const char *e = getenv("LPVS_BATCH_PANEL_GIB")) { const long g = atol(e); if (g > 0) budget = (size_t)g << 30; }
+    int64_t bw = (int64_t)(budget / (sizeof(double) * (size_t)round_up(n, 64) * (size_t)ld));
     if (bw < 1) bw = 1;
     if (bw > nwin) bw = nwin;
-    if (bw > 16384) bw = 16384;
+    if (bw > 8192) bw = 8192;
+    const GramPlan pl = make_gram_plan(nreg, n, bw);
+    const int64_t nrows = pl.ksplit * pl.rows_per_chunk;
+    const size_t panel_bytes = sizeof(double) * (size_t)nrows * (size_t)ld;
+    while (bw > 1 && panel_bytes * (size_t)bw > budget) --bw;
 
     // the part of y, t this call touches
     const int64_t step = n - noverlap, s0 = win_lo * step, s1 = (win_hi - 1) * step + n;
@@ -665,6 +759,7 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         LPVS_TRY(copy_to_device(Wp.p, W, sizeof(double) * (size_t)n, s));
         Wdev = Wp.as<double>();
     }
+    PhaseTrace tr(s);
     DevBuf P, slab, M, bvec, x, z, u, rhs, status, work, istat, offs, scr;
     LPVS_TRY(P.alloc(panel_bytes * (size_t)bw));
     LPVS_TRY(slab.alloc(pl.slab_bytes * (size_t)bw));
@@ -676,6 +771,7 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
     LPVS_TRY(offs.alloc(sizeof(int64_t) * (size_t)bw));
     LPVS_TRY(scr.alloc(rhs_scratch_bytes(n, nreg) * (size_t)bw));
 
+    tr.mark("alloc");
     std::vector<double> S((size_t)Nf, 0.0), zh((size_t)np * (size_t)bw), re((size_t)Nf), im((size_t)Nf);
     std::vector<int64_t> hoff((size_t)bw);
     std::vector<AdmmStatus> hst((size_t)bw);
@@ -689,7 +785,9 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         for (int q = 0; q < nb_; ++q) hoff[q] = (win_lo + w0 + q) * step;           // arraysplit offsets, src/windows.jl:33
         LPVS_HIP(hipMemcpyAsync(offs.p, hoff.data(), sizeof(int64_t) * (size_t)nb_, hipMemcpyHostToDevice, s));
         LPVS_TRY(launch_window_panels(dt.p, offs.as<int64_t>(), nb_, n, nrows, df.p, Nf, (int)zf, P.as<double>(), ld, s));
+        tr.mark("panels");
         LPVS_TRY(launch_gram_panel_batch(pl, nb_, P.as<double>(), nrows * ld, ld, Wdev, slab.as<double>(), s));
+        tr.mark("gram");
         LPVS_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
         LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
         LPVS_TRY(launch_gram_reduce_batch(pl, nb_, slab.as<double>(), M.as<double>(), np, s));     // Q = A'WA   src/lasso.jl:119
@@ -702,12 +800,14 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
             LPVS_HIP(hipMemcpyAsync(bvec.p, zh.data(), sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyHostToDevice, s));
             LPVS_HIP(hipStreamSynchronize(s));
         }
+        tr.mark("reduce+rhs");
         LPVS_TRY(launch_add_diag_batch(M.as<double>(), np, nreg, 1.0 / mu, nb_, s));
         LPVS_TRY(spd_inverse_inplace_batch(M.as<double>(), np, nb_, work.as<double>(), istat.as<int>(), s));
         LPVS_HIP(hipMemcpyAsync(hist_.data(), istat.p, sizeof(int) * (size_t)nb_, hipMemcpyDeviceToHost, s));
         LPVS_HIP(hipStreamSynchronize(s));
         for (int q = 0; q < nb_; ++q)
             if (hist_[q] != 0) { set_error("window %lld: (Q + I/mu) is not positive definite", (long long)(win_lo + w0 + q)); return LPVS_ENUMERIC; }
+        tr.mark("inverse");
         AdmmBatch ab{M.as<double>(), np, nreg, nb_, bvec.as<double>(), x.as<double>(), z.as<double>(), u.as<double>(), rhs.as<double>(),
                      mu, tol, prox_kind, prox_param, group_len, status.as<AdmmStatus>()};
         LPVS_TRY(launch_admm_batch_init(ab, s));
@@ -721,6 +821,7 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
             for (int q = 0; q < nb_; ++q) all = all && hst[q].converged;
             if (all) break;
         }
+        tr.mark("admm");
         LPVS_HIP(hipMemcpyAsync(zh.data(), z.p, sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyDeviceToHost, s));
         LPVS_HIP(hipStreamSynchronize(s));
         for (int q = 0; q < nb_; ++q) {

@@ -492,15 +492,15 @@ TileList make_tiles_pairs(int64_t np2, int64_t P) {
     return tl;
 }
 
-static void choose_split(GramPlan &pl, int64_t N) {
-    // split the samples so that (tiles x chunks) fills the 256 CUs in whole rounds
+static void choose_split(GramPlan &pl, int64_t N, int64_t nbatch = 1) {
+    // split the samples so that (tiles x chunks [x problems of a batch]) fills the 256 CUs in whole rounds
     const int64_t nstage = ceil_div(N, BK_ALIGN);
     const int64_t max_split = nstage / 8 > 0 ? nstage / 8 : 1;  // >= 512 samples per chunk
-    int64_t want = ceil_div(256 * 16, pl.tiles);
+    int64_t want = ceil_div(256 * 16, pl.tiles * nbatch);
     if (want > max_split) want = max_split;
     int64_t best = 1; double best_eff = -1;
     for (int64_t ks = want / 2 > 0 ? want / 2 : 1; ks <= want * 2 && ks <= max_split; ++ks) {
-        const int64_t items = pl.tiles * ks;
+        const int64_t items = pl.tiles * ks * nbatch;
         const double eff = (double)items / (double)(ceil_div(items, 256) * 256);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
     }
@@ -519,11 +519,11 @@ GramPlan make_gram_plan_pairs(int64_t Nf, int64_t nb, int64_t N) {
     return pl;
 }
 
-GramPlan make_gram_plan(int64_t n, int64_t N) {
+GramPlan make_gram_plan(int64_t n, int64_t N, int64_t nbatch) {
     GramPlan pl;
     pl.n = n; pl.N = N;
     pl.tiles = (int64_t)make_tiles(n).host.size();
-    choose_split(pl, N);
+    choose_split(pl, N, nbatch < 1 ? 1 : nbatch);
     return pl;
 }
 
@@ -535,7 +535,7 @@ GramPlan make_gram_plan(int64_t n, int64_t N) {
     if (want > max_split) want = max_split;
     int64_t best = 1; double best_eff = -1;
     for (int64_t ks = want / 2 > 0 ? want / 2 : 1; ks <= want * 2 && ks <= max_split; ++ks) {
-        const int64_t items = pl.tiles * ks;
+        const int64_t items = pl.tiles * ks * nbatch;
         const double eff = (double)items / (double)(ceil_div(items, 256) * 256);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
     }

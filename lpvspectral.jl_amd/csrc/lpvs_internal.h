@@ -33,7 +33,8 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // RAII device allocation; copy_in accepts a host or a device source pointer.
 struct DevBuf {
     void *p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;   // true size of the block (>= the size asked for when it came from the cache)
+    int dev = -1;
     int32_t alloc(size_t nbytes);
     void release();
     ~DevBuf() { release(); }
@@ -86,7 +87,7 @@ struct GramPlan {
     int64_t pairs = 0;   // KRS: nb(nb+1)/2, else 0
     int64_t np2 = 0;     // KRS: row space 2Nf
 };
-GramPlan make_gram_plan(int64_t n, int64_t N);
+GramPlan make_gram_plan(int64_t n, int64_t N, int64_t nbatch = 1);   // nbatch: problems solved together
 GramPlan make_gram_plan_pairs(int64_t Nf, int64_t nb, int64_t N);
 bool gram_krs_fits(int64_t nb);   // does the symmetric-pair form fit LDS for this many basis functions?
 // symmetric-pair form of the LPV Gram (see gram.hip): KK = pair products of the activation table
