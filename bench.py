@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=LOG2N, help="diagnostic only; the judged size is 20")
     ap.add_argument("--iters", type=int, default=ADMM_ITERS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI, the judged path) or gloo (functional rehearsal)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: map every rank onto the visible GPUs modulo their count")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,13 +99,19 @@ def main():
     import lpvspectral_jl_amd as L   # loads torch's HIP runtime first, then liblpvspectral.so
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.share_gpu:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective buffers live
 
     N = 1 << args.log2n
     y, X, V, w = synth_signal(N, NF, rank, dev)          # inputs resident in HBM before the timed region
@@ -123,13 +131,13 @@ def main():
         params, it, nxz, tm = solve(L, y, X, V, w, NV, args.iters, local)
         tms.append(tm)
     if dist is not None:                                 # final gather of the coefficients (RCCL)
-        mine = torch.view_as_real(torch.tensor(params, device=dev)).contiguous()
+        mine = torch.view_as_real(torch.tensor(params, device=cdev)).contiguous()
         allp = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -147,7 +155,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg3: ls_sparse_spectral_lpv group-lasso N=2^%d Nf=%d Nv=%d n=%d lambda=%g mu=%g iters=%d tol=0, one signal per GPU"
                                    % (args.log2n, NF, NV, 2 * NF * NV, LAMBDA, MU, args.iters),
-                       "signals_per_step_per_gpu": 1, "final_gather": "rccl all_gather" if world > 1 else "none"},
+                       "signals_per_step_per_gpu": 1, "final_gather": ("rccl" if args.backend == "nccl" else args.backend) + " all_gather" if world > 1 else "none"},
             "admm_iters_per_sec": args.iters / (admm_ms * 1e-3),
             "phase_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("basis_ms", "gram_ms", "reduce_rhs_ms", "factor_ms", "admm_ms")},
             "final_nxz": nxz,
