@@ -113,6 +113,15 @@ int32_t lpvs_problem_get_gram_f64(lpvs_problem *h, double *G_out, double *b_out)
  * regressor's column order. */
 int32_t lpvs_problem_solve_ridge_f64(lpvs_problem *h, double ridge, double *x_out);
 
+/* ---- ls_spectral(y,t,f; lam): [A; lam I] \ [y; 0]                src/lsfft.jl:62-67, src/utilities.jl:56-60
+ * The minimiser is computed from a Gram on device, in the better-conditioned of its two forms:
+ *   N >= Nreg (tall):  x = (A'A + lam^2 I)^-1 A'y          (primal normal equations)
+ *   N <  Nreg (fat):   x = A' (A A' + lam^2 I)^-1 y        (dual form; e.g. default_freqs of an even-length t
+ *                                                           has Nreg = N+1 and a vanishing Nyquist sine column)
+ * re/im: Nf entries, fourier2complex of x. */
+int32_t lpvs_ls_spectral_f64(const double *y, const double *t, int64_t N, const double *f, int64_t Nf, double lam,
+                             int32_t device, double *re_out, double *im_out);
+
 /* ---- ADMM                                                          src/lasso.jl:136-171
  * set_prox: the g of z <- prox_{mu g}(x+u).  init: x <- x0 (zeros if NULL), z <- x, u <- 0,
  * factorises (G + I/mu) once (LPVS_EASSERT unless 0 <= mu <= 1).  run: up to max_iters more

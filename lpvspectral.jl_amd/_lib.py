@@ -55,6 +55,7 @@ SIGNATURES = {
     "lpvs_problem_zerofreq": (_I32, [_P, _PI64]),
     "lpvs_problem_get_gram_f64": (_I32, [_P, _P, _P]),
     "lpvs_problem_solve_ridge_f64": (_I32, [_P, _F64, _P]),
+    "lpvs_ls_spectral_f64": (_I32, [_P, _P, _I64, _P, _I64, _F64, _I32, _P, _P]),
     "lpvs_problem_set_prox": (_I32, [_P, _I32, _F64, _I64]),
     "lpvs_admm_init_f64": (_I32, [_P, _P, _F64, _F64, _I32]),
     "lpvs_admm_run": (_I32, [_P, _I64, _PI64, C.POINTER(_F64), C.POINTER(_I32)]),

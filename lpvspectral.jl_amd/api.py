@@ -41,6 +41,12 @@ class SpectralExt:
     Σ: Any
 
 
+def abs2(x):
+    """Julia's ``abs2``: re² + im² (not hypot²), so that e.g. ``ls_cohere(y,y) == 1`` holds exactly."""
+    x = np.asarray(x)
+    return x.real * x.real + x.imag * x.imag if np.iscomplexobj(x) else x * x
+
+
 def reshape_params(x, Nf):
     """src/utilities.jl:77: params as an [Nω × Nv] matrix."""
     return np.reshape(np.asarray(x), (int(Nf), -1), order="F")
@@ -49,7 +55,7 @@ def reshape_params(x, Nf):
 def psd(se: SpectralExt):
     """src/lsfft.jl:214-217."""
     rp = reshape_params(np.array(se.x, copy=True), len(np.ravel(se.w)))
-    return np.abs(rp.sum(axis=1, keepdims=True)) ** 2
+    return abs2(rp.sum(axis=1, keepdims=True))
 
 
 # --------------------------------------------------------------------------- small host helpers
@@ -311,13 +317,21 @@ def ls_spectral(y, t, f=None, W=None, λ=1e-10, verbose=False, device=0):
     """``ls_spectral(y,t,f=default_freqs(t); λ=1e-10)`` (src/lsfft.jl:62-67) and the weighted
     ``ls_spectral(y,t,f,W; λ)`` (:74-80) -> ``(x, f)``.
 
-    Both solve the normal equations from the device Gram: the weighted form is the reference's own
-    formula ``(A'WA + λI) \\ A'Wy``; the unweighted one is the normal-equation form of
-    ``[A; λI] \\ [y; 0]`` (ridge λ²) -- identical minimiser, no SVD."""
+    The weighted form is the reference's own formula ``(A'WA + λI) \\ A'Wy`` on the device Gram.  The
+    unweighted form ``[A; λI] \\ [y; 0]`` is solved from normal equations in the better-conditioned shape:
+    primal ``(A'A+λ²I)⁻¹A'y`` for tall systems, dual ``A'(AA'+λ²I)⁻¹y`` for fat ones (the reference's default
+    frequency grid on an even-length record has one more column than rows) -- identical minimiser, no SVD."""
     f = default_freqs(t) if f is None else f
+    if W is None:
+        ky, py, N = as_f64(y)
+        kt, pt, Nt = as_f64(t)
+        kf, pf, Nf = as_f64(f)
+        assert N == Nt, "y and t has to be the same length"
+        re, im = np.zeros(Nf), np.zeros(Nf)
+        check(lib().lpvs_ls_spectral_f64(py, pt, N, pf, Nf, float(λ), int(device), out_ptr(re), out_ptr(im)))
+        return re + 1j * im, _host(f)
     with Problem.fourier(y, t, f, W, device=device) as prob:
-        ridge = λ if W is not None else λ * λ
-        x = prob.solve_ridge(ridge)
+        x = prob.solve_ridge(λ)
         if verbose:
             G, _ = prob.get_gram()
             log.info("Condition number: %s\n", round(float(np.linalg.cond(G)), 2))
@@ -432,8 +446,46 @@ def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimato
     S = np.zeros(len(freqs))
     for yi, ti in windows:                                          # :120
         x = estimator(yi, ti, freqs, windows.W, **kwargs)[0]        # :121
-        S += np.abs(np.asarray(x)) ** 2                             # :122
+        S += abs2(x)                                                # :122
     return S / k ** 2, freqs                                        # :125
+
+
+def ls_windowcsd(y, u, t, freqs=None, nw=10, noverlap=-1, window_func=rect, estimator=None, **kwargs):
+    """``ls_windowcsd(y,u,t,freqs; nw, noverlap, window_func, estimator=ls_spectral)`` (src/lsfft.jl:140-156):
+    cross spectral density, ``S += xy .* conj(xu)`` over the windows, returned as ``S/nw``."""
+    estimator = ls_spectral if estimator is None else estimator
+    n = len(y) // nw
+    if freqs is None:
+        freqs = default_freqs(t, n=n)
+    S = np.zeros(len(freqs), dtype=np.complex128)
+    wy = Windows2(y, t, n, noverlap, window_func)
+    wu = Windows2(u, t, n, noverlap, window_func)
+    k = len(wy)
+    for (yi, ti), (ui, _) in zip(wy, wu):
+        xy = estimator(yi, ti, freqs, wy.W, **kwargs)[0]
+        xu = estimator(ui, ti, freqs, wu.W, **kwargs)[0]
+        S = S + np.asarray(xy) * np.conj(np.asarray(xu))
+    return S / k, freqs
+
+
+def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, **kwargs):
+    """``ls_cohere(y,u,t,freqs; nw, noverlap, estimator=ls_spectral)`` (src/lsfft.jl:176-193): magnitude-squared
+    coherence over Hann-weighted windows (``Windows3(y,t,u,n,noverlap,hanning)``, :182)."""
+    from .windows import hanning
+    estimator = ls_spectral if estimator is None else estimator
+    n = len(y) // nw
+    if freqs is None:
+        freqs = default_freqs(t, n=n)
+    Syy, Suu = np.zeros(len(freqs)), np.zeros(len(freqs))
+    Syu = np.zeros(len(freqs), dtype=np.complex128)
+    windows = Windows3(y, t, u, n, noverlap, hanning)
+    for yi, ti, ui in windows:
+        xy = np.asarray(estimator(yi, ti, freqs, windows.W, **kwargs)[0])
+        xu = np.asarray(estimator(ui, ti, freqs, windows.W, **kwargs)[0])
+        Syu += xy * np.conj(xu)
+        Syy += abs2(xy)
+        Suu += abs2(xu)
+    return abs2(Syu) / (Suu * Syy), freqs
 
 
 def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, **kwargs):
@@ -444,5 +496,5 @@ def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, **kwargs):
     for y, x, v in windows:
         se = ls_spectral_lpv(y, x, v, w, Nv, **kwargs)
         rp = reshape_params(se.x, len(w))
-        S = S + np.abs(rp.sum(axis=1)) ** 2
+        S = S + abs2(rp.sum(axis=1))
     return S

@@ -601,6 +601,31 @@ static void launch_symv_raw(const double *M, int64_t np, const double *rhs, doub
         hipLaunchKernelGGL(symv_kernel<1>, dim3((unsigned)ceil_div(np, 4)), dim3(256), 0, s, M, np, rhs, x, st);
 }
 
+// out[r] = sum_c A[r*ld + c] v[c], r < rows, c < cols (cols % 2 == 0, 16-B aligned rows): one wave per row
+__global__ void __launch_bounds__(256)
+rect_matvec_kernel(const double *__restrict__ A, int64_t rows, int64_t cols, int64_t ld, const double *__restrict__ v,
+                   double *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const double2 *a2 = reinterpret_cast<const double2 *>(A + r * ld);
+    const double2 *v2 = reinterpret_cast<const double2 *>(v);
+    double acc = 0;
+    for (int64_t j = lane; j < cols / 2; j += 64) {
+        const double2 m = a2[j], w = v2[j];
+        acc = fma(m.x, w.x, acc);
+        acc = fma(m.y, w.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[r] = acc;
+}
+
+int32_t launch_rect_matvec(const double *A, int64_t rows, int64_t cols, int64_t ld, const double *v, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(rect_matvec_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, A, rows, cols, ld, v, out);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s) {
     launch_symv_raw(M, np, rhs, x, nullptr, s);
     LPVS_HIP(hipGetLastError());

@@ -706,6 +706,63 @@ struct PhaseTrace {
     }
 };
 
+// ---- ls_spectral: primal or dual normal equations ---------------------------------------------------------
+int32_t lpvs_ls_spectral_f64(const double *y, const double *t, int64_t N, const double *f, int64_t Nf, double lam, int32_t device,
+                             double *re_out, double *im_out) {
+    if (N <= 0 || Nf <= 0) { set_error("N and Nf must be positive"); return LPVS_EARGUMENT; }
+    int64_t zf = 0;
+    LPVS_TRY(lpvs_check_freq_f64(f, Nf, &zf));
+    const int64_t nreg = zf ? 2 * Nf - 1 : 2 * Nf;
+    lpvs_problem *h = nullptr;
+    if (N >= nreg) {   // tall: the ordinary Gram problem
+        LPVS_TRY(lpvs_problem_create_fourier_f64(y, t, N, f, Nf, nullptr, device, &h));
+        std::vector<double> x((size_t)nreg);
+        int32_t rc = lpvs_problem_solve_ridge_f64(h, lam * lam, x.data());
+        if (rc == LPVS_OK) rc = lpvs_problem_pack_params_f64(h, x.data(), re_out, im_out);
+        lpvs_problem_destroy(h);
+        return rc;
+    }
+    // fat: Gram over the regressor columns, G2 = A A' (N x N), alpha = (G2 + lam^2 I)^-1 y, x = A' alpha
+    lpvs_problem *dummy = nullptr;
+    LPVS_TRY(problem_begin(device, &dummy, &h));
+    struct Guard { lpvs_problem *h; ~Guard() { delete h; } } guard{h};
+    hipStream_t s = h->stream;
+    h->kind = 0; h->N = nreg; h->Nf = Nf; h->zerofreq = zf; h->n = N; h->np = round_up(N, 128);
+    const GramPlan pl = make_gram_plan(N, nreg);
+    const int64_t rows = pl.ksplit * pl.rows_per_chunk, ldn = round_up(N, 256);
+    DevArg dy, dt, df;
+    LPVS_TRY(dy.set(y, N, s)); LPVS_TRY(dt.set(t, N, s)); LPVS_TRY(df.set(f, Nf, s));
+    LPVS_TRY(h->G.alloc(sizeof(double) * (size_t)h->np * (size_t)h->np));
+    LPVS_TRY(h->b.alloc(sizeof(double) * (size_t)h->np));
+    LPVS_HIP(hipMemsetAsync(h->G.p, 0, h->G.bytes, s));
+    LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
+    LPVS_TRY(alloc_state(h));
+    LPVS_HIP(hipMemcpyAsync(h->b.p, dy.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));   // right-hand side = y
+    DevBuf D, slab, xo;
+    LPVS_TRY(D.alloc(sizeof(double) * (size_t)rows * (size_t)ldn));
+    LPVS_TRY(launch_fourier_dual_panel(dt.p, N, df.p, Nf, (int)zf, D.as<double>(), ldn, rows, s));
+    LPVS_TRY(slab.alloc(pl.slab_bytes));
+    LPVS_TRY(launch_gram_panel(pl, D.as<double>(), ldn, nullptr, slab.as<double>(), s));
+    LPVS_TRY(launch_gram_reduce(pl, slab.as<double>(), h->G.as<double>(), h->np, s));
+    LPVS_TRY(factorize(h, lam * lam));
+    LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->b.as<double>(), h->scratch.as<double>(), s));       // alpha (pad = 0)
+    LPVS_TRY(xo.alloc(sizeof(double) * (size_t)rows));
+    // x[c] = sum_n D[c][n] alpha[n]; alpha is zero beyond N and np <= ldn may not hold, so use min(np, ldn) columns
+    const int64_t cols = h->np < ldn ? h->np : ldn;
+    LPVS_TRY(launch_rect_matvec(D.as<double>(), nreg, cols, ldn, h->scratch.as<double>(), xo.as<double>(), s));
+    std::vector<double> x((size_t)nreg);
+    LPVS_TRY(copy_from_device(x.data(), xo.p, sizeof(double) * (size_t)nreg, s));
+    // pack with the Fourier layout (kind 0, Nf, zerofreq are set; n is the dual size, so pack by hand)
+    std::vector<double> re((size_t)Nf), im((size_t)Nf);
+    if (!zf) for (int64_t i = 0; i < Nf; ++i) { re[i] = x[i]; im[i] = x[Nf + i]; }
+    else { re[0] = x[0]; im[0] = 0.0; for (int64_t i = 1; i < Nf; ++i) { re[i] = x[i]; im[i] = x[Nf + i - 1]; } }
+    const size_t bytes = sizeof(double) * (size_t)Nf;
+    if (re_out) { if (is_device_ptr(re_out)) { LPVS_HIP(hipMemcpy(re_out, re.data(), bytes, hipMemcpyHostToDevice)); } else memcpy(re_out, re.data(), bytes); }
+    if (im_out) { if (is_device_ptr(im_out)) { LPVS_HIP(hipMemcpy(im_out, im.data(), bytes, hipMemcpyHostToDevice)); } else memcpy(im_out, im.data(), bytes); }
+    LPVS_HIP(hipStreamSynchronize(s));
+    return LPVS_OK;
+}
+
 // ---- batched windows ------------------------------------------------------------------------------------
 int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,
                                   const double *freqs, int64_t Nf, int32_t prox_kind, double prox_param, int64_t group_len,

@@ -30,6 +30,30 @@ fourier_regressor_colmajor_kernel(const double *__restrict__ t, int64_t N,
     if (!(zerofreq && fn == 0)) A[n + (fn + sinoffset) * N] = -s * dd;
 }
 
+// ---- a2 transposed: D[col][ldn] (one regressor column per row, samples along the row) ---------------
+// = the column-major regressor with leading dimension ldn; it is the k-major panel of the DUAL Gram
+// A A' (contraction over regressor columns).  Rows >= Nreg and samples >= N are zero.
+__global__ void __launch_bounds__(256)
+fourier_dual_panel_kernel(const double *__restrict__ t, int64_t N, const double *__restrict__ f, int64_t Nf, int zerofreq,
+                          double *__restrict__ D, int64_t ldn, int64_t nrows) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = blockIdx.y;                                   // row of D = regressor column
+    if (n >= ldn) return;
+    const int64_t nreg = zerofreq ? 2 * Nf - 1 : 2 * Nf;
+    double v = 0.0;
+    if (r < nreg && n < N) {
+        const double dd = 1.0 / sqrt((double)(2 * Nf));
+        const bool is_sin = r >= Nf;
+        const int64_t fn = is_sin ? r - (zerofreq ? Nf - 1 : Nf) : r;
+        const double phi = (kTwoPi * f[fn]) * t[n];
+        double s, c;
+        sincos(phi, &s, &c);
+        v = is_sin ? -s * dd : c * dd;
+    }
+    (void)nrows;
+    D[r * ldn + n] = v;
+}
+
 // ---- a2 as a k-major panel P[n][ld]: the operand layout of the Gram kernel ---------------
 __global__ void __launch_bounds__(256)
 fourier_panel_kernel(const double *__restrict__ t, int64_t N, const double *__restrict__ f,
@@ -200,6 +224,14 @@ int32_t launch_fourier_regressor_colmajor(const double *t, int64_t N, const doub
     if (N == 0 || Nf == 0) return LPVS_OK;
     dim3 grid((unsigned)ceil_div(N, 256), (unsigned)Nf);
     hipLaunchKernelGGL(fourier_regressor_colmajor_kernel, grid, dim3(256), 0, s, t, N, f, Nf, zerofreq, A);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_fourier_dual_panel(const double *t, int64_t N, const double *f, int64_t Nf, int zerofreq, double *D, int64_t ldn,
+                                  int64_t nrows, hipStream_t s) {
+    dim3 grid((unsigned)ceil_div(ldn, 256), (unsigned)nrows);
+    hipLaunchKernelGGL(fourier_dual_panel_kernel, grid, dim3(256), 0, s, t, N, f, Nf, zerofreq, D, ldn, nrows);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

@@ -277,18 +277,37 @@ def test_callback_and_printing(L):
 
 
 # ------------------------------------------------------------------ dense estimators + windows (a16, a18)
-def test_ls_spectral_known_answers_on_device(L):
-    """test/runtests.jl:185-195 through the device path (weighted form; the 3-arg form needs N >= Nreg)."""
+def test_ls_spectral_known_answers_on_device(L, oracle):
+    """test/runtests.jl:185-195 through the device path: the default grid (501 frequencies, Nreg = 1001 > N = 1000,
+    vanishing Nyquist sine column) goes through the dual form, the weighted method through the primal one."""
     t = np.arange(1000) * 0.1
     y = np.sin(2 * np.pi * t)
+    x, freqs = L.ls_spectral(y, t)
+    p = np.abs(x) ** 2
+    assert len(freqs) == 501 and abs(p.max() - 2.0 * len(freqs)) < 1e-4 and p.argmax() + 1 == 101
+    xo, _ = oracle.ls_spectral(y, t)
+    assert rel(x, xo) <= 1e-6                           # same minimiser as the SVD solve
     f = L.default_freqs(t)
     x, _ = L.ls_spectral(y, t, f, np.ones(len(y)))
     p = np.abs(x) ** 2
     assert abs(p.max() - 2.0 * len(f)) < 1e-4 and p.argmax() + 1 == 101
-    f2 = f[:-1]                                   # drop Nyquist: tall, full-rank system
+    f2 = f[:-1]                                          # drop Nyquist: tall, full-rank system (primal form)
     x2, _ = L.ls_spectral(y, t, f2)
     p2 = np.abs(x2) ** 2
     assert abs(p2.max() - 2.0 * len(f2)) < 1e-4 and p2.argmax() + 1 == 101
+    xo2, _ = oracle.ls_spectral(y, t, f2)
+    assert rel(x2, xo2) <= 1e-8
+
+
+def test_ls_windowcsd_and_cohere_known_answers(L):
+    """test/runtests.jl:203-208."""
+    t = np.arange(1000) * 0.1
+    y = np.sin(2 * np.pi * t)
+    x, freqs = L.ls_windowcsd(y, y, t, noverlap=0)
+    a = np.abs(x)
+    assert abs(a.max() - 2.0 * len(freqs)) < 1e-4 and a.argmax() + 1 == 11
+    c, _ = L.ls_cohere(y, y, t)
+    assert np.all(c == 1)
 
 
 def test_ls_windowpsd_known_answers_on_device(L, oracle):
