@@ -94,6 +94,14 @@ int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_
 int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const double *V, int64_t N,
                                     const double *w, int64_t Nf, int64_t Nv, int32_t normalize,
                                     int32_t coulomb, int32_t device, lpvs_problem **out);
+/* lpv_multi: ns signals sharing (X, V, w) -- Y is N x ns column-major (multichannel records): ONE Gram, ns
+ *          right-hand sides b_q = Phi' y_q; every ADMM kernel then advances all ns signals in one pass over M,
+ *          each with its own convergence flag and iteration count (extension: the reference has no batched
+ *          entry point, SURVEY.md section 8(b) "Gaps").  x0 / iterates / params are n x ns (resp. m x ns). */
+int32_t lpvs_problem_create_lpv_multi_f64(const double *Y, int64_t ns, const double *X, const double *V, int64_t N,
+                                          const double *w, int64_t Nf, int64_t Nv, int32_t normalize,
+                                          int32_t coulomb, int32_t device, lpvs_problem **out);
+int32_t lpvs_problem_num_signals(const lpvs_problem *h, int64_t *ns);
 /* dense:   A (m x n column-major) supplied by the caller: G = A' diag(W) A, b = A' diag(W) y --
  *          the generic ADMM(x, LeastSquares(A,y,iterative=true), proxg) plugin path, src/lasso.jl:136 */
 int32_t lpvs_problem_create_dense_f64(const double *A, const double *y, int64_t m, int64_t n,
@@ -133,6 +141,8 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
                            int32_t linear_sign);
 int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, double *nxz,
                       int32_t *converged);
+/* per-signal state of a multi-signal handle (lpvs_admm_run reports the slowest signal / the largest ||x-z||) */
+int32_t lpvs_admm_status(lpvs_problem *h, int64_t signal, int64_t *iters_done, double *nxz, int32_t *converged);
 /* iterates in the solver's own (regressor-column) order; any pointer may be NULL */
 int32_t lpvs_admm_get_f64(lpvs_problem *h, double *x_out, double *z_out, double *u_out);
 

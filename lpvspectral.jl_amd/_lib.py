@@ -48,6 +48,9 @@ SIGNATURES = {
     "lpvs_lpv_regressor_f64": (_I32, [_P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P]),
     "lpvs_problem_create_fourier_f64": (_I32, [_P, _P, _I64, _P, _I64, _P, _I32, C.POINTER(_P)]),
     "lpvs_problem_create_lpv_f64": (_I32, [_P, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.POINTER(_P)]),
+    "lpvs_problem_create_lpv_multi_f64": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.POINTER(_P)]),
+    "lpvs_problem_num_signals": (_I32, [_P, _PI64]),
+    "lpvs_admm_status": (_I32, [_P, _I64, _PI64, C.POINTER(_F64), C.POINTER(_I32)]),
     "lpvs_problem_create_dense_f64": (_I32, [_P, _P, _I64, _I64, _P, _I32, C.POINTER(_P)]),
     "lpvs_problem_create_gram_f64": (_I32, [_P, _P, _I64, _I32, C.POINTER(_P)]),
     "lpvs_problem_destroy": (_I32, [_P]),

@@ -141,6 +141,8 @@ def fourier2complex(x, zerofreq):
 class Problem:
     """Owner of one ``lpvs_problem`` handle (regressor + Gram resident on one MI355X)."""
 
+    ns = 1   # signals sharing the regressor (lpv_multi)
+
     def __init__(self, handle, kind):
         self._h = handle
         self.kind = kind
@@ -174,6 +176,28 @@ class Problem:
         check(lib().lpvs_problem_create_lpv_f64(py, px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), int(device), C.byref(h)))
         p = cls(h, "lpv")
         p.Nf, p.nb = Nf, (2 * Nv if coulomb else Nv)
+        return p
+
+    @classmethod
+    def lpv_multi(cls, Y, X, V, w, Nv, normalize=True, coulomb=False, device=0):
+        """``Y`` is N x ns (one column per signal / channel) sharing ``X, V, w``: one Gram, ns right-hand sides."""
+        if _lib.is_device_array(Y):
+            assert Y.dim() == 2
+            ns, N = Y.shape[1], Y.shape[0]
+            Yc = Y.t().contiguous()                 # column-major N x ns == row-major [ns][N]
+            ky, py = Yc, C.c_void_p(Yc.data_ptr())
+        else:
+            Yh = np.asfortranarray(_host(Y))
+            N, ns = Yh.shape
+            ky, py = Yh, out_ptr(Yh)
+        kx, px, Nx = as_f64(X)
+        kv, pv, Nvv = as_f64(V)
+        kw, pw, Nf = as_f64(w)
+        assert N == Nx == Nvv, "Y, X and V has to have the same number of samples"
+        h = C.c_void_p()
+        check(lib().lpvs_problem_create_lpv_multi_f64(py, int(ns), px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), int(device), C.byref(h)))
+        p = cls(h, "lpv")
+        p.Nf, p.nb, p.ns = Nf, (2 * Nv if coulomb else Nv), int(ns)
         return p
 
     @classmethod
@@ -246,13 +270,20 @@ class Problem:
         return int(it.value), float(nxz.value), bool(conv.value)
 
     def admm_get(self):
-        x, z, u = np.zeros(self.n), np.zeros(self.n), np.zeros(self.n)
+        shape = self.n if self.ns == 1 else (self.n, self.ns)
+        x, z, u = (np.zeros(shape, order="F") for _ in range(3))
         check(lib().lpvs_admm_get_f64(self._h, out_ptr(x), out_ptr(z), out_ptr(u)))
         return x, z, u
 
+    def admm_status(self, signal=0):
+        it, nxz, conv = C.c_int64(0), C.c_double(0), C.c_int32(0)
+        check(lib().lpvs_admm_status(self._h, int(signal), C.byref(it), C.byref(nxz), C.byref(conv)))
+        return int(it.value), float(nxz.value), bool(conv.value)
+
     def params(self, which=0):
         m = self.Nf * self.nb if self.kind == "lpv" else self.Nf
-        re, im = np.zeros(m), np.zeros(m)
+        shape = m if self.ns == 1 else (m, self.ns)
+        re, im = np.zeros(shape, order="F"), np.zeros(shape, order="F")
         check(lib().lpvs_problem_get_params_f64(self._h, int(which), out_ptr(re), out_ptr(im)))
         return re + 1j * im
 
@@ -380,6 +411,24 @@ def ls_sparse_spectral_lpv(y, X, V, w, Nv, λ=1, coulomb=False, normalize=True, 
             log.info("Aborting")
             params = prob.params(1)                                  # z = copy(x)
     return SpectralExt(y, X, V, w, Nv, λ, coulomb, normalize, params, None)
+
+
+def ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, λ=1, normalize=True, device=0, proxg=None, **kwargs):
+    """Batched multichannel form of :func:`ls_sparse_spectral_lpv` (extension; BASELINE.json config 5): the columns
+    of ``Y`` (N x ns) are independent signals sharing ``X, V, w``.  One Gram / factorisation, every ADMM kernel
+    advances all signals; each signal stops at its own ``‖x−z‖₂ < tol``.  Returns a list of :class:`SpectralExt`
+    whose entries equal the single-signal results."""
+    w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
+    Nf, Nv = len(w), int(Nv)
+    with Problem.lpv_multi(Y, X, V, w, Nv, normalize, False, device=device) as prob:
+        g = SlicedSeparableSum.frequency_groups(λ, Nf, 2 * Nv) if proxg is None else proxg
+        _admm_on_problem(prob, None, g, _lib.LINEAR_LEAST_SQUARES, **kwargs)
+        P = prob.params(0)
+        ns = prob.ns
+    P = P.reshape(-1, ns, order="F")
+    Yh = Y if not _lib.is_device_array(Y) else None
+    return [SpectralExt(None if Yh is None else np.asarray(Yh)[:, q], X, V, w, Nv, λ, False, normalize, P[:, q].copy(), None)
+            for q in range(ns)]
 
 
 def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, device=0):

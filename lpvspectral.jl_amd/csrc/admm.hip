@@ -24,9 +24,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 // x = M rhs.  Wave handles RPW rows; lane covers columns 2*lane + 128*t.
 template <int RPW>
 __global__ void __launch_bounds__(256)
-symv_kernel(const double *__restrict__ M, int64_t np, const double *__restrict__ rhs, double *__restrict__ x,
+symv_kernel(const double *__restrict__ M, int64_t np, const double *__restrict__ rhs_all, double *__restrict__ x_all,
             const AdmmStatus *status) {
-    if (status != nullptr && status->converged) return;
+    const int sg = blockIdx.y;                                   // signal (right-hand side) of a shared-regressor batch
+    if (status != nullptr && status[sg].converged) return;
+    const double *rhs = rhs_all + (int64_t)sg * np;
+    double *x = x_all + (int64_t)sg * np;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW;
     if (row0 >= np) return;
@@ -57,16 +60,18 @@ symv_kernel(const double *__restrict__ M, int64_t np, const double *__restrict__
 
 __global__ void __launch_bounds__(256)
 admm_init_kernel(AdmmParams p) {
+    const int sg = blockIdx.y;
+    const int64_t o = (int64_t)sg * p.np;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.np; i += (int64_t)gridDim.x * 256) {
         const bool ok = i < p.n;
-        const double xi = ok ? p.x[i] : 0.0;
-        p.x[i] = xi;
-        p.z[i] = xi;                                    // z = copy(x)      src/lasso.jl:146
-        p.u[i] = 0.0;                                   // u = zeros        src/lasso.jl:147
-        p.rhs[i] = ok ? p.b[i] + (xi - 0.0) / p.mu : 0.0;  // b + (z-u)/mu
+        const double xi = ok ? p.x[o + i] : 0.0;
+        p.x[o + i] = xi;
+        p.z[o + i] = xi;                                    // z = copy(x)      src/lasso.jl:146
+        p.u[o + i] = 0.0;                                   // u = zeros        src/lasso.jl:147
+        p.rhs[o + i] = ok ? p.b[o + i] + (xi - 0.0) / p.mu : 0.0;  // b + (z-u)/mu
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        p.status->iters = 0; p.status->converged = 0; p.status->nxz = 0.0;
+        p.status[sg].iters = 0; p.status[sg].converged = 0; p.status[sg].nxz = 0.0;
     }
 }
 
@@ -131,14 +136,16 @@ admm_prox_kernel(AdmmParams p) {
     __shared__ int scan[1024];
     __shared__ double sq[PASS];        // v^2 of the current pass (group prox)
     __shared__ double gscale[PASS];    // per-group scale of the current pass
-    if (p.status->converged) return;
-    const int64_t n = p.n;
+    const int sg = blockIdx.x;         // one workgroup per signal
+    AdmmStatus *status = p.status + sg;
+    if (status->converged) return;
+    const int64_t n = p.n, so = (int64_t)sg * p.np;
     const double mu = p.mu;
-    const double *__restrict__ X = p.x;
-    const double *__restrict__ B = p.b;
-    double *__restrict__ Z = p.z;
-    double *__restrict__ U = p.u;
-    double *__restrict__ R = p.rhs;
+    const double *__restrict__ X = p.x + so;
+    const double *__restrict__ B = p.b + so;
+    double *__restrict__ Z = p.z + so;
+    double *__restrict__ U = p.u + so;
+    double *__restrict__ R = p.rhs + so;
     double ss = 0;  // sum (x-z)^2 over this thread's elements
 
     auto finish = [&](int64_t i, double xi, double ui, double bi, double zi) {
@@ -152,7 +159,7 @@ admm_prox_kernel(AdmmParams p) {
     const int kind = p.prox_kind;
     double thr_l1 = mu * p.prox_param, thr_l0 = sqrt(2.0 * mu * p.prox_param);
     unsigned long long ball_thr = 0; long long ball_keep_eq = 0, ball_r = (long long)p.prox_param;
-    double *vbuf = p.scratch;
+    double *vbuf = p.scratch + 2 * so;
     if (kind == LPVS_PROX_BALL_L0 && ball_r > 0 && ball_r < n) {
         for (int64_t i = threadIdx.x; i < n; i += 1024) vbuf[i] = X[i] + U[i];
         __syncthreads();
@@ -248,9 +255,9 @@ admm_prox_kernel(AdmmParams p) {
     const double tot = block_sum_1024(ss, sh);
     if (threadIdx.x == 0) {
         const double nxz = sqrt(tot);          // norm(tmp)               src/lasso.jl:157
-        p.status->iters += 1;
-        p.status->nxz = nxz;
-        if (nxz < p.tol) p.status->converged = 1;  //                    src/lasso.jl:164
+        status->iters += 1;
+        status->nxz = nxz;
+        if (nxz < p.tol) status->converged = 1;  //                      src/lasso.jl:164
     }
 }
 
@@ -282,51 +289,61 @@ pack_tiles_kernel(const double *__restrict__ M, int64_t np, double *__restrict__
 }
 
 __global__ void __launch_bounds__(256)
-symv_tile_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs, double *__restrict__ part1,
-                 double *__restrict__ part2, const AdmmStatus *status) {
-    if (status != nullptr && status->converged) return;
+symv_tile_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
+                 double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    if (status != nullptr) {   // nothing to do once every signal has converged
+        bool all = true;
+        for (int q = 0; q < ns; ++q) all = all && status[q].converged;
+        if (all) return;
+    }
     __shared__ double sI[TS], sJ[TS], sT[4][TS];
     const int t = blockIdx.x;
     int I, J;
     tile_index(t, I, J);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double2 *base = reinterpret_cast<const double2 *>(Mp + (int64_t)t * TS * TS + wave * 32 * TS) + lane;
-    double2 m[32];
+    double2 m[32];   // the tile is read once and applied to every right-hand side
 #pragma unroll
     for (int r = 0; r < 32; ++r) m[r] = base[r * (TS / 2)];
-    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
-    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
-    __syncthreads();
-    const double rj0 = sJ[2 * lane], rj1 = sJ[2 * lane + 1];
-    double t0 = 0, t1 = 0, v[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        const double ri = sI[wave * 32 + r];
-        t0 = fma(m[r].x, ri, t0);
-        t1 = fma(m[r].y, ri, t1);
-        v[r] = fma(m[r].x, rj0, m[r].y * rj1);
-    }
-    // halving butterfly: after the step with mask w a lane keeps the rows whose bit matches its own
-#pragma unroll
-    for (int w = 32, cnt = 16; w >= 2; w >>= 1, cnt >>= 1) {
-        const bool hi = (lane & w) != 0;
-#pragma unroll
-        for (int k = 0; k < cnt; ++k) {
-            const double send = hi ? v[k] : v[k + cnt];
-            const double keep = hi ? v[k + cnt] : v[k];
-            v[k] = keep + __shfl_xor(send, w, 64);
-        }
-    }
-    v[0] += __shfl_xor(v[0], 1, 64);
-    if ((lane & 1) == 0) {
-        const int row = ((lane & 32) ? 16 : 0) + ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
-        part1[(int64_t)t * TS + wave * 32 + row] = v[0];
-    }
-    if (I != J) {
-        sT[wave][2 * lane] = t0; sT[wave][2 * lane + 1] = t1;
+    for (int sg = 0; sg < ns; ++sg) {
+        if (status != nullptr && status[sg].converged) continue;
+        const double *rhs = rhs_all + (int64_t)sg * np;
+        double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
+        __syncthreads();   // previous signal's readers are done with sI / sJ / sT
+        if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+        else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
         __syncthreads();
-        if (threadIdx.x < TS)
-            part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+        const double rj0 = sJ[2 * lane], rj1 = sJ[2 * lane + 1];
+        double t0 = 0, t1 = 0, v[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const double ri = sI[wave * 32 + r];
+            t0 = fma(m[r].x, ri, t0);
+            t1 = fma(m[r].y, ri, t1);
+            v[r] = fma(m[r].x, rj0, m[r].y * rj1);
+        }
+        // halving butterfly: after the step with mask w a lane keeps the rows whose bit matches its own
+#pragma unroll
+        for (int w = 32, cnt = 16; w >= 2; w >>= 1, cnt >>= 1) {
+            const bool hi = (lane & w) != 0;
+#pragma unroll
+            for (int k = 0; k < cnt; ++k) {
+                const double send = hi ? v[k] : v[k + cnt];
+                const double keep = hi ? v[k + cnt] : v[k];
+                v[k] = keep + __shfl_xor(send, w, 64);
+            }
+        }
+        v[0] += __shfl_xor(v[0], 1, 64);
+        if ((lane & 1) == 0) {
+            const int row = ((lane & 32) ? 16 : 0) + ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
+            part1[(int64_t)t * TS + wave * 32 + row] = v[0];
+        }
+        if (I != J) {
+            sT[wave][2 * lane] = t0; sT[wave][2 * lane + 1] = t1;
+            __syncthreads();
+            if (threadIdx.x < TS)
+                part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+        }
     }
 }
 
@@ -364,27 +381,33 @@ __device__ __forceinline__ double gather_x(const double *__restrict__ part1, con
 }
 
 __global__ void __launch_bounds__(256)
-symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, double *__restrict__ x,
-                   const AdmmStatus *status) {
-    if (status != nullptr && status->converged) return;
+symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, int ntiles, int64_t np,
+                   double *__restrict__ x, const AdmmStatus *status) {
+    const int sg = blockIdx.y;
+    if (status != nullptr && status[sg].converged) return;
     __shared__ double sh[TS];
-    const double s = gather_x(part1, part2, nblk, blockIdx.x, sh);
-    if (threadIdx.x < TS) x[(int64_t)blockIdx.x * TS + threadIdx.x] = s;
+    const double s = gather_x(part1 + (int64_t)sg * ntiles * TS, part2 + (int64_t)sg * ntiles * TS, nblk, blockIdx.x, sh);
+    if (threadIdx.x < TS) x[(int64_t)sg * np + (int64_t)blockIdx.x * TS + threadIdx.x] = s;
 }
 
 // ---- fused: gather x from the tile partials + prox_g + dual update + next rhs, one workgroup per
 // 128-row block; ||x-z||^2 is combined by the last-arriving workgroup in fixed block order (deterministic).
 // Valid for element-wise prox (L1, L0) and for group prox with 128 % group_len == 0, n % group_len == 0.
 __global__ void __launch_bounds__(256)
-admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1, const double *__restrict__ part2, int nblk,
-                         double *__restrict__ blocknorm, unsigned int *__restrict__ ticket) {
-    if (p.status->converged) return;
+admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk,
+                         int ntiles, double *__restrict__ blocknorm_all, unsigned int *__restrict__ ticket_all) {
+    const int sg = blockIdx.y;
+    AdmmStatus *status = p.status + sg;
+    if (status->converged) return;
     __shared__ double sh[TS], sq[TS], gs[TS];
     __shared__ int last;
+    const double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
+    double *blocknorm = blocknorm_all + (int64_t)sg * nblk;
+    unsigned int *ticket = ticket_all + sg;
     const int I = blockIdx.x, i = threadIdx.x & 127;
-    const int64_t gi = (int64_t)I * TS + i;
+    const int64_t li_ = (int64_t)I * TS + i, gi = (int64_t)sg * p.np + li_;
     const double xs = gather_x(part1, part2, nblk, I, sh);
-    const bool row = threadIdx.x < TS, ok = row && gi < p.n;
+    const bool row = threadIdx.x < TS, ok = row && li_ < p.n;
     const double xi = xs, ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;
     const double v = xi + ui;
     double zi = 0.0, d2 = 0.0;
@@ -437,9 +460,9 @@ admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1, const d
         __syncthreads();
         if (threadIdx.x == 0) {
             const double nxz = sqrt(((sq[0] + sq[1]) + sq[2]) + sq[3]);   // norm(tmp)   src/lasso.jl:157
-            p.status->iters += 1;
-            p.status->nxz = nxz;
-            if (nxz < p.tol) p.status->converged = 1;                     //             src/lasso.jl:164
+            status->iters += 1;
+            status->nxz = nxz;
+            if (nxz < p.tol) status->converged = 1;                       //             src/lasso.jl:164
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -551,14 +574,14 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
 }
 
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s) {
-    hipLaunchKernelGGL(admm_init_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(admm_init_kernel, dim3((unsigned)ceil_div(p.np, 256), (unsigned)p.ns), dim3(256), 0, s, p);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
 
-size_t symv_part_doubles(int64_t np) {
+size_t symv_part_doubles(int64_t np, int64_t ns) {
     const int64_t nblk = np / TS;
-    return (size_t)(nblk * (nblk + 1) / 2) * TS * 2 + (size_t)nblk + 16;   // part1, part2, block norms, ticket
+    return ((size_t)(nblk * (nblk + 1) / 2) * TS * 2 + (size_t)nblk + 2) * (size_t)ns + 16;   // part1, part2, block norms, tickets
 }
 size_t symv_packed_doubles(int64_t np) {
     const int64_t nblk = np / TS;
@@ -581,24 +604,25 @@ static bool fused_ok(const AdmmParams &p) {
 static void launch_iteration_sym(const AdmmParams &p, hipStream_t s) {
     const int nblk = (int)(p.np / TS);
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
-    double *part1 = p.part, *part2 = p.part + (size_t)ntiles * TS;
-    double *blocknorm = part2 + (size_t)ntiles * TS;
-    unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + nblk);
-    hipLaunchKernelGGL(symv_tile_kernel, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, part1, part2, p.status);
+    const unsigned ns = (unsigned)p.ns;
+    double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
+    double *blocknorm = part2 + (size_t)ntiles * TS * ns;
+    unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
+    hipLaunchKernelGGL(symv_tile_kernel, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     if (fused_ok(p)) {
-        hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p, part1, part2, nblk, blocknorm, ticket);
+        hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
     } else {
-        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, s, part1, part2, nblk, p.x, p.status);
-        hipLaunchKernelGGL(admm_prox_kernel, dim3(1), dim3(1024), 0, s, p);
+        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status);
+        hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
     }
 }
 
-static void launch_symv_raw(const double *M, int64_t np, const double *rhs, double *x, const AdmmStatus *st,
+static void launch_symv_raw(const double *M, int64_t np, const double *rhs, double *x, const AdmmStatus *st, int ns,
                             hipStream_t s) {
     if (np >= 4096)
-        hipLaunchKernelGGL(symv_kernel<4>, dim3((unsigned)ceil_div(np, 16)), dim3(256), 0, s, M, np, rhs, x, st);
+        hipLaunchKernelGGL(symv_kernel<4>, dim3((unsigned)ceil_div(np, 16), (unsigned)ns), dim3(256), 0, s, M, np, rhs, x, st);
     else
-        hipLaunchKernelGGL(symv_kernel<1>, dim3((unsigned)ceil_div(np, 4)), dim3(256), 0, s, M, np, rhs, x, st);
+        hipLaunchKernelGGL(symv_kernel<1>, dim3((unsigned)ceil_div(np, 4), (unsigned)ns), dim3(256), 0, s, M, np, rhs, x, st);
 }
 
 // out[r] = sum_c A[r*ld + c] v[c], r < rows, c < cols (cols % 2 == 0, 16-B aligned rows): one wave per row
@@ -627,7 +651,7 @@ int32_t launch_rect_matvec(const double *A, int64_t rows, int64_t cols, int64_t 
 }
 
 int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s) {
-    launch_symv_raw(M, np, rhs, x, nullptr, s);
+    launch_symv_raw(M, np, rhs, x, nullptr, 1, s);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -638,8 +662,8 @@ int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s
         if (sym) {
             launch_iteration_sym(p, s);
         } else {
-            launch_symv_raw(p.M, p.np, p.rhs, p.x, p.status, s);
-            hipLaunchKernelGGL(admm_prox_kernel, dim3(1), dim3(1024), 0, s, p);
+            launch_symv_raw(p.M, p.np, p.rhs, p.x, p.status, p.ns, s);
+            hipLaunchKernelGGL(admm_prox_kernel, dim3((unsigned)p.ns), dim3(1024), 0, s, p);
         }
     }
     LPVS_HIP(hipGetLastError());

@@ -209,6 +209,7 @@ struct lpvs_problem {
     int device = 0;
     hipStream_t stream = nullptr;
     int64_t n = 0, np = 0, N = 0, Nf = 0, nb = 0, zerofreq = 0;
+    int64_t ns = 1;   // signals sharing the regressor (right-hand sides); state vectors are [ns][np]
     DevBuf G, b, M, x, z, u, rhs, bs, scratch, status, work, istat, part, Mp;
     bool M_valid = false; double M_shift = 0;
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
@@ -246,13 +247,27 @@ int32_t problem_begin(int32_t device, lpvs_problem **out, lpvs_problem **hp) {
 }
 
 int32_t alloc_state(lpvs_problem *h) {
-    const size_t v = sizeof(double) * (size_t)h->np;
+    const size_t v = sizeof(double) * (size_t)h->np * (size_t)h->ns;
     LPVS_TRY(h->x.alloc(v)); LPVS_TRY(h->z.alloc(v)); LPVS_TRY(h->u.alloc(v)); LPVS_TRY(h->rhs.alloc(v));
     LPVS_TRY(h->bs.alloc(v)); LPVS_TRY(h->scratch.alloc(2 * v));
-    LPVS_TRY(h->status.alloc(sizeof(AdmmStatus))); LPVS_TRY(h->istat.alloc(sizeof(int)));
-    LPVS_TRY(h->part.alloc(sizeof(double) * symv_part_doubles(h->np)));
+    LPVS_TRY(h->status.alloc(sizeof(AdmmStatus) * (size_t)h->ns)); LPVS_TRY(h->istat.alloc(sizeof(int)));
+    LPVS_TRY(h->part.alloc(sizeof(double) * symv_part_doubles(h->np, h->ns)));
     LPVS_HIP(hipMemsetAsync(h->x.p, 0, v, h->stream));
-    LPVS_HIP(hipMemsetAsync(h->status.p, 0, sizeof(AdmmStatus), h->stream));
+    LPVS_HIP(hipMemsetAsync(h->status.p, 0, sizeof(AdmmStatus) * (size_t)h->ns, h->stream));
+    return LPVS_OK;
+}
+
+// device [ns][np] (first n of every row valid)  <->  caller's n x ns column-major array
+int32_t copy_state_out(lpvs_problem *h, const void *dev, double *dst) {
+    LPVS_HIP(hipMemcpy2DAsync(dst, sizeof(double) * (size_t)h->n, dev, sizeof(double) * (size_t)h->np, sizeof(double) * (size_t)h->n,
+                              (size_t)h->ns, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    LPVS_HIP(hipStreamSynchronize(h->stream));
+    return LPVS_OK;
+}
+int32_t copy_state_in(lpvs_problem *h, void *dev, const double *src) {
+    LPVS_HIP(hipMemcpy2DAsync(dev, sizeof(double) * (size_t)h->np, src, sizeof(double) * (size_t)h->n, sizeof(double) * (size_t)h->n,
+                              (size_t)h->ns, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    LPVS_HIP(hipStreamSynchronize(h->stream));
     return LPVS_OK;
 }
 
@@ -426,23 +441,23 @@ int32_t lpvs_lpv_regressor_f64(const double *X, const double *V, int64_t N, cons
     return dP.finish(s);
 }
 
-int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
-                                    int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out) {
-    if (N <= 0 || Nf <= 0 || Nv <= 0) { set_error("N, Nf and Nv must be positive"); return LPVS_EARGUMENT; }
+static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
+                               int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out) {
+    if (N <= 0 || Nf <= 0 || Nv <= 0 || ns <= 0) { set_error("N, Nf, Nv and the number of signals must be positive"); return LPVS_EARGUMENT; }
     lpvs_problem *h = nullptr;
     LPVS_TRY(problem_begin(device, out, &h));
     struct Guard { lpvs_problem *h; ~Guard() { delete h; } } guard{h};
     hipStream_t s = h->stream;
     const int64_t nb = coulomb ? 2 * Nv : Nv;
-    h->kind = 1; h->N = N; h->Nf = Nf; h->nb = nb; h->n = 2 * Nf * nb; h->np = round_up(h->n, 128);
+    h->kind = 1; h->N = N; h->Nf = Nf; h->nb = nb; h->n = 2 * Nf * nb; h->np = round_up(h->n, 128); h->ns = ns;
     const bool krs = gram_krs_fits(nb);   // symmetric-pair form unless the pair table does not fit LDS
     const GramPlan pl = krs ? make_gram_plan_pairs(Nf, nb, N) : make_gram_plan(h->n, N);
     const int64_t Npad = pl.ksplit * pl.rows_per_chunk;
 
     DevArg dy, dX, dV, dw;
-    LPVS_TRY(dy.set(y, N, s)); LPVS_TRY(dX.set(X, N, s)); LPVS_TRY(dV.set(V, N, s)); LPVS_TRY(dw.set(w, Nf, s));
+    LPVS_TRY(dy.set(y, N * ns, s)); LPVS_TRY(dX.set(X, N, s)); LPVS_TRY(dV.set(V, N, s)); LPVS_TRY(dw.set(w, Nf, s));
     LPVS_TRY(h->G.alloc(sizeof(double) * (size_t)h->np * (size_t)h->np));
-    LPVS_TRY(h->b.alloc(sizeof(double) * (size_t)h->np));
+    LPVS_TRY(h->b.alloc(sizeof(double) * (size_t)h->np * (size_t)ns));
     LPVS_HIP(hipMemsetAsync(h->G.p, 0, h->G.bytes, s));
     LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
     LPVS_TRY(alloc_state(h));
@@ -465,7 +480,8 @@ int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const doub
     LPVS_HIP(hipEventRecord(h->ev[2].a, s));
     if (krs) LPVS_TRY(launch_gram_reduce_krs(pl, slab.as<double>(), nb, G3.as<double>(), h->G.as<double>(), h->np, s));
     else LPVS_TRY(launch_gram_reduce(pl, slab.as<double>(), h->G.as<double>(), h->np, s));
-    LPVS_TRY(launch_rhs_kr(T.as<double2>(), Nf, K.as<double>(), ldk, nb, dy.p, N, h->b.as<double>(), scr.as<double>(), scr.bytes, s));
+    for (int64_t q = 0; q < ns; ++q)   // b_q = Phi' y_q for every signal sharing the regressor
+        LPVS_TRY(launch_rhs_kr(T.as<double2>(), Nf, K.as<double>(), ldk, nb, dy.p + q * N, N, h->b.as<double>() + q * h->np, scr.as<double>(), scr.bytes, s));
     LPVS_HIP(hipEventRecord(h->ev[2].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
@@ -473,6 +489,17 @@ int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const doub
     guard.h = nullptr;
     *out = h;
     return LPVS_OK;
+}
+
+int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
+                                    int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out) {
+    return create_lpv_impl(y, 1, X, V, N, w, Nf, Nv, normalize, coulomb, device, out);
+}
+
+int32_t lpvs_problem_create_lpv_multi_f64(const double *Y, int64_t ns, const double *X, const double *V, int64_t N, const double *w,
+                                          int64_t Nf, int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device,
+                                          lpvs_problem **out) {
+    return create_lpv_impl(Y, ns, X, V, N, w, Nf, Nv, normalize, coulomb, device, out);
 }
 
 int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_t N, const double *f, int64_t Nf, const double *W,
@@ -598,17 +625,18 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     }
     LPVS_HIP(hipMemsetAsync(h->part.p, 0, h->part.bytes, s));   // zero the ticket / block norms
     h->mu = mu; h->tol = tol; h->sign = linear_sign;
-    const size_t v = sizeof(double) * (size_t)h->np;
-    if (x0) { LPVS_TRY(copy_to_device(h->x.p, x0, sizeof(double) * (size_t)h->n, s)); }
-    else LPVS_HIP(hipMemsetAsync(h->x.p, 0, v, s));
+    const size_t v = sizeof(double) * (size_t)h->np * (size_t)h->ns;
+    LPVS_HIP(hipMemsetAsync(h->x.p, 0, v, s));
+    if (x0) LPVS_TRY(copy_state_in(h, h->x.p, x0));
     // signed linear term
-    std::vector<double> hb((size_t)h->np, 0.0);
-    LPVS_TRY(copy_from_device(hb.data(), h->b.p, sizeof(double) * (size_t)h->n, s));
+    std::vector<double> hb((size_t)h->np * (size_t)h->ns, 0.0);
+    LPVS_HIP(hipMemcpyAsync(hb.data(), h->b.p, v, hipMemcpyDeviceToHost, s));
+    LPVS_HIP(hipStreamSynchronize(s));
     if (linear_sign < 0) for (auto &q : hb) q = -q;
     LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
     AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
                  h->rhs.as<double>(), mu, tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
-                 h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr};
+                 h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr, (int)h->ns};
     LPVS_TRY(launch_admm_init(p, s));
     LPVS_HIP(hipStreamSynchronize(s));
     h->inited = true;
@@ -622,18 +650,48 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     hipStream_t s = h->stream;
     AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
                  h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
-                 h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr};
-    AdmmStatus st0{}, st{};
-    LPVS_HIP(hipMemcpyAsync(&st0, h->status.p, sizeof(st0), hipMemcpyDeviceToHost, s));
+                 h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr, (int)h->ns};
+    const size_t ns = (size_t)h->ns;
+    std::vector<AdmmStatus> st0(ns), st(ns);
+    LPVS_HIP(hipMemcpyAsync(st0.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
     LPVS_HIP(hipStreamSynchronize(s));
-    if (max_iters > 0 && !st0.converged) {
+    bool all0 = true;
+    for (auto &q : st0) all0 = all0 && q.converged;
+    if (max_iters > 0 && !all0) {
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
         LPVS_TRY(launch_admm_iterations(p, max_iters, s));
         LPVS_HIP(hipEventRecord(h->ev[0].b, s));
     }
-    LPVS_HIP(hipMemcpyAsync(&st, h->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
+    LPVS_HIP(hipMemcpyAsync(st.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
     LPVS_HIP(hipStreamSynchronize(s));
-    if (max_iters > 0 && !st0.converged) { h->t_admm += h->ev[0].ms(); h->admm_iters_timed += (double)(st.iters - st0.iters); }
+    long long it_max = 0, it0_max = 0; double nxz_max = 0; bool all = true;
+    for (size_t q = 0; q < ns; ++q) {
+        if (st[q].iters > it_max) it_max = st[q].iters;
+        if (st0[q].iters > it0_max) it0_max = st0[q].iters;
+        if (st[q].nxz > nxz_max) nxz_max = st[q].nxz;
+        all = all && st[q].converged;
+    }
+    if (max_iters > 0 && !all0) { h->t_admm += h->ev[0].ms(); h->admm_iters_timed += (double)(it_max - it0_max); }
+    if (iters_done) *iters_done = it_max;     // ns > 1: the slowest signal; per-signal values via lpvs_admm_status
+    if (nxz) *nxz = nxz_max;
+    if (converged) *converged = all ? 1 : 0;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_num_signals(const lpvs_problem *h, int64_t *ns) {
+    if (!h || !ns) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    *ns = h->ns;
+    return LPVS_OK;
+}
+
+int32_t lpvs_admm_status(lpvs_problem *h, int64_t signal, int64_t *iters_done, double *nxz, int32_t *converged) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    if (!h->inited) { set_error("lpvs_admm_status before lpvs_admm_init"); return LPVS_ESTATE; }
+    if (signal < 0 || signal >= h->ns) { set_error("signal %lld out of range", (long long)signal); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    AdmmStatus st{};
+    LPVS_HIP(hipMemcpyAsync(&st, h->status.as<AdmmStatus>() + signal, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    LPVS_HIP(hipStreamSynchronize(h->stream));
     if (iters_done) *iters_done = st.iters;
     if (nxz) *nxz = st.nxz;
     if (converged) *converged = st.converged;
@@ -644,14 +702,13 @@ int32_t lpvs_admm_get_f64(lpvs_problem *h, double *x_out, double *z_out, double 
     if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
     if (!h->inited) { set_error("lpvs_admm_get before lpvs_admm_init"); return LPVS_ESTATE; }
     LPVS_HIP(hipSetDevice(h->device));
-    const size_t v = sizeof(double) * (size_t)h->n;
-    if (x_out) LPVS_TRY(copy_from_device(x_out, h->x.p, v, h->stream));
-    if (z_out) LPVS_TRY(copy_from_device(z_out, h->z.p, v, h->stream));
-    if (u_out) LPVS_TRY(copy_from_device(u_out, h->u.p, v, h->stream));
+    if (x_out) LPVS_TRY(copy_state_out(h, h->x.p, x_out));
+    if (z_out) LPVS_TRY(copy_state_out(h, h->z.p, z_out));
+    if (u_out) LPVS_TRY(copy_state_out(h, h->u.p, u_out));
     return LPVS_OK;
 }
 
-static int32_t pack_host(const lpvs_problem *h, const std::vector<double> &c, double *re_out, double *im_out) {
+static int32_t pack_host(const lpvs_problem *h, const double *c, double *re_out, double *im_out) {
     const int64_t Nf = h->Nf, nb = h->nb;
     const int64_t m = h->kind == 1 ? Nf * nb : Nf;
     std::vector<double> re((size_t)m), im((size_t)m);
@@ -672,9 +729,12 @@ int32_t lpvs_problem_get_params_f64(lpvs_problem *h, int32_t which, double *re_o
     if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
     if (!h->inited) { set_error("lpvs_problem_get_params before lpvs_admm_init"); return LPVS_ESTATE; }
     LPVS_HIP(hipSetDevice(h->device));
-    std::vector<double> c((size_t)h->n);
-    LPVS_TRY(copy_from_device(c.data(), which == 1 ? h->x.p : h->z.p, sizeof(double) * (size_t)h->n, h->stream));
-    return pack_host(h, c, re_out, im_out);
+    std::vector<double> c((size_t)h->n * (size_t)h->ns);
+    LPVS_TRY(copy_state_out(h, which == 1 ? h->x.p : h->z.p, c.data()));
+    const int64_t m = h->kind == 1 ? h->Nf * h->nb : h->Nf;
+    for (int64_t q = 0; q < h->ns; ++q)   // signal q -> columns q of the m x ns outputs
+        LPVS_TRY(pack_host(h, c.data() + q * h->n, re_out ? re_out + q * m : nullptr, im_out ? im_out + q * m : nullptr));
+    return LPVS_OK;
 }
 
 int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double *re_out, double *im_out) {
@@ -682,7 +742,7 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
     LPVS_HIP(hipSetDevice(h->device));
     std::vector<double> c;
     LPVS_TRY(fetch_host(c, coef, h->n));
-    return pack_host(h, c, re_out, im_out);
+    return pack_host(h, c.data(), re_out, im_out);
 }
 
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out) {

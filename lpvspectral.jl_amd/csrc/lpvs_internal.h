@@ -151,8 +151,9 @@ struct AdmmParams {
     double *scratch;   // >= 2*np doubles (top-r selection keys)
     double *part;      // symv_part_doubles(np) doubles of tile partials, or nullptr (full mat-vec)
     const double *Mp;  // tile-packed lower triangle of M (symv_packed_doubles(np)), or nullptr
+    int ns;            // right-hand sides sharing M (signals of a shared-regressor batch); vectors are [ns][np]
 };
-size_t symv_part_doubles(int64_t np);
+size_t symv_part_doubles(int64_t np, int64_t ns = 1);
 size_t symv_packed_doubles(int64_t np);
 int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s);
 constexpr int64_t kSymmetricMinNp = 2048;  // below this the iteration is launch-latency bound: plain mat-vec

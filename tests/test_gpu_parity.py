@@ -371,3 +371,34 @@ def test_windowpsd_batched_equals_sequential_and_oracle(L, oracle, noverlap, zer
     xa, Sa, _ = L.windowpsd_sparse_batched(y, t, f, n, noverlap, W, win_lo=0, win_hi=k // 2, **kw)
     xc, Sc, _ = L.windowpsd_sparse_batched(y, t, f, n, noverlap, W, win_lo=k // 2, win_hi=k, **kw)
     assert np.array_equal(np.vstack([xa, xc]), xb)
+
+
+# ------------------------------------------------------------------ shared-regressor batch (cfg5 engine)
+@pytest.mark.parametrize("Nf,Nv,prox", [(12, 8, "group"), (140, 8, "group"), (140, 8, "ball"), (12, 4, "l1")])
+def test_lpv_multi_equals_single_signal_runs(L, Nf, Nv, prox):
+    """ns signals sharing (X, V, w): one Gram, ns right-hand sides; every column must equal the single-signal
+    solve bit for bit (same kernels, same order), with its own stopping iteration."""
+    rng = np.random.default_rng(13)
+    N, ns = 1500, 3
+    X = np.sort(10 * rng.random(N)); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) * 25 / Nf
+    Y = np.stack([np.cos(w[(3 * q + 1) % Nf] * X) * (1 + q * V) + 0.3 * np.sin(w[(5 * q + 2) % Nf] * X) + 0.05 * rng.standard_normal(N)
+                  for q in range(ns)], axis=1)
+    n = 2 * Nf * Nv
+    g = {"group": None, "ball": L.IndBallL0(6), "l1": L.NormL1(2.0)}[prox]
+    kw = dict(λ=3.0, iters=400, tol=1e-7, μ=0.05, printerval=100000)
+    ses = L.ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, proxg=g, **kw)
+    assert len(ses) == ns
+    its = []
+    for q in range(ns):
+        se = L.ls_sparse_spectral_lpv(Y[:, q].copy(), X, V, w, Nv, proxg=g, **kw)
+        assert np.array_equal(ses[q].x, se.x), (q, rel(ses[q].x, se.x))
+        its.append(np.count_nonzero(se.x))
+    assert (n >= 2048) == (Nf == 140)            # both the packed-symmetric and the plain mat-vec paths are covered
+    with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
+        p.set_prox(L.SlicedSeparableSum.frequency_groups(3.0, Nf, 2 * Nv) if g is None else g)
+        p.admm_init(None, μ=0.05, tol=1e-3)
+        it, nxz, conv = p.admm_run(5000)
+        per = [p.admm_status(q) for q in range(ns)]
+    assert conv and all(c for _, _, c in per) and it == max(i for i, _, _ in per)
+    assert len({i for i, _, _ in per}) > 1       # signals stop at their own iteration
