@@ -402,3 +402,66 @@ def test_lpv_multi_equals_single_signal_runs(L, Nf, Nv, prox):
         per = [p.admm_status(q) for q in range(ns)]
     assert conv and all(c for _, _, c in per) and it == max(i for i, _, _ in per)
     assert len({i for i, _, _ in per}) > 1       # signals stop at their own iteration
+
+
+# ------------------------------------------------------------------ edge cases
+def test_tiny_and_ragged_problems(L, oracle):
+    """Sizes below one tile / one stage, single frequency, N < n (fat), odd everything."""
+    rng = np.random.default_rng(21)
+    # Fourier: N = 5 samples, 1 and 3 frequencies (with and without the zero frequency)
+    for f in (np.array([0.3]), np.array([0.0, 0.2, 0.45]), np.array([0.1, 0.2, 0.45])):
+        t = np.sort(rng.random(5)) * 10; y = rng.standard_normal(5)
+        A, zf = L.get_fourier_regressor(t, f)
+        Ao, zo = oracle.get_fourier_regressor(t, f)
+        assert zf == zo and np.abs(A - Ao).max() < 1e-15
+        with L.Problem.fourier(y, t, f) as p:
+            G, b = p.get_gram()
+        assert np.abs(G - Ao.T @ Ao).max() <= 1e-13 and np.abs(b - Ao.T @ y).max() <= 1e-13
+        x, _ = L.ls_sparse_spectral(y, t, f, λ=0.01, iters=50, tol=0, printerval=1000)
+        xo, _, _ = oracle.ls_sparse_spectral(y, t, f, lam=0.01, iters=50, tol=0)
+        assert rel(x, xo) <= 1e-8
+    # LPV: N = 7 < n = 2*3*2 = 12 (fat), Nv = 2
+    N = 7
+    X = np.sort(rng.random(N)) * 3; V = rng.random(N); Y = rng.standard_normal(N)
+    w = np.array([1.0, 2.5, 4.0])
+    se = L.ls_sparse_spectral_lpv(Y, X, V, w, 2, λ=0.1, iters=80, tol=0, printerval=1000)
+    po, ro = oracle.ls_sparse_spectral_lpv(Y, X, V, w, 2, lam=0.1, iters=80, tol=0)
+    assert rel(se.x, po) <= 1e-6
+    # group prox with a length that does not divide 128 (n = 2*5*3 = 30, groups of 6)
+    N = 300
+    X = np.sort(rng.random(N)) * 10; V = np.linspace(0, 1, N)
+    w = 2 * np.pi * np.arange(1, 6.0)
+    Y = np.cos(w[1] * X) * V + 0.05 * rng.standard_normal(N)
+    se = L.ls_sparse_spectral_lpv(Y, X, V, w, 3, λ=2.0, iters=200, tol=0, printerval=1000)
+    G, b = oracle.gram(oracle.lpv_regressor(X, V, w, 3), Y)
+    rg = oracle.admm_gram(G, b, oracle.GroupL2(2.0, 6), iters=200, tol=0)
+    assert rel(se.x, oracle.lpv_unpermute(rg["z"], 5, 3)) <= 1e-9
+
+
+def test_windows_edge_cases_on_device(L):
+    t = np.arange(40.0); y = np.sin(t)
+    f = np.array([0.0, 0.1, 0.2])
+    x, S, its = L.windowpsd_sparse_batched(y, t, f, 50, 0, None, iters=5)        # L < n: no windows
+    assert x.shape == (0, 3) and np.all(S == 0) and len(its) == 0
+    x, S, its = L.windowpsd_sparse_batched(y, t, f, 40, 0, None, iters=5, tol=0)  # exactly one window
+    assert x.shape == (1, 3) and its[0] == 5
+    with pytest.raises(L.DomainError):
+        L.windowpsd_sparse_batched(y, t, f, 10, 10, None, iters=5)
+    with pytest.raises(ValueError):
+        L.windowpsd_sparse_batched(y, t, np.array([0.1, 0.0]), 10, 0, None, iters=5)
+    with pytest.raises(AssertionError):
+        L.windowpsd_sparse_batched(y, t, f, 10, 0, None, iters=5, μ=2.0)
+
+
+def test_warm_start_and_reinit(L, oracle):
+    """init=true warm start (src/lasso.jl:92-97) and re-initialising a handle with another mu."""
+    y, t, f = sines(400, 33)
+    x1, _ = L.ls_sparse_spectral(y, t, f, init=True, λ=1.0, iters=40, tol=0, printerval=1000)
+    xo, _, _ = oracle.ls_sparse_spectral(y, t, f, init=True, lam=1.0, iters=40, tol=0)
+    assert rel(x1, xo) <= 1e-6
+    with L.Problem.fourier(y, t, f) as p:
+        p.set_prox(L.NormL1(1.0))
+        p.admm_init(None, μ=0.05, tol=0); p.admm_run(30); _, z1, _ = p.admm_get()
+        p.admm_init(None, μ=0.5, tol=0); p.admm_run(30); _, z2, _ = p.admm_get()      # new factorisation
+        p.admm_init(None, μ=0.05, tol=0); p.admm_run(30); _, z3, _ = p.admm_get()     # back: identical to the first
+    assert np.array_equal(z1, z3) and not np.array_equal(z1, z2)
