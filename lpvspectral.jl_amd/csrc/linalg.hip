@@ -17,47 +17,76 @@ namespace {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int NB = 64;
 
-// P = inv(A_kk) by in-LDS Gauss-Jordan; status[0] |= 1 on a non-positive pivot.
+// P = inv(A_kk) by Gauss-Jordan without pivoting (SPD); status |= 1 on a non-positive pivot.
+// 256 threads, each owning a 4x4 sub-block in registers; per pivot only the pivot row and column travel
+// through LDS (two barriers), instead of the whole 64x64 block.
 __global__ void __launch_bounds__(256)
 diag_inverse_kernel(const double *__restrict__ Aall, int64_t np, int k, double *__restrict__ Pall, int *status,
                     int64_t strideA, int64_t strideW) {
-    __shared__ double S[NB][NB + 1];
     __shared__ double colp[NB], rowp[NB];
     const double *A = Aall + (int64_t)blockIdx.x * strideA;     // blockIdx.x = problem of a batch
     double *P = Pall + (int64_t)blockIdx.x * strideW;
     const double *blk = A + (int64_t)k * NB * np + (int64_t)k * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {  // only the lower triangle of A is current
-        const int i = e / NB, j = e % NB;
-        S[i][j] = j <= i ? blk[(int64_t)i * np + j] : blk[(int64_t)j * np + i];
-    }
-    __syncthreads();
-    for (int p = 0; p < NB; ++p) {
-        const double d = S[p][p];
-        if (threadIdx.x < NB) { colp[threadIdx.x] = S[threadIdx.x][p]; rowp[threadIdx.x] = S[p][threadIdx.x]; }
-        if (threadIdx.x == 0 && !(d > 0)) atomicOr(status + blockIdx.x, 1);
-        __syncthreads();
-        const double inv = 1.0 / d;
-        for (int e = threadIdx.x; e < NB * NB; e += 256) {
-            const int i = e / NB, j = e % NB;
-            double v;
-            if (i == p && j == p) v = inv;
-            else if (i == p) v = rowp[j] * inv;
-            else if (j == p) v = -colp[i] * inv;
-            else v = S[i][j] - colp[i] * (rowp[j] * inv);
-            S[i][j] = v;
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;     // owns rows 4ti..4ti+3, cols 4tj..4tj+3
+    double v[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                            // only the lower triangle of A is current
+            const int i = 4 * ti + a, j = 4 * tj + b;
+            v[a][b] = j <= i ? blk[(int64_t)i * np + j] : blk[(int64_t)j * np + i];
         }
-        __syncthreads();
+    for (int pb = 0; pb < NB / 4; ++pb) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int p = 4 * pb + pp;
+            if (tj == pb) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) colp[4 * ti + a] = v[a][pp];
+            }
+            if (ti == pb) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) rowp[4 * tj + b] = v[pp][b];
+            }
+            __syncthreads();
+            const double d = colp[p];
+            if (threadIdx.x == 0 && !(d > 0)) atomicOr(status + blockIdx.x, 1);
+            const double inv = 1.0 / d;
+            double cp[4], rp[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { cp[a] = colp[4 * ti + a]; rp[a] = rowp[4 * tj + a] * inv; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = 4 * ti + a, j = 4 * tj + b;
+                    double nv;
+                    if (i == p && j == p) nv = inv;
+                    else if (i == p) nv = rp[b];
+                    else if (j == p) nv = -cp[a] * inv;
+                    else nv = v[a][b] - cp[a] * rp[b];
+                    v[a][b] = nv;
+                }
+            __syncthreads();
+        }
     }
-    // symmetrise (P is symmetric up to rounding) so that C = B P and the mirrored stores agree
+    // symmetrise (P is symmetric up to rounding): exchange with the transposed owner through global memory
+    __shared__ double T[NB][NB + 1];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) T[4 * ti + a][4 * tj + b] = v[a][b];
+    __syncthreads();
     for (int e = threadIdx.x; e < NB * NB; e += 256) {
         const int i = e / NB, j = e % NB;
-        P[e] = 0.5 * (S[i][j] + S[j][i]);
+        P[e] = 0.5 * (T[i][j] + T[j][i]);
     }
 }
 
 // One workgroup per 64-row block i: B_i = A[i,k] (taken from the lower triangle: A[k,i]' for i < k; zero for
-// i == k), C_i = B_i P; panels are stored column-major np x 64 (element (r,c) at r + c*np), the MFMA operand
-// layout of the update kernel.  Writes back C_i into the lower triangle (A[i,k] or A[k,i]') and A[k,k] = -P.
+// i == k), C_i = B_i P; panels are stored operand-major: the 16 rows x 4 k values one MFMA operand needs are 64
+// contiguous doubles (element (r,c) at ((r/16)*16 + c/4)*64 + (c%4)*16 + r%16), so a wave's operand load is
+// one coalesced 512-byte read.  Writes back C_i into the lower triangle (A[i,k] or A[k,i]') and A[k,k] = -P.
 __global__ void __launch_bounds__(256)
 panel_kernel(double *__restrict__ Aall, int64_t np, int k, const double *__restrict__ Pall,
              double *__restrict__ Bpall, double *__restrict__ Cpall, int64_t strideA, int64_t strideW) {
@@ -84,8 +113,9 @@ panel_kernel(double *__restrict__ Aall, int64_t np, int k, const double *__restr
         const int r = e % NB, c = e / NB;  // r fastest: coalesced panel stores
         double s = 0;
         for (int q = 0; q < NB; ++q) s = fma(sB[r][q], sP[q][c], s);
-        Bp[(r0 + r) + (int64_t)c * np] = sB[r][c];
-        Cp[(r0 + r) + (int64_t)c * np] = s;
+        const int64_t po = (((r0 + r) >> 4) * 16 + (c >> 2)) * 64 + (c & 3) * 16 + ((r0 + r) & 15);
+        Bp[po] = sB[r][c];
+        Cp[po] = s;
         res[u] = (i == k) ? -sP[r][c] : s;
     }
     __syncthreads();                       // every product has consumed sB before it is overwritten
@@ -119,19 +149,26 @@ sweep_update_kernel(double *__restrict__ Aall, int64_t np, int k, const double *
     const int bi = ti * 2 + (wave >> 1), bj = tj * 2 + (wave & 1);
     if (bi < bj || bi == k || bj == k) return;
     const int li = lane & 15, lk = lane >> 4;
-    const double *cbase = Cp + (int64_t)bi * NB + li;
-    const double *bbase = Bp + (int64_t)bj * NB + li;
+    // operand q (16 rows) of k-step kk sits at ((block*4 + q)*16 + kk)*64 + lane
+    const double *cbase = Cp + ((int64_t)bi * 4 * 16) * 64 + lane;
+    const double *bbase = Bp + ((int64_t)bj * 4 * 16) * 64 + lane;
     f64x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
+    double nA[4], nB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { nA[q] = cbase[(q * 16 + 0) * 64]; nB[q] = bbase[(q * 16 + 0) * 64]; }
+#pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
-        const int64_t koff = (int64_t)(kk * 4 + lk) * np;
         double opA[4], opB[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { opA[q] = cbase[koff + q * 16]; opB[q] = bbase[koff + q * 16]; }
+        for (int q = 0; q < 4; ++q) { opA[q] = nA[q]; opB[q] = nB[q]; }
+        if (kk + 1 < NB / 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { nA[q] = cbase[(q * 16 + kk + 1) * 64]; nB[q] = bbase[(q * 16 + kk + 1) * 64]; }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
