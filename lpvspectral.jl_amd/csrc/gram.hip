@@ -216,6 +216,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
     stage_load(buf0, r_begin);
     __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the image
 
+    // A wave whose 64x64 block lies entirely above the diagonal produces only entries nobody reads (the
+    // reduce / expand kernels take the lower triangle): it keeps staging and hitting the barriers but issues no
+    // MFMAs, which leaves the matrix pipe of its SIMD to the partner wave (band tiles finish ~1.8x sooner).
+    bool skip_wave;
+    if (MODE == 2) skip_wave = (b0 + wb * 64) / a.npair > a0 + wa * 64 + 63;       // first p' of the block > its last row p
+    else skip_wave = b0 + wb * 64 > a0 + wa * 64 + 63;                             // first column > last row
     const bool weighted = (MODE == 1) && a.W != nullptr;
     // KR with 2*nb == 16: every 16-wide MFMA tile is one frequency, so all eight tiles of a lane use the
     // same activation K[k][lane & 7] -> one LDS read per k-step instead of eight.
@@ -264,7 +270,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
         if (s + 1 < nstages) stage_load(nxt, r_begin + (int64_t)(s + 1) * BK);
 
         const double *img = cur, *aux = cur + img_pad;
-        if (VAR == 0) {
+        if (skip_wave) {
+            // nothing to compute
+        } else if (VAR == 0) {
 #pragma unroll 2
             for (int kk = 0; kk < BK / 4; ++kk) {
                 fetch(img, aux, kk);
@@ -326,6 +334,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
 
     // ---- epilogue: partial tile -> slab[tile][chunk][TM][TN] -------------------------------
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+    if (skip_wave) return;
     double *out = a.slab + (((int64_t)prob * a.ntiles + tile) * a.ksplit + chunk) * (TM * TN);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
