@@ -148,6 +148,13 @@ def main():
         issued = tms[0]["gram_issued_flops"]
         achieved = flops / (gram_ms * 1e-3) * 1e-12
         issued_rate = issued / (gram_ms * 1e-3) * 1e-12
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
+        if os.path.exists(pmc) and args.log2n == LOG2N:   # PMC passes cannot run inside the timed bench: use the committed
+            for r in json.load(open(pmc)):                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this command
+                if r["kernel"].startswith("gram_kernel"):
+                    traffic = r["fetch_corrected_bytes_per_launch"] + r["write_bytes_per_launch"]
+                    traffic_src = "profiles/r01_final_pmc_traffic.json (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, bytes per launch)"
         out = {
             "metric": "signals/sec, ls_sparse_spectral_lpv group lasso N=2^%d Nf=%d Nv=%d (%d ADMM iters; iters/sec in admm_iters_per_sec)" % (args.log2n, NF, NV, args.iters),
             "value": world * args.steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": args.steps,
@@ -161,7 +168,7 @@ def main():
             "final_nxz": nxz,
             "roofline": {"bound": "mfma", "kernel": "gram_kernel<KRS> (v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "algorithmic_flops_per_launch": flops, "launch_ms": gram_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops_per_launch": flops, "launch_ms": gram_ms,
                          "issued_flops_per_launch": issued, "issued_tflops": issued_rate,
                          "issued_frac_of_peak": issued_rate / F64_MFMA_PEAK_TFLOPS,
                          "note": "achieved = N*n*(n+1) algorithmic flops / launch time; it can exceed the MFMA peak because the "
