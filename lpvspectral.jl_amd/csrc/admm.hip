@@ -348,7 +348,7 @@ symv_tile_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs_a
 }
 
 // x[I*128+i] = sum_{J<=I} part1[(I,J)][i] + sum_{K>I} part2[(K,I)][i]; both sums in fixed order.
-// 256 threads: 0..127 walk part1, 128..255 walk part2, 8 independent loads in flight each.
+// 256 threads: 0..127 walk part1, 128..255 walk part2, 16 independent loads in flight each.
 __device__ __forceinline__ double gather_x(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, int I,
                                            double *sh /*[128]*/) {
     const int i = threadIdx.x & 127, half = threadIdx.x >> 7;
@@ -356,22 +356,22 @@ __device__ __forceinline__ double gather_x(const double *__restrict__ part1, con
     if (half == 0) {
         const double *p = part1 + ((int64_t)I * (I + 1) / 2) * TS + i;
         int J = 0;
-        for (; J + 8 <= I + 1; J += 8) {
-            double a[8];
+        for (; J + 16 <= I + 1; J += 16) {
+            double a[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = p[(int64_t)(J + q) * TS];
+            for (int q = 0; q < 16; ++q) a[q] = p[(int64_t)(J + q) * TS];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += a[q];
+            for (int q = 0; q < 16; ++q) s += a[q];
         }
         for (; J <= I; ++J) s += p[(int64_t)J * TS];
     } else {
         int K = I + 1;
-        for (; K + 8 <= nblk; K += 8) {
-            double a[8];
+        for (; K + 16 <= nblk; K += 16) {
+            double a[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = part2[((int64_t)(K + q) * (K + q + 1) / 2 + I) * TS + i];
+            for (int q = 0; q < 16; ++q) a[q] = part2[((int64_t)(K + q) * (K + q + 1) / 2 + I) * TS + i];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += a[q];
+            for (int q = 0; q < 16; ++q) s += a[q];
         }
         for (; K < nblk; ++K) s += part2[((int64_t)K * (K + 1) / 2 + I) * TS + i];
         sh[i] = s;

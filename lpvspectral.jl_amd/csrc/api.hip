@@ -473,15 +473,26 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     LPVS_TRY(slab.alloc(pl.slab_bytes));
     LPVS_TRY(scr.alloc(rhs_scratch_bytes(N, h->n)));
     if (krs) LPVS_TRY(G3.alloc(sizeof(double) * (size_t)pl.np2 * (size_t)(pl.np2 * pl.pairs)));
+    // b_q = Phi' y_q is HBM-bound (it streams the trig table) while the Gram is MFMA-bound and leaves registers
+    // free for small workgroups: run it on a side stream underneath the Gram kernel.
+    struct Side { hipStream_t s = nullptr; hipEvent_t ready = nullptr, done = nullptr;
+                  ~Side() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } if (ready) (void)hipEventDestroy(ready); if (done) (void)hipEventDestroy(done); } } side;
+    LPVS_HIP(hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking));
+    LPVS_HIP(hipEventCreateWithFlags(&side.ready, hipEventDisableTiming));
+    LPVS_HIP(hipEventCreateWithFlags(&side.done, hipEventDisableTiming));
+    LPVS_HIP(hipEventRecord(side.ready, s));                 // tables are complete at this point of the main stream
+    LPVS_HIP(hipStreamWaitEvent(side.s, side.ready, 0));
     LPVS_HIP(hipEventRecord(h->ev[1].a, s));
     if (krs) LPVS_TRY(launch_gram_krs(pl, T.as<double2>(), Nf, KK.as<double>(), nb, slab.as<double>(), s));
     else LPVS_TRY(launch_gram_kr(pl, T.as<double2>(), Nf, K.as<double>(), ldk, nb, slab.as<double>(), s));
     LPVS_HIP(hipEventRecord(h->ev[1].b, s));
+    for (int64_t q = 0; q < ns; ++q)   // b_q = Phi' y_q for every signal sharing the regressor
+        LPVS_TRY(launch_rhs_kr(T.as<double2>(), Nf, K.as<double>(), ldk, nb, dy.p + q * N, N, h->b.as<double>() + q * h->np, scr.as<double>(), scr.bytes, side.s));
+    LPVS_HIP(hipEventRecord(side.done, side.s));
     LPVS_HIP(hipEventRecord(h->ev[2].a, s));
     if (krs) LPVS_TRY(launch_gram_reduce_krs(pl, slab.as<double>(), nb, G3.as<double>(), h->G.as<double>(), h->np, s));
     else LPVS_TRY(launch_gram_reduce(pl, slab.as<double>(), h->G.as<double>(), h->np, s));
-    for (int64_t q = 0; q < ns; ++q)   // b_q = Phi' y_q for every signal sharing the regressor
-        LPVS_TRY(launch_rhs_kr(T.as<double2>(), Nf, K.as<double>(), ldk, nb, dy.p + q * N, N, h->b.as<double>() + q * h->np, scr.as<double>(), scr.bytes, s));
+    LPVS_HIP(hipStreamWaitEvent(s, side.done, 0));
     LPVS_HIP(hipEventRecord(h->ev[2].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();

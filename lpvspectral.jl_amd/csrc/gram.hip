@@ -16,7 +16,7 @@
 //   PANEL (Fourier, src/lsfft.jl:26-49): Phi[k][c] = P[k][c], a k-major panel staged as is,
 //         with the optional row weight of A' diag(W) A (src/lasso.jl:119) applied to the A operand.
 // Staging is LDS-DMA (global_load_lds_dwordx4, dense lane-linear LDS images, two buffers, one
-// barrier per 32-sample stage).  Work items are (lower-triangle 128x256 tile) x (sample chunk);
+// barrier per 32-sample stage); the k-loop is software-pipelined by hand.  Work items are (lower-triangle 128x256 tile) x (sample chunk);
 // each writes its partial tile to a slab and a second kernel sums the chunks in fixed order, so
 // the result is bit-reproducible (no float atomics).
 //
@@ -67,7 +67,7 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MODE, int BK, int VAR>  // MODE 0 = KR, 1 = PANEL; BK = samples per stage; VAR = k-loop schedule
+template <int MODE, int BK>  // MODE 0 = KR, 1 = PANEL, 2 = KRS; BK = samples per stage
 __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
 
@@ -270,35 +270,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
         if (s + 1 < nstages) stage_load(nxt, r_begin + (int64_t)(s + 1) * BK);
 
         const double *img = cur, *aux = cur + img_pad;
-        if (skip_wave) {
-            // nothing to compute
-        } else if (VAR == 0) {
-#pragma unroll 2
-            for (int kk = 0; kk < BK / 4; ++kk) {
-                fetch(img, aux, kk);
-                double opA[4], opB[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (MODE == 2) {
-                        opA[t] = rT[t];
-                        opB[t] = rT[4 + t] * rK[4 + t];
-                    } else if (MODE == 0) {
-                        opA[t] = rT[t] * (one_k ? rK[0] : rK[t]);
-                        opB[t] = rT[4 + t] * (one_k ? rK[0] : rK[4 + t]);
-                    } else {
-                        opA[t] = weighted ? rT[t] * rK[0] : rT[t];
-                        opB[t] = rT[4 + t];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-            // software pipeline: the LDS reads of k-step kk+1 are issued before the 16 MFMAs of k-step kk
-            // and land while the matrix pipe works (sched_barrier pins that order)
+        if (!skip_wave) {
+            // software pipeline: the LDS reads of k-step kk+1 are issued before the 16 MFMAs of k-step kk and
+            // land while the matrix pipe works (sched_barrier pins that order)
             fetch(img, aux, 0);
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -319,13 +293,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < BK / 4) fetch(img, aux, kk + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
-                if (VAR == 2) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -536,24 +508,6 @@ GramPlan make_gram_plan(int64_t n, int64_t N, int64_t nbatch) {
     return pl;
 }
 
-#if 0
-    // split the samples so that (tiles x chunks) fills the 256 CUs in whole rounds
-    const int64_t nstage = ceil_div(N, BK_ALIGN);
-    const int64_t max_split = nstage / 16 > 0 ? nstage / 16 : 1;  // >= 512 samples per chunk
-    int64_t want = ceil_div(256 * 16, pl.tiles);
-    if (want > max_split) want = max_split;
-    int64_t best = 1; double best_eff = -1;
-    for (int64_t ks = want / 2 > 0 ? want / 2 : 1; ks <= want * 2 && ks <= max_split; ++ks) {
-        const int64_t items = pl.tiles * ks * nbatch;
-        const double eff = (double)items / (double)(ceil_div(items, 256) * 256);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
-    }
-    pl.ksplit = best;
-    pl.rows_per_chunk = round_up(ceil_div(N, pl.ksplit), BK_ALIGN);
-    pl.slab_bytes = sizeof(double) * (size_t)pl.tiles * (size_t)pl.ksplit * TM * TN;
-    return pl;
-}
-#endif
 
 // Device copy of the tile list, cached per (n, pairs) on the calling thread.
 static int32_t get_tiles(int64_t n, int64_t pairs, hipStream_t s, const int2 **out, int *count) {
@@ -596,19 +550,13 @@ static size_t gram_lds_bytes(int mode, int BK, int64_t nb, int64_t ldk) {
     return sizeof(double) * 2 * (size_t)(img_pad + aux_pad);
 }
 
-template <int MODE, int BK, int VAR = 1>
+template <int MODE, int BK>
 static int32_t launch_gram_t(const GramArgs &a, unsigned grid, size_t lds, hipStream_t s) {
-    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<MODE, BK, VAR>),
+    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_kernel<MODE, BK>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gram_kernel<MODE, BK, VAR>), dim3(grid), dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL((gram_kernel<MODE, BK>), dim3(grid), dim3(NTHREADS), lds, s, a);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
-}
-
-// development knob (A/B runs of k-loop schedules in one process): LPVS_GRAM_VARIANT=<bk><var>, e.g. 320, 321, 641
-static int gram_variant() {
-    const char *e = getenv("LPVS_GRAM_VARIANT");
-    return e ? atoi(e) : -1;
 }
 
 constexpr size_t kLdsBudget = 160 * 1024;
@@ -621,15 +569,6 @@ int32_t launch_gram_kr(const GramPlan &pl, const double2 *T, int64_t Nf, const d
     a.slab = slab; a.T = T; a.K = K; a.Nf = (int)Nf; a.nb = (int)nb; a.ldk = (int)ldk;
     const unsigned grid = (unsigned)(pl.tiles * pl.ksplit);
     // deepest stage whose two LDS images fit (few basis functions -> many frequencies per tile)
-    switch (gram_variant()) {
-    case 320: return launch_gram_t<0, 32, 0>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
-    case 321: return launch_gram_t<0, 32, 1>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
-    case 322: return launch_gram_t<0, 32, 2>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
-    case 640: return launch_gram_t<0, 64, 0>(a, grid, gram_lds_bytes(0, 64, nb, ldk), s);
-    case 641: return launch_gram_t<0, 64, 1>(a, grid, gram_lds_bytes(0, 64, nb, ldk), s);
-    case 642: return launch_gram_t<0, 64, 2>(a, grid, gram_lds_bytes(0, 64, nb, ldk), s);
-    default: break;
-    }
     if (gram_lds_bytes(0, 32, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 32>(a, grid, gram_lds_bytes(0, 32, nb, ldk), s);
     if (gram_lds_bytes(0, 16, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 16>(a, grid, gram_lds_bytes(0, 16, nb, ldk), s);
     if (gram_lds_bytes(0, 8, nb, ldk) <= kLdsBudget) return launch_gram_t<0, 8>(a, grid, gram_lds_bytes(0, 8, nb, ldk), s);
