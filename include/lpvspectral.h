@@ -115,6 +115,12 @@ int32_t lpvs_problem_zerofreq(const lpvs_problem *h, int64_t *zerofreq);
 /* copy out G (n x n, full symmetric) and/or b (n); either pointer may be NULL */
 int32_t lpvs_problem_get_gram_f64(lpvs_problem *h, double *G_out, double *b_out);
 
+/* all right-hand sides b_q = Phi' y_q of a (multi-signal) handle, n x ns column-major */
+int32_t lpvs_problem_get_rhs_f64(lpvs_problem *h, double *b_out);
+/* (G + shift*I)^-1 (n x n, symmetric) -- e.g. the parameter covariance of ls_spectral_lpv up to the factor var(e),
+ * src/lsfft.jl:252-254.  Leaves the handle's factorisation cached for that shift. */
+int32_t lpvs_problem_get_inverse_f64(lpvs_problem *h, double shift, double *Minv_out);
+
 /* ---- dense (ridge) solve from the same Gram:  (G + ridge*I) x = b ---------------------
  * ls_spectral weighted form (src/lsfft.jl:77, ridge = lam), fourier_solve / real_complex_bs in
  * normal-equation form (src/utilities.jl:49-60, ridge = lam^2).  x_out has n entries in the

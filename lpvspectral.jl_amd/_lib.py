@@ -57,6 +57,8 @@ SIGNATURES = {
     "lpvs_problem_size": (_I32, [_P, _PI64]),
     "lpvs_problem_zerofreq": (_I32, [_P, _PI64]),
     "lpvs_problem_get_gram_f64": (_I32, [_P, _P, _P]),
+    "lpvs_problem_get_rhs_f64": (_I32, [_P, _P]),
+    "lpvs_problem_get_inverse_f64": (_I32, [_P, _F64, _P]),
     "lpvs_problem_solve_ridge_f64": (_I32, [_P, _F64, _P]),
     "lpvs_ls_spectral_f64": (_I32, [_P, _P, _I64, _P, _I64, _F64, _I32, _P, _P]),
     "lpvs_problem_set_prox": (_I32, [_P, _I32, _F64, _I64]),

@@ -247,6 +247,16 @@ class Problem:
         check(lib().lpvs_problem_get_gram_f64(self._h, out_ptr(G), out_ptr(b)))
         return G, b
 
+    def get_rhs(self):
+        b = np.zeros(self.n if self.ns == 1 else (self.n, self.ns), order="F")
+        check(lib().lpvs_problem_get_rhs_f64(self._h, out_ptr(b)))
+        return b
+
+    def get_inverse(self, shift):
+        M = np.zeros((self.n, self.n), order="F")
+        check(lib().lpvs_problem_get_inverse_f64(self._h, float(shift), out_ptr(M)))
+        return M
+
     def solve_ridge(self, ridge):
         x = np.zeros(self.n)
         check(lib().lpvs_problem_solve_ridge_f64(self._h, float(ridge), out_ptr(x)))
@@ -431,16 +441,44 @@ def ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, λ=1, normalize=True, device=0,
             for q in range(ns)]
 
 
-def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, device=0):
-    """``ls_spectral_lpv(Y,X,V,w,Nv; λ, coulomb, normalize)`` (src/lsfft.jl:239-259).
+def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, device=0, covariance=True):
+    """``ls_spectral_lpv(Y,X,V,w,Nv; λ, coulomb, normalize)`` (src/lsfft.jl:239-259) -> :class:`SpectralExt`.
 
-    Ridge solve ``[Ar; λI] \\ [Y; 0]`` in normal-equation form on the device Gram (the Gram of the
-    permuted Φ; the solution is un-permuted by the same packing as the sparse path).  ``Σ`` (the
-    parameter covariance, :252-254) is not computed on device yet and is returned as ``None``."""
+    Ridge solve ``[Ar; λI] \\ [Y; 0]`` in normal-equation form on the device Gram (built in the permuted column
+    order; ridge and solution are permutation-invariant and are un-permuted by the same packing as the sparse path).
+    The residual statistics come from the same Gram, with the constant signal as a second right-hand side:
+    ``‖e‖² = x'Gx − 2b'x + Y'Y``, ``Σe = (Φ'1)'x − ΣY`` ⇒ ``var(e)``; ``Σ = var(e)·(AA'AA + λI)⁻¹`` (:252-254, λ not
+    squared, as written) in the reference's ``[re; im]`` parameter order; the fva warning of :255-256 is issued."""
     w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
-    with Problem.lpv(Y, X, V, w, int(Nv), normalize, coulomb, device=device) as prob:
-        params = prob.pack(prob.solve_ridge(λ * λ))
-    return SpectralExt(Y, X, V, w, int(Nv), λ, coulomb, normalize, params, None)
+    Nv = int(Nv)
+    Yh = _host(Y)
+    if not covariance:
+        with Problem.lpv(Y, X, V, w, Nv, normalize, coulomb, device=device) as prob:
+            params = prob.pack(prob.solve_ridge(λ * λ))
+        return SpectralExt(Y, X, V, w, Nv, λ, coulomb, normalize, params, None)
+    Y2 = np.stack([Yh, np.ones_like(Yh)], axis=1)
+    with Problem.lpv_multi(Y2, X, V, w, Nv, normalize, coulomb, device=device) as prob:
+        x = prob.solve_ridge(λ * λ)                      # first right-hand side = Y
+        params = prob.pack(x)
+        G, _ = prob.get_gram()
+        B = prob.get_rhs()
+        Minv = prob.get_inverse(λ)
+        Nf, nb = prob.Nf, prob.nb
+    N = len(Yh)
+    e2 = float(x @ (G @ x) - 2.0 * (B[:, 0] @ x) + Yh @ Yh)         # ‖AA·x − Y‖²
+    esum = float(B[:, 1] @ x - Yh.sum())
+    var_e = (e2 - esum * esum / N) / (N - 1)                         # var(e), corrected (Statistics.var)
+    var_y = float(np.var(Yh, ddof=1))
+    # un-permute: reference order u = c·Nf·nb + j·Nf + f  <-  device order p = f·2nb + c·nb + j
+    f_, c_, j_ = np.meshgrid(np.arange(Nf), np.arange(2), np.arange(nb), indexing="ij")
+    perm = np.empty(2 * Nf * nb, dtype=np.int64)
+    perm[(c_ * Nf * nb + j_ * Nf + f_).ravel()] = (f_ * 2 * nb + c_ * nb + j_).ravel()
+    Sigma = var_e * Minv[np.ix_(perm, perm)]
+    fva = 1.0 - var_e / var_y                                        # :255
+    if fva < 0.9:
+        import warnings
+        warnings.warn(f"Fraction of variance explained = {fva}")    # :256
+    return SpectralExt(Y, X, V, w, Nv, λ, coulomb, normalize, params, Sigma)
 
 
 def windowpsd_sparse_batched(y, t, freqs, n, noverlap=-1, W=None, proxg=None, λ=1.0, μ=0.05, tol=1e-5, iters=10000,

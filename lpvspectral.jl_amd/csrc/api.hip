@@ -603,6 +603,23 @@ int32_t lpvs_problem_get_gram_f64(lpvs_problem *h, double *G_out, double *b_out)
     return LPVS_OK;
 }
 
+int32_t lpvs_problem_get_rhs_f64(lpvs_problem *h, double *b_out) {
+    if (!h || !b_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    return copy_state_out(h, h->b.p, b_out);
+}
+
+int32_t lpvs_problem_get_inverse_f64(lpvs_problem *h, double shift, double *Minv_out) {
+    if (!h || !Minv_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    h->inited = false;   // M is re-used
+    LPVS_TRY(factorize(h, shift));
+    LPVS_HIP(hipMemcpy2DAsync(Minv_out, sizeof(double) * (size_t)h->n, h->M.p, sizeof(double) * (size_t)h->np, sizeof(double) * (size_t)h->n,
+                              (size_t)h->n, is_device_ptr(Minv_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    LPVS_HIP(hipStreamSynchronize(h->stream));
+    return LPVS_OK;
+}
+
 int32_t lpvs_problem_solve_ridge_f64(lpvs_problem *h, double ridge, double *x_out) {
     if (!h || !x_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     LPVS_HIP(hipSetDevice(h->device));

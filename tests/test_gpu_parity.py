@@ -339,6 +339,12 @@ def test_ls_spectral_lpv_top3(L, oracle):
     assert rel(se.x, xo) <= 1e-6
     Sw = L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02)
     assert set(np.argsort(-Sw)[:3] + 1) == {1, 5, 10}
+    # covariance (src/lsfft.jl:252-254) against a direct numpy evaluation in the reference's [re; im] order
+    Ar = oracle.lpv_regressor(X, V, w_test, 50, permuted=False)
+    xr = np.concatenate([se.x.real, se.x.imag])
+    e = Ar @ xr - Y
+    Sig = np.var(e, ddof=1) * np.linalg.inv(Ar.T @ Ar + 0.02 * np.eye(Ar.shape[1]))
+    assert se.Σ.shape == Sig.shape and np.abs(se.Σ - Sig).max() <= 1e-6 * np.abs(Sig).max()
 
 
 # ------------------------------------------------------------------ batched windows (cfg4 engine)
