@@ -324,12 +324,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) gram_kernel(const GramArgs a) {
 __global__ void __launch_bounds__(256)
 gram_reduce_kernel(const double *__restrict__ slab, const int2 *__restrict__ tiles, int ksplit, int64_t n,
                    double *__restrict__ Gall, int64_t ldg) {
-    const int tile = blockIdx.x;                      // blockIdx.y = problem of a batch
+    // blockIdx.x = tile, blockIdx.y = 1/32 slice of the tile (few tiles x many chunks must still fill the chip),
+    // blockIdx.z = problem of a batch
+    const int tile = blockIdx.x;
     const int2 tt = tiles[tile];
     const int64_t a0 = (int64_t)tt.x * TM, b0 = (int64_t)tt.y * TN;
-    const double *base = slab + ((int64_t)blockIdx.y * gridDim.x + tile) * ksplit * (TM * TN);
-    double *G = Gall + (int64_t)blockIdx.y * ldg * ldg;
-    for (int e = threadIdx.x; e < TM * TN; e += 256) {
+    const double *base = slab + ((int64_t)blockIdx.z * gridDim.x + tile) * ksplit * (TM * TN);
+    double *G = Gall + (int64_t)blockIdx.z * ldg * ldg;
+    constexpr int SLICE = TM * TN / 32;
+    for (int e = blockIdx.y * SLICE + threadIdx.x; e < (int)(blockIdx.y + 1) * SLICE; e += 256) {
         const int il = e / TN, jl = e - il * TN;
         const int64_t ga = a0 + il, gb = b0 + jl;
         if (ga >= n || gb > ga) continue;
@@ -385,7 +388,7 @@ pair_table_kernel(const double *__restrict__ K, int64_t ldk, int nb, int64_t Npa
 }
 
 // ---- right-hand side b = Phi' (W .* y) -----------------------------------------------------
-constexpr int RHS_ROWS = 2048;  // samples per partial
+constexpr int RHS_ROWS = 512;   // samples per partial (many short, independent chains: the kernel is latency-bound otherwise)
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -402,13 +405,26 @@ rhs_kernel(const double2 *__restrict__ T, int Nf, const double *__restrict__ K, 
         const int f = (int)(col / g2), c = (int)(col - (int64_t)f * g2);
         const int cs = c >= nb, j = c - cs * nb;
         const double *Td = reinterpret_cast<const double *>(T);
-        for (int64_t r = r0; r < r1; ++r)
-            s = fma(Td[(r * Nf + f) * 2 + cs] * K[r * ldk + j], y[r], s);
-    } else {
-        for (int64_t r = r0; r < r1; ++r) {
-            const double yy = W ? W[r] * y[r] : y[r];
-            s = fma(P[r * ld + col], yy, s);
+        double s1 = 0, s2 = 0, s3 = 0;
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {   // four independent chains, loads of a group issued together
+            const double a0 = Td[((r + 0) * Nf + f) * 2 + cs] * K[(r + 0) * ldk + j], a1 = Td[((r + 1) * Nf + f) * 2 + cs] * K[(r + 1) * ldk + j];
+            const double a2 = Td[((r + 2) * Nf + f) * 2 + cs] * K[(r + 2) * ldk + j], a3 = Td[((r + 3) * Nf + f) * 2 + cs] * K[(r + 3) * ldk + j];
+            s = fma(a0, y[r], s); s1 = fma(a1, y[r + 1], s1); s2 = fma(a2, y[r + 2], s2); s3 = fma(a3, y[r + 3], s3);
         }
+        for (; r < r1; ++r) s = fma(Td[(r * Nf + f) * 2 + cs] * K[r * ldk + j], y[r], s);
+        s = (s + s1) + (s2 + s3);
+    } else {
+        double s1 = 0, s2 = 0, s3 = 0;
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            const double p0 = P[(r + 0) * ld + col], p1 = P[(r + 1) * ld + col], p2 = P[(r + 2) * ld + col], p3 = P[(r + 3) * ld + col];
+            const double y0 = W ? W[r] * y[r] : y[r], y1 = W ? W[r + 1] * y[r + 1] : y[r + 1];
+            const double y2 = W ? W[r + 2] * y[r + 2] : y[r + 2], y3 = W ? W[r + 3] * y[r + 3] : y[r + 3];
+            s = fma(p0, y0, s); s1 = fma(p1, y1, s1); s2 = fma(p2, y2, s2); s3 = fma(p3, y3, s3);
+        }
+        for (; r < r1; ++r) s = fma(P[r * ld + col], W ? W[r] * y[r] : y[r], s);
+        s = (s + s1) + (s2 + s3);
     }
     part[(int64_t)blockIdx.y * ncol + col] = s;
 }
@@ -424,11 +440,16 @@ rhs_panel_batch_kernel(const double *__restrict__ Pall, int64_t strideP, int64_t
     if (col >= ncol) return;
     const double *P = Pall + (int64_t)blockIdx.z * strideP;
     const double *y = yall + yoff[blockIdx.z];
-    double s = 0;
-    for (int64_t r = r0; r < r1; ++r) {
-        const double yy = W ? W[r] * y[r] : y[r];
-        s = fma(P[r * ld + col], yy, s);
+    double s = 0, s1 = 0, s2 = 0, s3 = 0;
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const double p0 = P[(r + 0) * ld + col], p1 = P[(r + 1) * ld + col], p2 = P[(r + 2) * ld + col], p3 = P[(r + 3) * ld + col];
+        const double y0 = W ? W[r] * y[r] : y[r], y1 = W ? W[r + 1] * y[r + 1] : y[r + 1];
+        const double y2 = W ? W[r + 2] * y[r + 2] : y[r + 2], y3 = W ? W[r + 3] * y[r + 3] : y[r + 3];
+        s = fma(p0, y0, s); s1 = fma(p1, y1, s1); s2 = fma(p2, y2, s2); s3 = fma(p3, y3, s3);
     }
+    for (; r < r1; ++r) s = fma(P[r * ld + col], W ? W[r] * y[r] : y[r], s);
+    s = (s + s1) + (s2 + s3);
     partall[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * ncol + col] = s;
 }
 
@@ -640,7 +661,7 @@ int32_t launch_gram_panel_batch(const GramPlan &pl, int nbatch, const double *P,
 int32_t launch_gram_reduce_batch(const GramPlan &pl, int nbatch, const double *slab, double *G, int64_t ldg, hipStream_t s) {
     const int2 *tiles; int nt;
     LPVS_TRY(get_tiles(pl.n, 0, s, &tiles, &nt));
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)nt, (unsigned)nbatch), dim3(256), 0, s, slab, tiles, (int)pl.ksplit, pl.n, G, ldg);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)nt, 32, (unsigned)nbatch), dim3(256), 0, s, slab, tiles, (int)pl.ksplit, pl.n, G, ldg);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -648,7 +669,7 @@ int32_t launch_gram_reduce_batch(const GramPlan &pl, int nbatch, const double *s
 int32_t launch_gram_reduce(const GramPlan &pl, const double *slab, double *G, int64_t ldg, hipStream_t s) {
     const int2 *tiles; int nt;
     LPVS_TRY(get_tiles(pl.n, 0, s, &tiles, &nt));
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)nt), dim3(256), 0, s, slab, tiles, (int)pl.ksplit, pl.n, G, ldg);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)nt, 32, 1), dim3(256), 0, s, slab, tiles, (int)pl.ksplit, pl.n, G, ldg);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
