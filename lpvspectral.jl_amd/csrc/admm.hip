@@ -277,9 +277,11 @@ __device__ __forceinline__ void tile_index(int t, int &I, int &J) {
 }
 
 __global__ void __launch_bounds__(256)
-pack_tiles_kernel(const double *__restrict__ M, int64_t np, double *__restrict__ Mp) {
+pack_tiles_kernel(const double *__restrict__ Mall, int64_t np, double *__restrict__ Mpall) {
     int I, J;
     tile_index(blockIdx.x, I, J);
+    const double *M = Mall + (int64_t)blockIdx.y * np * np;                       // blockIdx.y = problem of a batch
+    double *Mp = Mpall + (int64_t)blockIdx.y * gridDim.x * TS * TS;
     const double2 *src = reinterpret_cast<const double2 *>(M + (int64_t)I * TS * np + (int64_t)J * TS);
     double2 *dst = reinterpret_cast<double2 *>(Mp + (int64_t)blockIdx.x * TS * TS);
     for (int e = threadIdx.x; e < TS * TS / 2; e += 256) {
@@ -344,6 +346,58 @@ symv_tile_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs_a
             if (threadIdx.x < TS)
                 part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
         }
+    }
+}
+
+// Same tile product for a batch of problems that each own their matrix (windows): blockIdx.y = problem.
+__global__ void __launch_bounds__(256)
+symv_tile_batch_kernel(const double *__restrict__ Mp_all, int64_t mp_stride, const double *__restrict__ rhs_all, int64_t np,
+                       int ntiles, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    const int sg = blockIdx.y;
+    if (status[sg].converged) return;
+    __shared__ double sI[TS], sJ[TS], sT[4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double2 *base = reinterpret_cast<const double2 *>(Mp_all + (int64_t)sg * mp_stride + (int64_t)t * TS * TS + wave * 32 * TS) + lane;
+    double2 m[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) m[r] = base[r * (TS / 2)];
+    const double *rhs = rhs_all + (int64_t)sg * np;
+    double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
+    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+    __syncthreads();
+    const double rj0 = sJ[2 * lane], rj1 = sJ[2 * lane + 1];
+    double t0 = 0, t1 = 0, v[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const double ri = sI[wave * 32 + r];
+        t0 = fma(m[r].x, ri, t0);
+        t1 = fma(m[r].y, ri, t1);
+        v[r] = fma(m[r].x, rj0, m[r].y * rj1);
+    }
+#pragma unroll
+    for (int w = 32, cnt = 16; w >= 2; w >>= 1, cnt >>= 1) {
+        const bool hi = (lane & w) != 0;
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const double send = hi ? v[k] : v[k + cnt];
+            const double keep = hi ? v[k + cnt] : v[k];
+            v[k] = keep + __shfl_xor(send, w, 64);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1, 64);
+    if ((lane & 1) == 0) {
+        const int row = ((lane & 32) ? 16 : 0) + ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
+        part1[(int64_t)t * TS + wave * 32 + row] = v[0];
+    }
+    if (I != J) {
+        sT[wave][2 * lane] = t0; sT[wave][2 * lane + 1] = t1;
+        __syncthreads();
+        if (threadIdx.x < TS)
+            part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
     }
 }
 
@@ -564,10 +618,36 @@ int32_t launch_admm_batch_init(const AdmmBatch &p, hipStream_t s) {
     return LPVS_OK;
 }
 
+int32_t launch_pack_tiles_batch(const double *M, int64_t np, int nbatch, double *Mp, hipStream_t s) {
+    const int nblk = (int)(np / TS);
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2), (unsigned)nbatch), dim3(256), 0, s, M, np, Mp);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+bool fused_ok(const AdmmParams &p);
+
 int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s) {
-    for (int64_t i = 0; i < iters; ++i) {
-        hipLaunchKernelGGL(symv_batch_kernel, dim3((unsigned)ceil_div(p.np, 4), (unsigned)p.nbatch), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(admm_batch_prox_kernel, dim3((unsigned)p.nbatch), dim3(256), 0, s, p);
+    // packed-symmetric form (half the matrix bytes per iteration) when the batch has tile-packed matrices and the
+    // prox can be fused; AdmmParams with ns = nbatch has the layout the fused update kernel expects
+    AdmmParams q{p.M, p.np, p.n, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len, p.status,
+                 nullptr, p.part, p.Mp, p.nbatch};
+    if (p.Mp != nullptr && p.part != nullptr && fused_ok(q)) {
+        const int nblk = (int)(p.np / TS);
+        const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), ns = (unsigned)p.nbatch;
+        double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
+        double *blocknorm = part2 + (size_t)ntiles * TS * ns;
+        unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
+        for (int64_t i = 0; i < iters; ++i) {
+            hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
+                               (int)ntiles, part1, part2, p.status);
+            hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, q, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
+        }
+    } else {
+        for (int64_t i = 0; i < iters; ++i) {
+            hipLaunchKernelGGL(symv_batch_kernel, dim3((unsigned)ceil_div(p.np, 4), (unsigned)p.nbatch), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(admm_batch_prox_kernel, dim3((unsigned)p.nbatch), dim3(256), 0, s, p);
+        }
     }
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
@@ -595,7 +675,7 @@ int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s
     return LPVS_OK;
 }
 
-static bool fused_ok(const AdmmParams &p) {
+bool fused_ok(const AdmmParams &p) {
     if (p.prox_kind == LPVS_PROX_L1 || p.prox_kind == LPVS_PROX_L0) return true;
     return p.prox_kind == LPVS_PROX_GROUP_L2 && p.group_len <= TS && TS % p.group_len == 0 && p.n % p.group_len == 0;
 }

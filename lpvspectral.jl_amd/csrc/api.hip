@@ -905,8 +905,10 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         Wdev = Wp.as<double>();
     }
     PhaseTrace tr(s);
-    DevBuf P, slab, M, bvec, x, z, u, rhs, status, work, istat, offs, scr;
+    DevBuf P, slab, M, bvec, x, z, u, rhs, status, work, istat, offs, scr, part, Mp;
     LPVS_TRY(P.alloc(panel_bytes * (size_t)bw));
+    LPVS_TRY(part.alloc(sizeof(double) * symv_part_doubles(np, bw)));
+    LPVS_TRY(Mp.alloc(sizeof(double) * symv_packed_doubles(np) * (size_t)bw));
     LPVS_TRY(slab.alloc(pl.slab_bytes * (size_t)bw));
     LPVS_TRY(M.alloc(sizeof(double) * (size_t)np * (size_t)np * (size_t)bw));
     const size_t vb = sizeof(double) * (size_t)np * (size_t)bw;
@@ -953,8 +955,10 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         for (int q = 0; q < nb_; ++q)
             if (hist_[q] != 0) { set_error("window %lld: (Q + I/mu) is not positive definite", (long long)(win_lo + w0 + q)); return LPVS_ENUMERIC; }
         tr.mark("inverse");
+        LPVS_TRY(launch_pack_tiles_batch(M.as<double>(), np, nb_, Mp.as<double>(), s));
+        LPVS_HIP(hipMemsetAsync(part.p, 0, part.bytes, s));   // tickets / block norms
         AdmmBatch ab{M.as<double>(), np, nreg, nb_, bvec.as<double>(), x.as<double>(), z.as<double>(), u.as<double>(), rhs.as<double>(),
-                     mu, tol, prox_kind, prox_param, group_len, status.as<AdmmStatus>()};
+                     mu, tol, prox_kind, prox_param, group_len, status.as<AdmmStatus>(), part.as<double>(), Mp.as<double>()};
         LPVS_TRY(launch_admm_batch_init(ab, s));
         for (int64_t done = 0; done < iters;) {   // chunks: stop early once every window of the batch has converged
             const int64_t chunk = iters - done < 256 ? iters - done : 256;

@@ -169,7 +169,10 @@ struct AdmmBatch {
     double prox_param;
     int64_t group_len;
     AdmmStatus *status;   // [nbatch]
+    double *part;         // symv_part_doubles(np, nbatch) doubles, zeroed before the first iteration (or nullptr)
+    const double *Mp;     // [nbatch] tile-packed lower triangles (or nullptr: plain mat-vec)
 };
+int32_t launch_pack_tiles_batch(const double *M, int64_t np, int nbatch, double *Mp, hipStream_t s);
 int32_t launch_admm_batch_init(const AdmmBatch &p, hipStream_t s);
 int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s);
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s);              // z=x, u=0, rhs, status=0
