@@ -89,38 +89,75 @@ __device__ double block_sum_1024(double v, double *sh) {
 
 __device__ unsigned long long abs_key(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 
-// Threshold key of the r-th largest |v| (radix select, 8 bits per pass) and the number of
-// equal-key elements to keep (lowest indices first).  All 1024 threads participate.
+// Threshold key of the r-th largest |v| (radix select, 8 bits per pass, most significant first) and the number of
+// equal-key elements to keep (lowest indices first).  All 1024 threads participate.  Histogram updates are
+// aggregated per wave (the leading bytes of |v| fall into a handful of bins, which would serialise plain LDS
+// atomics), and the bin holding the r-th largest is found by a parallel suffix scan of the 256 counts.
 __device__ void topr_threshold(const double *v, int64_t n, int64_t r, unsigned long long *thr,
-                               long long *keep_equal, unsigned int *hist /*[256]*/, long long *shll /*[2]*/) {
+                               long long *keep_equal, long long *equal_count, unsigned int *hist /*[256]*/,
+                               long long *shll /*[3]*/) {
     unsigned long long prefix = 0, mask = 0;
     long long remaining = r;  // how many of the candidates (matching prefix) we still need
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+    __syncthreads();
     for (int pass = 7; pass >= 0; --pass) {
         const int shift = pass * 8;
-        for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
-        __syncthreads();
-        for (int64_t i = threadIdx.x; i < n; i += 1024) {
-            const unsigned long long k = abs_key(v[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
+        for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+            const int64_t i = i0 + threadIdx.x;
+            const unsigned long long k = i < n ? abs_key(v[i]) : 0ull;
+            bool todo = i < n && (k & mask) == prefix;
+            const unsigned int bin = (unsigned int)((k >> shift) & 255);
+            unsigned long long pending = __ballot(todo);
+            while (pending) {                                   // one LDS atomic per distinct bin of the wave
+                const int leader = __ffsll((long long)pending) - 1;
+                const unsigned int lb = __shfl(bin, leader, 64);
+                const unsigned long long same = __ballot(todo && bin == lb);
+                if (lane == leader) atomicAdd(&hist[lb], (unsigned int)__popcll(same));
+                if (todo && bin == lb) todo = false;
+                pending &= ~same;
+            }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            long long need = remaining;
-            int b = 255;
-            for (; b > 0; --b) {
-                if ((long long)hist[b] >= need) break;
-                need -= hist[b];
+        if (threadIdx.x < 64) {   // wave 0: suffix sums over the 256 bins, 4 bins per lane, no workgroup barrier inside
+            unsigned int c[4], tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = hist[4 * lane + q]; tot += c[q]; hist[4 * lane + q] = 0; }   // cleared for the next pass
+            unsigned int sfx = tot;                                                                          // inclusive suffix over lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = __shfl_down(sfx, o, 64);
+                if (lane + o < 64) sfx += t;
             }
-            shll[0] = b; shll[1] = need;
+            unsigned int above = sfx - tot;                     // counts in bins of higher lanes
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                const unsigned int S = above + c[q];            // S[b] for b = 4*lane+q, above = S[b+1]
+                if ((long long)S >= remaining && (long long)above < remaining) { shll[0] = 4 * lane + q; shll[1] = remaining - above; shll[2] = c[q]; }
+                above = S;
+            }
         }
         __syncthreads();
         prefix |= ((unsigned long long)shll[0]) << shift;
         mask |= 255ull << shift;
         remaining = shll[1];
-        __syncthreads();
+        const long long in_bin = shll[2];   // (shll is rewritten only after the next pass's barrier)
+        if (in_bin == 1 && pass > 0) {
+            // a single candidate is left (the usual case after two or three bytes): its key is the threshold
+            __syncthreads();                // everyone has read shll before it is reused
+            for (int64_t i = threadIdx.x; i < n; i += 1024) {
+                const unsigned long long k = abs_key(v[i]);
+                if ((k & mask) == prefix) shll[0] = (long long)k;     // exactly one writer
+            }
+            __syncthreads();
+            prefix = (unsigned long long)shll[0];
+            __syncthreads();
+            break;
+        }
     }
     *thr = prefix;
     *keep_equal = remaining;
+    *equal_count = shll[2];   // elements whose key equals the threshold (count of the last pass's bin)
 }
 
 // Elements are processed in coalesced passes of 1024 threads x EPT elements: all loads of a pass are
@@ -132,7 +169,7 @@ __global__ void __launch_bounds__(1024)
 admm_prox_kernel(AdmmParams p) {
     __shared__ double sh[16];
     __shared__ unsigned int hist[256];
-    __shared__ long long shll[2];
+    __shared__ long long shll[3];
     __shared__ int scan[1024];
     __shared__ double sq[PASS];        // v^2 of the current pass (group prox)
     __shared__ double gscale[PASS];    // per-group scale of the current pass
@@ -158,13 +195,14 @@ admm_prox_kernel(AdmmParams p) {
 
     const int kind = p.prox_kind;
     double thr_l1 = mu * p.prox_param, thr_l0 = sqrt(2.0 * mu * p.prox_param);
-    unsigned long long ball_thr = 0; long long ball_keep_eq = 0, ball_r = (long long)p.prox_param;
-    double *vbuf = p.scratch + 2 * so;
+    unsigned long long ball_thr = 0; long long ball_keep_eq = 0, ball_eq_count = 0, ball_r = (long long)p.prox_param;
+    double *vbuf = n <= PASS ? sq : p.scratch + 2 * so;   // v = x + u is scanned 8 times: keep it in LDS when it fits
     if (kind == LPVS_PROX_BALL_L0 && ball_r > 0 && ball_r < n) {
         for (int64_t i = threadIdx.x; i < n; i += 1024) vbuf[i] = X[i] + U[i];
         __syncthreads();
-        topr_threshold(vbuf, n, ball_r, &ball_thr, &ball_keep_eq, hist, shll);
+        topr_threshold(vbuf, n, ball_r, &ball_thr, &ball_keep_eq, &ball_eq_count, hist, shll);
     }
+    const bool ball_ties = ball_keep_eq < ball_eq_count;   // only then do equal keys have to be ranked by index
     long long eq_seen = 0;  // equal-key elements at lower indices (uniform across threads)
 
     if (kind == LPVS_PROX_GROUP_L2) {
@@ -225,6 +263,14 @@ admm_prox_kernel(AdmmParams p) {
                     else if (kind == LPVS_PROX_L0) zi = fabs(v) > thr_l0 ? v : 0.0;
                     else zi = ball_r >= n ? v : 0.0;
                     finish(i, xv[k], uv[k], bv[k], zi);
+                }
+            } else if (!ball_ties) {  // IndBallL0, every key equal to the threshold is kept: no ranking needed
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    const int64_t i = c0 + threadIdx.x + 1024 * k;
+                    if (i >= n) continue;
+                    const double v = xv[k] + uv[k];
+                    finish(i, xv[k], uv[k], bv[k], abs_key(v) >= ball_thr ? v : 0.0);
                 }
             } else {  // IndBallL0: keys > threshold, plus the first keep_eq equal keys in index order
 #pragma unroll

@@ -471,3 +471,19 @@ def test_warm_start_and_reinit(L, oracle):
         p.admm_init(None, μ=0.5, tol=0); p.admm_run(30); _, z2, _ = p.admm_get()      # new factorisation
         p.admm_init(None, μ=0.05, tol=0); p.admm_run(30); _, z3, _ = p.admm_get()     # back: identical to the first
     assert np.array_equal(z1, z3) and not np.array_equal(z1, z2)
+
+
+def test_ball_prox_with_ties(L, oracle):
+    """IndBallL0 when several |v| are exactly equal at the cut: lowest indices win (the reference's
+    partialsortperm leaves the order unspecified; the oracle uses the same rule)."""
+    n = 64
+    G = np.zeros((n, n)); b = np.zeros(n)
+    b[[3, 10, 20, 30, 40, 50]] = [5.0, 2.0, -2.0, 2.0, -2.0, 1.0]     # x = mu*b on the first step: four equal magnitudes
+    for r in (2, 3, 4):
+        with L.Problem.gram(G, b) as p:
+            p.set_prox(L.IndBallL0(r)); p.admm_init(None, μ=0.5, tol=0); p.admm_run(1)
+            x, z, u = p.admm_get()
+        ro = oracle.admm_gram(G, b, oracle.IndBallL0(r), iters=1, tol=0, mu=0.5)
+        assert np.array_equal(z != 0, ro["z"] != 0) and np.count_nonzero(z) == r      # same winners: lowest indices
+        assert np.allclose(z, ro["z"], rtol=1e-14, atol=0)
+        assert list(np.nonzero(z)[0]) == [3, 10, 20, 30][:r]
