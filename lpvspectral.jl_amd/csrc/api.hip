@@ -217,7 +217,12 @@ struct lpvs_problem {
     // timing (ms) -- see lpvs_problem_get_timing
     double t_basis = 0, t_gram = 0, t_reduce = 0, t_factor = 0, t_admm = 0, gram_launches = 0, gram_flops = 0, admm_iters_timed = 0;
     EventPair ev[4];
+    // launch-bound regime (small n): a chunk of ADMM iterations captured once into a hipGraph and replayed
+    hipGraphExec_t admm_graph = nullptr;
+    int64_t admm_graph_iters = 0;
+    void drop_graph() { if (admm_graph) (void)hipGraphExecDestroy(admm_graph); admm_graph = nullptr; admm_graph_iters = 0; }
     ~lpvs_problem() {
+        drop_graph();
         for (auto &e : ev) e.destroy();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -635,6 +640,7 @@ int32_t lpvs_problem_set_prox(lpvs_problem *h, int32_t kind, double param, int64
     if (kind == LPVS_PROX_GROUP_L2 && group_len <= 0) { set_error("group_len must be positive"); return LPVS_EARGUMENT; }
     if (kind == LPVS_PROX_GROUP_L2 && group_len > 8192) { set_error("group_len > 8192 is not supported by the device prox"); return LPVS_EUNSUPPORTED; }
     h->prox_kind = kind; h->prox_param = param; h->group_len = group_len;
+    h->drop_graph();   // kernel parameters are baked into the captured graph
     return LPVS_OK;
 }
 
@@ -645,6 +651,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     if (linear_sign != 1 && linear_sign != -1) { set_error("linear_sign must be +1 or -1"); return LPVS_EARGUMENT; }
     LPVS_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
+    h->drop_graph();
     const bool had_M = h->M_valid && h->M_shift == 1.0 / mu && h->Mp.p != nullptr;
     LPVS_TRY(factorize(h, 1.0 / mu));
     if (h->np >= kSymmetricMinNp && !had_M) {   // tile-packed lower triangle for the half-traffic mat-vec
@@ -687,7 +694,30 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     for (auto &q : st0) all0 = all0 && q.converged;
     if (max_iters > 0 && !all0) {
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
-        LPVS_TRY(launch_admm_iterations(p, max_iters, s));
+        int64_t todo = max_iters;
+        constexpr int64_t kGraphIters = 50;
+        if (h->np < kSymmetricMinNp && todo >= 2 * kGraphIters) {
+            // two launches of a few microseconds per iteration: host launch cost dominates, so replay a captured
+            // chunk.  Iterations past convergence are no-ops (device flag), and exactly max_iters are enqueued.
+            if (!h->admm_graph) {
+                hipGraph_t g = nullptr;
+                LPVS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int32_t rc = launch_admm_iterations(p, kGraphIters, s);
+                const hipError_t e = hipStreamEndCapture(s, &g);
+                if (rc != LPVS_OK || e != hipSuccess || g == nullptr) {
+                    (void)hipGetLastError();
+                    if (g) (void)hipGraphDestroy(g);
+                    set_error("hipGraph capture of the ADMM chunk failed");
+                    return LPVS_EDEVICE;
+                }
+                const hipError_t ei = hipGraphInstantiate(&h->admm_graph, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (ei != hipSuccess) { (void)hipGetLastError(); h->admm_graph = nullptr; set_error("hipGraphInstantiate failed"); return LPVS_EDEVICE; }
+                h->admm_graph_iters = kGraphIters;
+            }
+            while (todo >= h->admm_graph_iters) { LPVS_HIP(hipGraphLaunch(h->admm_graph, s)); todo -= h->admm_graph_iters; }
+        }
+        if (todo > 0) LPVS_TRY(launch_admm_iterations(p, todo, s));
         LPVS_HIP(hipEventRecord(h->ev[0].b, s));
     }
     LPVS_HIP(hipMemcpyAsync(st.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
