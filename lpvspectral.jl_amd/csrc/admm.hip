@@ -789,7 +789,14 @@ int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s
             launch_iteration_sym(p, s);
         } else {
             launch_symv_raw(p.M, p.np, p.rhs, p.x, p.status, p.ns, s);
-            hipLaunchKernelGGL(admm_prox_kernel, dim3((unsigned)p.ns), dim3(1024), 0, s, p);
+            if (p.prox_kind != LPVS_PROX_BALL_L0 && p.n <= 4096) {
+                // small problems: the light 256-thread kernel (no 128 KiB LDS image) has the shorter latency
+                AdmmBatch q{p.M, p.np, p.n, p.ns, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len,
+                            p.status, nullptr, nullptr};
+                hipLaunchKernelGGL(admm_batch_prox_kernel, dim3((unsigned)p.ns), dim3(256), 0, s, q);
+            } else {
+                hipLaunchKernelGGL(admm_prox_kernel, dim3((unsigned)p.ns), dim3(1024), 0, s, p);
+            }
         }
     }
     LPVS_HIP(hipGetLastError());
