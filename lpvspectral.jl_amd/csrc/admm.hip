@@ -160,6 +160,90 @@ __device__ void topr_threshold(const double *v, int64_t n, int64_t r, unsigned l
     *equal_count = shll[2];   // elements whose key equals the threshold (count of the last pass's bin)
 }
 
+// Two-level top-r for n <= 32768: a radix select on monotone 32-bit float keys held in LDS decides everything except
+// the few elements whose float key equals the threshold's; those candidates are ranked exactly (64-bit key, lowest
+// index first on ties) and the winners are marked in an LDS bitmap.  Returns false (nothing written) when there
+// are more than 1024 candidates -- the caller then falls back to the 64-bit select.
+//   keep(i) = key32[i] > thr32  ||  bit i of `mark`
+__device__ bool topr_float_keys(const double *__restrict__ X, const double *__restrict__ U, int64_t n, long long r,
+                                unsigned int *key32 /*[n] LDS*/, unsigned int *mark /*[1024] LDS words*/,
+                                unsigned int *hist /*[256]*/, long long *shll /*[3]*/, int *scan /*[1024] LDS*/,
+                                unsigned int *thr_out) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) key32[i] = __float_as_uint((float)fabs(X[i] + U[i]));   // monotone in |v|
+    for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+    for (int i = threadIdx.x; i < 1024; i += 1024) mark[i] = 0;
+    __syncthreads();
+    unsigned int prefix = 0, mask = 0;
+    long long remaining = r;
+    for (int pass = 3; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+            const int64_t i = i0 + threadIdx.x;
+            const unsigned int k = i < n ? key32[i] : 0u;
+            bool todo = i < n && (k & mask) == prefix;
+            const unsigned int bin = (k >> shift) & 255;
+            unsigned long long pending = __ballot(todo);
+            while (pending) {
+                const int leader = __ffsll((long long)pending) - 1;
+                const unsigned int lb = __shfl(bin, leader, 64);
+                const unsigned long long same = __ballot(todo && bin == lb);
+                if (lane == leader) atomicAdd(&hist[lb], (unsigned int)__popcll(same));
+                if (todo && bin == lb) todo = false;
+                pending &= ~same;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            unsigned int c[4], tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = hist[4 * lane + q]; tot += c[q]; hist[4 * lane + q] = 0; }
+            unsigned int sfx = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = __shfl_down(sfx, o, 64);
+                if (lane + o < 64) sfx += t;
+            }
+            unsigned int above = sfx - tot;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                const unsigned int S = above + c[q];
+                if ((long long)S >= remaining && (long long)above < remaining) { shll[0] = 4 * lane + q; shll[1] = remaining - above; shll[2] = c[q]; }
+                above = S;
+            }
+        }
+        __syncthreads();
+        prefix |= ((unsigned int)shll[0]) << shift;
+        mask |= 255u << shift;
+        remaining = shll[1];
+        __syncthreads();
+    }
+    const long long need = remaining, ncand = shll[2];   // keep `need` of the `ncand` elements with key32 == prefix
+    *thr_out = prefix;
+    if (ncand > 1023) return false;                       // (uniform) candidate list lives in scan[1..1023]
+    __syncthreads();
+    if (threadIdx.x == 0) scan[0] = 0;
+    __syncthreads();
+    int *cidx = scan + 1;
+    for (int64_t i = threadIdx.x; i < n; i += 1024)
+        if (key32[i] == prefix) cidx[atomicAdd(&scan[0], 1)] = (int)i;
+    __syncthreads();
+    // exact rank among the candidates: 64-bit key descending, index ascending
+    if ((long long)threadIdx.x < ncand) {
+        const int me = cidx[threadIdx.x];
+        const unsigned long long km = abs_key(X[me] + U[me]);
+        int rank = 0;
+        for (int c = 0; c < (int)ncand; ++c) {
+            const int o = cidx[c];
+            const unsigned long long ko = abs_key(X[o] + U[o]);
+            rank += (ko > km) || (ko == km && o < me);
+        }
+        if (rank < need) atomicOr(&mark[me >> 5], 1u << (me & 31));
+    }
+    __syncthreads();
+    return true;
+}
+
 // Elements are processed in coalesced passes of 1024 threads x EPT elements: all loads of a pass are
 // issued before any store (no aliasing-serialised round trips); group norms go through LDS.
 constexpr int EPT = 8;                 // elements per thread per pass
@@ -171,8 +255,10 @@ admm_prox_kernel(AdmmParams p) {
     __shared__ unsigned int hist[256];
     __shared__ long long shll[3];
     __shared__ int scan[1024];
-    __shared__ double sq[PASS];        // v^2 of the current pass (group prox)
-    __shared__ double gscale[PASS];    // per-group scale of the current pass
+    __shared__ double lds2[2 * PASS];  // 128 KiB: group prox uses it as sq / gscale, IndBallL0 as float keys or v cache
+    __shared__ unsigned int mark[1024];
+    double *sq = lds2;                 // v^2 of the current pass (group prox)
+    double *gscale = lds2 + PASS;      // per-group scale of the current pass
     const int sg = blockIdx.x;         // one workgroup per signal
     AdmmStatus *status = p.status + sg;
     if (status->converged) return;
@@ -197,10 +283,17 @@ admm_prox_kernel(AdmmParams p) {
     double thr_l1 = mu * p.prox_param, thr_l0 = sqrt(2.0 * mu * p.prox_param);
     unsigned long long ball_thr = 0; long long ball_keep_eq = 0, ball_eq_count = 0, ball_r = (long long)p.prox_param;
     double *vbuf = n <= PASS ? sq : p.scratch + 2 * so;   // v = x + u is scanned 8 times: keep it in LDS when it fits
+    unsigned int *key32 = reinterpret_cast<unsigned int *>(lds2);
+    unsigned int thr32 = 0;
+    bool ball_fast = false;                                // two-level selection with float keys in LDS succeeded
     if (kind == LPVS_PROX_BALL_L0 && ball_r > 0 && ball_r < n) {
-        for (int64_t i = threadIdx.x; i < n; i += 1024) vbuf[i] = X[i] + U[i];
-        __syncthreads();
-        topr_threshold(vbuf, n, ball_r, &ball_thr, &ball_keep_eq, &ball_eq_count, hist, shll);
+        if (n <= 4 * PASS) ball_fast = topr_float_keys(X, U, n, ball_r, key32, mark, hist, shll, scan, &thr32);
+        if (!ball_fast) {
+            __syncthreads();
+            for (int64_t i = threadIdx.x; i < n; i += 1024) vbuf[i] = X[i] + U[i];
+            __syncthreads();
+            topr_threshold(vbuf, n, ball_r, &ball_thr, &ball_keep_eq, &ball_eq_count, hist, shll);
+        }
     }
     const bool ball_ties = ball_keep_eq < ball_eq_count;   // only then do equal keys have to be ranked by index
     long long eq_seen = 0;  // equal-key elements at lower indices (uniform across threads)
@@ -263,6 +356,15 @@ admm_prox_kernel(AdmmParams p) {
                     else if (kind == LPVS_PROX_L0) zi = fabs(v) > thr_l0 ? v : 0.0;
                     else zi = ball_r >= n ? v : 0.0;
                     finish(i, xv[k], uv[k], bv[k], zi);
+                }
+            } else if (ball_fast) {   // IndBallL0, two-level selection: float key above the threshold, or a marked candidate
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    const int64_t i = c0 + threadIdx.x + 1024 * k;
+                    if (i >= n) continue;
+                    const double v = xv[k] + uv[k];
+                    const bool keep = key32[i] > thr32 || ((mark[i >> 5] >> (i & 31)) & 1u);
+                    finish(i, xv[k], uv[k], bv[k], keep ? v : 0.0);
                 }
             } else if (!ball_ties) {  // IndBallL0, every key equal to the threshold is kept: no ranking needed
 #pragma unroll
