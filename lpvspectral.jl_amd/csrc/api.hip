@@ -7,6 +7,7 @@
 #include <ctime>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "lpvs_internal.h"
@@ -455,10 +456,6 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     hipStream_t s = h->stream;
     const int64_t nb = coulomb ? 2 * Nv : Nv;
     h->kind = 1; h->N = N; h->Nf = Nf; h->nb = nb; h->n = 2 * Nf * nb; h->np = round_up(h->n, 128); h->ns = ns;
-    const bool krs = gram_krs_fits(nb);   // symmetric-pair form unless the pair table does not fit LDS
-    const GramPlan pl = krs ? make_gram_plan_pairs(Nf, nb, N) : make_gram_plan(h->n, N);
-    const int64_t Npad = pl.ksplit * pl.rows_per_chunk;
-
     DevArg dy, dX, dV, dw;
     LPVS_TRY(dy.set(y, N * ns, s)); LPVS_TRY(dX.set(X, N, s)); LPVS_TRY(dV.set(V, N, s)); LPVS_TRY(dw.set(w, Nf, s));
     LPVS_TRY(h->G.alloc(sizeof(double) * (size_t)h->np * (size_t)h->np));
@@ -466,6 +463,82 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     LPVS_HIP(hipMemsetAsync(h->G.p, 0, h->G.bytes, s));
     LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
     LPVS_TRY(alloc_state(h));
+
+    // ---- Gram form.  LPVS_GRAM_FORM = auto (default) | ap | krs | kr
+    //   ap : w is an arithmetic progression up to rounding -> 3Nf-1 non-uniform Fourier sums per activation pair
+    //        (nudft.hip); admitted when max|eps_f| * max|x| <= 1e-7 (second-order term <= 5e-15)
+    //   krs / kr : dense MFMA contraction for arbitrary w (gram.hip)
+    const char *form_env = getenv("LPVS_GRAM_FORM");
+    const std::string form = form_env ? form_env : "auto";
+    bool use_ap = false;
+    std::vector<double> hw, heps, om_hi, om_lo;
+    if (form == "auto" || form == "ap") {
+        LPVS_TRY(fetch_host(hw, w, Nf));
+        double xlo, xhi, xam;
+        LPVS_TRY(device_minmax(dX.p, N, &xlo, &xhi, &xam, s));
+        const long double a0 = hw[0], D = Nf > 1 ? ((long double)hw[Nf - 1] - (long double)hw[0]) / (long double)(Nf - 1) : 0.0L;
+        heps.resize((size_t)Nf);
+        double emax = 0;
+        for (int64_t f = 0; f < Nf; ++f) {
+            heps[f] = (double)((long double)hw[f] - (a0 + (long double)f * D));
+            emax = std::fmax(emax, std::fabs(heps[f]));
+        }
+        use_ap = std::isfinite(emax) && emax * xam <= 1e-7;
+        if (form == "ap" && !use_ap) { set_error("LPVS_GRAM_FORM=ap but w is not an arithmetic progression (max|eps|*max|x| = %.3g)", emax * xam); return LPVS_EARGUMENT; }
+        if (use_ap) {
+            const int64_t nsl = 3 * Nf - 1;
+            om_hi.resize((size_t)nsl); om_lo.resize((size_t)nsl);
+            for (int64_t m = 0; m < Nf; ++m) { const long double v = (long double)m * D; om_hi[m] = (double)v; om_lo[m] = (double)(v - (long double)om_hi[m]); }
+            for (int64_t q = 0; q < 2 * Nf - 1; ++q) {
+                const long double v = 2.0L * a0 + (long double)q * D;
+                om_hi[Nf + q] = (double)v; om_lo[Nf + q] = (double)(v - (long double)om_hi[Nf + q]);
+            }
+        }
+    }
+    if (use_ap) {
+        const int64_t nsl = 3 * Nf - 1, P = nb * (nb + 1) / 2;
+        double lo, hi, am, gamma; std::vector<double> vc;
+        DevBuf K, KK, dvc, dhi, dlo, deps, part, tab, tabb;
+        LPVS_HIP(hipEventRecord(h->ev[0].a, s));
+        LPVS_TRY(device_minmax(dV.p, N, &lo, &hi, &am, s));
+        basis_centers(lo, hi, am, Nv, coulomb, vc, &gamma);
+        const int64_t ldk = nb + 1;
+        LPVS_TRY(dvc.alloc(sizeof(double) * vc.size()));
+        LPVS_TRY(copy_to_device(dvc.p, vc.data(), sizeof(double) * vc.size(), s));
+        LPVS_TRY(K.alloc(sizeof(double) * (size_t)N * (size_t)ldk));
+        LPVS_TRY(KK.alloc(sizeof(double) * (size_t)N * (size_t)P));
+        LPVS_TRY(launch_basis_table(dV.p, N, dvc.as<double>(), nb, gamma, normalize, coulomb, K.as<double>(), ldk, s));
+        LPVS_TRY(launch_pair_table(K.as<double>(), ldk, nb, N, KK.as<double>(), s));
+        LPVS_TRY(dhi.alloc(sizeof(double) * (size_t)nsl)); LPVS_TRY(dlo.alloc(sizeof(double) * (size_t)nsl)); LPVS_TRY(deps.alloc(sizeof(double) * (size_t)Nf));
+        LPVS_TRY(copy_to_device(dhi.p, om_hi.data(), sizeof(double) * (size_t)nsl, s));
+        LPVS_TRY(copy_to_device(dlo.p, om_lo.data(), sizeof(double) * (size_t)nsl, s));
+        LPVS_TRY(copy_to_device(deps.p, heps.data(), sizeof(double) * (size_t)Nf, s));
+        LPVS_HIP(hipEventRecord(h->ev[0].b, s));
+        LPVS_TRY(part.alloc(nudft_partial_bytes(N, nsl, P, 4)));
+        LPVS_TRY(tab.alloc(sizeof(double) * (size_t)nsl * (size_t)P * 4));
+        LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)Nf * (size_t)nb * 2));
+        LPVS_HIP(hipEventRecord(h->ev[1].a, s));
+        LPVS_TRY(launch_nudft(dX.p, nullptr, N, KK.as<double>(), P, (int)P, dhi.as<double>(), dlo.as<double>(), (int)nsl, 4, part.as<double>(), tab.as<double>(), s));
+        LPVS_TRY(launch_ap_assemble(tab.as<double>(), deps.as<double>(), Nf, nb, h->n, h->G.as<double>(), h->np, s));
+        LPVS_HIP(hipEventRecord(h->ev[1].b, s));
+        LPVS_HIP(hipEventRecord(h->ev[2].a, s));
+        for (int64_t q = 0; q < ns; ++q) {   // b_q = Phi' y_q: Nf slots at the frequencies w_f themselves, weights y K_j
+            LPVS_TRY(launch_nudft(dX.p, dy.p + q * N, N, K.as<double>(), ldk, (int)nb, dw.p, nullptr, (int)Nf, 2, part.as<double>(), tabb.as<double>(), s));
+            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
+        }
+        LPVS_HIP(hipEventRecord(h->ev[2].b, s));
+        LPVS_HIP(hipStreamSynchronize(s));
+        h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
+        h->gram_launches = 8.0 * (double)N * (double)nsl * (double)P;   // flops the structured form issues (4 fma per sample, slot, pair)
+        h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
+        guard.h = nullptr;
+        *out = h;
+        return LPVS_OK;
+    }
+
+    const bool krs = form != "kr" && gram_krs_fits(nb);   // symmetric-pair form unless the pair table does not fit LDS
+    const GramPlan pl = krs ? make_gram_plan_pairs(Nf, nb, N) : make_gram_plan(h->n, N);
+    const int64_t Npad = pl.ksplit * pl.rows_per_chunk;
 
     DevBuf T, K, KK, G3, slab, scr; int64_t ldk;
     LPVS_HIP(hipEventRecord(h->ev[0].a, s));

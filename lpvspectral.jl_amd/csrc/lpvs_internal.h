@@ -119,6 +119,13 @@ int32_t launch_rhs_panel_batch(int nbatch, const double *P, int64_t strideP, int
                                const double *y, const int64_t *yoff_dev, int64_t N, double *b, int64_t ldb, double *scratch,
                                size_t scratch_bytes, hipStream_t s);
 
+// ---- structured Gram for arithmetic-progression frequency grids (nudft.hip) ----------------------------------
+size_t nudft_partial_bytes(int64_t N, int64_t nslots, int64_t nq, int nv);
+int32_t launch_nudft(const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq, const double *om_hi,
+                     const double *om_lo, int nslots, int nv, double *partial, double *tab, hipStream_t s);
+int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t nb, int64_t n, double *G, int64_t ldg, hipStream_t s);
+int32_t launch_ap_rhs(const double *tab, int64_t Nf, int64_t nb, double *b, hipStream_t s);
+
 // ---- dense symmetric inverse (linalg.hip) ------------------------------------------------
 // In-place inverse of the SPD matrix A (np x np, np % 64 == 0, full symmetric storage) by
 // blocked symmetric sweeps; work holds 2 panels of np x 64 + one 64 x 64 block.

@@ -37,25 +37,30 @@ def test_cfg3_gram_additivity_and_forms(L):
     # end points in both halves (interleaved split)
     ev, od = slice(0, N, 2), slice(1, N, 2)
     Vfix = V.clone()
-    with L.Problem.lpv(y, X, Vfix, w, 8) as p:
-        G, b = p.get_gram()
-        n = p.n
+    grams = {}
+    for form in ("ap", "krs", "kr"):          # structured (w is an arithmetic progression), symmetric-pair MFMA, plain MFMA
+        os.environ["LPVS_GRAM_FORM"] = form
+        try:
+            with L.Problem.lpv(y, X, Vfix, w, 8) as p:
+                grams[form] = p.get_gram()
+                n = p.n
+        finally:
+            del os.environ["LPVS_GRAM_FORM"]
+    G, b = grams["krs"]
     assert n == 8192 and np.array_equal(G, G.T) and np.isfinite(G).all()
-    # halves: rows 0..N/2 and N/2..N, with V's min/max pinned by appending the two extreme samples with y = 0
-    # contributes only to G; instead compare forms on the full set (exact same inputs):
-    os.environ["LPVS_GRAM_FORM"] = "kr"
-    try:
-        with L.Problem.lpv(y, X, Vfix, w, 8) as p:
-            G2, b2 = p.get_gram()
-    finally:
-        del os.environ["LPVS_GRAM_FORM"]
     scale = np.abs(G).max()
-    assert np.abs(G - G2).max() <= 1e-12 * scale
-    assert np.array_equal(b, b2)
+    assert np.abs(G - grams["kr"][0]).max() <= 1e-12 * scale and np.array_equal(b, grams["kr"][1])   # same operands, same b kernel
+    # structured vs dense: exact phases vs the reference's rounded phases fl(w*x): |w x| 2^-53 rad per term
+    tol = 1e-12 + 4.5e-16 * float(w.max().item() * X.max().item())
+    assert np.abs(grams["ap"][0] - G).max() <= tol * scale
+    assert np.abs(grams["ap"][1] - b).max() <= tol * np.abs(b).max() * 10
+    with L.Problem.lpv(y, X, Vfix, w, 8) as p:        # default = auto -> structured here
+        Gd, bd = p.get_gram()
+    assert np.array_equal(Gd, grams["ap"][0]) and np.array_equal(bd, grams["ap"][1])
     # linearity of b in y
     with L.Problem.lpv(2.0 * y, X, Vfix, w, 8) as p:
         _, b3 = p.get_gram()
-    assert np.abs(b3 - 2.0 * b).max() <= 1e-13 * np.abs(b).max()
+    assert np.abs(b3 - 2.0 * bd).max() <= 1e-13 * np.abs(bd).max()
 
 
 def test_fourier_gram_additivity_cfg2(L):

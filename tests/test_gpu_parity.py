@@ -487,3 +487,46 @@ def test_ball_prox_with_ties(L, oracle):
         assert np.array_equal(z != 0, ro["z"] != 0) and np.count_nonzero(z) == r      # same winners: lowest indices
         assert np.allclose(z, ro["z"], rtol=1e-14, atol=0)
         assert list(np.nonzero(z)[0]) == [3, 10, 20, 30][:r]
+
+
+# ------------------------------------------------------------------ Gram forms
+def test_gram_form_selection_and_agreement(L, oracle):
+    """auto picks the structured form only for arithmetic-progression w; all forms agree with the oracle Gram."""
+    import os
+    rng = np.random.default_rng(77)
+    N, Nv = 700, 5
+    X = np.sort(rng.random(N)) * 50; V = rng.random(N); Y = rng.standard_normal(N)
+    w_ap = 2 * np.pi * np.arange(2, 40, 2.0) / 7.0
+    w_jit = w_ap * (1 + 1e-9 * rng.standard_normal(len(w_ap)))        # off the progression by far more than rounding
+    def gram(w, form=None):
+        if form: os.environ["LPVS_GRAM_FORM"] = form
+        try:
+            with L.Problem.lpv(Y, X, V, w, Nv) as p:
+                return p.get_gram()
+        finally:
+            os.environ.pop("LPVS_GRAM_FORM", None)
+    for w in (w_ap, w_jit):
+        Phi = oracle.lpv_regressor(X, V, w, Nv)
+        Go, bo = Phi.T @ Phi, Phi.T @ Y
+        tol = 1e-12 + 4.5e-16 * float(w.max() * X.max())
+        for form in (None, "krs", "kr") + (("ap",) if w is w_ap else ()):
+            G, b = gram(w, form)
+            assert np.abs(G - Go).max() <= tol * np.abs(Go).max(), form
+            assert np.abs(b - bo).max() <= tol * np.abs(bo).max() * 10, form
+    assert np.array_equal(gram(w_ap)[0], gram(w_ap, "ap")[0])          # auto == structured on the progression
+    assert np.array_equal(gram(w_jit)[0], gram(w_jit, "krs")[0])       # auto == dense otherwise
+    with pytest.raises(ValueError):
+        gram(w_jit, "ap")
+    # frequencies that are a progression only up to rounding (as produced by 2*pi*(1:Nf)*c): first-order residual correction
+    w_r = 2 * np.pi * (np.arange(40) + 1.0) * (25.0 / 512)
+    Xb = np.sort(rng.random(N)) * 2e4
+    with L.Problem.lpv(Y, Xb, V, w_r, Nv) as p:
+        Ga, _ = p.get_gram()
+    os.environ["LPVS_GRAM_FORM"] = "krs"
+    try:
+        with L.Problem.lpv(Y, Xb, V, w_r, Nv) as p:
+            Gk, _ = p.get_gram()
+    finally:
+        os.environ.pop("LPVS_GRAM_FORM", None)
+    assert not np.array_equal(Ga, Gk)
+    assert np.abs(Ga - Gk).max() <= (1e-12 + 4.5e-16 * float(w_r.max() * Xb.max())) * np.abs(Gk).max()
