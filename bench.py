@@ -3,13 +3,15 @@
 size N=2^20, Nf=512, Nv=8 (n = 8192 unknowns) on N GPUs of one node, one process per GPU.
 
 A step = one complete solve of one synthetic signal whose inputs (y, X, V, w) are already resident
-in HBM: basis tables -> f64 MFMA Gram + rhs -> factorisation of (G + I/mu) -> 2000 ADMM iterations
-(tol = 0, so exactly 2000) -> parameter read-back.  Ranks solve independent signals (weak scaling,
+in HBM: basis tables -> Gram + rhs -> factorisation of (G + I/mu) -> 2000 ADMM iterations (tol = 0,
+so exactly 2000) -> parameter read-back.  The workload's w is the reference's uniform grid, so the
+library takes its structured Gram (nudft.hip); the dense f64-MFMA Gram used for arbitrary w is
+measured once more outside the timed region and reported under "gram_general_path".  Ranks solve independent signals (weak scaling,
 no data-path collective); RCCL is used only for the final gather of the coefficient vectors.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with
-  roofline     : the dominant kernel (Gram) against the f64 MFMA peak, from HIP-event timings taken
-                 inside the library on the stream the kernel runs on
+  roofline     : the dominant kernel (the ADMM mat-vec, HBM-bound) against the HBM peak, from HIP-event
+                 timings taken inside the library on the stream the kernel runs on
   cpu_baseline : the faithful CPU restatement of the reference algorithm (oracle, "port") timed on
                  this host on a bounded sample and extrapolated (rank 0, N=1 only).
 """
@@ -27,6 +29,7 @@ import torch
 
 LOG2N, NF, NV = 20, 512, 8
 ADMM_ITERS, LAMBDA, MU = 2000, 5.0, 0.05
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 F64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet FP64 matrix; MI355X_MICROARCH.md lists no f64 MFMA row
 
 
@@ -82,11 +85,12 @@ def cpu_baseline(log2n_sample=14, iters=6):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=LOG2N, help="diagnostic only; the judged size is 20")
     ap.add_argument("--iters", type=int, default=ADMM_ITERS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-general-path", action="store_true", help="skip the extra (untimed) dense-MFMA Gram measurement")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI, the judged path) or gloo (functional rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: map every rank onto the visible GPUs modulo their count")
     args = ap.parse_args()
@@ -142,19 +146,47 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        gram_ms = float(np.mean([t["gram_ms"] for t in tms]))
-        admm_ms = float(np.mean([t["admm_ms"] for t in tms]))
-        flops = tms[0]["gram_flops"]
-        issued = tms[0]["gram_issued_flops"]
-        achieved = flops / (gram_ms * 1e-3) * 1e-12
-        issued_rate = issued / (gram_ms * 1e-3) * 1e-12
+        phase = {k: float(np.mean([t[k] for t in tms])) for k in ("basis_ms", "gram_ms", "reduce_rhs_ms", "factor_ms", "admm_ms")}
+        form = tms[0]["gram_form"]
+        # ---- dominant kernel of the step: the ADMM mat-vec (one launch per iteration, HBM-bound: it streams the
+        # tile-packed lower triangle of M once).  Launch duration measured live with HIP events on the library's stream.
+        with L.Problem.lpv(y, X, V, w, NV, True, False, device=local) as p:
+            p.set_prox(L.SlicedSeparableSum.frequency_groups(LAMBDA, len(w), 2 * NV))
+            p.admm_init(None, μ=MU, tol=0.0)
+            mv_us, mv_bytes = p.time_matvec(300)
+        mv_share = args.iters * mv_us * 1e-3 / (elapsed / args.steps * 1e3)
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_ap_pmc_traffic.json")
         if os.path.exists(pmc) and args.log2n == LOG2N:   # PMC passes cannot run inside the timed bench: use the committed
             for r in json.load(open(pmc)):                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this command
-                if r["kernel"].startswith("gram_kernel"):
+                if r["kernel"].startswith("symv_tile_kernel"):
                     traffic = r["fetch_corrected_bytes_per_launch"] + r["write_bytes_per_launch"]
-                    traffic_src = "profiles/r01_final_pmc_traffic.json (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, bytes per launch)"
+                    traffic_src = "profiles/r01_ap_pmc_traffic.json (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, bytes per launch)"
+        achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
+        # ---- the dense f64-MFMA Gram the library uses when w is NOT an arithmetic progression: measured once outside
+        # the timed region (same inputs, LPVS_GRAM_FORM=krs) so both rooflines are on the record.
+        general = None
+        if not args.no_general_path:
+            os.environ["LPVS_GRAM_FORM"] = "krs"
+            try:
+                gt = None
+                for _ in range(2):
+                    with L.Problem.lpv(y, X, V, w, NV, True, False, device=local) as p:
+                        gt = p.timing()
+            finally:
+                del os.environ["LPVS_GRAM_FORM"]
+            g_alg = gt["gram_flops"] / (gt["gram_ms"] * 1e-3) * 1e-12
+            g_iss = gt["gram_issued_flops"] / (gt["gram_ms"] * 1e-3) * 1e-12
+            general = {"bound": "mfma", "kernel": "gram_kernel<KRS> (v_mfma_f64_16x16x4_f64)", "launch_ms": gt["gram_ms"],
+                       "achieved": g_alg, "issued_tflops": g_iss, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": g_alg / F64_MFMA_PEAK_TFLOPS, "issued_frac_of_peak": g_iss / F64_MFMA_PEAK_TFLOPS,
+                       "algorithmic_flops_per_launch": gt["gram_flops"], "issued_flops_per_launch": gt["gram_issued_flops"],
+                       "step_ms_with_this_form": elapsed / args.steps * 1e3 - phase["gram_ms"] - phase["reduce_rhs_ms"] - phase["basis_ms"]
+                                                 + gt["gram_ms"] + gt["reduce_rhs_ms"] + gt["basis_ms"],
+                       "note": "arbitrary-w path (not taken by this workload, whose w is an arithmetic progression); algorithmic "
+                               "N*n*(n+1) flops / launch time can exceed the MFMA peak because the symmetric-pair contraction "
+                               "issues 2Nv/(Nv+1) = 1.78x fewer flops than the n x n lower triangle; issued_tflops is the rate "
+                               "the matrix cores run at (issue ceiling measured by tools/mfma_f64_peak.hip: 66-67 TFLOP/s)"}
         out = {
             "metric": "signals/sec, ls_sparse_spectral_lpv group lasso N=2^%d Nf=%d Nv=%d (%d ADMM iters; iters/sec in admm_iters_per_sec)" % (args.log2n, NF, NV, args.iters),
             "value": world * args.steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": args.steps,
@@ -162,19 +194,18 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg3: ls_sparse_spectral_lpv group-lasso N=2^%d Nf=%d Nv=%d n=%d lambda=%g mu=%g iters=%d tol=0, one signal per GPU"
                                    % (args.log2n, NF, NV, 2 * NF * NV, LAMBDA, MU, args.iters),
-                       "signals_per_step_per_gpu": 1, "final_gather": ("rccl" if args.backend == "nccl" else args.backend) + " all_gather" if world > 1 else "none"},
-            "admm_iters_per_sec": args.iters / (admm_ms * 1e-3),
-            "phase_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("basis_ms", "gram_ms", "reduce_rhs_ms", "factor_ms", "admm_ms")},
+                       "signals_per_step_per_gpu": 1, "gram_form": form,
+                       "final_gather": ("rccl" if args.backend == "nccl" else args.backend) + " all_gather" if world > 1 else "none"},
+            "admm_iters_per_sec": args.iters / (phase["admm_ms"] * 1e-3),
+            "phase_ms": phase,
             "final_nxz": nxz,
-            "roofline": {"bound": "mfma", "kernel": "gram_kernel<KRS> (v_mfma_f64_16x16x4_f64)", "achieved": achieved,
-                         "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops_per_launch": flops, "launch_ms": gram_ms,
-                         "issued_flops_per_launch": issued, "issued_tflops": issued_rate,
-                         "issued_frac_of_peak": issued_rate / F64_MFMA_PEAK_TFLOPS,
-                         "note": "achieved = N*n*(n+1) algorithmic flops / launch time; it can exceed the MFMA peak because the "
-                                 "symmetric-pair contraction issues 2Nv/(Nv+1) (1.78x) fewer flops than the n x n lower triangle; "
-                                 "issued_tflops is the rate the matrix cores actually run at",
-                         "peak_source": "AMD datasheet FP64 matrix (no f64 MFMA row in MI355X_MICROARCH.md); issue-rate ceiling measured on this pool by tools/mfma_f64_peak.hip: 60-66 TFLOP/s"},
+            "roofline": {"bound": "hbm", "kernel": "symv_tile_kernel (ADMM mat-vec with the tile-packed lower triangle of (G + I/mu)^-1)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": mv_bytes,
+                         "launch_us": mv_us, "launches_per_step": args.iters, "share_of_step": mv_share,
+                         "note": "algorithmic bytes = 8 B x np(np+64)/2 (np = 8192: 272.6 MB, M read once per iteration); duration = "
+                                 "HIP events around 300 back-to-back launches on the library's stream"},
+            "gram_general_path": general,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -11,7 +11,11 @@
  *   - every array argument may be a HOST pointer or a DEVICE (HIP) pointer of the
  *     current device; the library detects which (hipPointerGetAttributes).  The
  *     caller owns all argument memory; it is never retained or freed here, and is
- *     only read/written for the duration of the call.
+ *     only read/written for the duration of the call.  Device arguments are read on the
+ *     library's own streams: work the caller has queued on other streams to produce them
+ *     must be complete before the call (the Python mirror synchronises torch's current
+ *     stream; a Julia wrapper calls AMDGPU.synchronize()).  Device outputs are complete
+ *     when the call returns.
  *   - a handle owns one HIP stream on one device; handles are not thread-safe,
  *     different handles may be used concurrently.
  *   - arithmetic type: fp64 (suffix _f64), the eltype of every reference test.
@@ -165,9 +169,16 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
 /* ---- timing: HIP-event durations (ms) of the handle's phases, measured on its stream ---
  * out[0] basis tables, out[1] Gram kernel(s), out[2] Gram reduce + rhs, out[3] factorisation,
  * out[4] ADMM iterations (sum over lpvs_admm_run calls), out[5] flops the Gram kernel's MFMA core
- * actually issues (tiles*128*256*2*Npad), out[6] algorithmic Gram flops N*n*(n+1), out[7] ADMM
- * iterations timed in out[4]. */
+ * actually issues (tiles*128*256*2*Npad; the structured form: 8*N*(3Nf-1)*P VALU flops), out[6]
+ * algorithmic Gram flops N*n*(n+1), out[7] ADMM iterations timed in out[4], out[8] Gram form used:
+ * 0 none (Gram given), 1 n x n lower triangle, 2 symmetric-pair, 3 k-major panel, 4 structured
+ * (arithmetic-progression w, nudft.hip). */
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out);
+
+/* average duration (microseconds) of the ADMM mat-vec kernel of this handle over `reps` back-to-back launches, from
+ * HIP events on the handle's stream (benchmark instrumentation; needs lpvs_admm_init; iterates are not modified).
+ * *bytes_per_launch = bytes of M the kernel streams per launch (tile-packed lower triangle, or the full matrix). */
+int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_launch, double *bytes_per_launch);
 
 /* ---- a15 window bookkeeping (DSP.arraysplit as used by src/windows.jl:27-36) ---------- */
 int32_t lpvs_window_count(int64_t L, int64_t n, int64_t noverlap, int64_t *count);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "lpvs_problem_set_prox": (_I32, [_P, _I32, _F64, _I64]),
     "lpvs_admm_init_f64": (_I32, [_P, _P, _F64, _F64, _I32]),
     "lpvs_admm_run": (_I32, [_P, _I64, _PI64, C.POINTER(_F64), C.POINTER(_I32)]),
+    "lpvs_admm_time_matvec": (_I32, [_P, _I32, C.POINTER(_F64), C.POINTER(_F64)]),
     "lpvs_admm_get_f64": (_I32, [_P, _P, _P, _P]),
     "lpvs_problem_get_params_f64": (_I32, [_P, _I32, _P, _P]),
     "lpvs_problem_pack_params_f64": (_I32, [_P, _P, _P, _P]),
@@ -145,6 +146,8 @@ def as_f64(a):
         if a.dtype != torch.float64:
             raise TypeError("device arrays must be float64 (the reference's eltype)")
         t = a if a.is_contiguous() else a.contiguous()
+        # the library works on its own streams: whatever torch has queued to produce this tensor must be complete
+        torch.cuda.current_stream(t.device).synchronize()
         return t, C.c_void_p(t.data_ptr()), t.numel()
     if hasattr(a, "detach") and hasattr(a, "numpy"):  # CPU torch tensor
         a = a.detach().numpy()

@@ -285,6 +285,12 @@ class Problem:
         check(lib().lpvs_admm_get_f64(self._h, out_ptr(x), out_ptr(z), out_ptr(u)))
         return x, z, u
 
+    def time_matvec(self, reps=200):
+        """(microseconds per launch, bytes of M streamed per launch) of the ADMM mat-vec kernel, HIP events on the handle's stream."""
+        us, nbytes = C.c_double(0), C.c_double(0)
+        check(lib().lpvs_admm_time_matvec(self._h, int(reps), C.byref(us), C.byref(nbytes)))
+        return float(us.value), float(nbytes.value)
+
     def admm_status(self, signal=0):
         it, nxz, conv = C.c_int64(0), C.c_double(0), C.c_int32(0)
         check(lib().lpvs_admm_status(self._h, int(signal), C.byref(it), C.byref(nxz), C.byref(conv)))
@@ -305,10 +311,11 @@ class Problem:
         return re + 1j * im
 
     def timing(self):
-        t = np.zeros(8)
-        check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 8))
+        t = np.zeros(9)
+        check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 9))
         return dict(basis_ms=t[0], gram_ms=t[1], reduce_rhs_ms=t[2], factor_ms=t[3], admm_ms=t[4],
-                    gram_issued_flops=t[5], gram_flops=t[6], admm_iters=t[7])
+                    gram_issued_flops=t[5], gram_flops=t[6], admm_iters=t[7],
+                    gram_form=("given", "kr", "krs", "panel", "ap")[int(t[8])])
 
 
 # --------------------------------------------------------------------------- ADMM driver

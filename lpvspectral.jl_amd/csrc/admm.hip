@@ -884,6 +884,23 @@ int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, h
     return LPVS_OK;
 }
 
+int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
+    const bool sym = p.part != nullptr && p.Mp != nullptr;
+    for (int i = 0; i < reps; ++i) {
+        if (sym) {
+            const int nblk = (int)(p.np / TS);
+            const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
+            double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * (unsigned)p.ns;
+            hipLaunchKernelGGL(symv_tile_kernel, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2,
+                               (const AdmmStatus *)nullptr);
+        } else {
+            launch_symv_raw(p.M, p.np, p.rhs, p.x, nullptr, p.ns, s);
+        }
+    }
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s) {
     const bool sym = p.part != nullptr && p.Mp != nullptr;
     for (int64_t i = 0; i < iters; ++i) {

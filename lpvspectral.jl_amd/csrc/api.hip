@@ -216,7 +216,7 @@ struct lpvs_problem {
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
     // timing (ms) -- see lpvs_problem_get_timing
-    double t_basis = 0, t_gram = 0, t_reduce = 0, t_factor = 0, t_admm = 0, gram_launches = 0, gram_flops = 0, admm_iters_timed = 0;
+    double t_basis = 0, t_gram = 0, t_reduce = 0, t_factor = 0, t_admm = 0, gram_launches = 0, gram_flops = 0, admm_iters_timed = 0, gram_form = 0;
     EventPair ev[4];
     // launch-bound regime (small n): a chunk of ADMM iterations captured once into a hipGraph and replayed
     hipGraphExec_t admm_graph = nullptr;
@@ -345,6 +345,7 @@ static int32_t create_panel_problem(lpvs_problem *h, const double *y, const doub
     LPVS_HIP(hipStreamSynchronize(s));
     h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
     h->gram_launches = (double)pl.tiles * 128.0 * 256.0 * 2.0 * (double)(pl.ksplit * pl.rows_per_chunk);   // flops the MFMA core issues
+    h->gram_form = 3;
     h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
     return LPVS_OK;
 }
@@ -531,6 +532,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
         h->gram_launches = 8.0 * (double)N * (double)nsl * (double)P;   // flops the structured form issues (4 fma per sample, slot, pair)
         h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
+        h->gram_form = 4;
         guard.h = nullptr;
         *out = h;
         return LPVS_OK;
@@ -575,6 +577,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     LPVS_HIP(hipStreamSynchronize(s));
     h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
     h->gram_launches = (double)pl.tiles * 128.0 * 256.0 * 2.0 * (double)(pl.ksplit * pl.rows_per_chunk); h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
+    h->gram_form = krs ? 2 : 1;
     guard.h = nullptr;
     *out = h;
     return LPVS_OK;
@@ -809,6 +812,26 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     return LPVS_OK;
 }
 
+int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_launch, double *bytes_per_launch) {
+    if (!h || !us_per_launch) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (!h->inited) { set_error("lpvs_admm_time_matvec before lpvs_admm_init"); return LPVS_ESTATE; }
+    if (reps <= 0) { set_error("reps must be positive"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const bool sym = h->np >= kSymmetricMinNp;
+    AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
+                 h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
+                 h->scratch.as<double>(), h->part.as<double>(), sym ? h->Mp.as<double>() : nullptr, (int)h->ns};
+    LPVS_TRY(launch_admm_matvec_only(p, 3, s));   // warm
+    LPVS_HIP(hipEventRecord(h->ev[1].a, s));
+    LPVS_TRY(launch_admm_matvec_only(p, reps, s));
+    LPVS_HIP(hipEventRecord(h->ev[1].b, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    *us_per_launch = h->ev[1].ms() * 1e3 / reps;
+    if (bytes_per_launch) *bytes_per_launch = sizeof(double) * (double)(sym ? symv_packed_doubles(h->np) : (size_t)h->np * (size_t)h->np);
+    return LPVS_OK;
+}
+
 int32_t lpvs_problem_num_signals(const lpvs_problem *h, int64_t *ns) {
     if (!h || !ns) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     *ns = h->ns;
@@ -878,8 +901,8 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
 
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out) {
     if (!h || !out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
-    const double v[8] = {h->t_basis, h->t_gram, h->t_reduce, h->t_factor, h->t_admm, h->gram_launches, h->gram_flops, h->admm_iters_timed};
-    for (int i = 0; i < n_out && i < 8; ++i) out[i] = v[i];
+    const double v[9] = {h->t_basis, h->t_gram, h->t_reduce, h->t_factor, h->t_admm, h->gram_launches, h->gram_flops, h->admm_iters_timed, h->gram_form};
+    for (int i = 0; i < n_out && i < 9; ++i) out[i] = v[i];
     return LPVS_OK;
 }
 

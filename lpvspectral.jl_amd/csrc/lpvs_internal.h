@@ -184,6 +184,8 @@ int32_t launch_admm_batch_init(const AdmmBatch &p, hipStream_t s);
 int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s);
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s);              // z=x, u=0, rhs, status=0
 int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s);
+// the mat-vec kernel alone, `reps` times (x is recomputed from the current rhs; nothing else changes)
+int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s);
 int32_t launch_rect_matvec(const double *A, int64_t rows, int64_t cols, int64_t ld, const double *v, double *out, hipStream_t s);
 int32_t launch_fourier_dual_panel(const double *t, int64_t N, const double *f, int64_t Nf, int zerofreq, double *D, int64_t ldn,
                                   int64_t nrows, hipStream_t s);
