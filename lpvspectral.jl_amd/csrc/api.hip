@@ -218,6 +218,7 @@ struct lpvs_problem {
     // timing (ms) -- see lpvs_problem_get_timing
     double t_basis = 0, t_gram = 0, t_reduce = 0, t_factor = 0, t_admm = 0, gram_launches = 0, gram_flops = 0, admm_iters_timed = 0, gram_form = 0;
     EventPair ev[4];
+    SweepAux sweep_aux;   // side stream + events of the factorisation's look-ahead
     // launch-bound regime (small n): a chunk of ADMM iterations captured once into a hipGraph and replayed
     hipGraphExec_t admm_graph = nullptr;
     int64_t admm_graph_iters = 0;
@@ -286,7 +287,7 @@ int32_t factorize(lpvs_problem *h, double shift) {
     LPVS_HIP(hipEventRecord(h->ev[3].a, h->stream));
     LPVS_HIP(hipMemcpyAsync(h->M.p, h->G.p, sizeof(double) * (size_t)np * (size_t)np, hipMemcpyDeviceToDevice, h->stream));
     LPVS_TRY(launch_add_diag(h->M.as<double>(), np, n, shift, h->stream));
-    LPVS_TRY(spd_inverse_inplace(h->M.as<double>(), np, h->work.as<double>(), h->istat.as<int>(), h->stream));
+    LPVS_TRY(spd_inverse_inplace(h->M.as<double>(), np, h->work.as<double>(), h->istat.as<int>(), h->stream, &h->sweep_aux));
     LPVS_HIP(hipEventRecord(h->ev[3].b, h->stream));
     int st = 0;
     LPVS_HIP(hipMemcpyAsync(&st, h->istat.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));

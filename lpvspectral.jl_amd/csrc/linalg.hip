@@ -10,6 +10,12 @@
 // negates and mirrors it, so the result is exactly symmetric.
 #include "lpvs_internal.h"
 
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace lpvs {
 
 namespace {
@@ -188,6 +194,301 @@ sweep_update_kernel(double *__restrict__ Aall, int64_t np, int k, const double *
             }
 }
 
+
+// ---- two-level sweep (one large matrix) ---------------------------------------------------------------------
+// The 64-wide sweep above streams the whole lower triangle once per 64 pivots (128 read-modify-write passes over
+// 268 MB at np = 8192: HBM-bound, ~17 TFLOP/s).  For large matrices the same sweep is applied with 256-wide pivot
+// blocks: the pivot block is inverted by the 64-wide sweep (recursion), the panel C = B P is one small MFMA GEMM,
+// and the trailing update A -= C B' has depth 256 (4x fewer passes over A, MFMA-bound, LDS-DMA staged like gram.hip).
+constexpr int KW = 256;                      // outer pivot width
+constexpr int RU_TM = 128, RU_TN = 256;      // trailing-update tile: rows x cols
+constexpr int RU_BK = 16;                    // pivots per LDS stage
+constexpr int RU_THREADS = 512;              // 8 waves: 2 (rows) x 4 (cols), 64x64 outputs each
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// P[r][c] = A[k0+r][k0+c] (only the lower triangle is meaningful, which is all the 64-wide sweep reads)
+__global__ void __launch_bounds__(256)
+pivot_extract_kernel(const double *__restrict__ A, int64_t np, int64_t k0, int kw, double *__restrict__ P) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < kw; c += 256) P[(int64_t)r * kw + c] = A[(k0 + r) * np + k0 + c];
+}
+
+
+// P = inv(A_kk) for a W x W pivot block (W = 256 or 128) in ONE workgroup: the symmetric sweep operator applied W
+// times to the lower triangle held in registers.  The block is cut into 8x8 sub-blocks; thread t owns sub-block
+// (ti, tj), ti >= tj, of the lower triangle (G(G+1)/2 threads, G = W/8).  Per pivot p the symmetric column
+// w[i] = A[i][p] is published through LDS by the owners of block column / block row p/8 (two barriers), then
+//     A[i][j] -= w[i] w[j] / d   (i, j != p),   A[i][p] = w[i] / d,   A[p][p] = -1/d.
+// After W sweeps the registers hold -inv(A_kk); it is negated and mirrored on the way out.  status |= 1 on a
+// non-positive pivot (the remaining Schur complement of an SPD matrix stays positive definite).
+template <int W>
+__global__ void __launch_bounds__(((W / 8) * (W / 8 + 1) / 2 + 63) / 64 * 64)
+pivot_inverse_kernel(const double *__restrict__ A, int64_t np, int64_t k0, double *__restrict__ P, int *status) {
+    constexpr int G = W / 8, NBLK = G * (G + 1) / 2;
+    __shared__ double w[W];
+    const int t = threadIdx.x;
+    const bool live = t < NBLK;
+    int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    int tj = t - ti * (ti + 1) / 2;
+    if (!live) { ti = G - 1; tj = 0; }        // idle lanes of the last wave: harmless duplicates that never publish or store
+    const double *blk = A + (k0 + 8 * ti) * np + k0 + 8 * tj;
+    double v[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v[a][b] = blk[(int64_t)a * np + b];
+    if (ti == tj) {   // diagonal sub-blocks: only the lower triangle of A is current
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = a + 1; b < 8; ++b) v[a][b] = v[b][a];
+    }
+    for (int pb = 0; pb < G; ++pb) {
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int p = 8 * pb + pp;
+            if (live && tj == pb) {            // block column pb: rows 8ti .. 8ti+7 of column p
+#pragma unroll
+                for (int a = 0; a < 8; ++a) w[8 * ti + a] = v[a][pp];
+            } else if (live && ti == pb) {     // block row pb (tj < pb): columns 8tj .. 8tj+7 of row p
+#pragma unroll
+                for (int b = 0; b < 8; ++b) w[8 * tj + b] = v[pp][b];
+            }
+            __syncthreads();
+            const double d = w[p];
+            if (t == 0 && !(d > 0)) atomicOr(status, 1);
+            const double inv = 1.0 / d;
+            double rj[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) rj[b] = w[8 * tj + b] * inv;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const double wi = w[8 * ti + a];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) v[a][b] = fma(-wi, rj[b], v[a][b]);
+            }
+            if (ti == pb) {                    // row p of the block
+#pragma unroll
+                for (int b = 0; b < 8; ++b) v[pp][b] = rj[b];
+            }
+            if (tj == pb) {                    // column p of the block
+#pragma unroll
+                for (int a = 0; a < 8; ++a) v[a][pp] = w[8 * ti + a] * inv;
+            }
+            if (ti == pb && tj == pb) v[pp][pp] = -inv;
+            __syncthreads();
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int i = 8 * ti + a, j = 8 * tj + b;
+            if (j > i) continue;
+            const double o = -v[a][b];
+            P[(int64_t)i * W + j] = o;
+            P[(int64_t)j * W + i] = o;
+        }
+}
+
+// k-major panel Bk[c][R] = B[R][c]: B = A[:, pivot columns] read from the lower triangle, pivot rows and pad columns zero
+__global__ void __launch_bounds__(256)
+panel_gather_kernel(const double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, int kw, double *__restrict__ Bk) {
+    __shared__ double tile[64][65];
+    const int64_t R0 = (int64_t)blockIdx.x * 64;
+    if (R0 >= np || (R0 >= k0 && R0 < k0 + kw)) {
+        for (int e = threadIdx.x; e < kw * 64; e += 256) Bk[(int64_t)(e >> 6) * ldp + R0 + (e & 63)] = 0.0;
+        return;
+    }
+    if (R0 < k0) {   // B[R][c] = A[k0+c][R]: rows of A are rows of the panel
+        for (int e = threadIdx.x; e < kw * 64; e += 256) {
+            const int c = e >> 6, r = e & 63;
+            Bk[(int64_t)c * ldp + R0 + r] = A[(k0 + c) * np + R0 + r];
+        }
+        return;
+    }
+    for (int c0 = 0; c0 < kw; c0 += 64) {   // B[R][c] = A[R][k0+c]: transpose through LDS
+        for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            tile[r][c] = A[(R0 + r) * np + k0 + c0 + c];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+            const int c = e >> 6, r = e & 63;
+            Bk[(int64_t)(c0 + c) * ldp + R0 + r] = tile[r][c];
+        }
+        __syncthreads();
+    }
+}
+
+// C' = P Bk (k-major, P symmetric): the panel gets Ck = -C', A gets A[:,k] = C (lower-triangle positions) and
+// A_kk = -P.  A wave owns 64 pivot columns x 32 matrix rows.
+__global__ void __launch_bounds__(256)
+panel_gemm_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, int kw, const double *__restrict__ P,
+                  const double *__restrict__ Bk, double *__restrict__ Ck) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = kw / 64;                 // 64-wide pivot-column blocks: 4 or 2
+    const int rsub = wave / cb, cblk = wave - rsub * cb;
+    const int64_t R0 = ((int64_t)blockIdx.x * (4 / cb) + rsub) * 32;
+    if (R0 >= ldp) return;
+    const int li = lane & 15, lk = lane >> 4;
+    f64x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const double *pa = P + (int64_t)lk * kw + cblk * 64 + li;      // P[c][q] = P[q][c]
+    const double *pb = Bk + (int64_t)lk * ldp + R0 + li;
+    double nA[4], nB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nA[i] = pa[16 * i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) nB[j] = pb[16 * j];
+    const int nk = kw / 4;
+    for (int kk = 0; kk < nk; ++kk) {
+        double opA[4], opB[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) opA[i] = nA[i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) opB[j] = nB[j];
+        if (kk + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nA[i] = pa[(int64_t)(4 * (kk + 1)) * kw + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) nB[j] = pb[(int64_t)(4 * (kk + 1)) * ldp + 16 * j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = cblk * 64 + 16 * i + lk + 4 * r;
+                const int64_t R = R0 + 16 * j + li;
+                const double v = acc[i][j][r];
+                Ck[(int64_t)c * ldp + R] = -v;   // the trailing update accumulates A + (-C) B' on top of A
+                if (R < np) {
+                    if (R < k0) A[(k0 + c) * np + R] = v;
+                    else if (R >= k0 + kw) A[R * np + k0 + c] = v;
+                    else A[R * np + k0 + c] = -P[(R - k0) * kw + c];
+                }
+            }
+}
+
+// A[Ri][Rj] += sum_c Ck[c][Ri] Bk[c][Rj] (Ck = -C') on the lower triangle, skipping pivot rows / columns.  The
+// accumulators start from the tile of A itself (its loads fly while the first stage lands), so the epilogue is
+// stores only and the read-modify-write latency is not exposed.
+// which = 0: every tile; 1: only tiles inside the next pivot band [n0, n0+nw); 2: every tile outside it.
+__global__ void __launch_bounds__(RU_THREADS, 2)
+rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, int kw, const double *__restrict__ Ck,
+                   const double *__restrict__ Bk, const int2 *__restrict__ tiles, int ntiles, int which, int64_t n0, int nw) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 2, wb = wave & 3;
+    // XCD-aware: the 8 XCDs are dealt consecutive blocks round-robin; give each a contiguous run of the tile list
+    const int bq = ntiles / 8, br = ntiles % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;
+    const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
+    const int2 tt = tiles[item];
+    const int64_t a0 = (int64_t)tt.x * RU_TM, b0 = (int64_t)tt.y * RU_TN;
+    auto in_band = [&](int64_t lo, int64_t start, int64_t width) { return lo >= start && lo < start + width; };
+    auto dead = [&](int wa_, int wb_) {     // the wave's 64x64 block has nothing to update
+        const int64_t r = a0 + wa_ * 64, c = b0 + wb_ * 64;
+        if (c > r + 63 || c >= np) return true;
+        if (in_band(r, k0, kw) || in_band(c, k0, kw)) return true;
+        if (which != 0) {
+            const bool next = in_band(r, n0, nw) || in_band(c, n0, nw);
+            if ((which == 1) != next) return true;
+        }
+        return false;
+    };
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) any = any || !dead(q >> 2, q & 3);
+    if (!any) return;
+    const bool skip_wave = dead(wa, wb);
+
+    constexpr int ROW = RU_TM + RU_TN, STAGE = RU_BK * ROW;
+    double *buf0 = lds, *buf1 = lds + STAGE;
+    auto stage_load = [&](double *buf, int s0) {
+        for (int p = wave; p < RU_BK * 3; p += RU_THREADS / 64) {   // piece = (pivot, part): 128 panel values
+            const int k = p / 3, part = p - k * 3;
+            const double *src = part == 0 ? Ck + (int64_t)(s0 + k) * ldp + a0 : Bk + (int64_t)(s0 + k) * ldp + b0 + (part - 1) * 128;
+            glds16(src + 2 * lane, buf + p * 128);
+        }
+    };
+    const int li = lane & 15, lk = lane >> 4;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { offA[t] = wa * 64 + t * 16 + li; offB[t] = RU_TM + wb * 64 + t * 16 + li; }
+    const int nstages = kw / RU_BK;
+    stage_load(buf0, 0);
+    const int64_t r_lo = a0 + wa * 64, c_lo = b0 + wb * 64;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r_lo + i * 16 + lk + 4 * r, col = c_lo + j * 16 + li;
+                acc[i][j][r] = (!skip_wave && col <= row) ? A[row * np + col] : 0.0;
+            }
+    __syncthreads();
+    double rA[4], rB[4];
+    auto fetch = [&](const double *img, int kk) {
+        const double *row = img + (kk * 4 + lk) * ROW;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { rA[t] = row[offA[t]]; rB[t] = row[offB[t]]; }
+    };
+    for (int s = 0; s < nstages; ++s) {
+        double *cur = (s & 1) ? buf1 : buf0, *nxt = (s & 1) ? buf0 : buf1;
+        if (s + 1 < nstages) stage_load(nxt, (s + 1) * RU_BK);
+        if (!skip_wave) {
+            fetch(cur, 0);
+#pragma unroll
+            for (int kk = 0; kk < RU_BK / 4; ++kk) {
+                double opA[4], opB[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { opA[t] = rA[t]; opB[t] = rB[t]; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < RU_BK / 4) fetch(cur, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    if (skip_wave) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r_lo + i * 16 + lk + 4 * r, col = c_lo + j * 16 + li;
+                if (col <= row) A[row * np + col] = acc[i][j][r];
+            }
+}
+
 // diag(M) += shift on the valid part; the pad block becomes the identity
 __global__ void __launch_bounds__(256) add_diag_kernel(double *__restrict__ Mall, int64_t np, int64_t n, double shift) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -248,30 +549,161 @@ symm_matmul_kernel(const double *__restrict__ A, const double *__restrict__ B, d
 
 }  // namespace
 
-size_t spd_inverse_work_bytes(int64_t np) { return sizeof(double) * (size_t)(2 * np * NB + NB * NB); }
+constexpr int64_t kTwoLevelMinNp = 1024;
 
-// nbatch independent matrices A + q*np*np; work holds nbatch * spd_inverse_work_bytes(np); status_dev nbatch ints
-int32_t spd_inverse_inplace_batch(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s) {
-    if (np % 128 != 0) { set_error("spd_inverse: np=%lld not a multiple of 128", (long long)np); return LPVS_ESTATE; }
-    const int64_t strideW = (int64_t)(2 * np * NB + NB * NB), strideA = np * np;
+static size_t sweep64_work_doubles(int64_t np) { return (size_t)(2 * np * NB + NB * NB); }
+static size_t ru_tile_capacity(int64_t np) { const int64_t nr = np / RU_TM, nc = ceil_div(np, RU_TN); return (size_t)(nr * nc); }
+
+size_t spd_inverse_work_bytes(int64_t np) {
+    size_t d = sweep64_work_doubles(np);
+    if (np >= kTwoLevelMinNp) {
+        const int64_t ldp = round_up(np, RU_TN);
+        const size_t two = (size_t)(4 * KW * ldp + KW * KW) + sweep64_work_doubles(KW) + ru_tile_capacity(np);   // int2 = one double
+        if (two > d) d = two;
+    }
+    return sizeof(double) * d;
+}
+
+// the 64-wide sweep: A <- -A^-1 on the lower triangle (status is not cleared here)
+static void sweep64(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s) {
+    const int64_t strideW = (int64_t)sweep64_work_doubles(np), strideA = np * np;
     double *Bp = work, *Cp = work + np * NB, *P = work + 2 * np * NB;
     const int nblk = (int)(np / NB);
     const int nt = (int)(np / 128);
     const unsigned ntiles = (unsigned)(nt * (nt + 1) / 2);
-    LPVS_HIP(hipMemsetAsync(status_dev, 0, sizeof(int) * (size_t)nbatch, s));
     for (int k = 0; k < nblk; ++k) {
         hipLaunchKernelGGL(diag_inverse_kernel, dim3((unsigned)nbatch), dim3(256), 0, s, A, np, k, P, status_dev, strideA, strideW);
         hipLaunchKernelGGL(panel_kernel, dim3((unsigned)nblk, (unsigned)nbatch), dim3(256), 0, s, A, np, k, P, Bp, Cp, strideA, strideW);
         hipLaunchKernelGGL(sweep_update_kernel, dim3(ntiles, (unsigned)nbatch), dim3(256), 0, s, A, np, k, Bp, Cp, strideA, strideW);
     }
-    LPVS_HIP(hipGetLastError());
+}
+
+// lower-triangle tiles of the trailing update, in bands of four tile rows, column-major inside a band: consecutive
+// tiles (which the XCD-aware launch order keeps on one L2) share their B columns and a 512-row slice of C
+static const std::vector<int2> &ru_tiles(int64_t np) {
+    static std::mutex mu;
+    static std::map<int64_t, std::vector<int2>> cache;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(np);
+    if (it != cache.end()) return it->second;
+    std::vector<int2> t;
+    const int nr = (int)(np / RU_TM), nc = (int)ceil_div(np, RU_TN);
+    for (int band = 0; band < nr; band += 4)
+        for (int tj = 0; tj < nc; ++tj)
+            for (int ti = band; ti < band + 4 && ti < nr; ++ti)
+                if ((int64_t)tj * RU_TN <= (int64_t)ti * RU_TM + RU_TM - 1) t.push_back(make_int2(ti, tj));
+    return cache.emplace(np, std::move(t)).first->second;
+}
+
+int32_t SweepAux::ensure() {
+    if (side) return LPVS_OK;
+    int lo = 0, hi = 0;   // numerically lower = higher priority
+    LPVS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    LPVS_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
+    LPVS_HIP(hipEventCreateWithFlags(&panel, hipEventDisableTiming));
+    LPVS_HIP(hipEventCreateWithFlags(&rest, hipEventDisableTiming));
+    return LPVS_OK;
+}
+SweepAux::~SweepAux() {
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (panel) (void)hipEventDestroy(panel);
+    if (rest) (void)hipEventDestroy(rest);
+}
+
+// Step k of the outer sweep:  chain_k = { P = inv(A_kk); Bk = A[:,k]; Ck = -(Bk' P)'; A[:,k] = C; A_kk = -P },
+// then the trailing update U_k.  With look-ahead U_k is split: the tiles that intersect the NEXT pivot band run first
+// on the side stream, followed by chain_{k+1} (into the other panel buffer), while the rest of U_k runs on the main
+// stream; U_{k+1} starts when both are done.  The pivot chain (latency-bound, one workgroup) thus hides under the
+// MFMA-bound bulk update.
+static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *status_dev, hipStream_t s, SweepAux *aux) {
+    const int64_t ldp = round_up(np, RU_TN);
+    double *panelbuf[2] = {work, work + 2 * KW * ldp};   // {Bk, Ck} x 2
+    double *P = work + 4 * KW * ldp, *inner = P + KW * KW;
+    int2 *tiles = reinterpret_cast<int2 *>(inner + sweep64_work_doubles(KW));
+    const std::vector<int2> &ht = ru_tiles(np);   // persistent host copy: the async upload may outlive this call
+    LPVS_HIP(hipMemcpyAsync(tiles, ht.data(), sizeof(int2) * ht.size(), hipMemcpyHostToDevice, s));
+    const size_t lds = sizeof(double) * 2 * RU_BK * (RU_TM + RU_TN);
+    static const bool single_wg_pivot = [] { const char *e = getenv("LPVS_PIVOT"); return !(e && std::string(e) == "sweep64"); }();
+    static const bool lookahead_on = [] { const char *e = getenv("LPVS_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rank_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const int kw_outer = [] { const char *e = getenv("LPVS_KW"); return (e && atoi(e) == 256) ? 256 : 128; }();
+    const bool la = lookahead_on && aux != nullptr && np > kw_outer;
+    if (la) LPVS_TRY(aux->ensure());
+
+    auto width = [&](int64_t k0) { return (int)(np - k0 < kw_outer ? np - k0 : kw_outer); };   // with 256: 128 for a ragged last block
+    auto chain = [&](int64_t k0, double *Bk, double *Ck, hipStream_t st) {
+        const int kw = width(k0);
+        if (single_wg_pivot && kw == 128) {
+            hipLaunchKernelGGL(pivot_inverse_kernel<128>, dim3(1), dim3(192), 0, st, A, np, k0, P, status_dev);
+        } else {
+            hipLaunchKernelGGL(pivot_extract_kernel, dim3((unsigned)kw), dim3(256), 0, st, A, np, k0, kw, P);
+            sweep64(P, kw, 1, inner, status_dev, st);
+            hipLaunchKernelGGL(negate_mirror_kernel, dim3((unsigned)(kw / 32), (unsigned)(kw / 32), 1u), dim3(256), 0, st, P, (int64_t)kw);
+        }
+        hipLaunchKernelGGL(panel_gather_kernel, dim3((unsigned)(ldp / 64)), dim3(256), 0, st, A, np, ldp, k0, kw, Bk);
+        hipLaunchKernelGGL(panel_gemm_kernel, dim3((unsigned)(ldp / (32 * (4 / (kw / 64))))), dim3(256), 0, st, A, np, ldp, k0, kw, P, Bk, Ck);
+    };
+    auto update = [&](int64_t k0, const double *Bk, const double *Ck, int which, hipStream_t st) {
+        const int kw = width(k0);
+        const int64_t n0 = k0 + kw;
+        hipLaunchKernelGGL(rank_update_kernel, dim3((unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, k0, kw, Ck, Bk, tiles,
+                           (int)ht.size(), which, n0, n0 < np ? width(n0) : 0);
+    };
+
+    if (!la) {
+        for (int64_t k0 = 0; k0 < np; k0 += kw_outer) {
+            chain(k0, panelbuf[0], panelbuf[0] + KW * ldp, s);
+            update(k0, panelbuf[0], panelbuf[0] + KW * ldp, 0, s);
+            LPVS_HIP(hipGetLastError());
+        }
+        return LPVS_OK;
+    }
+    hipStream_t side = aux->side;
+    LPVS_HIP(hipEventRecord(aux->rest, s));                 // A is ready on the main stream
+    LPVS_HIP(hipStreamWaitEvent(side, aux->rest, 0));
+    chain(0, panelbuf[0], panelbuf[0] + KW * ldp, side);
+    LPVS_HIP(hipEventRecord(aux->panel, side));
+    int cur = 0;
+    for (int64_t k0 = 0; k0 < np; k0 += kw_outer, cur ^= 1) {
+        double *Bk = panelbuf[cur], *Ck = Bk + KW * ldp;
+        const int64_t n0 = k0 + width(k0);
+        const bool next = n0 < np;
+        LPVS_HIP(hipStreamWaitEvent(s, aux->panel, 0));     // panel k (captured before the side stream re-records the event)
+        if (next) {
+            LPVS_HIP(hipStreamWaitEvent(side, aux->rest, 0));   // bulk of U_{k-1}
+            update(k0, Bk, Ck, 1, side);
+            chain(n0, panelbuf[cur ^ 1], panelbuf[cur ^ 1] + KW * ldp, side);
+            LPVS_HIP(hipEventRecord(aux->panel, side));
+        }
+        update(k0, Bk, Ck, next ? 2 : 0, s);
+        LPVS_HIP(hipEventRecord(aux->rest, s));
+        LPVS_HIP(hipGetLastError());
+    }
+    return LPVS_OK;
+}
+
+// nbatch independent matrices A + q*np*np; work holds nbatch * spd_inverse_work_bytes(np); status_dev nbatch ints
+static int32_t spd_inverse_impl(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s, SweepAux *aux) {
+    if (np % 128 != 0) { set_error("spd_inverse: np=%lld not a multiple of 128", (long long)np); return LPVS_ESTATE; }
+    LPVS_HIP(hipMemsetAsync(status_dev, 0, sizeof(int) * (size_t)nbatch, s));
+    static const bool two_level_on = [] { const char *e = getenv("LPVS_FACTOR"); return !(e && std::string(e) == "sweep64"); }();
+    if (nbatch == 1 && np >= kTwoLevelMinNp && two_level_on) {
+        LPVS_TRY(spd_inverse_two_level(A, np, work, status_dev, s, aux));
+    } else {
+        sweep64(A, np, nbatch, work, status_dev, s);
+        LPVS_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(negate_mirror_kernel, dim3((unsigned)(np / 32), (unsigned)(np / 32), (unsigned)nbatch), dim3(256), 0, s, A, np);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
 
-int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s) {
-    return spd_inverse_inplace_batch(A, np, 1, work, status_dev, s);
+int32_t spd_inverse_inplace_batch(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s) {
+    return spd_inverse_impl(A, np, nbatch, work, status_dev, s, nullptr);
+}
+
+int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s, SweepAux *aux) {
+    return spd_inverse_impl(A, np, 1, work, status_dev, s, aux);
 }
 
 int32_t launch_add_diag_batch(double *M, int64_t np, int64_t n, double shift, int nbatch, hipStream_t s) {

@@ -129,8 +129,16 @@ int32_t launch_ap_rhs(const double *tab, int64_t Nf, int64_t nb, double *b, hipS
 // ---- dense symmetric inverse (linalg.hip) ------------------------------------------------
 // In-place inverse of the SPD matrix A (np x np, np % 64 == 0, full symmetric storage) by
 // blocked symmetric sweeps; work holds 2 panels of np x 64 + one 64 x 64 block.
+// Optional helper objects of the two-level sweep's look-ahead: the next pivot panel is prepared on a second
+// (high-priority) stream while the bulk of the current trailing update runs on the caller's stream.
+struct SweepAux {
+    hipStream_t side = nullptr;
+    hipEvent_t panel = nullptr, rest = nullptr;
+    int32_t ensure();
+    ~SweepAux();
+};
 size_t spd_inverse_work_bytes(int64_t np);
-int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s);
+int32_t spd_inverse_inplace(double *A, int64_t np, double *work, int *status_dev, hipStream_t s, SweepAux *aux = nullptr);
 int32_t launch_add_diag(double *M, int64_t np, int64_t n, double shift, hipStream_t s);
 int32_t launch_add_diag_batch(double *M, int64_t np, int64_t n, double shift, int nbatch, hipStream_t s);
 int32_t spd_inverse_inplace_batch(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s);

@@ -28,7 +28,7 @@ for rep in range(2):
     tm = p.timing()
     n = p.n
     print(f"rep{rep} N=2^{lg} n={n}: create {t1-t0:.3f}s init(factor) {t2-t1:.3f}s admm({it}) {t3-t2:.3f}s nxz={nxz:.3e}")
-    print("   ", {k: round(v, 3) for k, v in tm.items()})
+    print("   ", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tm.items()})
     print(f"    gram {tm['gram_flops']/tm['gram_ms']*1e-9:.2f} TFLOP/s algorithmic ({tm['gram_issued_flops']/tm['gram_ms']*1e-9:.2f} issued); admm {tm['admm_ms']/max(tm['admm_iters'],1)*1e3:.1f} us/iter "
           f"({n*n*8/ (tm['admm_ms']/max(tm['admm_iters'],1)*1e-3)*1e-12:.2f} TB/s of M)")
     p.close()
