@@ -582,6 +582,31 @@ __device__ __forceinline__ double gather_x(const double *__restrict__ part1, con
     return half == 0 ? s + sh[i] : 0.0;
 }
 
+// 512-thread variant: the nblk contributions of a row block (part1 entries for J <= I, part2 entries for K > I) form
+// one list; four groups of 128 lanes each sum a contiguous quarter (16 independent loads in flight at nblk = 64:
+// one memory latency), then a fixed-order combine through LDS.
+__device__ __forceinline__ double gather_x4(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, int I,
+                                            double *sh /*[3*128]*/) {
+    const int i = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const int per = (nblk + 3) / 4, e0 = g * per, e1 = e0 + per < nblk ? e0 + per : nblk;
+    auto at = [&](int e) -> const double * {
+        return e <= I ? part1 + ((int64_t)I * (I + 1) / 2 + e) * TS + i : part2 + ((int64_t)e * (e + 1) / 2 + I) * TS + i;
+    };
+    double s = 0;
+    int e = e0;
+    for (; e + 16 <= e1; e += 16) {
+        double a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = *at(e + q);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += a[q];
+    }
+    for (; e < e1; ++e) s += *at(e);
+    if (g > 0) sh[(g - 1) * TS + i] = s;
+    __syncthreads();
+    return g == 0 ? ((s + sh[i]) + sh[TS + i]) + sh[2 * TS + i] : 0.0;
+}
+
 __global__ void __launch_bounds__(256)
 symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, int ntiles, int64_t np,
                    double *__restrict__ x, const AdmmStatus *status) {
@@ -595,22 +620,22 @@ symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ 
 // ---- fused: gather x from the tile partials + prox_g + dual update + next rhs, one workgroup per
 // 128-row block; ||x-z||^2 is combined by the last-arriving workgroup in fixed block order (deterministic).
 // Valid for element-wise prox (L1, L0) and for group prox with 128 % group_len == 0, n % group_len == 0.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk,
                          int ntiles, double *__restrict__ blocknorm_all, unsigned int *__restrict__ ticket_all) {
     const int sg = blockIdx.y;
     AdmmStatus *status = p.status + sg;
     if (status->converged) return;
-    __shared__ double sh[TS], sq[TS], gs[TS];
+    __shared__ double sh[3 * TS], sq[TS], gs[TS];
     __shared__ int last;
     const double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
     double *blocknorm = blocknorm_all + (int64_t)sg * nblk;
     unsigned int *ticket = ticket_all + sg;
     const int I = blockIdx.x, i = threadIdx.x & 127;
     const int64_t li_ = (int64_t)I * TS + i, gi = (int64_t)sg * p.np + li_;
-    const double xs = gather_x(part1, part2, nblk, I, sh);
     const bool row = threadIdx.x < TS, ok = row && li_ < p.n;
-    const double xi = xs, ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;
+    const double ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;   // in flight together with the partials
+    const double xi = gather_x4(part1, part2, nblk, I, sh);
     const double v = xi + ui;
     double zi = 0.0, d2 = 0.0;
     if (p.prox_kind == LPVS_PROX_L1) {
@@ -655,13 +680,15 @@ admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1_all, con
     if (last) {  // every other workgroup has published its block norm
         if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
-        double part = 0;  // thread q sums blocks q, q+256, ... ; then a fixed-order combine
-        for (int q = threadIdx.x; q < nblk; q += 256) part += __hip_atomic_load(&blocknorm[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double w = wave_sum(part);
-        if ((threadIdx.x & 63) == 0) sq[threadIdx.x >> 6] = w;
+        if (threadIdx.x < 64) {   // lane q sums blocks q, q+64, ...; then the wave's fixed shuffle pattern
+            double part = 0;
+            for (int q = threadIdx.x; q < nblk; q += 64) part += __hip_atomic_load(&blocknorm[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double w = wave_sum(part);
+            if (threadIdx.x == 0) sq[0] = w;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const double nxz = sqrt(((sq[0] + sq[1]) + sq[2]) + sq[3]);   // norm(tmp)   src/lasso.jl:157
+            const double nxz = sqrt(sq[0]);                               // norm(tmp)   src/lasso.jl:157
             status->iters += 1;
             status->nxz = nxz;
             if (nxz < p.tol) status->converged = 1;                       //             src/lasso.jl:164
@@ -789,7 +816,7 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
         for (int64_t i = 0; i < iters; ++i) {
             hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
                                (int)ntiles, part1, part2, p.status);
-            hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, q, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
+            hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, q, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
         }
     } else {
         for (int64_t i = 0; i < iters; ++i) {
@@ -838,7 +865,7 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s) {
     unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
     hipLaunchKernelGGL(symv_tile_kernel, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     if (fused_ok(p)) {
-        hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
+        hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
     } else {
         hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status);
         hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
