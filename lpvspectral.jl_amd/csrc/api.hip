@@ -473,7 +473,9 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     const char *form_env = getenv("LPVS_GRAM_FORM");
     const std::string form = form_env ? form_env : "auto";
     bool use_ap = false;
-    std::vector<double> hw, heps, om_hi, om_lo;
+    std::vector<double> hw, heps, om_hi, om_lo, omr_hi, omr_lo;
+    ApStep step{};
+    int64_t nf8 = 0;
     if (form == "auto" || form == "ap") {
         LPVS_TRY(fetch_host(hw, w, Nf));
         double xlo, xhi, xam;
@@ -488,19 +490,22 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         use_ap = std::isfinite(emax) && emax * xam <= 1e-7;
         if (form == "ap" && !use_ap) { set_error("LPVS_GRAM_FORM=ap but w is not an arithmetic progression (max|eps|*max|x| = %.3g)", emax * xam); return LPVS_EARGUMENT; }
         if (use_ap) {
-            const int64_t nsl = 3 * Nf - 1;
-            om_hi.resize((size_t)nsl); om_lo.resize((size_t)nsl);
-            for (int64_t m = 0; m < Nf; ++m) { const long double v = (long double)m * D; om_hi[m] = (double)v; om_lo[m] = (double)(v - (long double)om_hi[m]); }
-            for (int64_t q = 0; q < 2 * Nf - 1; ++q) {
-                const long double v = 2.0L * a0 + (long double)q * D;
-                om_hi[Nf + q] = (double)v; om_lo[Nf + q] = (double)(v - (long double)om_hi[Nf + q]);
-            }
+            // slot tables, exact progressions in double-double, each family padded to a multiple of 8:
+            //   [0, Nf8): m*D (differences), [Nf8, Nf8+S8): 2a + s*D (sums); the rhs uses a + f*D, f < Nf8
+            nf8 = round_up(Nf, 8);
+            const int64_t s8 = round_up(2 * Nf - 1, 8), nsl = nf8 + s8;
+            auto split = [](long double v, double &hi, double &lo) { hi = (double)v; lo = (double)(v - (long double)hi); };
+            om_hi.resize((size_t)nsl); om_lo.resize((size_t)nsl); omr_hi.resize((size_t)nf8); omr_lo.resize((size_t)nf8);
+            for (int64_t m = 0; m < nf8; ++m) split((long double)m * D, om_hi[m], om_lo[m]);
+            for (int64_t q = 0; q < s8; ++q) split(2.0L * a0 + (long double)q * D, om_hi[nf8 + q], om_lo[nf8 + q]);
+            for (int64_t f = 0; f < nf8; ++f) split(a0 + (long double)f * D, omr_hi[f], omr_lo[f]);
+            for (int b = 0; b < 8; ++b) split((long double)b * D, step.hi[b], step.lo[b]);
         }
     }
     if (use_ap) {
-        const int64_t nsl = 3 * Nf - 1, P = nb * (nb + 1) / 2;
+        const int64_t s8 = round_up(2 * Nf - 1, 8), nsl = nf8 + s8, P = nb * (nb + 1) / 2;
         double lo, hi, am, gamma; std::vector<double> vc;
-        DevBuf K, KK, dvc, dhi, dlo, deps, part, tab, tabb;
+        DevBuf K, KK, dvc, dhi, dlo, drhi, drlo, deps, part, tab, tabb;
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
         LPVS_TRY(device_minmax(dV.p, N, &lo, &hi, &am, s));
         basis_centers(lo, hi, am, Nv, coulomb, vc, &gamma);
@@ -511,22 +516,26 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         LPVS_TRY(KK.alloc(sizeof(double) * (size_t)N * (size_t)P));
         LPVS_TRY(launch_basis_table(dV.p, N, dvc.as<double>(), nb, gamma, normalize, coulomb, K.as<double>(), ldk, s));
         LPVS_TRY(launch_pair_table(K.as<double>(), ldk, nb, N, KK.as<double>(), s));
-        LPVS_TRY(dhi.alloc(sizeof(double) * (size_t)nsl)); LPVS_TRY(dlo.alloc(sizeof(double) * (size_t)nsl)); LPVS_TRY(deps.alloc(sizeof(double) * (size_t)Nf));
+        LPVS_TRY(dhi.alloc(sizeof(double) * (size_t)nsl)); LPVS_TRY(dlo.alloc(sizeof(double) * (size_t)nsl));
+        LPVS_TRY(drhi.alloc(sizeof(double) * (size_t)nf8)); LPVS_TRY(drlo.alloc(sizeof(double) * (size_t)nf8));
+        LPVS_TRY(deps.alloc(sizeof(double) * (size_t)Nf));
         LPVS_TRY(copy_to_device(dhi.p, om_hi.data(), sizeof(double) * (size_t)nsl, s));
         LPVS_TRY(copy_to_device(dlo.p, om_lo.data(), sizeof(double) * (size_t)nsl, s));
+        LPVS_TRY(copy_to_device(drhi.p, omr_hi.data(), sizeof(double) * (size_t)nf8, s));
+        LPVS_TRY(copy_to_device(drlo.p, omr_lo.data(), sizeof(double) * (size_t)nf8, s));
         LPVS_TRY(copy_to_device(deps.p, heps.data(), sizeof(double) * (size_t)Nf, s));
         LPVS_HIP(hipEventRecord(h->ev[0].b, s));
-        LPVS_TRY(part.alloc(nudft_partial_bytes(N, nsl, P, 4)));
+        LPVS_TRY(part.alloc(std::max(nudft_partial_bytes(N, nsl, P), nudft_partial_bytes(N, nf8, nb))));
         LPVS_TRY(tab.alloc(sizeof(double) * (size_t)nsl * (size_t)P * 4));
-        LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)Nf * (size_t)nb * 2));
+        LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)nf8 * (size_t)nb * 4));
         LPVS_HIP(hipEventRecord(h->ev[1].a, s));
-        LPVS_TRY(launch_nudft(dX.p, nullptr, N, KK.as<double>(), P, (int)P, dhi.as<double>(), dlo.as<double>(), (int)nsl, 4, part.as<double>(), tab.as<double>(), s));
-        LPVS_TRY(launch_ap_assemble(tab.as<double>(), deps.as<double>(), Nf, nb, h->n, h->G.as<double>(), h->np, s));
+        LPVS_TRY(launch_nudft(dX.p, nullptr, N, KK.as<double>(), P, (int)P, dhi.as<double>(), dlo.as<double>(), (int)nsl, step, part.as<double>(), tab.as<double>(), s));
+        LPVS_TRY(launch_ap_assemble(tab.as<double>(), deps.as<double>(), Nf, nf8, nb, h->n, h->G.as<double>(), h->np, s));
         LPVS_HIP(hipEventRecord(h->ev[1].b, s));
         LPVS_HIP(hipEventRecord(h->ev[2].a, s));
-        for (int64_t q = 0; q < ns; ++q) {   // b_q = Phi' y_q: Nf slots at the frequencies w_f themselves, weights y K_j
-            LPVS_TRY(launch_nudft(dX.p, dy.p + q * N, N, K.as<double>(), ldk, (int)nb, dw.p, nullptr, (int)Nf, 2, part.as<double>(), tabb.as<double>(), s));
-            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
+        for (int64_t q = 0; q < ns; ++q) {   // b_q = Phi' y_q: Nf slots a + f*D, weights y K_j, first-order eps correction
+            LPVS_TRY(launch_nudft(dX.p, dy.p + q * N, N, K.as<double>(), ldk, (int)nb, drhi.as<double>(), drlo.as<double>(), (int)nf8, step, part.as<double>(), tabb.as<double>(), s));
+            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), deps.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
         }
         LPVS_HIP(hipEventRecord(h->ev[2].b, s));
         LPVS_HIP(hipStreamSynchronize(s));

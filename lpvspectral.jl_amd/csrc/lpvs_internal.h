@@ -120,11 +120,13 @@ int32_t launch_rhs_panel_batch(int nbatch, const double *P, int64_t strideP, int
                                size_t scratch_bytes, hipStream_t s);
 
 // ---- structured Gram for arithmetic-progression frequency grids (nudft.hip) ----------------------------------
-size_t nudft_partial_bytes(int64_t N, int64_t nslots, int64_t nq, int nv);
+struct ApStep { double hi[8], lo[8]; };   // b*D in double-double, b = 0..7 (in-group offsets of the slot progressions)
+size_t nudft_partial_bytes(int64_t N, int64_t nslots, int64_t nq);
 int32_t launch_nudft(const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq, const double *om_hi,
-                     const double *om_lo, int nslots, int nv, double *partial, double *tab, hipStream_t s);
-int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t nb, int64_t n, double *G, int64_t ldg, hipStream_t s);
-int32_t launch_ap_rhs(const double *tab, int64_t Nf, int64_t nb, double *b, hipStream_t s);
+                     const double *om_lo, int nslots, const ApStep &step, double *partial, double *tab, hipStream_t s);
+int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t s0, int64_t nb, int64_t n, double *G, int64_t ldg,
+                           hipStream_t s);
+int32_t launch_ap_rhs(const double *tab, const double *eps, int64_t Nf, int64_t nb, double *b, hipStream_t s);
 
 // ---- dense symmetric inverse (linalg.hip) ------------------------------------------------
 // In-place inverse of the SPD matrix A (np x np, np % 64 == 0, full symmetric storage) by

@@ -9,90 +9,156 @@
 //     C(omega)[q] = sum_n KK[n][q] cos(omega x_n),   S(omega)[q] = sum_n KK[n][q] sin(omega x_n),
 // plus their x-weighted twins (the omega-derivatives), which carry the first-order correction in eps.
 // The neglected second order is (eps * x)^2 / 2 <= 5e-15 under the admission test |eps| max|x| <= 1e-7.
-// Slot frequencies are kept in double-double and the phase omega*x is formed with an FMA-exact product, so
-// the sums are those of the exact real frequencies w_f +- w_f' of the given doubles.
+// The right-hand side b = Phi' y uses the same sums at the Nf slots a + f*D with weights y K_j.
 //
-// Work: N*(3Nf-1) sincos + 4*N*(3Nf-1)*P fma  (cfg3: 1.6e9 sincos + 2.3e11 flop) instead of the 4.2e13 flop
-// of the dense symmetric-pair contraction.  VALU / transcendental bound; deterministic (chunk partials are
-// summed in fixed order).
+// Slot frequencies are exact arithmetic progressions kept in double-double, eight slots to a group: per sample the
+// kernel evaluates sincos only for the group anchors (omega_{8a} x, phase formed with an FMA-exact product) and for
+// the eight in-group offsets (b D x), and gets every slot by one complex multiplication
+//     cis(omega_{8a+b} x) = cis(omega_{8a} x) cis(b D x)
+// -- 16 sincos per 64 slots instead of 64.  The weights of a (sample, pair) are wave-uniform and come through
+// scalar loads, so the inner loop is one LDS read of the slot's four trig values and 4 FMAs per pair.
+//
+// Work: 4*N*(3Nf-1)*P FMAs (cfg3: 2.3e11) + N*(3Nf-1)/4 sincos instead of the 4.2e13 flop of the dense
+// symmetric-pair contraction.  VALU bound; deterministic (chunk partials are summed in fixed order).
 #include "lpvs_internal.h"
+
+#include <cstdlib>
 
 namespace lpvs {
 
 namespace {
 
-constexpr int SLOTS = 64;   // slots per workgroup
-constexpr int QPT = 9;      // weights (activation pairs) per thread
-constexpr int RB = 4;       // rows per inner block (256 threads = 64 slots x 4 rows of sincos)
+constexpr int RB = 16;      // samples per inner block
+constexpr int ROWS_PER_CHUNK = 8192;
 
-// out[chunk][slot][q][v], v = {cos, sin, x*cos, x*sin} (NV = 4) or {cos, sin} (NV = 2)
-template <int NV>
+// out[chunk][slot][q][4] = sum over the chunk's samples of Wt[n][q] (y_n) {cos, sin, x cos, x sin}(omega_slot x_n)
+//
+// A workgroup owns 64*S consecutive slots (8*S groups of 8) and one q-block of 4*QPT pairs; thread (lane sl, wave g)
+// accumulates slots sl, sl+64, ... (S of them) against the wave's QPT pairs.  Per inner block of 16 samples:
+//   step A  one sincos per thread: the 8*S group anchors and the 8 in-group offsets of each sample; the samples'
+//           weights are staged in LDS
+//   step B  every (sample, slot) by one complex product -> trig[sample][slot] = y {c, s, x c, x s}
+//   step C  per sample: S LDS reads of 32 B (trig) + QPT/2 reads of 16 B (weights, same address in every lane),
+//           4*S*QPT FMAs.  S = 2 keeps the LDS behind the FMA pipe (4 (16 S + 4 QPT) <= 16 S QPT cycles).
+template <int QPT, int S>
 __global__ void __launch_bounds__(256)
 nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__ y, int64_t N, const double *__restrict__ Wt,
                         int64_t ldw, int nq, const double *__restrict__ om_hi, const double *__restrict__ om_lo, int nslots,
-                        int64_t rows_per_chunk, double *__restrict__ out) {
-    __shared__ double trig[RB][SLOTS][4];
-    __shared__ double wrow[RB][40];
-    const int sl = threadIdx.x & (SLOTS - 1), g = threadIdx.x >> 6;        // slot within block; row (phase 1) / q-group (phase 2)
-    const int slot = blockIdx.x * SLOTS + sl;
-    const bool live = slot < nslots;
-    const double wh = live ? om_hi[slot] : 0.0, wl = (live && om_lo) ? om_lo[slot] : 0.0;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
-    const int64_t r1 = r0 + rows_per_chunk < N ? r0 + rows_per_chunk : N;
-    const int qbase = blockIdx.z * (4 * QPT);                               // pair block (nq > 36: several passes over the samples)
-    const int nqb = nq - qbase < 4 * QPT ? nq - qbase : 4 * QPT;            // pairs of this block
+                        const ApStep step, double *__restrict__ out) {
+    constexpr int SLOTS = 64 * S, NA = 8 * S;                    // slots and anchors per workgroup
+    constexpr int WSTR = (QPT + 1) & ~1;                         // weight stride of a wave inside a staged sample (16-B aligned)
+    constexpr int NEF = NA + 8;                                  // sincos per sample: anchors + offsets
+    __shared__ __attribute__((aligned(16))) double trig[RB][SLOTS][4];
+    __shared__ __attribute__((aligned(16))) double wrow[RB][4 * WSTR];
+    __shared__ double ef[RB][NEF][2];
+    __shared__ double xs[RB], ys[RB];
+    const int t = threadIdx.x;
+    const int sl = t & 63;
+    const int g = __builtin_amdgcn_readfirstlane(t >> 6);        // wave = q-group of the accumulation phase
+    const int slot0 = blockIdx.x * SLOTS;
+    const int64_t r0 = (int64_t)blockIdx.y * ROWS_PER_CHUNK;
+    const int64_t r1 = r0 + ROWS_PER_CHUNK < N ? r0 + ROWS_PER_CHUNK : N;
+    const int qbase = blockIdx.z * (4 * QPT);
+    const int nqb = nq - qbase < 4 * QPT ? nq - qbase : 4 * QPT;  // pairs of this q-block
     const int q0 = g * QPT;
-    double acc[QPT][NV];
+    const int nvalid = nqb - q0 < QPT ? nqb - q0 : QPT;           // pairs of this wave (<= 0: the wave only helps with steps A, B)
+
+    double acc[S][QPT][4];
 #pragma unroll
-    for (int q = 0; q < QPT; ++q)
+    for (int u = 0; u < S; ++u)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[q][v] = 0.0;
+        for (int q = 0; q < QPT; ++q)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][q][v] = 0.0;
+
     for (int64_t rb = r0; rb < r1; rb += RB) {
-        {   // phase 1: thread (slot, row g) evaluates the trig factor of that (sample, frequency)
-            const int64_t r = rb + g;
-            double c = 0.0, s = 0.0, xv = 0.0;
+        // step A: sincos of (sample, anchor | offset), RB*NEF of them over 256 threads
+        for (int e = t; e < RB * NEF; e += 256) {
+            const int pr = e / NEF, pk = e - pr * NEF;
+            double wh, wl;
+            if (pk < NA) {
+                const int as = slot0 + 8 * pk;
+                const bool ok = as < nslots;
+                wh = ok ? om_hi[as] : 0.0; wl = ok ? om_lo[as] : 0.0;
+            } else {
+                wh = step.hi[pk - NA]; wl = step.lo[pk - NA];
+            }
+            const int64_t r = rb + pr;
+            double c = 1.0, sn = 0.0;
             if (r < r1) {
-                xv = x[r];
+                const double xv = x[r];
                 const double p = wh * xv;                       // rounded product
                 const double d = fma(wh, xv, -p) + wl * xv;     // its exact error + the low word: omega*x = p + d
-                sincos(p, &s, &c);
-                const double c2 = fma(-d, s, c), s2 = fma(d, c, s);
-                c = c2; s = s2;
+                sincos(p, &sn, &c);
+                const double c2 = fma(-d, sn, c), s2 = fma(d, c, sn);
+                c = c2; sn = s2;
+                if (pk == 0) { xs[pr] = xv; ys[pr] = y ? y[r] : 1.0; }
+            } else if (pk == 0) {
+                xs[pr] = 0.0; ys[pr] = 0.0;                     // samples past the end contribute nothing
             }
-            trig[g][sl][0] = c; trig[g][sl][1] = s;
-            if (NV == 4) { trig[g][sl][2] = xv * c; trig[g][sl][3] = xv * s; }
-            if (threadIdx.x < RB * 40) {                        // stage the weights of the RB rows
-                const int rr = threadIdx.x / 40, q = threadIdx.x % 40;
-                const int64_t r2 = rb + rr;
-                double wv = 0.0;
-                if (r2 < r1 && q < nqb) { wv = Wt[r2 * ldw + qbase + q]; if (y) wv = wv * y[r2]; }
-                wrow[rr][q] = wv;
+            ef[pr][pk][0] = c; ef[pr][pk][1] = sn;
+        }
+        for (int e = t; e < RB * 4 * QPT; e += 256) {           // weights of the block: [sample][wave][QPT (+pad)]
+            const int pr = e / (4 * QPT), q = e - pr * (4 * QPT);
+            const int64_t r = rb + pr;
+            const double wv = (r < r1 && q < nqb) ? Wt[r * ldw + qbase + q] : 0.0;
+            wrow[pr][(q / QPT) * WSTR + q % QPT] = wv;
+        }
+        __syncthreads();
+        // step B: trig[sample][slot] by one complex product; thread covers slot lanes sl + 64u for samples g, g+4, ...
+#pragma unroll
+        for (int i = 0; i < RB / 4; ++i) {
+            const int rr = g + 4 * i;
+            const double yv = ys[rr], xv = xs[rr];
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+                const int ls = sl + 64 * u;
+                const double ec = ef[rr][ls >> 3][0], es = ef[rr][ls >> 3][1];
+                const double fc = ef[rr][NA + (ls & 7)][0], fs = ef[rr][NA + (ls & 7)][1];
+                const double c = fma(ec, fc, -(es * fs)) * yv, sn = fma(es, fc, ec * fs) * yv;
+                double4 o; o.x = c; o.y = sn; o.z = xv * c; o.w = xv * sn;
+                *reinterpret_cast<double4 *>(&trig[rr][ls][0]) = o;
             }
         }
         __syncthreads();
-        if (q0 < nqb) {   // phase 2: thread (slot, q-group g) accumulates its QPT weights over the RB rows
+        if (nvalid > 0) {   // step C
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) {
-                double tv[NV];
+                double4 tv[S];
 #pragma unroll
-                for (int v = 0; v < NV; ++v) tv[v] = trig[rr][sl][v];
+                for (int u = 0; u < S; ++u) tv[u] = *reinterpret_cast<const double4 *>(&trig[rr][sl + 64 * u][0]);
+                double wq[WSTR];
 #pragma unroll
-                for (int q = 0; q < QPT; ++q) {
-                    const double wv = wrow[rr][q0 + q];         // zero beyond nq
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) acc[q][v] = fma(wv, tv[v], acc[q][v]);
+                for (int q = 0; q < WSTR; q += 2) {
+                    const double2 w2 = *reinterpret_cast<const double2 *>(&wrow[rr][g * WSTR + q]);
+                    wq[q] = w2.x; wq[q + 1] = w2.y;
                 }
+#pragma unroll
+                for (int q = 0; q < QPT; ++q)
+#pragma unroll
+                    for (int u = 0; u < S; ++u) {
+                        acc[u][q][0] = fma(wq[q], tv[u].x, acc[u][q][0]);
+                        acc[u][q][1] = fma(wq[q], tv[u].y, acc[u][q][1]);
+                        acc[u][q][2] = fma(wq[q], tv[u].z, acc[u][q][2]);
+                        acc[u][q][3] = fma(wq[q], tv[u].w, acc[u][q][3]);
+                    }
             }
         }
         __syncthreads();
     }
-    if (live && q0 < nqb) {
-        double *o = out + (((int64_t)blockIdx.y * nslots + slot) * nq + qbase) * NV;
+    if (nvalid > 0) {
 #pragma unroll
-        for (int q = 0; q < QPT; ++q)
-            if (q0 + q < nqb)
+        for (int u = 0; u < S; ++u) {
+            const int slot = slot0 + sl + 64 * u;
+            if (slot >= nslots) continue;
+            double *o = out + (((int64_t)blockIdx.y * nslots + slot) * nq + qbase + q0) * 4;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) o[(q0 + q) * NV + v] = acc[q][v];
+            for (int q = 0; q < QPT; ++q)
+                if (q < nvalid) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) o[q * 4 + v] = acc[u][q][v];
+                }
+        }
     }
 }
 
@@ -106,9 +172,9 @@ nudft_reduce_kernel(const double *__restrict__ part, int nchunks, int64_t count,
 }
 
 // G[a][b] = G[b][a], a >= b, from the slot tables tab[slot][q][4]; slots 0..Nf-1 are the differences m = f-f',
-// slots Nf..3Nf-2 the sums s = f+f'.
+// slots s0..s0+2Nf-2 the sums s = f+f' (s0 = Nf rounded up to a multiple of 8).
 __global__ void __launch_bounds__(256)
-ap_assemble_kernel(const double *__restrict__ tab, const double *__restrict__ eps, int Nf, int nb, int P, int64_t n,
+ap_assemble_kernel(const double *__restrict__ tab, const double *__restrict__ eps, int Nf, int s0, int nb, int P, int64_t n,
                    double *__restrict__ G, int64_t ldg) {
     const int64_t ga = blockIdx.y;
     const int64_t gb = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -122,7 +188,7 @@ ap_assemble_kernel(const double *__restrict__ tab, const double *__restrict__ ep
     const int m = fa - fb, s = fa + fb;                     // fa >= fb because a >= b
     const double dm = eps[fa] - eps[fb], dp = eps[fa] + eps[fb];
     const double *tm = tab + ((int64_t)m * P + q) * 4;
-    const double *tp = tab + ((int64_t)(Nf + s) * P + q) * 4;
+    const double *tp = tab + ((int64_t)(s0 + s) * P + q) * 4;
     const double cm = fma(-dm, tm[3], tm[0]), sm = fma(dm, tm[2], tm[1]);   // first order in the residuals
     const double cp = fma(-dp, tp[3], tp[0]), sp = fma(dp, tp[2], tp[1]);
     double v;
@@ -134,48 +200,62 @@ ap_assemble_kernel(const double *__restrict__ tab, const double *__restrict__ ep
     G[gb * ldg + ga] = v;
 }
 
-// b[f*2nb + j] = sum y K_j cos(w_f x),  b[f*2nb + nb + j] = -sum y K_j sin(w_f x)   from tab[f][j][2]
+// b[f*2nb + j] = sum y K_j cos(w_f x),  b[f*2nb + nb + j] = -sum y K_j sin(w_f x)   from tab[f][j][4] at the
+// slots a + f*D, corrected to first order for w_f = a + f*D + eps_f
 __global__ void __launch_bounds__(256)
-ap_rhs_kernel(const double *__restrict__ tab, int Nf, int nb, double *__restrict__ b) {
+ap_rhs_kernel(const double *__restrict__ tab, const double *__restrict__ eps, int Nf, int nb, double *__restrict__ b) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Nf * nb) return;
     const int f = i / nb, j = i - f * nb;
-    b[(int64_t)f * 2 * nb + j] = tab[((int64_t)f * nb + j) * 2 + 0];
-    b[(int64_t)f * 2 * nb + nb + j] = -tab[((int64_t)f * nb + j) * 2 + 1];
+    const double *t = tab + ((int64_t)f * nb + j) * 4;
+    const double e = eps[f];
+    b[(int64_t)f * 2 * nb + j] = fma(-e, t[3], t[0]);
+    b[(int64_t)f * 2 * nb + nb + j] = -fma(e, t[2], t[1]);
+}
+
+template <int QPT, int S>
+void launch_accumulate(unsigned nchunks, hipStream_t s, const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq,
+                       const double *om_hi, const double *om_lo, int nslots, const ApStep &step, double *partial) {
+    dim3 grid((unsigned)ceil_div(nslots, 64 * S), nchunks, (unsigned)ceil_div(nq, 4 * QPT));
+    hipLaunchKernelGGL((nudft_accumulate_kernel<QPT, S>), grid, dim3(256), 0, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
 }
 
 }  // namespace
 
-size_t nudft_chunks(int64_t N) { return (size_t)ceil_div(N, 8192); }
-size_t nudft_partial_bytes(int64_t N, int64_t nslots, int64_t nq, int nv) {
-    return sizeof(double) * nudft_chunks(N) * (size_t)nslots * (size_t)nq * (size_t)nv;
+size_t nudft_chunks(int64_t N) { return (size_t)ceil_div(N, ROWS_PER_CHUNK); }
+size_t nudft_partial_bytes(int64_t N, int64_t nslots, int64_t nq) {
+    return sizeof(double) * nudft_chunks(N) * (size_t)nslots * (size_t)nq * 4;
 }
 
-// tab[slot][q][nv] = sum_n (y_n) Wt[n][q] {cos, sin, (x cos, x sin)}(omega_slot x_n); om_lo may be null (plain phase)
+// tab[slot][q][4] = sum_n (y_n) Wt[n][q] {cos, sin, x cos, x sin}(omega_slot x_n).  The slots must form arithmetic
+// progressions with step D inside every aligned group of eight (nslots % 8 == 0); step holds b*D, b = 0..7.
 int32_t launch_nudft(const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq, const double *om_hi,
-                     const double *om_lo, int nslots, int nv, double *partial, double *tab, hipStream_t s) {
-    const int64_t rpc = 8192;
+                     const double *om_lo, int nslots, const ApStep &step, double *partial, double *tab, hipStream_t s) {
+    if (nslots % 8 != 0) { set_error("nudft: slot count %d is not a multiple of 8", nslots); return LPVS_ESTATE; }
     const unsigned nchunks = (unsigned)nudft_chunks(N);
-    dim3 grid((unsigned)ceil_div(nslots, SLOTS), nchunks, (unsigned)ceil_div(nq, 4 * QPT));
-    if (nv == 4) hipLaunchKernelGGL(nudft_accumulate_kernel<4>, grid, dim3(256), 0, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, rpc, partial);
-    else hipLaunchKernelGGL(nudft_accumulate_kernel<2>, grid, dim3(256), 0, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, rpc, partial);
+    static const int slots_per_thread = [] { const char *e = getenv("LPVS_NUDFT_S"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    if (nq <= 8) launch_accumulate<2, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
+    else if (nq <= 16) launch_accumulate<4, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
+    else if (slots_per_thread == 1) launch_accumulate<9, 1>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
+    else launch_accumulate<9, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
     LPVS_HIP(hipGetLastError());
-    const int64_t count = (int64_t)nslots * nq * nv;
+    const int64_t count = (int64_t)nslots * nq * 4;
     hipLaunchKernelGGL(nudft_reduce_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, partial, (int)nchunks, count, tab);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
 
-int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t nb, int64_t n, double *G, int64_t ldg, hipStream_t s) {
+int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t s0, int64_t nb, int64_t n, double *G, int64_t ldg,
+                           hipStream_t s) {
     const int P = (int)(nb * (nb + 1) / 2);
     dim3 grid((unsigned)ceil_div(n, 256), (unsigned)n);
-    hipLaunchKernelGGL(ap_assemble_kernel, grid, dim3(256), 0, s, tab, eps, (int)Nf, (int)nb, P, n, G, ldg);
+    hipLaunchKernelGGL(ap_assemble_kernel, grid, dim3(256), 0, s, tab, eps, (int)Nf, (int)s0, (int)nb, P, n, G, ldg);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
 
-int32_t launch_ap_rhs(const double *tab, int64_t Nf, int64_t nb, double *b, hipStream_t s) {
-    hipLaunchKernelGGL(ap_rhs_kernel, dim3((unsigned)ceil_div(Nf * nb, 256)), dim3(256), 0, s, tab, (int)Nf, (int)nb, b);
+int32_t launch_ap_rhs(const double *tab, const double *eps, int64_t Nf, int64_t nb, double *b, hipStream_t s) {
+    hipLaunchKernelGGL(ap_rhs_kernel, dim3((unsigned)ceil_div(Nf * nb, 256)), dim3(256), 0, s, tab, eps, (int)Nf, (int)nb, b);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
