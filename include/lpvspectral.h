@@ -105,6 +105,23 @@ int32_t lpvs_problem_create_lpv_f64(const double *y, const double *X, const doub
 int32_t lpvs_problem_create_lpv_multi_f64(const double *Y, int64_t ns, const double *X, const double *V, int64_t N,
                                           const double *w, int64_t Nf, int64_t Nv, int32_t normalize,
                                           int32_t coulomb, int32_t device, lpvs_problem **out);
+
+/* ---- one exchange step for a single large problem: the sample rows of one signal are sharded
+ * across devices, every shard forms its partial Gram G_r = Phi_r' Phi_r and b_r = Phi_r' y_r, the partials are
+ * summed (RCCL all-reduce on the device pointers below) and the ADMM runs replicated.  The basis centres of
+ * src/utilities.jl:24-32 depend on min/max of V over ALL rows, so a shard is built with the global ranges:
+ *   ranges4 = {min V, max V, max|V|, max|X|}   (lpvs_lpv_ranges_f64 gives a shard's own; combine with min/max)
+ * max|X| only steers the choice of Gram form, which must be the same on every shard. */
+int32_t lpvs_lpv_ranges_f64(const double *X, const double *V, int64_t N, double *out4);
+int32_t lpvs_problem_create_lpv_rows_f64(const double *Y, int64_t ns, const double *X, const double *V,
+                                         int64_t N_local, const double *w, int64_t Nf, int64_t Nv,
+                                         int32_t normalize, int32_t coulomb, const double *ranges4,
+                                         int32_t device, lpvs_problem **out);
+/* device pointers of the handle's Gram (np x np, leading dimension np, full symmetric storage, pad rows and
+ * columns zero) and right-hand sides (np per signal); valid while the handle lives.  After modifying them in
+ * place call lpvs_problem_gram_modified so that the cached factorisation is dropped. */
+int32_t lpvs_problem_device_gram_f64(lpvs_problem *h, double **G_dev, double **b_dev, int64_t *np);
+int32_t lpvs_problem_gram_modified(lpvs_problem *h);
 int32_t lpvs_problem_num_signals(const lpvs_problem *h, int64_t *ns);
 /* dense:   A (m x n column-major) supplied by the caller: G = A' diag(W) A, b = A' diag(W) y --
  *          the generic ADMM(x, LeastSquares(A,y,iterative=true), proxg) plugin path, src/lasso.jl:136 */

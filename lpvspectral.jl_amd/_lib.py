@@ -64,6 +64,10 @@ SIGNATURES = {
     "lpvs_problem_set_prox": (_I32, [_P, _I32, _F64, _I64]),
     "lpvs_admm_init_f64": (_I32, [_P, _P, _F64, _F64, _I32]),
     "lpvs_admm_run": (_I32, [_P, _I64, _PI64, C.POINTER(_F64), C.POINTER(_I32)]),
+    "lpvs_lpv_ranges_f64": (_I32, [_P, _P, _I64, _P]),
+    "lpvs_problem_create_lpv_rows_f64": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I32, C.POINTER(_P)]),
+    "lpvs_problem_device_gram_f64": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
+    "lpvs_problem_gram_modified": (_I32, [_P]),
     "lpvs_admm_time_matvec": (_I32, [_P, _I32, C.POINTER(_F64), C.POINTER(_F64)]),
     "lpvs_admm_get_f64": (_I32, [_P, _P, _P, _P]),
     "lpvs_problem_get_params_f64": (_I32, [_P, _I32, _P, _P]),

@@ -201,6 +201,25 @@ class Problem:
         return p
 
     @classmethod
+    def lpv_rows(cls, y, X, V, w, Nv, ranges, normalize=True, coulomb=False, device=0):
+        """Partial problem over a ROW SHARD ``(y, X, V)`` of one signal: ``ranges`` =
+        ``[min V, max V, max|V|, max|X|]`` over ALL rows.  Its Gram / rhs are partial sums; exchange them with
+        :meth:`device_gram` + an all-reduce, then :meth:`gram_modified`."""
+        ky, py, N = as_f64(y)
+        kx, px, Nx = as_f64(X)
+        kv, pv, Nvv = as_f64(V)
+        kw, pw, Nf = as_f64(w)
+        assert N == Nx == Nvv, "y, X and V has to be the same length"
+        r4 = np.ascontiguousarray(np.asarray(ranges, dtype=np.float64).ravel())
+        assert r4.size == 4
+        h = C.c_void_p()
+        check(lib().lpvs_problem_create_lpv_rows_f64(py, 1, px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)),
+                                                     out_ptr(r4), int(device), C.byref(h)))
+        p = cls(h, "lpv")
+        p.Nf, p.nb = Nf, (2 * Nv if coulomb else Nv)
+        return p
+
+    @classmethod
     def dense(cls, A, y, W=None, device=0):
         if _lib.is_device_array(A):
             raise TypeError("dense(): pass A as a host (numpy) column-major matrix or a transposed-contiguous device tensor via gram()")
@@ -251,6 +270,26 @@ class Problem:
         b = np.zeros(self.n if self.ns == 1 else (self.n, self.ns), order="F")
         check(lib().lpvs_problem_get_rhs_f64(self._h, out_ptr(b)))
         return b
+
+    def device_gram(self):
+        """Torch views (no copy) of the handle's device Gram ``[np, np]`` and right-hand sides ``[ns, np]`` for an
+        in-place exchange step; call :meth:`gram_modified` afterwards."""
+        import torch
+        G, b, npad = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        check(lib().lpvs_problem_device_gram_f64(self._h, C.byref(G), C.byref(b), C.byref(npad)))
+        n_p = int(npad.value)
+
+        class _View:   # __cuda_array_interface__ is how torch (CUDA and ROCm builds) adopts foreign device memory
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f8", "data": (int(ptr), False), "version": 3, "strides": None}
+
+        dev = torch.device("cuda", torch.cuda.current_device())
+        Gt = torch.as_tensor(_View(G.value, (n_p, n_p)), device=dev)
+        bt = torch.as_tensor(_View(b.value, (self.ns, n_p)), device=dev)
+        return Gt, bt
+
+    def gram_modified(self):
+        check(lib().lpvs_problem_gram_modified(self._h))
 
     def get_inverse(self, shift):
         M = np.zeros((self.n, self.n), order="F")
@@ -428,6 +467,37 @@ def ls_sparse_spectral_lpv(y, X, V, w, Nv, λ=1, coulomb=False, normalize=True, 
             log.info("Aborting")
             params = prob.params(1)                                  # z = copy(x)
     return SpectralExt(y, X, V, w, Nv, λ, coulomb, normalize, params, None)
+
+
+def lpv_ranges(X, V):
+    """``[min V, max V, max|V|, max|X|]`` of a (shard of a) signal, reduced on the device."""
+    kx, px, N = as_f64(X)
+    kv, pv, Nv_ = as_f64(V)
+    assert N == Nv_
+    out = np.zeros(4)
+    check(lib().lpvs_lpv_ranges_f64(px, pv, N, out_ptr(out)))
+    return out
+
+
+def ls_sparse_spectral_lpv_rowsharded(y, X, V, w, Nv, λ=1, normalize=True, device=0, proxg=None, dist=None, **kwargs):
+    """One signal whose SAMPLE ROWS are sharded over the ranks of ``dist`` (``torch.distributed``, initialised;
+    backend nccl = RCCL over xGMI): every rank passes its rows ``(y, X, V)``.  SURVEY.md §8(e)(2): each rank forms the
+    partial Gram / rhs of its rows on its GPU, ONE all-reduce sums them (n_p² + n_p f64 per rank), and the ADMM
+    (src/lasso.jl:136-171) then runs replicated, so every rank returns the same :class:`SpectralExt` as
+    :func:`ls_sparse_spectral_lpv` on the whole signal (up to the summation order of the Gram)."""
+    from . import sharding
+    w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
+    Nf, Nv = len(w), int(Nv)
+    ranges = sharding.allreduce_ranges(lpv_ranges(X, V), dist)
+    with Problem.lpv_rows(y, X, V, w, Nv, ranges, normalize, False, device=device) as prob:
+        G, b = prob.device_gram()
+        sharding.allreduce_sum_(G, dist)
+        sharding.allreduce_sum_(b, dist)
+        prob.gram_modified()
+        g = SlicedSeparableSum.frequency_groups(λ, Nf, 2 * Nv) if proxg is None else proxg
+        _admm_on_problem(prob, None, g, _lib.LINEAR_LEAST_SQUARES, **kwargs)
+        params = prob.params(0)
+    return SpectralExt(y, X, V, w, Nv, λ, False, normalize, params, None)
 
 
 def ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, λ=1, normalize=True, device=0, proxg=None, **kwargs):

@@ -414,10 +414,12 @@ int32_t lpvs_basis_activation_f64(const double *V, int64_t N, int64_t Nv, int32_
 
 // shared by lpvs_lpv_regressor_f64 and lpvs_problem_create_lpv_f64: T and K tables with Npad rows
 static int32_t build_lpv_tables(const double *dX, const double *dV, int64_t N, int64_t Npad, const double *dw, int64_t Nf,
-                                int64_t Nv, int normalize, int coulomb, DevBuf &T, DevBuf &K, int64_t *ldk_out, hipStream_t s) {
+                                int64_t Nv, int normalize, int coulomb, DevBuf &T, DevBuf &K, int64_t *ldk_out, hipStream_t s,
+                                const double *ranges = nullptr) {
     const int64_t nb = coulomb ? 2 * Nv : Nv, ldk = nb + 1;
     double lo, hi, am, gamma; std::vector<double> vc;
-    LPVS_TRY(device_minmax(dV, N, &lo, &hi, &am, s));
+    if (ranges) { lo = ranges[0]; hi = ranges[1]; am = ranges[2]; }
+    else LPVS_TRY(device_minmax(dV, N, &lo, &hi, &am, s));
     basis_centers(lo, hi, am, Nv, coulomb, vc, &gamma);
     DevBuf dvc; LPVS_TRY(dvc.alloc(sizeof(double) * vc.size()));
     LPVS_TRY(copy_to_device(dvc.p, vc.data(), sizeof(double) * vc.size(), s));
@@ -449,8 +451,10 @@ int32_t lpvs_lpv_regressor_f64(const double *X, const double *V, int64_t N, cons
     return dP.finish(s);
 }
 
+// ranges (optional) = {min V, max V, max|V|, max|X|} over ALL rows of the signal when (y, X, V) is only a row shard of it
 static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
-                               int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out) {
+                               int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out,
+                               const double *ranges = nullptr) {
     if (N <= 0 || Nf <= 0 || Nv <= 0 || ns <= 0) { set_error("N, Nf, Nv and the number of signals must be positive"); return LPVS_EARGUMENT; }
     lpvs_problem *h = nullptr;
     LPVS_TRY(problem_begin(device, out, &h));
@@ -479,7 +483,8 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     if (form == "auto" || form == "ap") {
         LPVS_TRY(fetch_host(hw, w, Nf));
         double xlo, xhi, xam;
-        LPVS_TRY(device_minmax(dX.p, N, &xlo, &xhi, &xam, s));
+        if (ranges) xam = ranges[3];
+        else LPVS_TRY(device_minmax(dX.p, N, &xlo, &xhi, &xam, s));
         const long double a0 = hw[0], D = Nf > 1 ? ((long double)hw[Nf - 1] - (long double)hw[0]) / (long double)(Nf - 1) : 0.0L;
         heps.resize((size_t)Nf);
         double emax = 0;
@@ -507,7 +512,8 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         double lo, hi, am, gamma; std::vector<double> vc;
         DevBuf K, KK, dvc, dhi, dlo, drhi, drlo, deps, part, tab, tabb;
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
-        LPVS_TRY(device_minmax(dV.p, N, &lo, &hi, &am, s));
+        if (ranges) { lo = ranges[0]; hi = ranges[1]; am = ranges[2]; }
+        else LPVS_TRY(device_minmax(dV.p, N, &lo, &hi, &am, s));
         basis_centers(lo, hi, am, Nv, coulomb, vc, &gamma);
         const int64_t ldk = nb + 1;
         LPVS_TRY(dvc.alloc(sizeof(double) * vc.size()));
@@ -554,7 +560,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
 
     DevBuf T, K, KK, G3, slab, scr; int64_t ldk;
     LPVS_HIP(hipEventRecord(h->ev[0].a, s));
-    LPVS_TRY(build_lpv_tables(dX.p, dV.p, N, Npad, dw.p, Nf, Nv, normalize, coulomb, T, K, &ldk, s));
+    LPVS_TRY(build_lpv_tables(dX.p, dV.p, N, Npad, dw.p, Nf, Nv, normalize, coulomb, T, K, &ldk, s, ranges));
     if (krs) {
         LPVS_TRY(KK.alloc(sizeof(double) * (size_t)Npad * (size_t)pl.pairs));
         LPVS_TRY(launch_pair_table(K.as<double>(), ldk, nb, Npad, KK.as<double>(), s));
@@ -602,6 +608,41 @@ int32_t lpvs_problem_create_lpv_multi_f64(const double *Y, int64_t ns, const dou
                                           int64_t Nf, int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device,
                                           lpvs_problem **out) {
     return create_lpv_impl(Y, ns, X, V, N, w, Nf, Nv, normalize, coulomb, device, out);
+}
+
+int32_t lpvs_lpv_ranges_f64(const double *X, const double *V, int64_t N, double *out4) {
+    if (!X || !V || !out4 || N <= 0) { set_error("NULL argument or N <= 0"); return LPVS_EARGUMENT; }
+    if (lpvs_device_count() == 0) { set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    hipStream_t s = nullptr;
+    DevArg dX, dV;
+    LPVS_TRY(dX.set(X, N, s)); LPVS_TRY(dV.set(V, N, s));
+    double xlo, xhi;
+    LPVS_TRY(device_minmax(dV.p, N, &out4[0], &out4[1], &out4[2], s));
+    LPVS_TRY(device_minmax(dX.p, N, &xlo, &xhi, &out4[3], s));
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_create_lpv_rows_f64(const double *Y, int64_t ns, const double *X, const double *V, int64_t N_local, const double *w,
+                                         int64_t Nf, int64_t Nv, int32_t normalize, int32_t coulomb, const double *ranges4,
+                                         int32_t device, lpvs_problem **out) {
+    if (!ranges4) { set_error("ranges4 is NULL"); return LPVS_EARGUMENT; }
+    if (!(ranges4[0] <= ranges4[1]) || !(ranges4[2] >= 0) || !(ranges4[3] >= 0)) { set_error("ranges4 = {min V, max V, max|V|, max|X|} is inconsistent"); return LPVS_EARGUMENT; }
+    return create_lpv_impl(Y, ns, X, V, N_local, w, Nf, Nv, normalize, coulomb, device, out, ranges4);
+}
+
+int32_t lpvs_problem_device_gram_f64(lpvs_problem *h, double **G_dev, double **b_dev, int64_t *np) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    if (G_dev) *G_dev = h->G.as<double>();
+    if (b_dev) *b_dev = h->b.as<double>();
+    if (np) *np = h->np;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_gram_modified(lpvs_problem *h) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    h->M_valid = false; h->inited = false;
+    h->drop_graph();
+    return LPVS_OK;
 }
 
 int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_t N, const double *f, int64_t Nf, const double *W,

@@ -58,3 +58,37 @@ def reduce_psd_in_order(x_units):
     for i in range(x_units.shape[0]):
         S += np.abs(x_units[i]) ** 2
     return S / x_units.shape[0] ** 2
+
+
+# ---- one exchange step for a single large problem: sample rows sharded, partial Grams summed ----
+def allreduce_ranges(r4, dist=None):
+    """Combine per-shard ``[min V, max V, max|V|, max|X|]`` into the global ranges (min for entry 0, max for the rest)."""
+    r4 = np.asarray(r4, dtype=np.float64).copy()
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return r4
+    import torch
+    dev = _collective_device(dist)
+    t = torch.tensor([-r4[0], r4[1], r4[2], r4[3]], dtype=torch.float64, device=dev)   # one MAX reduction: min = -max(-.)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = t.cpu().numpy()
+    out[0] = -out[0]
+    return out
+
+
+def allreduce_sum_(t, dist=None):
+    """In-place sum of a tensor over the ranks.  Device tensors go straight into RCCL (backend nccl); with a
+    host-only backend (gloo rehearsal) they are staged through host memory."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def _collective_device(dist):
+    import torch
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")

@@ -9,11 +9,13 @@ Tolerances (fp64 path):
   * index / window bookkeeping, iteration counts at tol = 0: bit-exact
 """
 import io
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rel(a, b):
@@ -530,3 +532,69 @@ def test_gram_form_selection_and_agreement(L, oracle):
         os.environ.pop("LPVS_GRAM_FORM", None)
     assert not np.array_equal(Ga, Gk)
     assert np.abs(Ga - Gk).max() <= (1e-12 + 4.5e-16 * float(w_r.max() * Xb.max())) * np.abs(Gk).max()
+
+
+# ---- row-sharded Gram + one exchange step ----------------------------------------------------------
+def _rowshard_signal(N=6000, Nf=24, seed=5):
+    rng = np.random.default_rng(seed)
+    X = np.sort(rng.uniform(0, 10 * N / 500, N)); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) * 25 / Nf / 8
+    y = 2 * V ** 2 * np.cos(w[3] * X) + 2 / (5 * V + 1) * np.cos(w[11] * X) + 0.1 * rng.standard_normal(N)
+    return y, X, V, w
+
+
+@pytest.mark.parametrize("form", ["auto", "krs"])
+def test_row_shards_sum_to_the_whole_gram(L, form, monkeypatch):
+    """Partial problems over row shards built with the GLOBAL ranges: their Grams / right-hand sides add up to the
+    whole problem's (same basis centres), for the structured and the dense Gram form."""
+    monkeypatch.setenv("LPVS_GRAM_FORM", form)
+    y, X, V, w = _rowshard_signal()
+    Nv = 4
+    with L.Problem.lpv(y, X, V, w, Nv) as p:
+        G, b = p.get_gram()
+    ranges = L.lpv_ranges(X, V)
+    assert np.array_equal(ranges, [V.min(), V.max(), np.abs(V).max(), np.abs(X).max()])
+    cuts = [0, 1777, 4001, len(y)]
+    Gs, bs = np.zeros_like(G), np.zeros_like(b)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        with L.Problem.lpv_rows(y[lo:hi], X[lo:hi], V[lo:hi], w, Nv, ranges) as p:
+            Gr, br = p.get_gram()
+            Gs += Gr; bs += br
+    tol = 1e-12 + 4.5e-16 * np.abs(w).max() * np.abs(X).max()
+    assert np.abs(Gs - G).max() <= tol * np.abs(G).max()
+    assert np.abs(bs - b).max() <= tol * np.abs(b).max() * 10
+
+
+def _rowshard_rank(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the test box
+    import lpvspectral_jl_amd as L2
+    y, X, V, w = _rowshard_signal()
+    lo, hi = L2.sharding.shard_range(len(y), world, rank)
+    se = L2.ls_sparse_spectral_lpv_rowsharded(y[lo:hi], X[lo:hi], V[lo:hi], w, 4, λ=2.0, dist=dist, iters=300, tol=0.0, printerval=1000)
+    dist.barrier()
+    q.put((rank, np.asarray(se.x)))
+    dist.destroy_process_group()
+
+
+def test_row_sharded_solve_two_ranks_matches_single_process(L):
+    """ls_sparse_spectral_lpv_rowsharded on 2 ranks (gloo, host-staged all-reduce; RCCL on a multi-GPU node) returns
+    on every rank the coefficients of the single-process solve of the whole signal."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    y, X, V, w = _rowshard_signal()
+    ref = L.ls_sparse_spectral_lpv(y, X, V, w, 4, λ=2.0, iters=300, tol=0.0, printerval=1000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rowshard_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    [p.join(timeout=60) for p in procs]
+    scale = np.abs(ref.x).max()
+    assert np.array_equal(res[0][1], res[1][1])                      # replicated ADMM: identical on both ranks
+    assert np.abs(res[0][1] - ref.x).max() <= 1e-9 * scale
+    assert np.array_equal(np.abs(res[0][1]) > 0, np.abs(ref.x) > 0)  # same support

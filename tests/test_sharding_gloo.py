@@ -66,3 +66,41 @@ def test_shard_range_properties():
     assert sharding.shard_range(1024, 8, 3) == (384, 512)          # cfg4: 128 windows per GPU
     assert sharding.window_sample_span(384, 512, 65536, 0) == (384 * 65536, 512 * 65536)
     assert sharding.window_sample_span(1, 3, 10, 1) == (9, 28)     # windows start at 9 and 18, each 10 long
+
+
+# ---- sample rows of ONE signal sharded, partial Grams summed by one all-reduce -------------------
+def _row_worker(rank, world, port, N, Nf, Nv, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lpvspectral_jl_amd import sharding
+    from oracle import oracle as o
+    rng = np.random.default_rng(99)
+    X = np.sort(rng.uniform(0, 10, N)); V = rng.uniform(-1, 2, N); y = rng.standard_normal(N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) / 4
+    lo, hi = sharding.shard_range(N, world, rank)
+    Xs, Vs = X[lo:hi], V[lo:hi]
+    local = np.array([Vs.min(), Vs.max(), np.abs(Vs).max(), np.abs(Xs).max()])
+    ranges = sharding.allreduce_ranges(local, dist)
+    ok = np.array_equal(ranges, [V.min(), V.max(), np.abs(V).max(), np.abs(X).max()])
+    # rows of the regressor depend on the other rows only through the basis centres, i.e. through `ranges`
+    Phi = o.lpv_regressor(X, V, w, Nv)
+    Gr = torch.from_numpy(Phi[lo:hi].T @ Phi[lo:hi]); br = torch.from_numpy(Phi[lo:hi].T @ y[lo:hi])
+    sharding.allreduce_sum_(Gr, dist); sharding.allreduce_sum_(br, dist)
+    G = Phi.T @ Phi; b = Phi.T @ y
+    ok = ok and np.allclose(Gr.numpy(), G, rtol=0, atol=1e-12 * np.abs(G).max())
+    ok = ok and np.allclose(br.numpy(), b, rtol=0, atol=1e-12 * np.abs(b).max())
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_row_sharded_gram_exchange_two_ranks_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, 301, 6, 3, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] for r in res), res
