@@ -56,6 +56,23 @@ def solve(L, y, X, V, w, Nv, iters, device_index):
     return params, it, nxz, tm
 
 
+def solve_rowsharded(L, ys, Xs, Vs, w, Nv, iters, device_index, dist):
+    """--row-sharded: ONE signal, sample rows split over the ranks: partial Gram per rank, one RCCL
+    all-reduce of G and b, ADMM replicated."""
+    ranges = L.sharding.allreduce_ranges(L.lpv_ranges(Xs, Vs), dist)
+    with L.Problem.lpv_rows(ys, Xs, Vs, w, Nv, ranges, True, False, device=device_index) as p:
+        G, b = p.device_gram()
+        L.sharding.allreduce_sum_(G, dist)
+        L.sharding.allreduce_sum_(b, dist)
+        p.gram_modified()
+        p.set_prox(L.SlicedSeparableSum.frequency_groups(LAMBDA, len(w), 2 * Nv))
+        p.admm_init(None, μ=MU, tol=0.0)
+        it, nxz, conv = p.admm_run(iters)
+        params = p.params(0)
+        tm = p.timing()
+    return params, it, nxz, tm
+
+
 def cpu_baseline(log2n_sample=14, iters=6):
     """Faithful CPU form (dense Phi in memory, warm-started CG on the lazy Phi'Phi + I/mu, extra Phi*x per
     iteration) on a bounded sample: N_s = 2^14 rows at the full n = 8192, a few ADMM iterations; the cost
@@ -92,6 +109,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-path", action="store_true", help="skip the extra (untimed) dense-MFMA Gram measurement")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI, the judged path) or gloo (functional rehearsal)")
+    ap.add_argument("--row-sharded", action="store_true",
+                    help="strong-scaling variant: one signal per step, its sample rows sharded over the ranks (one all-reduce of the Gram)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: map every rank onto the visible GPUs modulo their count")
     args = ap.parse_args()
 
@@ -118,7 +137,12 @@ def main():
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective buffers live
 
     N = 1 << args.log2n
-    y, X, V, w = synth_signal(N, NF, rank, dev)          # inputs resident in HBM before the timed region
+    y, X, V, w = synth_signal(N, NF, 0 if args.row_sharded else rank, dev)   # inputs resident in HBM before the timed region
+    rowsh = args.row_sharded and world > 1
+    if rowsh:
+        lo, hi = L.sharding.shard_range(N, world, rank)
+        y, X, V = y[lo:hi].contiguous(), X[lo:hi].contiguous(), V[lo:hi].contiguous()
+    run = (lambda: solve_rowsharded(L, y, X, V, w, NV, args.iters, local, dist)) if rowsh else (lambda: solve(L, y, X, V, w, NV, args.iters, local))
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -127,14 +151,14 @@ def main():
             torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        solve(L, y, X, V, w, NV, args.iters, local)
+        run()
     sync()
     t0 = time.perf_counter()
     tms, params = [], None
     for _ in range(args.steps):
-        params, it, nxz, tm = solve(L, y, X, V, w, NV, args.iters, local)
+        params, it, nxz, tm = run()
         tms.append(tm)
-    if dist is not None:                                 # final gather of the coefficients (RCCL)
+    if dist is not None and not rowsh:                   # final gather of the coefficients (RCCL)
         mine = torch.view_as_real(torch.tensor(params, device=cdev)).contiguous()
         allp = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)
@@ -166,7 +190,7 @@ def main():
         # ---- the dense f64-MFMA Gram the library uses when w is NOT an arithmetic progression: measured once outside
         # the timed region (same inputs, LPVS_GRAM_FORM=krs) so both rooflines are on the record.
         general = None
-        if not args.no_general_path:
+        if not args.no_general_path and not rowsh:
             os.environ["LPVS_GRAM_FORM"] = "krs"
             try:
                 gt = None
@@ -189,13 +213,14 @@ def main():
                                "the matrix cores run at (issue ceiling measured by tools/mfma_f64_peak.hip: 66-67 TFLOP/s)"}
         out = {
             "metric": "signals/sec, ls_sparse_spectral_lpv group lasso N=2^%d Nf=%d Nv=%d (%d ADMM iters; iters/sec in admm_iters_per_sec)" % (args.log2n, NF, NV, args.iters),
-            "value": world * args.steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": args.steps,
+            "value": (1 if rowsh else world) * args.steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if rowsh else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg3: ls_sparse_spectral_lpv group-lasso N=2^%d Nf=%d Nv=%d n=%d lambda=%g mu=%g iters=%d tol=0, one signal per GPU"
                                    % (args.log2n, NF, NV, 2 * NF * NV, LAMBDA, MU, args.iters),
-                       "signals_per_step_per_gpu": 1, "gram_form": form,
-                       "final_gather": ("rccl" if args.backend == "nccl" else args.backend) + " all_gather" if world > 1 else "none"},
+                       "signals_per_step_per_gpu": 1.0 / world if rowsh else 1, "gram_form": form,
+                       "sharding": "sample rows of one signal over the ranks, one all-reduce of the Gram (SURVEY 8(e)(2))" if rowsh else "independent signals",
+                       "final_gather": "none" if (world == 1 or rowsh) else ("rccl" if args.backend == "nccl" else args.backend) + " all_gather"},
             "admm_iters_per_sec": args.iters / (phase["admm_ms"] * 1e-3),
             "phase_ms": phase,
             "final_nxz": nxz,

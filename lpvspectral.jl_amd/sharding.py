@@ -86,6 +86,9 @@ def allreduce_sum_(t, dist=None):
         t.copy_(h)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda:   # the library reads the result on its own streams: the collective must be complete
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
     return t
 
 
