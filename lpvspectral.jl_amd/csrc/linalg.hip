@@ -197,13 +197,15 @@ sweep_update_kernel(double *__restrict__ Aall, int64_t np, int k, const double *
 
 // ---- two-level sweep (one large matrix) ---------------------------------------------------------------------
 // The 64-wide sweep above streams the whole lower triangle once per 64 pivots (128 read-modify-write passes over
-// 268 MB at np = 8192: HBM-bound, ~17 TFLOP/s).  For large matrices the same sweep is applied with 256-wide pivot
-// blocks: the pivot block is inverted by the 64-wide sweep (recursion), the panel C = B P is one small MFMA GEMM,
-// and the trailing update A -= C B' has depth 256 (4x fewer passes over A, MFMA-bound, LDS-DMA staged like gram.hip).
-constexpr int KW = 256;                      // outer pivot width
-constexpr int RU_TM = 128, RU_TN = 256;      // trailing-update tile: rows x cols
+// 268 MB at np = 8192: HBM-bound, ~17 TFLOP/s).  For large matrices the same sweep is applied with 128-wide pivot
+// blocks (LPVS_KW=256: 256-wide, pivot block inverted by the 64-wide sweep): the pivot block is inverted by one
+// workgroup in registers, the panel C = B P is one small MFMA GEMM, and the trailing update A -= C B' has depth 128
+// (half the passes over A, MFMA-bound, LDS-DMA staged like gram.hip).
+constexpr int KW = 256;                      // largest outer pivot width (sizes the panel buffers)
+constexpr int RU_TM = 128, RU_TN = 128;      // trailing-update tile: rows x cols
 constexpr int RU_BK = 16;                    // pivots per LDS stage
-constexpr int RU_THREADS = 512;              // 8 waves: 2 (rows) x 4 (cols), 64x64 outputs each
+constexpr int RU_WN = RU_TN / 64;            // waves along the columns
+constexpr int RU_THREADS = 64 * 2 * RU_WN;   // 2 (rows) x RU_WN (cols) waves, 64x64 outputs each; 64 KiB of LDS -> two workgroups per CU
 
 __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -398,7 +400,7 @@ rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wave >> 2, wb = wave & 3;
+    const int wa = wave / RU_WN, wb = wave % RU_WN;
     // XCD-aware: the 8 XCDs are dealt consecutive blocks round-robin; give each a contiguous run of the tile list
     const int bq = ntiles / 8, br = ntiles % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;
     const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
@@ -417,15 +419,16 @@ rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, 
     };
     bool any = false;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) any = any || !dead(q >> 2, q & 3);
+    for (int q = 0; q < 2 * RU_WN; ++q) any = any || !dead(q / RU_WN, q % RU_WN);
     if (!any) return;
     const bool skip_wave = dead(wa, wb);
 
     constexpr int ROW = RU_TM + RU_TN, STAGE = RU_BK * ROW;
     double *buf0 = lds, *buf1 = lds + STAGE;
     auto stage_load = [&](double *buf, int s0) {
-        for (int p = wave; p < RU_BK * 3; p += RU_THREADS / 64) {   // piece = (pivot, part): 128 panel values
-            const int k = p / 3, part = p - k * 3;
+        constexpr int PARTS = 1 + RU_TN / 128;
+        for (int p = wave; p < RU_BK * PARTS; p += RU_THREADS / 64) {   // piece = (pivot, part): 128 panel values
+            const int k = p / PARTS, part = p - k * PARTS;
             const double *src = part == 0 ? Ck + (int64_t)(s0 + k) * ldp + a0 : Bk + (int64_t)(s0 + k) * ldp + b0 + (part - 1) * 128;
             glds16(src + 2 * lane, buf + p * 128);
         }
