@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-path", action="store_true", help="skip the extra (untimed) dense-MFMA Gram measurement")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI, the judged path) or gloo (functional rehearsal)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="f32: float32 inputs through the _f32 entry points (double assembly, single-precision copy of M streamed by "
+                         "the ADMM mat-vec); the judged line is f64")
     ap.add_argument("--row-sharded", action="store_true",
                     help="strong-scaling variant: one signal per step, its sample rows sharded over the ranks (one all-reduce of the Gram)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: map every rank onto the visible GPUs modulo their count")
@@ -138,6 +141,8 @@ def main():
 
     N = 1 << args.log2n
     y, X, V, w = synth_signal(N, NF, 0 if args.row_sharded else rank, dev)   # inputs resident in HBM before the timed region
+    if args.dtype == "f32":
+        y, X, V, w = (a.to(torch.float32) for a in (y, X, V, w))
     rowsh = args.row_sharded and world > 1
     if rowsh:
         lo, hi = L.sharding.shard_range(N, world, rank)
@@ -215,7 +220,7 @@ def main():
             "metric": "signals/sec, ls_sparse_spectral_lpv group lasso N=2^%d Nf=%d Nv=%d (%d ADMM iters; iters/sec in admm_iters_per_sec)" % (args.log2n, NF, NV, args.iters),
             "value": (1 if rowsh else world) * args.steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if rowsh else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if rowsh else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "cfg3: ls_sparse_spectral_lpv group-lasso N=2^%d Nf=%d Nv=%d n=%d lambda=%g mu=%g iters=%d tol=0, one signal per GPU"
                                    % (args.log2n, NF, NV, 2 * NF * NV, LAMBDA, MU, args.iters),
                        "signals_per_step_per_gpu": 1.0 / world if rowsh else 1, "gram_form": form,

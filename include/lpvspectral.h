@@ -197,6 +197,33 @@ int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out);
  * *bytes_per_launch = bytes of M the kernel streams per launch (tile-packed lower triangle, or the full matrix). */
 int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_launch, double *bytes_per_launch);
 
+/* ---- single-precision entry points ------------------------------------------------------
+ * The reference is eltype-generic (src/lasso.jl:85,91,144: Float32 inputs run in Float32).  The
+ * _f32 functions take and return float arrays (host or device).  Inputs are widened exactly to
+ * double; assembly, Gram and factorisation run in double (at least as accurate as a Float32 run
+ * of the reference); a handle created here streams a single-precision copy of (G + I/mu)^-1 in
+ * the ADMM mat-vec of large problems (half the bytes per iteration, double accumulation);
+ * outputs are rounded to float.  Handle functions without a type suffix (set_prox, admm_run,
+ * admm_status, timing, destroy, ...) are shared with the _f64 handles. */
+int32_t lpvs_check_freq_f32(const float *f, int64_t Nf, int64_t *zerofreq);
+int32_t lpvs_fourier_regressor_f32(const float *t, int64_t N, const float *f, int64_t Nf,
+                                   float *A_out, int64_t *zerofreq);
+int32_t lpvs_lpv_regressor_f32(const float *X, const float *V, int64_t N, const float *w, int64_t Nf,
+                               int64_t Nv, int32_t normalize, int32_t coulomb, int32_t permuted,
+                               float *Phi_out);
+int32_t lpvs_problem_create_fourier_f32(const float *y, const float *t, int64_t N, const float *f,
+                                        int64_t Nf, const float *W, int32_t device,
+                                        lpvs_problem **out);
+int32_t lpvs_problem_create_lpv_f32(const float *y, const float *X, const float *V, int64_t N,
+                                    const float *w, int64_t Nf, int64_t Nv, int32_t normalize,
+                                    int32_t coulomb, int32_t device, lpvs_problem **out);
+int32_t lpvs_admm_init_f32(lpvs_problem *h, const float *x0, double mu, double tol,
+                           int32_t linear_sign);
+int32_t lpvs_admm_get_f32(lpvs_problem *h, float *x_out, float *z_out, float *u_out);
+int32_t lpvs_problem_get_params_f32(lpvs_problem *h, int32_t which, float *re_out, float *im_out);
+int32_t lpvs_ls_spectral_f32(const float *y, const float *t, int64_t N, const float *f, int64_t Nf,
+                             double lam, int32_t device, float *re_out, float *im_out);
+
 /* ---- a15 window bookkeeping (DSP.arraysplit as used by src/windows.jl:27-36) ---------- */
 int32_t lpvs_window_count(int64_t L, int64_t n, int64_t noverlap, int64_t *count);
 int32_t lpvs_window_offsets(int64_t L, int64_t n, int64_t noverlap, int64_t *offsets /* 0-based */,

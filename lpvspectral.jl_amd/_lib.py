@@ -68,6 +68,15 @@ SIGNATURES = {
     "lpvs_problem_create_lpv_rows_f64": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I32, C.POINTER(_P)]),
     "lpvs_problem_device_gram_f64": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "lpvs_problem_gram_modified": (_I32, [_P]),
+    "lpvs_check_freq_f32": (_I32, [_P, _I64, C.POINTER(_I64)]),
+    "lpvs_fourier_regressor_f32": (_I32, [_P, _I64, _P, _I64, _P, C.POINTER(_I64)]),
+    "lpvs_lpv_regressor_f32": (_I32, [_P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P]),
+    "lpvs_problem_create_fourier_f32": (_I32, [_P, _P, _I64, _P, _I64, _P, _I32, C.POINTER(_P)]),
+    "lpvs_problem_create_lpv_f32": (_I32, [_P, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.POINTER(_P)]),
+    "lpvs_admm_init_f32": (_I32, [_P, _P, _F64, _F64, _I32]),
+    "lpvs_admm_get_f32": (_I32, [_P, _P, _P, _P]),
+    "lpvs_problem_get_params_f32": (_I32, [_P, _I32, _P, _P]),
+    "lpvs_ls_spectral_f32": (_I32, [_P, _P, _I64, _P, _I64, _F64, _I32, _P, _P]),
     "lpvs_admm_time_matvec": (_I32, [_P, _I32, C.POINTER(_F64), C.POINTER(_F64)]),
     "lpvs_admm_get_f64": (_I32, [_P, _P, _P, _P]),
     "lpvs_problem_get_params_f64": (_I32, [_P, _I32, _P, _P]),
@@ -156,6 +165,34 @@ def as_f64(a):
     if hasattr(a, "detach") and hasattr(a, "numpy"):  # CPU torch tensor
         a = a.detach().numpy()
     arr = np.asarray(a, dtype=np.float64)
+    arr = np.asfortranarray(arr) if arr.ndim == 2 else np.ascontiguousarray(arr)
+    return arr, C.c_void_p(arr.ctypes.data), arr.size
+
+
+def is_f32(a) -> bool:
+    """True for float32 numpy arrays / torch tensors: such inputs take the _f32 entry points (the reference is
+    eltype-generic, src/lasso.jl:85,91,144)."""
+    if a is None:
+        return False
+    if hasattr(a, "data_ptr") and hasattr(a, "dtype"):
+        import torch
+        return a.dtype == torch.float32
+    return isinstance(a, np.ndarray) and a.dtype == np.float32
+
+
+def as_f32(a):
+    """(keepalive, pointer, length) of a contiguous float32 vector/matrix (host numpy or device torch)."""
+    if a is None:
+        return None, None, 0
+    if is_device_array(a):
+        import torch
+        t = a.to(torch.float32)
+        t = t if t.is_contiguous() else t.contiguous()
+        torch.cuda.current_stream(t.device).synchronize()
+        return t, C.c_void_p(t.data_ptr()), t.numel()
+    if hasattr(a, "detach") and hasattr(a, "numpy"):
+        a = a.detach().numpy()
+    arr = np.asarray(a, dtype=np.float32)
     arr = np.asfortranarray(arr) if arr.ndim == 2 else np.ascontiguousarray(arr)
     return arr, C.c_void_p(arr.ctypes.data), arr.size
 

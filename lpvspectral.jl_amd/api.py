@@ -18,7 +18,7 @@ from typing import Any, Callable, Optional
 import numpy as np
 
 from . import _lib
-from ._lib import as_f64, check, lib, out_ptr
+from ._lib import as_f32, is_f32, as_f64, check, lib, out_ptr
 from .prox import IndBallL0, LeastSquares, NormL0, NormL1, NormL2, Quadratic, SlicedSeparableSum
 from .windows import Windows2, Windows3, rect
 
@@ -85,21 +85,28 @@ def _host(a):
 
 def check_freq(f):
     """src/lsfft.jl:20-24 -> ``None`` or 1; ValueError (ArgumentError) if zero is not first."""
-    fa = np.ascontiguousarray(_host(f))
     z = C.c_int64(0)
-    check(lib().lpvs_check_freq_f64(out_ptr(fa), len(fa), C.byref(z)))
+    if is_f32(f):
+        kf, pf, Nf = as_f32(f)
+        check(lib().lpvs_check_freq_f32(pf, Nf, C.byref(z)))
+    else:
+        fa = np.ascontiguousarray(_host(f))
+        check(lib().lpvs_check_freq_f64(out_ptr(fa), len(fa), C.byref(z)))
     return None if z.value == 0 else int(z.value)
 
 
 def get_fourier_regressor(t, f):
     """src/lsfft.jl:26-49 -> ``(A, zerofreq)`` with A an N×Nreg column-major numpy array."""
-    kt, pt, N = as_f64(t)
-    kf, pf, Nf = as_f64(f)
+    f32 = is_f32(t)                                   # eltype of t decides, as T does in src/lsfft.jl:26
+    conv = as_f32 if f32 else as_f64
+    kt, pt, N = conv(t)
+    kf, pf, Nf = conv(f)
     zf = check_freq(f)
     nreg = 2 * Nf - (1 if zf else 0)
-    A = np.zeros((N, nreg), order="F")
+    A = np.zeros((N, nreg), order="F", dtype=np.float32 if f32 else np.float64)
     z = C.c_int64(0)
-    check(lib().lpvs_fourier_regressor_f64(pt, N, pf, Nf, out_ptr(A), C.byref(z)))
+    fn = lib().lpvs_fourier_regressor_f32 if f32 else lib().lpvs_fourier_regressor_f64
+    check(fn(pt, N, pf, Nf, out_ptr(A), C.byref(z)))
     return A, zf
 
 
@@ -116,12 +123,15 @@ def basis_activation_func(V, Nv, normalize=True, coulomb=False):
 
 def lpv_regressor(X, V, w, Nv, normalize=True, coulomb=False, permuted=True):
     """Materialised Φ of src/lasso.jl:35-50 (tests / small problems; the solve never forms it)."""
-    kx, px, N = as_f64(X)
-    kv, pv, _ = as_f64(V)
-    kw, pw, Nf = as_f64(np.ravel(_host(w)) if not _lib.is_device_array(w) else w)
+    f32 = is_f32(X)
+    conv = as_f32 if f32 else as_f64
+    kx, px, N = conv(X)
+    kv, pv, _ = conv(V)
+    kw, pw, Nf = conv(np.ravel(_host(w)) if not _lib.is_device_array(w) else w)
     nb = 2 * Nv if coulomb else Nv
-    Phi = np.zeros((N, 2 * Nf * nb), order="F")
-    check(lib().lpvs_lpv_regressor_f64(px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), int(bool(permuted)), out_ptr(Phi)))
+    Phi = np.zeros((N, 2 * Nf * nb), order="F", dtype=np.float32 if f32 else np.float64)
+    fn = lib().lpvs_lpv_regressor_f32 if f32 else lib().lpvs_lpv_regressor_f64
+    check(fn(px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), int(bool(permuted)), out_ptr(Phi)))
     return Phi
 
 
@@ -142,6 +152,7 @@ class Problem:
     """Owner of one ``lpvs_problem`` handle (regressor + Gram resident on one MI355X)."""
 
     ns = 1   # signals sharing the regressor (lpv_multi)
+    f32 = False   # created from float32 inputs: float I/O, single-precision copy of M in the ADMM mat-vec
 
     def __init__(self, handle, kind):
         self._h = handle
@@ -153,29 +164,35 @@ class Problem:
     # constructors -----------------------------------------------------------------------
     @classmethod
     def fourier(cls, y, t, f, W=None, device=0):
-        ky, py, N = as_f64(y)
-        kt, pt, Nt = as_f64(t)
-        kf, pf, Nf = as_f64(f)
-        kw, pw, Nw = as_f64(W)
+        f32 = is_f32(y)
+        conv = as_f32 if f32 else as_f64
+        ky, py, N = conv(y)
+        kt, pt, Nt = conv(t)
+        kf, pf, Nf = conv(f)
+        kw, pw, Nw = conv(W)
         assert N == Nt, "y and t has to be the same length"
         assert W is None or Nw == N, "W has to be the same length as y"
         h = C.c_void_p()
-        check(lib().lpvs_problem_create_fourier_f64(py, pt, N, pf, Nf, pw, int(device), C.byref(h)))
+        fn = lib().lpvs_problem_create_fourier_f32 if f32 else lib().lpvs_problem_create_fourier_f64
+        check(fn(py, pt, N, pf, Nf, pw, int(device), C.byref(h)))
         p = cls(h, "fourier")
-        p.Nf = Nf
+        p.Nf, p.f32 = Nf, f32
         return p
 
     @classmethod
     def lpv(cls, y, X, V, w, Nv, normalize=True, coulomb=False, device=0):
-        ky, py, N = as_f64(y)
-        kx, px, Nx = as_f64(X)
-        kv, pv, Nvv = as_f64(V)
-        kw, pw, Nf = as_f64(w)
+        f32 = is_f32(y)                                  # Y::AbstractVector{S}, src/lasso.jl:27
+        conv = as_f32 if f32 else as_f64
+        ky, py, N = conv(y)
+        kx, px, Nx = conv(X)
+        kv, pv, Nvv = conv(V)
+        kw, pw, Nf = conv(w)
         assert N == Nx == Nvv, "y, X and V has to be the same length"
         h = C.c_void_p()
-        check(lib().lpvs_problem_create_lpv_f64(py, px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), int(device), C.byref(h)))
+        fn = lib().lpvs_problem_create_lpv_f32 if f32 else lib().lpvs_problem_create_lpv_f64
+        check(fn(py, px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), int(device), C.byref(h)))
         p = cls(h, "lpv")
-        p.Nf, p.nb = Nf, (2 * Nv if coulomb else Nv)
+        p.Nf, p.nb, p.f32 = Nf, (2 * Nv if coulomb else Nv), f32
         return p
 
     @classmethod
@@ -309,9 +326,10 @@ class Problem:
         check(lib().lpvs_problem_set_prox(self._h, kind, float(param), int(glen)))
 
     def admm_init(self, x0=None, μ=0.05, tol=1e-5, linear_sign=_lib.LINEAR_LEAST_SQUARES):
-        k0, p0, n0 = as_f64(x0)
+        k0, p0, n0 = (as_f32 if self.f32 else as_f64)(x0)
         assert x0 is None or n0 == self.n, "x0 has the wrong length"
-        check(lib().lpvs_admm_init_f64(self._h, p0, float(μ), float(tol), int(linear_sign)))
+        fn = lib().lpvs_admm_init_f32 if self.f32 else lib().lpvs_admm_init_f64
+        check(fn(self._h, p0, float(μ), float(tol), int(linear_sign)))
 
     def admm_run(self, max_iters):
         it, nxz, conv = C.c_int64(0), C.c_double(0), C.c_int32(0)
@@ -320,8 +338,9 @@ class Problem:
 
     def admm_get(self):
         shape = self.n if self.ns == 1 else (self.n, self.ns)
-        x, z, u = (np.zeros(shape, order="F") for _ in range(3))
-        check(lib().lpvs_admm_get_f64(self._h, out_ptr(x), out_ptr(z), out_ptr(u)))
+        x, z, u = (np.zeros(shape, order="F", dtype=np.float32 if self.f32 else np.float64) for _ in range(3))
+        fn = lib().lpvs_admm_get_f32 if self.f32 else lib().lpvs_admm_get_f64
+        check(fn(self._h, out_ptr(x), out_ptr(z), out_ptr(u)))
         return x, z, u
 
     def time_matvec(self, reps=200):
@@ -338,9 +357,11 @@ class Problem:
     def params(self, which=0):
         m = self.Nf * self.nb if self.kind == "lpv" else self.Nf
         shape = m if self.ns == 1 else (m, self.ns)
-        re, im = np.zeros(shape, order="F"), np.zeros(shape, order="F")
-        check(lib().lpvs_problem_get_params_f64(self._h, int(which), out_ptr(re), out_ptr(im)))
-        return re + 1j * im
+        dt = np.float32 if self.f32 else np.float64
+        re, im = np.zeros(shape, order="F", dtype=dt), np.zeros(shape, order="F", dtype=dt)
+        fn = lib().lpvs_problem_get_params_f32 if self.f32 else lib().lpvs_problem_get_params_f64
+        check(fn(self._h, int(which), out_ptr(re), out_ptr(im)))
+        return (re + 1j * im).astype(np.complex64 if self.f32 else np.complex128)
 
     def pack(self, coef):
         m = self.Nf * self.nb if self.kind == "lpv" else self.Nf
@@ -410,13 +431,17 @@ def ls_spectral(y, t, f=None, W=None, λ=1e-10, verbose=False, device=0):
     frequency grid on an even-length record has one more column than rows) -- identical minimiser, no SVD."""
     f = default_freqs(t) if f is None else f
     if W is None:
-        ky, py, N = as_f64(y)
-        kt, pt, Nt = as_f64(t)
-        kf, pf, Nf = as_f64(f)
+        f32 = is_f32(y)
+        conv = as_f32 if f32 else as_f64
+        ky, py, N = conv(y)
+        kt, pt, Nt = conv(t)
+        kf, pf, Nf = conv(f)
         assert N == Nt, "y and t has to be the same length"
-        re, im = np.zeros(Nf), np.zeros(Nf)
-        check(lib().lpvs_ls_spectral_f64(py, pt, N, pf, Nf, float(λ), int(device), out_ptr(re), out_ptr(im)))
-        return re + 1j * im, _host(f)
+        dt = np.float32 if f32 else np.float64
+        re, im = np.zeros(Nf, dtype=dt), np.zeros(Nf, dtype=dt)
+        fn = lib().lpvs_ls_spectral_f32 if f32 else lib().lpvs_ls_spectral_f64
+        check(fn(py, pt, N, pf, Nf, float(λ), int(device), out_ptr(re), out_ptr(im)))
+        return (re + 1j * im).astype(np.complex64 if f32 else np.complex128), _host(f)
     with Problem.fourier(y, t, f, W, device=device) as prob:
         x = prob.solve_ridge(λ)
         if verbose:

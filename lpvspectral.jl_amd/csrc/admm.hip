@@ -424,6 +424,29 @@ __device__ __forceinline__ void tile_index(int t, int &I, int &J) {
     J = t - I * (I + 1) / 2;
 }
 
+// single-precision copy of the packed tiles (streamed by the _f32 problems)
+__global__ void __launch_bounds__(256)
+pack_tiles_f32_kernel(const double *__restrict__ M, int64_t np, float *__restrict__ Mp) {
+    int I, J;
+    tile_index(blockIdx.x, I, J);
+    const double2 *src = reinterpret_cast<const double2 *>(M + (int64_t)I * TS * np + (int64_t)J * TS);
+    float2 *dst = reinterpret_cast<float2 *>(Mp + (int64_t)blockIdx.x * TS * TS);
+    for (int e = threadIdx.x; e < TS * TS / 2; e += 256) {
+        const int r = e / (TS / 2), c = e % (TS / 2);
+        const double2 v = src[(int64_t)r * (np / 2) + c];
+        dst[e] = make_float2((float)v.x, (float)v.y);
+    }
+}
+
+__global__ void __launch_bounds__(256) cvt_f32_f64_kernel(const float *__restrict__ src, double *__restrict__ dst, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dst[i] = (double)src[i];
+}
+__global__ void __launch_bounds__(256) cvt_f64_f32_kernel(const double *__restrict__ src, float *__restrict__ dst, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dst[i] = (float)src[i];
+}
+
 __global__ void __launch_bounds__(256)
 pack_tiles_kernel(const double *__restrict__ Mall, int64_t np, double *__restrict__ Mpall) {
     int I, J;
@@ -438,9 +461,16 @@ pack_tiles_kernel(const double *__restrict__ Mall, int64_t np, double *__restric
     }
 }
 
+template <typename T> struct Pair;
+template <> struct Pair<double> { typedef double2 type; };
+template <> struct Pair<float> { typedef float2 type; };
+
+// T = storage type of the packed matrix (double, or float for the _f32 problems); products and sums are double
+template <typename T>
 __global__ void __launch_bounds__(256)
-symv_tile_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
+symv_tile_kernel(const T *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
                  double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    typedef typename Pair<T>::type T2;
     if (status != nullptr) {   // nothing to do once every signal has converged
         bool all = true;
         for (int q = 0; q < ns; ++q) all = all && status[q].converged;
@@ -451,8 +481,8 @@ symv_tile_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs_a
     int I, J;
     tile_index(t, I, J);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double2 *base = reinterpret_cast<const double2 *>(Mp + (int64_t)t * TS * TS + wave * 32 * TS) + lane;
-    double2 m[32];   // the tile is read once and applied to every right-hand side
+    const T2 *base = reinterpret_cast<const T2 *>(Mp + (int64_t)t * TS * TS + wave * 32 * TS) + lane;
+    T2 m[32];   // the tile is read once and applied to every right-hand side
 #pragma unroll
     for (int r = 0; r < 32; ++r) m[r] = base[r * (TS / 2)];
     for (int sg = 0; sg < ns; ++sg) {
@@ -468,9 +498,10 @@ symv_tile_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs_a
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
             const double ri = sI[wave * 32 + r];
-            t0 = fma(m[r].x, ri, t0);
-            t1 = fma(m[r].y, ri, t1);
-            v[r] = fma(m[r].x, rj0, m[r].y * rj1);
+            const double mx = (double)m[r].x, my = (double)m[r].y;
+            t0 = fma(mx, ri, t0);
+            t1 = fma(my, ri, t1);
+            v[r] = fma(mx, rj0, my * rj1);
         }
         // halving butterfly: after the step with mask w a lane keeps the rows whose bit matches its own
 #pragma unroll
@@ -843,6 +874,27 @@ size_t symv_packed_doubles(int64_t np) {
     return (size_t)(nblk * (nblk + 1) / 2) * TS * TS;
 }
 
+int32_t launch_pack_tiles_f32(const double *M, int64_t np, float *Mp, hipStream_t s) {
+    const int nblk = (int)(np / TS);
+    hipLaunchKernelGGL(pack_tiles_f32_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, M, np, Mp);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_cvt_f32_f64(const float *src, double *dst, int64_t count, hipStream_t s) {
+    if (count <= 0) return LPVS_OK;
+    hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, src, dst, count);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_cvt_f64_f32(const double *src, float *dst, int64_t count, hipStream_t s) {
+    if (count <= 0) return LPVS_OK;
+    hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, src, dst, count);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s) {
     const int nblk = (int)(np / TS);
     hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, M, np, Mp);
@@ -863,7 +915,11 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s) {
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
     unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
-    hipLaunchKernelGGL(symv_tile_kernel, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
+    if (p.mp_f32)
+        hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,
+                           (int)ntiles, part1, part2, p.status);
+    else
+        hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     if (fused_ok(p)) {
         hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
     } else {
@@ -918,8 +974,12 @@ int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
             const int nblk = (int)(p.np / TS);
             const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
             double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * (unsigned)p.ns;
-            hipLaunchKernelGGL(symv_tile_kernel, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2,
-                               (const AdmmStatus *)nullptr);
+            if (p.mp_f32)
+                hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np,
+                                   p.ns, (int)ntiles, part1, part2, (const AdmmStatus *)nullptr);
+            else
+                hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2,
+                                   (const AdmmStatus *)nullptr);
         } else {
             launch_symv_raw(p.M, p.np, p.rhs, p.x, nullptr, p.ns, s);
         }

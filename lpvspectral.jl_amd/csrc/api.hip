@@ -219,6 +219,7 @@ struct lpvs_problem {
     double t_basis = 0, t_gram = 0, t_reduce = 0, t_factor = 0, t_admm = 0, gram_launches = 0, gram_flops = 0, admm_iters_timed = 0, gram_form = 0;
     EventPair ev[4];
     SweepAux sweep_aux;   // side stream + events of the factorisation's look-ahead
+    bool f32 = false;     // created through an _f32 entry point: the ADMM mat-vec streams a single-precision copy of M
     // launch-bound regime (small n): a chunk of ADMM iterations captured once into a hipGraph and replayed
     hipGraphExec_t admm_graph = nullptr;
     int64_t admm_graph_iters = 0;
@@ -782,8 +783,9 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     const bool had_M = h->M_valid && h->M_shift == 1.0 / mu && h->Mp.p != nullptr;
     LPVS_TRY(factorize(h, 1.0 / mu));
     if (h->np >= kSymmetricMinNp && !had_M) {   // tile-packed lower triangle for the half-traffic mat-vec
-        if (!h->Mp.p) LPVS_TRY(h->Mp.alloc(sizeof(double) * symv_packed_doubles(h->np)));
-        LPVS_TRY(launch_pack_tiles(h->M.as<double>(), h->np, h->Mp.as<double>(), s));
+        if (!h->Mp.p) LPVS_TRY(h->Mp.alloc((h->f32 ? sizeof(float) : sizeof(double)) * symv_packed_doubles(h->np)));
+        if (h->f32) LPVS_TRY(launch_pack_tiles_f32(h->M.as<double>(), h->np, h->Mp.as<float>(), s));
+        else LPVS_TRY(launch_pack_tiles(h->M.as<double>(), h->np, h->Mp.as<double>(), s));
     }
     LPVS_HIP(hipMemsetAsync(h->part.p, 0, h->part.bytes, s));   // zero the ticket / block norms
     h->mu = mu; h->tol = tol; h->sign = linear_sign;
@@ -799,6 +801,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
                  h->rhs.as<double>(), mu, tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
                  h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr, (int)h->ns};
+    p.mp_f32 = h->f32 ? 1 : 0;
     LPVS_TRY(launch_admm_init(p, s));
     LPVS_HIP(hipStreamSynchronize(s));
     h->inited = true;
@@ -813,6 +816,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
                  h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
                  h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr, (int)h->ns};
+    p.mp_f32 = h->f32 ? 1 : 0;
     const size_t ns = (size_t)h->ns;
     std::vector<AdmmStatus> st0(ns), st(ns);
     LPVS_HIP(hipMemcpyAsync(st0.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
@@ -873,13 +877,14 @@ int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_laun
     AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
                  h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
                  h->scratch.as<double>(), h->part.as<double>(), sym ? h->Mp.as<double>() : nullptr, (int)h->ns};
+    p.mp_f32 = h->f32 ? 1 : 0;
     LPVS_TRY(launch_admm_matvec_only(p, 3, s));   // warm
     LPVS_HIP(hipEventRecord(h->ev[1].a, s));
     LPVS_TRY(launch_admm_matvec_only(p, reps, s));
     LPVS_HIP(hipEventRecord(h->ev[1].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     *us_per_launch = h->ev[1].ms() * 1e3 / reps;
-    if (bytes_per_launch) *bytes_per_launch = sizeof(double) * (double)(sym ? symv_packed_doubles(h->np) : (size_t)h->np * (size_t)h->np);
+    if (bytes_per_launch) *bytes_per_launch = (sym && h->f32 ? sizeof(float) : sizeof(double)) * (double)(sym ? symv_packed_doubles(h->np) : (size_t)h->np * (size_t)h->np);
     return LPVS_OK;
 }
 
@@ -1171,6 +1176,149 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
 }
 
 // ---- window bookkeeping (host integer arithmetic; src/windows.jl:27-36, :57-70) ----------------
+
+// ---- single-precision entry points (src/lasso.jl:85,91,144: the reference is eltype-generic) -------------------------
+// Inputs are widened exactly to double, the assembly / Gram / factorisation run in double (at least as accurate as a
+// Float32 run of the reference), the ADMM mat-vec of large problems streams a single-precision copy of M (half the
+// bytes per iteration) with double accumulation, and outputs are rounded to float.
+namespace {
+
+// read-only float argument (host or device) widened into a device double buffer
+struct WideArg {
+    DevBuf buf;
+    double *p = nullptr;
+    int32_t set(const float *src, int64_t count, hipStream_t s) {
+        if (src == nullptr || count <= 0) { p = nullptr; return LPVS_OK; }
+        LPVS_TRY(buf.alloc(sizeof(double) * (size_t)count));
+        p = buf.as<double>();
+        if (is_device_ptr(src)) {
+            LPVS_TRY(launch_cvt_f32_f64(src, p, count, s));
+            LPVS_HIP(hipStreamSynchronize(s));
+        } else {
+            std::vector<double> h((size_t)count);
+            for (int64_t i = 0; i < count; ++i) h[(size_t)i] = (double)src[i];
+            LPVS_TRY(copy_to_device(p, h.data(), sizeof(double) * (size_t)count, s));
+        }
+        return LPVS_OK;
+    }
+};
+
+// float output (host or device) produced from a device double buffer
+int32_t narrow_out(float *dst, const double *src_dev, int64_t count, hipStream_t s) {
+    if (dst == nullptr || count <= 0) return LPVS_OK;
+    if (is_device_ptr(dst)) {
+        LPVS_TRY(launch_cvt_f64_f32(src_dev, dst, count, s));
+        LPVS_HIP(hipStreamSynchronize(s));
+        return LPVS_OK;
+    }
+    std::vector<double> h((size_t)count);
+    LPVS_TRY(copy_from_device(h.data(), src_dev, sizeof(double) * (size_t)count, s));
+    for (int64_t i = 0; i < count; ++i) dst[i] = (float)h[(size_t)i];
+    return LPVS_OK;
+}
+
+int32_t need_device() {
+    if (lpvs_device_count() == 0) { set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    return LPVS_OK;
+}
+
+}  // namespace
+
+int32_t lpvs_check_freq_f32(const float *f, int64_t Nf, int64_t *zerofreq) {
+    if (!f || Nf <= 0) { set_error("NULL argument or Nf <= 0"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    WideArg df; LPVS_TRY(df.set(f, Nf, nullptr));
+    return lpvs_check_freq_f64(df.p, Nf, zerofreq);
+}
+
+int32_t lpvs_fourier_regressor_f32(const float *t, int64_t N, const float *f, int64_t Nf, float *A_out, int64_t *zerofreq) {
+    if (!t || !f || !A_out || N <= 0 || Nf <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    WideArg dt, df; LPVS_TRY(dt.set(t, N, nullptr)); LPVS_TRY(df.set(f, Nf, nullptr));
+    int64_t zf = 0;
+    LPVS_TRY(lpvs_check_freq_f64(df.p, Nf, &zf));
+    const int64_t nreg = zf ? 2 * Nf - 1 : 2 * Nf;
+    DevBuf A; LPVS_TRY(A.alloc(sizeof(double) * (size_t)N * (size_t)nreg));
+    LPVS_TRY(lpvs_fourier_regressor_f64(dt.p, N, df.p, Nf, A.as<double>(), zerofreq));
+    return narrow_out(A_out, A.as<double>(), N * nreg, nullptr);
+}
+
+int32_t lpvs_lpv_regressor_f32(const float *X, const float *V, int64_t N, const float *w, int64_t Nf, int64_t Nv, int32_t normalize,
+                               int32_t coulomb, int32_t permuted, float *Phi_out) {
+    if (!X || !V || !w || !Phi_out || N <= 0 || Nf <= 0 || Nv <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    WideArg dX, dV, dw; LPVS_TRY(dX.set(X, N, nullptr)); LPVS_TRY(dV.set(V, N, nullptr)); LPVS_TRY(dw.set(w, Nf, nullptr));
+    const int64_t n = 2 * Nf * (coulomb ? 2 * Nv : Nv);
+    DevBuf P; LPVS_TRY(P.alloc(sizeof(double) * (size_t)N * (size_t)n));
+    LPVS_TRY(lpvs_lpv_regressor_f64(dX.p, dV.p, N, dw.p, Nf, Nv, normalize, coulomb, permuted, P.as<double>()));
+    return narrow_out(Phi_out, P.as<double>(), N * n, nullptr);
+}
+
+int32_t lpvs_problem_create_fourier_f32(const float *y, const float *t, int64_t N, const float *f, int64_t Nf, const float *W,
+                                        int32_t device, lpvs_problem **out) {
+    if (!y || !t || !f || N <= 0 || Nf <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    LPVS_HIP(hipSetDevice(device));
+    WideArg dy, dt, df, dW;
+    LPVS_TRY(dy.set(y, N, nullptr)); LPVS_TRY(dt.set(t, N, nullptr)); LPVS_TRY(df.set(f, Nf, nullptr)); LPVS_TRY(dW.set(W, N, nullptr));
+    LPVS_TRY(lpvs_problem_create_fourier_f64(dy.p, dt.p, N, df.p, Nf, dW.p, device, out));
+    (*out)->f32 = true;
+    return LPVS_OK;
+}
+
+int32_t lpvs_problem_create_lpv_f32(const float *y, const float *X, const float *V, int64_t N, const float *w, int64_t Nf, int64_t Nv,
+                                    int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out) {
+    if (!y || !X || !V || !w || N <= 0 || Nf <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    LPVS_HIP(hipSetDevice(device));
+    WideArg dy, dX, dV, dw;
+    LPVS_TRY(dy.set(y, N, nullptr)); LPVS_TRY(dX.set(X, N, nullptr)); LPVS_TRY(dV.set(V, N, nullptr)); LPVS_TRY(dw.set(w, Nf, nullptr));
+    LPVS_TRY(lpvs_problem_create_lpv_f64(dy.p, dX.p, dV.p, N, dw.p, Nf, Nv, normalize, coulomb, device, out));
+    (*out)->f32 = true;
+    return LPVS_OK;
+}
+
+int32_t lpvs_admm_init_f32(lpvs_problem *h, const float *x0, double mu, double tol, int32_t linear_sign) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    WideArg d0; LPVS_TRY(d0.set(x0, h->n * h->ns, h->stream));
+    return lpvs_admm_init_f64(h, d0.p, mu, tol, linear_sign);
+}
+
+int32_t lpvs_admm_get_f32(lpvs_problem *h, float *x_out, float *z_out, float *u_out) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    const int64_t cnt = h->n * h->ns;
+    DevBuf t; LPVS_TRY(t.alloc(sizeof(double) * (size_t)cnt * 3));
+    double *tx = t.as<double>(), *tz = tx + cnt, *tu = tz + cnt;
+    LPVS_TRY(lpvs_admm_get_f64(h, x_out ? tx : nullptr, z_out ? tz : nullptr, u_out ? tu : nullptr));
+    LPVS_TRY(narrow_out(x_out, tx, cnt, h->stream));
+    LPVS_TRY(narrow_out(z_out, tz, cnt, h->stream));
+    return narrow_out(u_out, tu, cnt, h->stream);
+}
+
+int32_t lpvs_problem_get_params_f32(lpvs_problem *h, int32_t which, float *re_out, float *im_out) {
+    if (!h || !re_out || !im_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    const int64_t m = (h->kind == 1 ? h->Nf * h->nb : h->Nf) * h->ns;
+    DevBuf t; LPVS_TRY(t.alloc(sizeof(double) * (size_t)m * 2));
+    LPVS_TRY(lpvs_problem_get_params_f64(h, which, t.as<double>(), t.as<double>() + m));
+    LPVS_TRY(narrow_out(re_out, t.as<double>(), m, h->stream));
+    return narrow_out(im_out, t.as<double>() + m, m, h->stream);
+}
+
+int32_t lpvs_ls_spectral_f32(const float *y, const float *t, int64_t N, const float *f, int64_t Nf, double lam, int32_t device,
+                             float *re_out, float *im_out) {
+    if (!y || !t || !f || !re_out || !im_out || N <= 0 || Nf <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    LPVS_HIP(hipSetDevice(device));
+    WideArg dy, dt, df; LPVS_TRY(dy.set(y, N, nullptr)); LPVS_TRY(dt.set(t, N, nullptr)); LPVS_TRY(df.set(f, Nf, nullptr));
+    DevBuf o; LPVS_TRY(o.alloc(sizeof(double) * (size_t)Nf * 2));
+    LPVS_TRY(lpvs_ls_spectral_f64(dy.p, dt.p, N, df.p, Nf, lam, device, o.as<double>(), o.as<double>() + Nf));
+    LPVS_TRY(narrow_out(re_out, o.as<double>(), Nf, nullptr));
+    return narrow_out(im_out, o.as<double>() + Nf, Nf, nullptr);
+}
+
 int32_t lpvs_window_count(int64_t L, int64_t n, int64_t noverlap, int64_t *count) {
     if (!count) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (noverlap < 0) noverlap = n >> 1;  // src/windows.jl:29

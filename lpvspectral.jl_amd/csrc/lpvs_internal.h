@@ -169,10 +169,15 @@ struct AdmmParams {
     double *part;      // symv_part_doubles(np) doubles of tile partials, or nullptr (full mat-vec)
     const double *Mp;  // tile-packed lower triangle of M (symv_packed_doubles(np)), or nullptr
     int ns;            // right-hand sides sharing M (signals of a shared-regressor batch); vectors are [ns][np]
+    int mp_f32 = 0;    // Mp holds float (the _f32 entry points: M is streamed in single precision, arithmetic stays double)
 };
 size_t symv_part_doubles(int64_t np, int64_t ns = 1);
 size_t symv_packed_doubles(int64_t np);
 int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s);
+int32_t launch_pack_tiles_f32(const double *M, int64_t np, float *Mp, hipStream_t s);
+// element conversions for the _f32 entry points (device buffers)
+int32_t launch_cvt_f32_f64(const float *src, double *dst, int64_t count, hipStream_t s);
+int32_t launch_cvt_f64_f32(const double *src, float *dst, int64_t count, hipStream_t s);
 constexpr int64_t kSymmetricMinNp = 2048;  // below this the iteration is launch-latency bound: plain mat-vec
 // batch of nbatch independent problems of one shape: arrays are [nbatch][np] (matrices [nbatch][np][np])
 struct AdmmBatch {
