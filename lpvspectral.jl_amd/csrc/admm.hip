@@ -728,6 +728,66 @@ admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1_all, con
     }
 }
 
+
+// Small systems of a batch (np <= 1024, e.g. the windows of ls_windowpsd): ONE workgroup per problem does what
+// admm_fused_update_kernel does with nblk workgroups -- thread group g (128 lanes) owns row block g -- so the norm
+// ||x-z|| needs no cross-workgroup ticket (no agent-scope fences, no atomics).  blockDim = 128 * nblk.
+__global__ void __launch_bounds__(1024)
+admm_window_update_kernel(AdmmParams p, const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk, int ntiles) {
+    const int sg = blockIdx.x;
+    AdmmStatus *status = p.status + sg;
+    if (status->converged) return;
+    __shared__ double sq[8 * TS], gs[8 * TS], wsum_s[16];
+    const double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
+    const int I = threadIdx.x >> 7, i = threadIdx.x & 127;
+    const int64_t li_ = (int64_t)I * TS + i, gi = (int64_t)sg * p.np + li_;
+    const bool ok = li_ < p.n;
+    const double ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;
+    double a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        a[e] = e < nblk ? (e <= I ? part1[((int64_t)I * (I + 1) / 2 + e) * TS + i] : part2[((int64_t)e * (e + 1) / 2 + I) * TS + i]) : 0.0;
+    double xi = a[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) xi += a[e];                    // fixed order: tile column 0, 1, ...
+    const double v = xi + ui;
+    double zi = 0.0;
+    if (p.prox_kind == LPVS_PROX_L1) {
+        const double gl = p.mu * p.prox_param;
+        zi = v + (v <= -gl ? gl : (v >= gl ? -gl : -v));
+    } else if (p.prox_kind == LPVS_PROX_L0) {
+        zi = fabs(v) > sqrt(2.0 * p.mu * p.prox_param) ? v : 0.0;
+    } else {  // group: block soft-threshold, norms through LDS (128 % group_len == 0)
+        const int gl = (int)p.group_len;
+        sq[threadIdx.x] = v * v;
+        __syncthreads();
+        if (i < TS / gl) {
+            double s2 = 0;
+            for (int q = 0; q < gl; ++q) s2 += sq[I * TS + i * gl + q];
+            double scale = 1.0 - p.prox_param * p.mu / sqrt(s2);
+            if (!(scale > 0)) scale = 0.0;
+            gs[I * TS + i] = scale;
+        }
+        __syncthreads();
+        zi = gs[I * TS + i / gl] * v;
+    }
+    if (!ok) zi = 0.0;
+    const double d = xi - zi, un = ui + d;                       // src/lasso.jl:154-155
+    p.x[gi] = xi; p.z[gi] = zi; p.u[gi] = un;
+    p.rhs[gi] = ok ? bi + (zi - un) / p.mu : 0.0;
+    const double w = wave_sum(ok ? d * d : 0.0);
+    if ((threadIdx.x & 63) == 0) wsum_s[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0;
+        for (int q = 0; q < 2 * nblk; ++q) tot += wsum_s[q];     // wave order = row order
+        const double nxz = sqrt(tot);                            // norm(tmp)   src/lasso.jl:157
+        status->iters += 1;
+        status->nxz = nxz;
+        if (nxz < p.tol) status->converged = 1;                  //             src/lasso.jl:164
+    }
+}
+
 // ---- batch of independent small problems (windows of ls_windowpsd): problem q = blockIdx.y ----------------
 __global__ void __launch_bounds__(256)
 admm_batch_init_kernel(AdmmBatch p) {
@@ -847,7 +907,10 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
         for (int64_t i = 0; i < iters; ++i) {
             hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
                                (int)ntiles, part1, part2, p.status);
-            hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, q, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
+            if (nblk <= 8)
+                hipLaunchKernelGGL(admm_window_update_kernel, dim3(ns), dim3((unsigned)(TS * nblk)), 0, s, q, part1, part2, nblk, (int)ntiles);
+            else
+                hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, q, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
         }
     } else {
         for (int64_t i = 0; i < iters; ++i) {

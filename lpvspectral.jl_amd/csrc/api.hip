@@ -452,6 +452,52 @@ int32_t lpvs_lpv_regressor_f64(const double *X, const double *V, int64_t N, cons
     return dP.finish(s);
 }
 
+// Slot tables of the structured Gram (nudft.hip) for frequencies w_f = a + f*D + eps_f: exact progressions in
+// double-double, each family padded to a multiple of 8:
+//   [0, nf8): m*D (differences), [nf8, nf8+s8): 2a + s*D (sums); the right-hand side uses a + f*D, f < nf8.
+struct ApSlots {
+    bool ok = false;
+    double emax = 0;
+    int64_t nf8 = 0, s8 = 0, nsl = 0;
+    std::vector<double> eps, om_hi, om_lo, omr_hi, omr_lo;
+    ApStep step{};
+};
+static ApSlots make_ap_slots(const std::vector<double> &hw, double xam) {
+    ApSlots sl;
+    const int64_t Nf = (int64_t)hw.size();
+    const long double a0 = hw[0], D = Nf > 1 ? ((long double)hw[Nf - 1] - (long double)hw[0]) / (long double)(Nf - 1) : 0.0L;
+    sl.eps.resize((size_t)Nf);
+    for (int64_t f = 0; f < Nf; ++f) {
+        sl.eps[f] = (double)((long double)hw[f] - (a0 + (long double)f * D));
+        sl.emax = std::fmax(sl.emax, std::fabs(sl.eps[f]));
+    }
+    sl.ok = std::isfinite(sl.emax) && std::isfinite(xam) && sl.emax * xam <= 1e-7;   // second-order term (eps x)^2/2 <= 5e-15
+    if (!sl.ok) return sl;
+    sl.nf8 = round_up(Nf, 8); sl.s8 = round_up(2 * Nf - 1, 8); sl.nsl = sl.nf8 + sl.s8;
+    auto split = [](long double v, double &hi, double &lo) { hi = (double)v; lo = (double)(v - (long double)hi); };
+    sl.om_hi.resize((size_t)sl.nsl); sl.om_lo.resize((size_t)sl.nsl); sl.omr_hi.resize((size_t)sl.nf8); sl.omr_lo.resize((size_t)sl.nf8);
+    for (int64_t m = 0; m < sl.nf8; ++m) split((long double)m * D, sl.om_hi[m], sl.om_lo[m]);
+    for (int64_t q = 0; q < sl.s8; ++q) split(2.0L * a0 + (long double)q * D, sl.om_hi[sl.nf8 + q], sl.om_lo[sl.nf8 + q]);
+    for (int64_t f = 0; f < sl.nf8; ++f) split(a0 + (long double)f * D, sl.omr_hi[f], sl.omr_lo[f]);
+    for (int b = 0; b < 8; ++b) split((long double)b * D, sl.step.hi[b], sl.step.lo[b]);
+    return sl;
+}
+// device copies of the slot tables
+struct ApSlotsDev {
+    DevBuf hi, lo, rhi, rlo, eps;
+    int32_t upload(const ApSlots &sl, hipStream_t s) {
+        LPVS_TRY(hi.alloc(sizeof(double) * (size_t)sl.nsl)); LPVS_TRY(lo.alloc(sizeof(double) * (size_t)sl.nsl));
+        LPVS_TRY(rhi.alloc(sizeof(double) * (size_t)sl.nf8)); LPVS_TRY(rlo.alloc(sizeof(double) * (size_t)sl.nf8));
+        LPVS_TRY(eps.alloc(sizeof(double) * sl.eps.size()));
+        LPVS_TRY(copy_to_device(hi.p, sl.om_hi.data(), sizeof(double) * (size_t)sl.nsl, s));
+        LPVS_TRY(copy_to_device(lo.p, sl.om_lo.data(), sizeof(double) * (size_t)sl.nsl, s));
+        LPVS_TRY(copy_to_device(rhi.p, sl.omr_hi.data(), sizeof(double) * (size_t)sl.nf8, s));
+        LPVS_TRY(copy_to_device(rlo.p, sl.omr_lo.data(), sizeof(double) * (size_t)sl.nf8, s));
+        LPVS_TRY(copy_to_device(eps.p, sl.eps.data(), sizeof(double) * sl.eps.size(), s));
+        return LPVS_OK;
+    }
+};
+
 // ranges (optional) = {min V, max V, max|V|, max|X|} over ALL rows of the signal when (y, X, V) is only a row shard of it
 static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
                                int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out,
@@ -478,40 +524,23 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     const char *form_env = getenv("LPVS_GRAM_FORM");
     const std::string form = form_env ? form_env : "auto";
     bool use_ap = false;
-    std::vector<double> hw, heps, om_hi, om_lo, omr_hi, omr_lo;
-    ApStep step{};
-    int64_t nf8 = 0;
+    ApSlots sl;
     if (form == "auto" || form == "ap") {
+        std::vector<double> hw;
         LPVS_TRY(fetch_host(hw, w, Nf));
         double xlo, xhi, xam;
         if (ranges) xam = ranges[3];
         else LPVS_TRY(device_minmax(dX.p, N, &xlo, &xhi, &xam, s));
-        const long double a0 = hw[0], D = Nf > 1 ? ((long double)hw[Nf - 1] - (long double)hw[0]) / (long double)(Nf - 1) : 0.0L;
-        heps.resize((size_t)Nf);
-        double emax = 0;
-        for (int64_t f = 0; f < Nf; ++f) {
-            heps[f] = (double)((long double)hw[f] - (a0 + (long double)f * D));
-            emax = std::fmax(emax, std::fabs(heps[f]));
-        }
-        use_ap = std::isfinite(emax) && emax * xam <= 1e-7;
-        if (form == "ap" && !use_ap) { set_error("LPVS_GRAM_FORM=ap but w is not an arithmetic progression (max|eps|*max|x| = %.3g)", emax * xam); return LPVS_EARGUMENT; }
-        if (use_ap) {
-            // slot tables, exact progressions in double-double, each family padded to a multiple of 8:
-            //   [0, Nf8): m*D (differences), [Nf8, Nf8+S8): 2a + s*D (sums); the rhs uses a + f*D, f < Nf8
-            nf8 = round_up(Nf, 8);
-            const int64_t s8 = round_up(2 * Nf - 1, 8), nsl = nf8 + s8;
-            auto split = [](long double v, double &hi, double &lo) { hi = (double)v; lo = (double)(v - (long double)hi); };
-            om_hi.resize((size_t)nsl); om_lo.resize((size_t)nsl); omr_hi.resize((size_t)nf8); omr_lo.resize((size_t)nf8);
-            for (int64_t m = 0; m < nf8; ++m) split((long double)m * D, om_hi[m], om_lo[m]);
-            for (int64_t q = 0; q < s8; ++q) split(2.0L * a0 + (long double)q * D, om_hi[nf8 + q], om_lo[nf8 + q]);
-            for (int64_t f = 0; f < nf8; ++f) split(a0 + (long double)f * D, omr_hi[f], omr_lo[f]);
-            for (int b = 0; b < 8; ++b) split((long double)b * D, step.hi[b], step.lo[b]);
-        }
+        sl = make_ap_slots(hw, xam);
+        use_ap = sl.ok;
+        if (form == "ap" && !use_ap) { set_error("LPVS_GRAM_FORM=ap but w is not an arithmetic progression (max|eps|*max|x| = %.3g)", sl.emax * xam); return LPVS_EARGUMENT; }
     }
     if (use_ap) {
-        const int64_t s8 = round_up(2 * Nf - 1, 8), nsl = nf8 + s8, P = nb * (nb + 1) / 2;
+        const int64_t nf8 = sl.nf8, nsl = sl.nsl, P = nb * (nb + 1) / 2;
+        const ApStep &step = sl.step;
         double lo, hi, am, gamma; std::vector<double> vc;
-        DevBuf K, KK, dvc, dhi, dlo, drhi, drlo, deps, part, tab, tabb;
+        DevBuf K, KK, dvc, part, tab, tabb;
+        ApSlotsDev sd;
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
         if (ranges) { lo = ranges[0]; hi = ranges[1]; am = ranges[2]; }
         else LPVS_TRY(device_minmax(dV.p, N, &lo, &hi, &am, s));
@@ -523,26 +552,19 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         LPVS_TRY(KK.alloc(sizeof(double) * (size_t)N * (size_t)P));
         LPVS_TRY(launch_basis_table(dV.p, N, dvc.as<double>(), nb, gamma, normalize, coulomb, K.as<double>(), ldk, s));
         LPVS_TRY(launch_pair_table(K.as<double>(), ldk, nb, N, KK.as<double>(), s));
-        LPVS_TRY(dhi.alloc(sizeof(double) * (size_t)nsl)); LPVS_TRY(dlo.alloc(sizeof(double) * (size_t)nsl));
-        LPVS_TRY(drhi.alloc(sizeof(double) * (size_t)nf8)); LPVS_TRY(drlo.alloc(sizeof(double) * (size_t)nf8));
-        LPVS_TRY(deps.alloc(sizeof(double) * (size_t)Nf));
-        LPVS_TRY(copy_to_device(dhi.p, om_hi.data(), sizeof(double) * (size_t)nsl, s));
-        LPVS_TRY(copy_to_device(dlo.p, om_lo.data(), sizeof(double) * (size_t)nsl, s));
-        LPVS_TRY(copy_to_device(drhi.p, omr_hi.data(), sizeof(double) * (size_t)nf8, s));
-        LPVS_TRY(copy_to_device(drlo.p, omr_lo.data(), sizeof(double) * (size_t)nf8, s));
-        LPVS_TRY(copy_to_device(deps.p, heps.data(), sizeof(double) * (size_t)Nf, s));
+        LPVS_TRY(sd.upload(sl, s));
         LPVS_HIP(hipEventRecord(h->ev[0].b, s));
         LPVS_TRY(part.alloc(std::max(nudft_partial_bytes(N, nsl, P), nudft_partial_bytes(N, nf8, nb))));
         LPVS_TRY(tab.alloc(sizeof(double) * (size_t)nsl * (size_t)P * 4));
         LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)nf8 * (size_t)nb * 4));
         LPVS_HIP(hipEventRecord(h->ev[1].a, s));
-        LPVS_TRY(launch_nudft(dX.p, nullptr, N, KK.as<double>(), P, (int)P, dhi.as<double>(), dlo.as<double>(), (int)nsl, step, part.as<double>(), tab.as<double>(), s));
-        LPVS_TRY(launch_ap_assemble(tab.as<double>(), deps.as<double>(), Nf, nf8, nb, h->n, h->G.as<double>(), h->np, s));
+        LPVS_TRY(launch_nudft(dX.p, nullptr, N, KK.as<double>(), P, (int)P, sd.hi.as<double>(), sd.lo.as<double>(), (int)nsl, step, part.as<double>(), tab.as<double>(), s));
+        LPVS_TRY(launch_ap_assemble(tab.as<double>(), sd.eps.as<double>(), Nf, nf8, nb, h->n, h->G.as<double>(), h->np, s));
         LPVS_HIP(hipEventRecord(h->ev[1].b, s));
         LPVS_HIP(hipEventRecord(h->ev[2].a, s));
         for (int64_t q = 0; q < ns; ++q) {   // b_q = Phi' y_q: Nf slots a + f*D, weights y K_j, first-order eps correction
-            LPVS_TRY(launch_nudft(dX.p, dy.p + q * N, N, K.as<double>(), ldk, (int)nb, drhi.as<double>(), drlo.as<double>(), (int)nf8, step, part.as<double>(), tabb.as<double>(), s));
-            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), deps.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
+            LPVS_TRY(launch_nudft(dX.p, dy.p + q * N, N, K.as<double>(), ldk, (int)nb, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)nf8, step, part.as<double>(), tabb.as<double>(), s));
+            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), sd.eps.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
         }
         LPVS_HIP(hipEventRecord(h->ev[2].b, s));
         LPVS_HIP(hipStreamSynchronize(s));
@@ -658,6 +680,53 @@ int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_
     h->kind = 0; h->N = N; h->Nf = Nf; h->zerofreq = zf; h->n = zf ? 2 * Nf - 1 : 2 * Nf;
     DevArg dt, df;
     LPVS_TRY(dt.set(t, N, s)); LPVS_TRY(df.set(f, Nf, s));
+    // structured Gram when T(2pi)*f is an arithmetic progression (default_freqs and every grid of the reference's tests)
+    const char *form_env = getenv("LPVS_GRAM_FORM");
+    const std::string form = form_env ? form_env : "auto";
+    if (form == "auto" || form == "ap") {
+        std::vector<double> hw;
+        LPVS_TRY(fetch_host(hw, f, Nf));
+        for (auto &v : hw) v = 6.283185307179586 * v;          // rounded as the regressor kernel does (src/lsfft.jl:33)
+        double tlo, thi, tam;
+        LPVS_TRY(device_minmax(dt.p, N, &tlo, &thi, &tam, s));
+        const ApSlots sl = make_ap_slots(hw, tam);
+        if (form == "ap" && !sl.ok) { set_error("LPVS_GRAM_FORM=ap but 2*pi*f is not an arithmetic progression (max|eps|*max|t| = %.3g)", sl.emax * tam); return LPVS_EARGUMENT; }
+        if (sl.ok) {
+            h->np = round_up(h->n, 128);
+            DevArg dy, dW;
+            LPVS_TRY(dy.set(y, N, s));
+            if (W) LPVS_TRY(dW.set(W, N, s));
+            LPVS_TRY(h->G.alloc(sizeof(double) * (size_t)h->np * (size_t)h->np));
+            LPVS_TRY(h->b.alloc(sizeof(double) * (size_t)h->np));
+            LPVS_HIP(hipMemsetAsync(h->G.p, 0, h->G.bytes, s));
+            LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
+            LPVS_TRY(alloc_state(h));
+            ApSlotsDev sd; DevBuf part, tab, tabb;
+            LPVS_HIP(hipEventRecord(h->ev[0].a, s));
+            LPVS_TRY(sd.upload(sl, s));
+            LPVS_HIP(hipEventRecord(h->ev[0].b, s));
+            LPVS_TRY(part.alloc(nudft_partial_bytes(N, sl.nsl, 1)));
+            LPVS_TRY(tab.alloc(sizeof(double) * (size_t)sl.nsl * 4));
+            LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)sl.nf8 * 4));
+            const double *Wd = W ? dW.p : nullptr;               // A' diag(W) A and A' (W .* y), src/lasso.jl:119-120
+            LPVS_HIP(hipEventRecord(h->ev[1].a, s));
+            LPVS_TRY(launch_nudft(dt.p, nullptr, N, Wd, 1, 1, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, part.as<double>(), tab.as<double>(), s));
+            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.nf8, (int)zf, h->n, h->G.as<double>(), h->np, 1, 0, 0, s));
+            LPVS_HIP(hipEventRecord(h->ev[1].b, s));
+            LPVS_HIP(hipEventRecord(h->ev[2].a, s));
+            LPVS_TRY(launch_nudft(dt.p, dy.p, N, Wd, 1, 1, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, part.as<double>(), tabb.as<double>(), s));
+            LPVS_TRY(launch_ap_rhs_fourier(tabb.as<double>(), sd.eps.as<double>(), Nf, (int)zf, h->b.as<double>(), 1, 0, 0, s));
+            LPVS_HIP(hipEventRecord(h->ev[2].b, s));
+            LPVS_HIP(hipStreamSynchronize(s));
+            h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
+            h->gram_launches = 8.0 * (double)N * (double)sl.nsl;
+            h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
+            h->gram_form = 4;
+            guard.h = nullptr;
+            *out = h;
+            return LPVS_OK;
+        }
+    }
     LPVS_TRY(create_panel_problem(h, y, W, N, [&](double *P, int64_t ld) {
         return launch_fourier_panel(dt.p, N, df.p, Nf, (int)zf, P, ld, s);
     }));
@@ -1068,16 +1137,40 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
     if (bw < 1) bw = 1;
     if (bw > nwin) bw = nwin;
     if (bw > 8192) bw = 8192;
-    const GramPlan pl = make_gram_plan(nreg, n, bw);
-    const int64_t nrows = pl.ksplit * pl.rows_per_chunk;
-    const size_t panel_bytes = sizeof(double) * (size_t)nrows * (size_t)ld;
-    while (bw > 1 && panel_bytes * (size_t)bw > budget) --bw;
-
     // the part of y, t this call touches
     const int64_t step = n - noverlap, s0 = win_lo * step, s1 = (win_hi - 1) * step + n;
     DevArg dy, dt, df;
     LPVS_TRY(dy.set(y, L, s)); LPVS_TRY(dt.set(t, L, s)); LPVS_TRY(df.set(freqs, Nf, s));
     (void)s0; (void)s1;
+    // structured Gram (nudft.hip) when T(2pi)*freqs is an arithmetic progression: no regressor panels at all
+    ApSlots sl;
+    {
+        const char *form_env = getenv("LPVS_GRAM_FORM");
+        const std::string form = form_env ? form_env : "auto";
+        if (form == "auto" || form == "ap") {
+            std::vector<double> hw;
+            LPVS_TRY(fetch_host(hw, freqs, Nf));
+            for (auto &v : hw) v = 6.283185307179586 * v;
+            double tlo, thi, tam;
+            LPVS_TRY(device_minmax(dt.p, L, &tlo, &thi, &tam, s));
+            sl = make_ap_slots(hw, tam);
+            if (form == "ap" && !sl.ok) { set_error("LPVS_GRAM_FORM=ap but 2*pi*freqs is not an arithmetic progression (max|eps|*max|t| = %.3g)", sl.emax * tam); return LPVS_EARGUMENT; }
+        }
+    }
+    const bool ap = sl.ok;
+    if (ap) {   // windows per pass bounded by the matrices (M, packed M, work): 32 GiB
+        bw = (int64_t)(((size_t)32 << 30) / (sizeof(double) * (size_t)np * (size_t)np * 2));
+        if (bw < 1) bw = 1;
+        if (bw > nwin) bw = nwin;
+        if (bw > 8192) bw = 8192;
+    }
+    const GramPlan pl = make_gram_plan(nreg, n, bw);
+    const int64_t nrows = ap ? n : pl.ksplit * pl.rows_per_chunk;
+    const size_t panel_bytes = ap ? 0 : sizeof(double) * (size_t)nrows * (size_t)ld;
+    while (!ap && bw > 1 && panel_bytes * (size_t)bw > budget) --bw;
+    // structured form: every window is cut into segments of rpcw samples, one workgroup row per segment
+    const int64_t rpcw = ap ? std::min<int64_t>(n, nudft_rows_per_chunk(n * bw, sl.nsl)) : 0;
+    const int spw = ap ? (int)ceil_div(n, rpcw) : 0;
     DevBuf Wp;
     const double *Wdev = nullptr;
     if (W != nullptr) {
@@ -1087,20 +1180,30 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         Wdev = Wp.as<double>();
     }
     PhaseTrace tr(s);
-    DevBuf P, slab, M, bvec, x, z, u, rhs, status, work, istat, offs, scr, part, Mp;
-    LPVS_TRY(P.alloc(panel_bytes * (size_t)bw));
+    DevBuf P, slab, M, bvec, x, z, u, rhs, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb;
+    ApSlotsDev sd;
+    if (ap) {
+        LPVS_TRY(sd.upload(sl, s));
+        LPVS_TRY(seg.alloc(sizeof(int64_t) * 3 * (size_t)bw * (size_t)spw));
+        LPVS_TRY(npart.alloc(sizeof(double) * (size_t)bw * (size_t)spw * (size_t)sl.nsl * 4));
+        LPVS_TRY(tab.alloc(sizeof(double) * (size_t)bw * (size_t)sl.nsl * 4));
+        LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)bw * (size_t)sl.nf8 * 4));
+    } else {
+        LPVS_TRY(P.alloc(panel_bytes * (size_t)bw));
+        LPVS_TRY(slab.alloc(pl.slab_bytes * (size_t)bw));
+    }
     LPVS_TRY(part.alloc(sizeof(double) * symv_part_doubles(np, bw)));
     LPVS_TRY(Mp.alloc(sizeof(double) * symv_packed_doubles(np) * (size_t)bw));
-    LPVS_TRY(slab.alloc(pl.slab_bytes * (size_t)bw));
     LPVS_TRY(M.alloc(sizeof(double) * (size_t)np * (size_t)np * (size_t)bw));
     const size_t vb = sizeof(double) * (size_t)np * (size_t)bw;
     LPVS_TRY(bvec.alloc(vb)); LPVS_TRY(x.alloc(vb)); LPVS_TRY(z.alloc(vb)); LPVS_TRY(u.alloc(vb)); LPVS_TRY(rhs.alloc(vb));
     LPVS_TRY(status.alloc(sizeof(AdmmStatus) * (size_t)bw)); LPVS_TRY(istat.alloc(sizeof(int) * (size_t)bw));
     LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)bw));
     LPVS_TRY(offs.alloc(sizeof(int64_t) * (size_t)bw));
-    LPVS_TRY(scr.alloc(rhs_scratch_bytes(n, nreg) * (size_t)bw));
+    if (!ap) LPVS_TRY(scr.alloc(rhs_scratch_bytes(n, nreg) * (size_t)bw));
 
     tr.mark("alloc");
+    std::vector<int64_t> hseg((size_t)3 * (size_t)bw * (size_t)spw);
     std::vector<double> S((size_t)Nf, 0.0), zh((size_t)np * (size_t)bw), re((size_t)Nf), im((size_t)Nf);
     std::vector<int64_t> hoff((size_t)bw);
     std::vector<AdmmStatus> hst((size_t)bw);
@@ -1113,15 +1216,36 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         const int nb_ = (int)((nwin - w0 < bw) ? nwin - w0 : bw);
         for (int q = 0; q < nb_; ++q) hoff[q] = (win_lo + w0 + q) * step;           // arraysplit offsets, src/windows.jl:33
         LPVS_HIP(hipMemcpyAsync(offs.p, hoff.data(), sizeof(int64_t) * (size_t)nb_, hipMemcpyHostToDevice, s));
-        LPVS_TRY(launch_window_panels(dt.p, offs.as<int64_t>(), nb_, n, nrows, df.p, Nf, (int)zf, P.as<double>(), ld, s));
-        tr.mark("panels");
-        LPVS_TRY(launch_gram_panel_batch(pl, nb_, P.as<double>(), nrows * ld, ld, Wdev, slab.as<double>(), s));
-        tr.mark("gram");
-        LPVS_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
-        LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
-        LPVS_TRY(launch_gram_reduce_batch(pl, nb_, slab.as<double>(), M.as<double>(), np, s));     // Q = A'WA   src/lasso.jl:119
-        LPVS_TRY(launch_rhs_panel_batch(nb_, P.as<double>(), nrows * ld, ld, nreg, Wdev, dy.p, offs.as<int64_t>(), n, bvec.as<double>(), np,
-                                        scr.as<double>(), scr.bytes, s));                          // q = A'Wy   src/lasso.jl:120
+        if (ap) {
+            for (int q = 0; q < nb_; ++q)
+                for (int c = 0; c < spw; ++c) {
+                    int64_t *e = hseg.data() + 3 * ((size_t)q * (size_t)spw + (size_t)c);
+                    e[0] = hoff[q] + (int64_t)c * rpcw;
+                    e[1] = std::min(hoff[q] + n, e[0] + rpcw);
+                    e[2] = hoff[q];
+                }
+            LPVS_TRY(copy_to_device(seg.p, hseg.data(), sizeof(int64_t) * 3 * (size_t)nb_ * (size_t)spw, s));
+            LPVS_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
+            LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
+            LPVS_TRY(launch_nudft_windows(dt.p, nullptr, Wdev, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, seg.as<int64_t>(), nb_, spw,
+                                          npart.as<double>(), tab.as<double>(), s));
+            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.nf8, (int)zf, nreg, M.as<double>(), np, nb_, sl.nsl * 4,
+                                                np * np, s));                                       // Q = A'WA   src/lasso.jl:119
+            tr.mark("gram (structured)");
+            LPVS_TRY(launch_nudft_windows(dt.p, dy.p, Wdev, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, seg.as<int64_t>(), nb_, spw,
+                                          npart.as<double>(), tabb.as<double>(), s));
+            LPVS_TRY(launch_ap_rhs_fourier(tabb.as<double>(), sd.eps.as<double>(), Nf, (int)zf, bvec.as<double>(), nb_, sl.nf8 * 4, np, s));   // q = A'Wy   :120
+        } else {
+            LPVS_TRY(launch_window_panels(dt.p, offs.as<int64_t>(), nb_, n, nrows, df.p, Nf, (int)zf, P.as<double>(), ld, s));
+            tr.mark("panels");
+            LPVS_TRY(launch_gram_panel_batch(pl, nb_, P.as<double>(), nrows * ld, ld, Wdev, slab.as<double>(), s));
+            tr.mark("gram");
+            LPVS_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
+            LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
+            LPVS_TRY(launch_gram_reduce_batch(pl, nb_, slab.as<double>(), M.as<double>(), np, s));     // Q = A'WA   src/lasso.jl:119
+            LPVS_TRY(launch_rhs_panel_batch(nb_, P.as<double>(), nrows * ld, ld, nreg, Wdev, dy.p, offs.as<int64_t>(), n, bvec.as<double>(), np,
+                                            scr.as<double>(), scr.bytes, s));                          // q = A'Wy   src/lasso.jl:120
+        }
         if (linear_sign < 0) {  // Quadratic(Q, +q): the x-update's linear term is -q
             LPVS_HIP(hipMemcpyAsync(zh.data(), bvec.p, sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyDeviceToHost, s));
             LPVS_HIP(hipStreamSynchronize(s));

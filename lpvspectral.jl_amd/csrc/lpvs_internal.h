@@ -122,8 +122,17 @@ int32_t launch_rhs_panel_batch(int nbatch, const double *P, int64_t strideP, int
 // ---- structured Gram for arithmetic-progression frequency grids (nudft.hip) ----------------------------------
 struct ApStep { double hi[8], lo[8]; };   // b*D in double-double, b = 0..7 (in-group offsets of the slot progressions)
 size_t nudft_partial_bytes(int64_t N, int64_t nslots, int64_t nq);
+int64_t nudft_rows_per_chunk(int64_t N, int64_t nslots);
 int32_t launch_nudft(const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq, const double *om_hi,
                      const double *om_lo, int nslots, const ApStep &step, double *partial, double *tab, hipStream_t s);
+// windows of one signal: seg_dev holds nwin*segs_per_window triples {first sample, end sample, first sample of the window}
+int32_t launch_nudft_windows(const double *x, const double *y, const double *Wt, const double *om_hi, const double *om_lo, int nslots,
+                             const ApStep &step, const int64_t *seg_dev, int nwin, int segs_per_window, double *partial, double *tab,
+                             hipStream_t s);
+int32_t launch_ap_assemble_fourier(const double *tab, const double *eps, int64_t Nf, int64_t s0, int zf, int64_t n, double *G, int64_t ldg,
+                                   int nbatch, int64_t tab_stride, int64_t g_stride, hipStream_t s);
+int32_t launch_ap_rhs_fourier(const double *tab, const double *eps, int64_t Nf, int zf, double *b, int nbatch, int64_t tab_stride,
+                              int64_t b_stride, hipStream_t s);
 int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t s0, int64_t nb, int64_t n, double *G, int64_t ldg,
                            hipStream_t s);
 int32_t launch_ap_rhs(const double *tab, const double *eps, int64_t Nf, int64_t nb, double *b, hipStream_t s);

@@ -29,7 +29,6 @@ namespace lpvs {
 namespace {
 
 constexpr int RB = 16;      // samples per inner block
-constexpr int ROWS_PER_CHUNK = 8192;
 
 // out[chunk][slot][q][4] = sum over the chunk's samples of Wt[n][q] (y_n) {cos, sin, x cos, x sin}(omega_slot x_n)
 //
@@ -44,7 +43,7 @@ template <int QPT, int S>
 __global__ void __launch_bounds__(256)
 nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__ y, int64_t N, const double *__restrict__ Wt,
                         int64_t ldw, int nq, const double *__restrict__ om_hi, const double *__restrict__ om_lo, int nslots,
-                        const ApStep step, double *__restrict__ out) {
+                        const ApStep step, double *__restrict__ out, const int64_t *__restrict__ seg, int64_t rows_per_chunk) {
     constexpr int SLOTS = 64 * S, NA = 8 * S;                    // slots and anchors per workgroup
     constexpr int WSTR = (QPT + 1) & ~1;                         // weight stride of a wave inside a staged sample (16-B aligned)
     constexpr int NEF = NA + 8;                                  // sincos per sample: anchors + offsets
@@ -56,8 +55,12 @@ nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__
     const int sl = t & 63;
     const int g = __builtin_amdgcn_readfirstlane(t >> 6);        // wave = q-group of the accumulation phase
     const int slot0 = blockIdx.x * SLOTS;
-    const int64_t r0 = (int64_t)blockIdx.y * ROWS_PER_CHUNK;
-    const int64_t r1 = r0 + ROWS_PER_CHUNK < N ? r0 + ROWS_PER_CHUNK : N;
+    // sample range of this y-block: a chunk of the signal, or (windows) seg = {begin, end, first sample of the window}:
+    // weights are indexed relative to the window start, x and y by the absolute sample
+    int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    int64_t r1 = r0 + rows_per_chunk < N ? r0 + rows_per_chunk : N;
+    int64_t wbase = 0;
+    if (seg != nullptr) { r0 = seg[3 * blockIdx.y]; r1 = seg[3 * blockIdx.y + 1]; wbase = seg[3 * blockIdx.y + 2]; }
     const int qbase = blockIdx.z * (4 * QPT);
     const int nqb = nq - qbase < 4 * QPT ? nq - qbase : 4 * QPT;  // pairs of this q-block
     const int q0 = g * QPT;
@@ -101,7 +104,7 @@ nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__
         for (int e = t; e < RB * 4 * QPT; e += 256) {           // weights of the block: [sample][wave][QPT (+pad)]
             const int pr = e / (4 * QPT), q = e - pr * (4 * QPT);
             const int64_t r = rb + pr;
-            const double wv = (r < r1 && q < nqb) ? Wt[r * ldw + qbase + q] : 0.0;
+            const double wv = (r < r1 && q < nqb) ? (Wt ? Wt[(r - wbase) * ldw + qbase + q] : 1.0) : 0.0;   // Wt == NULL: unit weights
             wrow[pr][(q / QPT) * WSTR + q % QPT] = wv;
         }
         __syncthreads();
@@ -162,13 +165,58 @@ nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__
     }
 }
 
+// blockIdx.y = problem of a batch (its nchunks partials are consecutive)
 __global__ void __launch_bounds__(256)
-nudft_reduce_kernel(const double *__restrict__ part, int nchunks, int64_t count, double *__restrict__ out) {
+nudft_reduce_kernel(const double *__restrict__ part_all, int nchunks, int64_t count, double *__restrict__ out_all) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
+    const double *part = part_all + (int64_t)blockIdx.y * nchunks * count;
     double s = 0;
     for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * count + i];
-    out[i] = s;
+    out_all[(int64_t)blockIdx.y * count + i] = s;
+}
+
+// Fourier layout (src/lsfft.jl:26-49): column a < Nf is cos(w_a x) dd, column a >= Nf is -sin(w_k x) dd with
+// k = a - Nf + zf (zf = 1 when the zero frequency is present and has no sine column), dd = 1/sqrt(2 Nf).
+// One activation "pair" (weight W_n or 1).  blockIdx.z = problem of a batch.
+__global__ void __launch_bounds__(256)
+ap_assemble_fourier_kernel(const double *__restrict__ tab_all, const double *__restrict__ eps, int Nf, int s0, int zf, double scale,
+                           int64_t n, double *__restrict__ G_all, int64_t ldg, int64_t tab_stride, int64_t g_stride) {
+    const int64_t ga = blockIdx.y;
+    const int64_t gb = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gb > ga || ga >= n) return;
+    const double *tab = tab_all + (int64_t)blockIdx.z * tab_stride;
+    double *G = G_all + (int64_t)blockIdx.z * g_stride;
+    const int ca = ga >= Nf, cb = gb >= Nf;
+    const int ka = ca ? (int)ga - Nf + zf : (int)ga, kb = cb ? (int)gb - Nf + zf : (int)gb;
+    const int hi = ka >= kb ? ka : kb, lo = ka >= kb ? kb : ka;
+    const double dm = eps[hi] - eps[lo], dp = eps[ka] + eps[kb];
+    const double *tm = tab + (int64_t)(hi - lo) * 4;
+    const double *tp = tab + (int64_t)(s0 + ka + kb) * 4;
+    const double cm = fma(-dm, tm[3], tm[0]);
+    double sm = fma(dm, tm[2], tm[1]);                       // sin((w_hi - w_lo) x)
+    if (ka < kb) sm = -sm;                                   // -> sin((w_a - w_b) x)
+    const double cp = fma(-dp, tp[3], tp[0]), sp = fma(dp, tp[2], tp[1]);
+    double v;
+    if (!ca && !cb) v = 0.5 * (cm + cp);
+    else if (ca && cb) v = 0.5 * (cm - cp);
+    else if (!ca && cb) v = -0.5 * (sp - sm);
+    else v = -0.5 * (sp + sm);
+    v *= scale;
+    G[ga * ldg + gb] = v;
+    G[gb * ldg + ga] = v;
+}
+
+__global__ void __launch_bounds__(256)
+ap_rhs_fourier_kernel(const double *__restrict__ tab_all, const double *__restrict__ eps, int Nf, int zf, double dd,
+                      double *__restrict__ b_all, int64_t tab_stride, int64_t b_stride) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Nf) return;
+    const double *t = tab_all + (int64_t)blockIdx.y * tab_stride + (int64_t)k * 4;
+    double *b = b_all + (int64_t)blockIdx.y * b_stride;
+    const double e = eps[k];
+    b[k] = dd * fma(-e, t[3], t[0]);
+    if (k >= zf) b[Nf + k - zf] = -dd * fma(e, t[2], t[1]);
 }
 
 // G[a][b] = G[b][a], a >= b, from the slot tables tab[slot][q][4]; slots 0..Nf-1 are the differences m = f-f',
@@ -215,32 +263,72 @@ ap_rhs_kernel(const double *__restrict__ tab, const double *__restrict__ eps, in
 
 template <int QPT, int S>
 void launch_accumulate(unsigned nchunks, hipStream_t s, const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq,
-                       const double *om_hi, const double *om_lo, int nslots, const ApStep &step, double *partial) {
+                       const double *om_hi, const double *om_lo, int nslots, const ApStep &step, double *partial, const int64_t *seg,
+                       int64_t rpc) {
     dim3 grid((unsigned)ceil_div(nslots, 64 * S), nchunks, (unsigned)ceil_div(nq, 4 * QPT));
-    hipLaunchKernelGGL((nudft_accumulate_kernel<QPT, S>), grid, dim3(256), 0, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
+    hipLaunchKernelGGL((nudft_accumulate_kernel<QPT, S>), grid, dim3(256), 0, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
 }
 
 }  // namespace
 
-size_t nudft_chunks(int64_t N) { return (size_t)ceil_div(N, ROWS_PER_CHUNK); }
+// samples per workgroup: 8192, fewer for short signals so that (slot groups) x (chunks) still fills the chip
+int64_t nudft_rows_per_chunk(int64_t N, int64_t nslots) {
+    const int64_t groups = ceil_div(nslots, 128);
+    int64_t rpc = 8192;
+    while (rpc > 512 && groups * ceil_div(N, rpc) < 2048) rpc >>= 1;
+    return rpc;
+}
+size_t nudft_chunks(int64_t N, int64_t nslots) { return (size_t)ceil_div(N, nudft_rows_per_chunk(N, nslots)); }
 size_t nudft_partial_bytes(int64_t N, int64_t nslots, int64_t nq) {
-    return sizeof(double) * nudft_chunks(N) * (size_t)nslots * (size_t)nq * 4;
+    return sizeof(double) * nudft_chunks(N, nslots) * (size_t)nslots * (size_t)nq * 4;
 }
 
 // tab[slot][q][4] = sum_n (y_n) Wt[n][q] {cos, sin, x cos, x sin}(omega_slot x_n).  The slots must form arithmetic
 // progressions with step D inside every aligned group of eight (nslots % 8 == 0); step holds b*D, b = 0..7.
-int32_t launch_nudft(const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq, const double *om_hi,
-                     const double *om_lo, int nslots, const ApStep &step, double *partial, double *tab, hipStream_t s) {
+// Wt == NULL means unit weights (nq = 1).  seg != NULL: nseg y-blocks {begin, end, weight base} (device array) grouped
+// nbatch x (nseg / nbatch) -- windows of a signal; tab then holds one table per batch entry.
+static int32_t nudft_impl(const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq, const double *om_hi,
+                          const double *om_lo, int nslots, const ApStep &step, double *partial, double *tab, const int64_t *seg,
+                          unsigned nseg, unsigned nbatch, hipStream_t s) {
     if (nslots % 8 != 0) { set_error("nudft: slot count %d is not a multiple of 8", nslots); return LPVS_ESTATE; }
-    const unsigned nchunks = (unsigned)nudft_chunks(N);
+    const unsigned nchunks = seg ? nseg : (unsigned)nudft_chunks(N, nslots);
+    const int64_t rpc = seg ? 0 : nudft_rows_per_chunk(N, nslots);
     static const int slots_per_thread = [] { const char *e = getenv("LPVS_NUDFT_S"); return (e && atoi(e) == 1) ? 1 : 2; }();
-    if (nq <= 8) launch_accumulate<2, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
-    else if (nq <= 16) launch_accumulate<4, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
-    else if (slots_per_thread == 1) launch_accumulate<9, 1>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
-    else launch_accumulate<9, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial);
+    if (nq <= 8) launch_accumulate<2, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
+    else if (nq <= 16) launch_accumulate<4, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
+    else if (slots_per_thread == 1) launch_accumulate<9, 1>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
+    else launch_accumulate<9, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
     LPVS_HIP(hipGetLastError());
     const int64_t count = (int64_t)nslots * nq * 4;
-    hipLaunchKernelGGL(nudft_reduce_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, partial, (int)nchunks, count, tab);
+    hipLaunchKernelGGL(nudft_reduce_kernel, dim3((unsigned)ceil_div(count, 256), nbatch), dim3(256), 0, s, partial, (int)(nchunks / nbatch), count, tab);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_nudft(const double *x, const double *y, int64_t N, const double *Wt, int64_t ldw, int nq, const double *om_hi,
+                     const double *om_lo, int nslots, const ApStep &step, double *partial, double *tab, hipStream_t s) {
+    return nudft_impl(x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, tab, nullptr, 0, 1, s);
+}
+
+int32_t launch_nudft_windows(const double *x, const double *y, const double *Wt, const double *om_hi, const double *om_lo, int nslots,
+                             const ApStep &step, const int64_t *seg_dev, int nwin, int segs_per_window, double *partial, double *tab,
+                             hipStream_t s) {
+    return nudft_impl(x, y, 0, Wt, 1, 1, om_hi, om_lo, nslots, step, partial, tab, seg_dev, (unsigned)(nwin * segs_per_window), (unsigned)nwin, s);
+}
+
+int32_t launch_ap_assemble_fourier(const double *tab, const double *eps, int64_t Nf, int64_t s0, int zf, int64_t n, double *G, int64_t ldg,
+                                   int nbatch, int64_t tab_stride, int64_t g_stride, hipStream_t s) {
+    dim3 grid((unsigned)ceil_div(n, 256), (unsigned)n, (unsigned)nbatch);
+    hipLaunchKernelGGL(ap_assemble_fourier_kernel, grid, dim3(256), 0, s, tab, eps, (int)Nf, (int)s0, zf, 1.0 / (double)(2 * Nf), n, G, ldg,
+                       tab_stride, g_stride);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_ap_rhs_fourier(const double *tab, const double *eps, int64_t Nf, int zf, double *b, int nbatch, int64_t tab_stride,
+                              int64_t b_stride, hipStream_t s) {
+    hipLaunchKernelGGL(ap_rhs_fourier_kernel, dim3((unsigned)ceil_div(Nf, 256), (unsigned)nbatch), dim3(256), 0, s, tab, eps, (int)Nf, zf,
+                       1.0 / sqrt((double)(2 * Nf)), b, tab_stride, b_stride);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

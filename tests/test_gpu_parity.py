@@ -598,3 +598,31 @@ def test_row_sharded_solve_two_ranks_matches_single_process(L):
     assert np.array_equal(res[0][1], res[1][1])                      # replicated ADMM: identical on both ranks
     assert np.abs(res[0][1] - ref.x).max() <= 1e-9 * scale
     assert np.array_equal(np.abs(res[0][1]) > 0, np.abs(ref.x) > 0)  # same support
+
+
+@pytest.mark.parametrize("zero_first,weighted", [(True, False), (False, True), (True, True)])
+def test_fourier_structured_gram_agrees_with_dense(L, oracle, zero_first, weighted, monkeypatch):
+    """Fourier problems on a uniform frequency grid take the structured Gram (nudft.hip); it must agree with the dense
+    MFMA panel form and with the oracle, with and without the zero frequency / weights."""
+    rng = np.random.default_rng(17)
+    N, Nf = 5000, 40
+    t = np.sort(rng.random(N) * 300.0)
+    f = (np.arange(Nf) if zero_first else np.arange(1, Nf + 1)) / 97.0
+    y = np.sin(2 * np.pi * f[7] * t) + 0.2 * rng.standard_normal(N)
+    W = rng.random(N) + 0.5 if weighted else None
+    res = {}
+    for form in ("auto", "panel"):
+        monkeypatch.setenv("LPVS_GRAM_FORM", form)
+        with L.Problem.fourier(y, t, f, W) as p:
+            res[form] = p.get_gram() + (p.timing()["gram_form"],)
+    assert res["auto"][2] == "ap" and res["panel"][2] == "panel"
+    A, zf = oracle.get_fourier_regressor(t, f)
+    Go, bo = oracle.gram(A, y, W)
+    tol = 1e-12 + 4.5e-16 * 2 * np.pi * f.max() * t.max()
+    for form in ("auto", "panel"):
+        G, b, _ = res[form]
+        assert np.abs(G - Go).max() <= tol * np.abs(Go).max(), form
+        assert np.abs(b - bo).max() <= 10 * tol * np.abs(bo).max(), form
+    monkeypatch.setenv("LPVS_GRAM_FORM", "ap")                      # forcing the structured form on a non-uniform grid is an error
+    with pytest.raises(ValueError):
+        L.Problem.fourier(y, t, np.sort(rng.random(Nf)) + 0.01, W)
