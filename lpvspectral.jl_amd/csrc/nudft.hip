@@ -165,6 +165,97 @@ nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__
     }
 }
 
+
+// Single weight per sample (Fourier problems: W_n or 1, times y_n for the right-hand side).  With one weight there is
+// nothing to share between q-groups, so the trig values never go through LDS: per block of 16 samples the workgroup
+// evaluates the anchors / offsets (step A, as above), then wave g takes samples g, g+4, ... and every thread forms its
+// S slots' cis by one complex product and accumulates in registers.  The four waves' sums are combined in wave order
+// at the end of the chunk.  One barrier per block (the anchor table is double-buffered).
+template <int S>
+__global__ void __launch_bounds__(256)
+nudft_single_kernel(const double *__restrict__ x, const double *__restrict__ y, int64_t N, const double *__restrict__ Wt, int64_t ldw,
+                    const double *__restrict__ om_hi, const double *__restrict__ om_lo, int nslots, const ApStep step,
+                    double *__restrict__ out, const int64_t *__restrict__ seg, int64_t rows_per_chunk) {
+    constexpr int NA = 8 * S, NEF = NA + 8;
+    __shared__ __attribute__((aligned(16))) double ef[2][RB][NEF][2];
+    __shared__ double xs[2][RB], ws[2][RB];
+    __shared__ __attribute__((aligned(16))) double comb[3][64 * S][4];
+    const int t = threadIdx.x, sl = t & 63;
+    const int g = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int slot0 = blockIdx.x * 64 * S;
+    int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    int64_t r1 = r0 + rows_per_chunk < N ? r0 + rows_per_chunk : N;
+    int64_t wbase = 0;
+    if (seg != nullptr) { r0 = seg[3 * blockIdx.y]; r1 = seg[3 * blockIdx.y + 1]; wbase = seg[3 * blockIdx.y + 2]; }
+    double acc[S][4];
+#pragma unroll
+    for (int u = 0; u < S; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+    int buf = 0;
+    for (int64_t rb = r0; rb < r1; rb += RB, buf ^= 1) {
+        for (int e = t; e < RB * NEF; e += 256) {               // step A
+            const int pr = e / NEF, pk = e - pr * NEF;
+            double wh, wl;
+            if (pk < NA) {
+                const int as = slot0 + 8 * pk;
+                const bool ok = as < nslots;
+                wh = ok ? om_hi[as] : 0.0; wl = ok ? om_lo[as] : 0.0;
+            } else {
+                wh = step.hi[pk - NA]; wl = step.lo[pk - NA];
+            }
+            const int64_t r = rb + pr;
+            double c = 1.0, sn = 0.0;
+            if (r < r1) {
+                const double xv = x[r];
+                const double p = wh * xv;
+                const double d = fma(wh, xv, -p) + wl * xv;     // omega*x = p + d
+                sincos(p, &sn, &c);
+                const double c2 = fma(-d, sn, c), s2 = fma(d, c, sn);
+                c = c2; sn = s2;
+                if (pk == 0) { xs[buf][pr] = xv; ws[buf][pr] = (Wt ? Wt[(r - wbase) * ldw] : 1.0) * (y ? y[r] : 1.0); }
+            } else if (pk == 0) {
+                xs[buf][pr] = 0.0; ws[buf][pr] = 0.0;           // samples past the end contribute nothing
+            }
+            ef[buf][pr][pk][0] = c; ef[buf][pr][pk][1] = sn;
+        }
+        __syncthreads();   // also orders this block's reads of buffer `buf` against the writes two blocks later
+#pragma unroll
+        for (int i = 0; i < RB / 4; ++i) {                      // steps B + C fused, samples g, g+4, ...
+            const int rr = g + 4 * i;
+            const double wv = ws[buf][rr], xv = xs[buf][rr];
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+                const int ls = sl + 64 * u;
+                const double2 e2 = *reinterpret_cast<const double2 *>(&ef[buf][rr][ls >> 3][0]);
+                const double2 f2 = *reinterpret_cast<const double2 *>(&ef[buf][rr][NA + (ls & 7)][0]);
+                const double c = fma(e2.x, f2.x, -(e2.y * f2.y)) * wv, sn = fma(e2.y, f2.x, e2.x * f2.y) * wv;
+                acc[u][0] += c; acc[u][1] += sn;
+                acc[u][2] = fma(xv, c, acc[u][2]); acc[u][3] = fma(xv, sn, acc[u][3]);
+            }
+        }
+    }
+    __syncthreads();
+    if (g > 0) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            double4 o; o.x = acc[u][0]; o.y = acc[u][1]; o.z = acc[u][2]; o.w = acc[u][3];
+            *reinterpret_cast<double4 *>(&comb[g - 1][sl + 64 * u][0]) = o;
+        }
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int slot = slot0 + sl + 64 * u;
+            if (slot >= nslots) continue;
+            double *o = out + ((int64_t)blockIdx.y * nslots + slot) * 4;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) o[v] = ((acc[u][v] + comb[0][sl + 64 * u][v]) + comb[1][sl + 64 * u][v]) + comb[2][sl + 64 * u][v];
+        }
+    }
+}
+
 // blockIdx.y = problem of a batch (its nchunks partials are consecutive)
 __global__ void __launch_bounds__(256)
 nudft_reduce_kernel(const double *__restrict__ part_all, int nchunks, int64_t count, double *__restrict__ out_all) {
@@ -294,7 +385,10 @@ static int32_t nudft_impl(const double *x, const double *y, int64_t N, const dou
     const unsigned nchunks = seg ? nseg : (unsigned)nudft_chunks(N, nslots);
     const int64_t rpc = seg ? 0 : nudft_rows_per_chunk(N, nslots);
     static const int slots_per_thread = [] { const char *e = getenv("LPVS_NUDFT_S"); return (e && atoi(e) == 1) ? 1 : 2; }();
-    if (nq <= 8) launch_accumulate<2, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
+    if (nq == 1) {
+        dim3 grid((unsigned)ceil_div(nslots, 128), nchunks, 1);
+        hipLaunchKernelGGL(nudft_single_kernel<2>, grid, dim3(256), 0, s, x, y, N, Wt, ldw, om_hi, om_lo, nslots, step, partial, seg, rpc);
+    } else if (nq <= 8) launch_accumulate<2, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
     else if (nq <= 16) launch_accumulate<4, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
     else if (slots_per_thread == 1) launch_accumulate<9, 1>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
     else launch_accumulate<9, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
