@@ -47,10 +47,9 @@ nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__
     constexpr int SLOTS = 64 * S, NA = 8 * S;                    // slots and anchors per workgroup
     constexpr int WSTR = (QPT + 1) & ~1;                         // weight stride of a wave inside a staged sample (16-B aligned)
     constexpr int NEF = NA + 8;                                  // sincos per sample: anchors + offsets
-    __shared__ __attribute__((aligned(16))) double trig[RB][SLOTS][4];
-    __shared__ __attribute__((aligned(16))) double wrow[RB][4 * WSTR];
-    __shared__ double ef[RB][NEF][2];
-    __shared__ double xs[RB], ys[RB];
+    __shared__ __attribute__((aligned(16))) double wrow[2][RB][4 * WSTR];
+    __shared__ __attribute__((aligned(16))) double ef[2][RB][NEF][2];
+    __shared__ double xs[2][RB], ys[2][RB];
     const int t = threadIdx.x;
     const int sl = t & 63;
     const int g = __builtin_amdgcn_readfirstlane(t >> 6);        // wave = q-group of the accumulation phase
@@ -64,7 +63,7 @@ nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__
     const int qbase = blockIdx.z * (4 * QPT);
     const int nqb = nq - qbase < 4 * QPT ? nq - qbase : 4 * QPT;  // pairs of this q-block
     const int q0 = g * QPT;
-    const int nvalid = nqb - q0 < QPT ? nqb - q0 : QPT;           // pairs of this wave (<= 0: the wave only helps with steps A, B)
+    const int nvalid = nqb - q0 < QPT ? nqb - q0 : QPT;           // pairs of this wave (<= 0: the wave only helps with step A)
 
     double acc[S][QPT][4];
 #pragma unroll
@@ -74,8 +73,10 @@ nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[u][q][v] = 0.0;
 
-    for (int64_t rb = r0; rb < r1; rb += RB) {
-        // step A: sincos of (sample, anchor | offset), RB*NEF of them over 256 threads
+    int buf = 0;
+    for (int64_t rb = r0; rb < r1; rb += RB, buf ^= 1) {
+        // step A: sincos of (sample, anchor | offset), RB*NEF of them over 256 threads; tables are double-buffered, so
+        // one barrier per block orders both this block's reads and the overwrite two blocks later
         for (int e = t; e < RB * NEF; e += 256) {
             const int pr = e / NEF, pk = e - pr * NEF;
             double wh, wl;
@@ -95,59 +96,50 @@ nudft_accumulate_kernel(const double *__restrict__ x, const double *__restrict__
                 sincos(p, &sn, &c);
                 const double c2 = fma(-d, sn, c), s2 = fma(d, c, sn);
                 c = c2; sn = s2;
-                if (pk == 0) { xs[pr] = xv; ys[pr] = y ? y[r] : 1.0; }
+                if (pk == 0) { xs[buf][pr] = xv; ys[buf][pr] = y ? y[r] : 1.0; }
             } else if (pk == 0) {
-                xs[pr] = 0.0; ys[pr] = 0.0;                     // samples past the end contribute nothing
+                xs[buf][pr] = 0.0; ys[buf][pr] = 0.0;           // samples past the end contribute nothing
             }
-            ef[pr][pk][0] = c; ef[pr][pk][1] = sn;
+            ef[buf][pr][pk][0] = c; ef[buf][pr][pk][1] = sn;
         }
         for (int e = t; e < RB * 4 * QPT; e += 256) {           // weights of the block: [sample][wave][QPT (+pad)]
             const int pr = e / (4 * QPT), q = e - pr * (4 * QPT);
             const int64_t r = rb + pr;
             const double wv = (r < r1 && q < nqb) ? (Wt ? Wt[(r - wbase) * ldw + qbase + q] : 1.0) : 0.0;   // Wt == NULL: unit weights
-            wrow[pr][(q / QPT) * WSTR + q % QPT] = wv;
+            wrow[buf][pr][(q / QPT) * WSTR + q % QPT] = wv;
         }
         __syncthreads();
-        // step B: trig[sample][slot] by one complex product; thread covers slot lanes sl + 64u for samples g, g+4, ...
-#pragma unroll
-        for (int i = 0; i < RB / 4; ++i) {
-            const int rr = g + 4 * i;
-            const double yv = ys[rr], xv = xs[rr];
-#pragma unroll
-            for (int u = 0; u < S; ++u) {
-                const int ls = sl + 64 * u;
-                const double ec = ef[rr][ls >> 3][0], es = ef[rr][ls >> 3][1];
-                const double fc = ef[rr][NA + (ls & 7)][0], fs = ef[rr][NA + (ls & 7)][1];
-                const double c = fma(ec, fc, -(es * fs)) * yv, sn = fma(es, fc, ec * fs) * yv;
-                double4 o; o.x = c; o.y = sn; o.z = xv * c; o.w = xv * sn;
-                *reinterpret_cast<double4 *>(&trig[rr][ls][0]) = o;
-            }
-        }
-        __syncthreads();
-        if (nvalid > 0) {   // step C
+        if (nvalid > 0) {   // steps B + C: the slot's cis by one complex product (recomputed by every q-group: 14 ops against
+                            // 16 QPT FMAs), then the wave's QPT weights
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) {
-                double4 tv[S];
+                const double yv = ys[buf][rr], xv = xs[buf][rr];
+                double tv[S][4];
 #pragma unroll
-                for (int u = 0; u < S; ++u) tv[u] = *reinterpret_cast<const double4 *>(&trig[rr][sl + 64 * u][0]);
+                for (int u = 0; u < S; ++u) {
+                    const int ls = sl + 64 * u;
+                    const double2 e2 = *reinterpret_cast<const double2 *>(&ef[buf][rr][ls >> 3][0]);
+                    const double2 f2 = *reinterpret_cast<const double2 *>(&ef[buf][rr][NA + (ls & 7)][0]);
+                    const double c = fma(e2.x, f2.x, -(e2.y * f2.y)) * yv, sn = fma(e2.y, f2.x, e2.x * f2.y) * yv;
+                    tv[u][0] = c; tv[u][1] = sn; tv[u][2] = xv * c; tv[u][3] = xv * sn;
+                }
                 double wq[WSTR];
 #pragma unroll
                 for (int q = 0; q < WSTR; q += 2) {
-                    const double2 w2 = *reinterpret_cast<const double2 *>(&wrow[rr][g * WSTR + q]);
+                    const double2 w2 = *reinterpret_cast<const double2 *>(&wrow[buf][rr][g * WSTR + q]);
                     wq[q] = w2.x; wq[q + 1] = w2.y;
                 }
 #pragma unroll
                 for (int q = 0; q < QPT; ++q)
 #pragma unroll
                     for (int u = 0; u < S; ++u) {
-                        acc[u][q][0] = fma(wq[q], tv[u].x, acc[u][q][0]);
-                        acc[u][q][1] = fma(wq[q], tv[u].y, acc[u][q][1]);
-                        acc[u][q][2] = fma(wq[q], tv[u].z, acc[u][q][2]);
-                        acc[u][q][3] = fma(wq[q], tv[u].w, acc[u][q][3]);
+                        acc[u][q][0] = fma(wq[q], tv[u][0], acc[u][q][0]);
+                        acc[u][q][1] = fma(wq[q], tv[u][1], acc[u][q][1]);
+                        acc[u][q][2] = fma(wq[q], tv[u][2], acc[u][q][2]);
+                        acc[u][q][3] = fma(wq[q], tv[u][3], acc[u][q][3]);
                     }
             }
         }
-        __syncthreads();
     }
     if (nvalid > 0) {
 #pragma unroll
