@@ -396,15 +396,21 @@ panel_gemm_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, i
 // which = 0: every tile; 1: only tiles inside the next pivot band [n0, n0+nw); 2: every tile outside it.
 __global__ void __launch_bounds__(RU_THREADS, 2)
 rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, int kw, const double *__restrict__ Ck,
-                   const double *__restrict__ Bk, const int2 *__restrict__ tiles, int ntiles, int which, int64_t n0, int nw) {
+                   const double *__restrict__ Bk, const int2 *__restrict__ tiles, int ntiles, int which, int64_t n0, int nw, int band_tile) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave / RU_WN, wb = wave % RU_WN;
     // XCD-aware: the 8 XCDs are dealt consecutive blocks round-robin; give each a contiguous run of the tile list
-    const int bq = ntiles / 8, br = ntiles % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;
-    const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
-    const int2 tt = tiles[item];
+    int2 tt;
+    if (band_tile >= 0) {   // band launch (grid = tile rows): the tiles of tile row / tile column band_tile, enumerated directly
+        const int e = blockIdx.x;
+        tt = e <= band_tile ? make_int2(band_tile, e) : make_int2(e, band_tile);
+    } else {
+        const int bq = ntiles / 8, br = ntiles % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;
+        const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
+        tt = tiles[item];
+    }
     const int64_t a0 = (int64_t)tt.x * RU_TM, b0 = (int64_t)tt.y * RU_TN;
     auto in_band = [&](int64_t lo, int64_t start, int64_t width) { return lo >= start && lo < start + width; };
     auto dead = [&](int wa_, int wb_) {     // the wave's 64x64 block has nothing to update
@@ -605,12 +611,14 @@ int32_t SweepAux::ensure() {
     LPVS_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
     LPVS_HIP(hipEventCreateWithFlags(&panel, hipEventDisableTiming));
     LPVS_HIP(hipEventCreateWithFlags(&rest, hipEventDisableTiming));
+    LPVS_HIP(hipEventCreateWithFlags(&band, hipEventDisableTiming));
     return LPVS_OK;
 }
 SweepAux::~SweepAux() {
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (panel) (void)hipEventDestroy(panel);
     if (rest) (void)hipEventDestroy(rest);
+    if (band) (void)hipEventDestroy(band);
 }
 
 // Step k of the outer sweep:  chain_k = { P = inv(A_kk); Bk = A[:,k]; Ck = -(Bk' P)'; A[:,k] = C; A_kk = -P },
@@ -649,8 +657,11 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     auto update = [&](int64_t k0, const double *Bk, const double *Ck, int which, hipStream_t st) {
         const int kw = width(k0);
         const int64_t n0 = k0 + kw;
-        hipLaunchKernelGGL(rank_update_kernel, dim3((unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, k0, kw, Ck, Bk, tiles,
-                           (int)ht.size(), which, n0, n0 < np ? width(n0) : 0);
+        const int nw = n0 < np ? width(n0) : 0;
+        // a 128-wide band is one tile row + one tile column: launch just those (32k early-exit workgroups cost 0.3 ms at np = 32768)
+        const bool direct = which == 1 && nw == RU_TM && RU_TM == RU_TN;
+        hipLaunchKernelGGL(rank_update_kernel, dim3(direct ? (unsigned)(np / RU_TM) : (unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, k0,
+                           kw, Ck, Bk, tiles, (int)ht.size(), which, n0, nw, direct ? (int)(n0 / RU_TM) : -1);
     };
 
     if (!la) {
@@ -675,8 +686,12 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
         if (next) {
             LPVS_HIP(hipStreamWaitEvent(side, aux->rest, 0));   // bulk of U_{k-1}
             update(k0, Bk, Ck, 1, side);
+            LPVS_HIP(hipEventRecord(aux->band, side));
             chain(n0, panelbuf[cur ^ 1], panelbuf[cur ^ 1] + KW * ldp, side);
             LPVS_HIP(hipEventRecord(aux->panel, side));
+            // the bulk starts when the band is done: the one-workgroup pivot inverse (which needs most of a CU's
+            // registers) is then dispatched onto an empty chip instead of starving behind the bulk's workgroups
+            LPVS_HIP(hipStreamWaitEvent(s, aux->band, 0));
         }
         update(k0, Bk, Ck, next ? 2 : 0, s);
         LPVS_HIP(hipEventRecord(aux->rest, s));

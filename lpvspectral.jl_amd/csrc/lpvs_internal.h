@@ -144,7 +144,7 @@ int32_t launch_ap_rhs(const double *tab, const double *eps, int64_t Nf, int64_t 
 // (high-priority) stream while the bulk of the current trailing update runs on the caller's stream.
 struct SweepAux {
     hipStream_t side = nullptr;
-    hipEvent_t panel = nullptr, rest = nullptr;
+    hipEvent_t panel = nullptr, rest = nullptr, band = nullptr;
     int32_t ensure();
     ~SweepAux();
 };
