@@ -528,6 +528,81 @@ symv_tile_kernel(const T *__restrict__ Mp, const double *__restrict__ rhs_all, i
     }
 }
 
+
+// Several right-hand sides sharing M (multichannel problems): same tile product, but the right-hand sides of up to NSB
+// signals are staged together and the column sums of all of them are reduced together -- two barriers per block of
+// signals instead of three per signal (the barriers, not the arithmetic, kept the memory pipe idle between tiles).
+template <typename T, int NSB>
+__global__ void __launch_bounds__(256)
+symv_tile_multi_kernel(const T *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
+                       double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    typedef typename Pair<T>::type T2;
+    if (status != nullptr) {
+        bool all = true;
+        for (int q = 0; q < ns; ++q) all = all && status[q].converged;
+        if (all) return;
+    }
+    __shared__ double sI[NSB][TS], sJ[NSB][TS], sT[NSB][4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T2 *base = reinterpret_cast<const T2 *>(Mp + (int64_t)t * TS * TS + wave * 32 * TS) + lane;
+    T2 m[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) m[r] = base[r * (TS / 2)];
+    for (int s0 = 0; s0 < ns; s0 += NSB) {
+        const int nsb = ns - s0 < NSB ? ns - s0 : NSB;
+        if (s0 > 0) __syncthreads();   // previous block's readers are done with the staging arrays
+        for (int e = threadIdx.x; e < nsb * 2 * TS; e += 256) {
+            const int q = e / (2 * TS), i = e - q * 2 * TS;
+            const double *rhs = rhs_all + (int64_t)(s0 + q) * np;
+            if (i < TS) sI[q][i] = rhs[(int64_t)I * TS + i];
+            else sJ[q][i - TS] = rhs[(int64_t)J * TS + i - TS];
+        }
+        __syncthreads();
+        for (int q = 0; q < nsb; ++q) {
+            const int sg = s0 + q;
+            if (status != nullptr && status[sg].converged) continue;   // uniform
+            double *part1 = part1_all + (int64_t)sg * ntiles * TS;
+            const double rj0 = sJ[q][2 * lane], rj1 = sJ[q][2 * lane + 1];
+            double t0 = 0, t1 = 0, v[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const double ri = sI[q][wave * 32 + r];
+                const double mx = (double)m[r].x, my = (double)m[r].y;
+                t0 = fma(mx, ri, t0);
+                t1 = fma(my, ri, t1);
+                v[r] = fma(mx, rj0, my * rj1);
+            }
+#pragma unroll
+            for (int w = 32, cnt = 16; w >= 2; w >>= 1, cnt >>= 1) {
+                const bool hi = (lane & w) != 0;
+#pragma unroll
+                for (int k = 0; k < cnt; ++k) {
+                    const double send = hi ? v[k] : v[k + cnt];
+                    const double keep = hi ? v[k + cnt] : v[k];
+                    v[k] = keep + __shfl_xor(send, w, 64);
+                }
+            }
+            v[0] += __shfl_xor(v[0], 1, 64);
+            if ((lane & 1) == 0) {
+                const int row = ((lane & 32) ? 16 : 0) + ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
+                part1[(int64_t)t * TS + wave * 32 + row] = v[0];
+            }
+            sT[q][wave][2 * lane] = t0; sT[q][wave][2 * lane + 1] = t1;
+        }
+        if (I != J) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < nsb * TS; e += 256) {
+                const int q = e / TS, i = e - q * TS;
+                if (status != nullptr && status[s0 + q].converged) continue;
+                part2_all[(int64_t)(s0 + q) * ntiles * TS + (int64_t)t * TS + i] = ((sT[q][0][i] + sT[q][1][i]) + sT[q][2][i]) + sT[q][3][i];
+            }
+        }
+    }
+}
+
 // Same tile product for a batch of problems that each own their matrix (windows): blockIdx.y = problem.
 __global__ void __launch_bounds__(256)
 symv_tile_batch_kernel(const double *__restrict__ Mp_all, int64_t mp_stride, const double *__restrict__ rhs_all, int64_t np,
@@ -978,7 +1053,9 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s) {
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
     unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
-    if (p.mp_f32)
+    if (p.ns > 1 && !p.mp_f32)
+        hipLaunchKernelGGL((symv_tile_multi_kernel<double, 8>), dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
+    else if (p.mp_f32)
         hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,
                            (int)ntiles, part1, part2, p.status);
     else
