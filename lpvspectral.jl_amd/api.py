@@ -451,6 +451,29 @@ def ls_spectral(y, t, f=None, W=None, λ=1e-10, verbose=False, device=0):
     return params, _host(f)
 
 
+def tls_spectral(y, t, f=None, device=0):
+    """``tls_spectral(y,t,f=default_freqs(t)[1:end-1])`` (src/lsfft.jl:85-99) -> ``(x, f)``: total least squares.
+
+    The reference takes the right singular vector of the smallest singular value of ``[A y]``; it is the eigenvector of
+    the smallest eigenvalue of ``[A y]'[A y] = [[A'A, A'y], [y'A, y'y]]``.  The O(N n²) part -- ``A'A`` and ``A'y`` -- is
+    the device Gram of the Fourier problem; the (n+1)×(n+1) symmetric eigenproblem goes to the host LAPACK, as the
+    reference's own ``LAPACK.gesvd!`` does."""
+    f = default_freqs(t)[:-1] if f is None else f
+    yh = _host(y).astype(np.float64)
+    with Problem.fourier(y, t, f, None, device=device) as prob:
+        G, b = prob.get_gram()
+        n = prob.n
+        H = np.empty((n + 1, n + 1))
+        H[:n, :n] = G
+        H[:n, n] = b
+        H[n, :n] = b
+        H[n, n] = float(np.dot(yh, yh))
+        _, V = np.linalg.eigh(H)
+        v = V[:, 0]                                                  # smallest eigenvalue first
+        params = prob.pack(-v[:n] / v[n])                            # x = -V21 / V22, fourier2complex
+    return params, _host(f)
+
+
 def ls_sparse_spectral(y, t, f=None, W=None, init=False, λ=1.0, proxg=None, device=0, **kwargs):
     """``ls_sparse_spectral(y,t,f; init, λ, proxg=NormL1(λ), kwargs...)`` (src/lasso.jl:85-102) and the
     weighted 4-argument method ``(y,t,f,W; ...)`` (:105-126) -> ``(params, f)``.

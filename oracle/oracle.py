@@ -301,6 +301,19 @@ def ls_spectral(y, t, f=None, W=None, lam=1e-10):
     return fourier2complex(x, zf), f
 
 
+def tls_spectral(y, t, f=None):
+    """src/lsfft.jl:85-99: total least squares through the SVD of [A y]; x = -V21 / V22 with the right singular vector of
+    the smallest singular value (LAPACK.gesvd!('S','S'): rows of Vt ordered by decreasing singular value)."""
+    y, t = _f64(y), _f64(t)
+    f = default_freqs(t)[:-1] if f is None else _f64(f)
+    A, zf = get_fourier_regressor(t, f)
+    AA = np.hstack([A, y[:, None]])
+    _, _, Vt = np.linalg.svd(AA, full_matrices=False)
+    n = A.shape[1]
+    x = -Vt[n, :n] / Vt[n, n]
+    return fourier2complex(x, zf), f
+
+
 def ls_spectral_lpv(Y, X, V, w, Nv, lam=1e-8, normalize=True, coulomb=False):
     """src/lsfft.jl:239-259 (params only; covariance omitted): [Ar; lam I] \\ [Y; 0]."""
     Ar = lpv_regressor(X, V, w, Nv, normalize, coulomb, permuted=False)

@@ -626,3 +626,20 @@ def test_fourier_structured_gram_agrees_with_dense(L, oracle, zero_first, weight
     monkeypatch.setenv("LPVS_GRAM_FORM", "ap")                      # forcing the structured form on a non-uniform grid is an error
     with pytest.raises(ValueError):
         L.Problem.fourier(y, t, np.sort(rng.random(Nf)) + 0.01, W)
+
+
+def test_tls_spectral_known_answer_and_oracle(L, oracle):
+    """src/lsfft.jl:85-99 / test/runtests.jl:194-195: findmax(abs2(x)) ~ (2 length(freqs), 101) for y = sin(2 pi t); and
+    agreement with the SVD form on a noisy record."""
+    t = np.arange(0, 100, 0.1)
+    y = np.sin(2 * np.pi * t)
+    x, f = L.tls_spectral(y, t)
+    p = np.abs(x) ** 2
+    assert len(f) == 500 and abs(p.max() - 1000.0) < 1e-4 and p.argmax() + 1 == 101
+    rng = np.random.default_rng(8)
+    t2 = np.sort(rng.random(800) * 80)
+    f2 = np.arange(1, 41) / 16.0
+    y2 = np.sin(2 * np.pi * f2[9] * t2) + 0.3 * rng.standard_normal(800)
+    x2, _ = L.tls_spectral(y2, t2, f2)
+    xo, _ = oracle.tls_spectral(y2, t2, f2)
+    assert rel(x2, xo) <= 1e-9

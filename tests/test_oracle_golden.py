@@ -62,6 +62,16 @@ def test_ls_spectral_known_answer(oracle):
     assert abs(p.max() - g["findmax_abs2"][0]) < g["atol"] and p.argmax() + 1 == g["findmax_abs2"][1]
 
 
+def test_tls_spectral_known_answer(oracle):
+    g = GOLD["tls_spectral_sine"]
+    t = _t()
+    y = np.sin(2 * np.pi * t)
+    x, f = oracle.tls_spectral(y, t)
+    p = np.abs(x) ** 2
+    assert len(f) == 500
+    assert abs(p.max() - g["findmax_abs2"][0]) < g["atol"] and p.argmax() + 1 == g["findmax_abs2"][1]
+
+
 @pytest.mark.parametrize("case", GOLD["ls_windowpsd"])
 def test_ls_windowpsd_known_answer(oracle, case):
     t = _t()
