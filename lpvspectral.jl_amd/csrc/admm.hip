@@ -71,7 +71,7 @@ admm_init_kernel(AdmmParams p) {
         p.rhs[o + i] = ok ? p.b[o + i] + (xi - 0.0) / p.mu : 0.0;  // b + (z-u)/mu
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        p.status[sg].iters = 0; p.status[sg].converged = 0; p.status[sg].nxz = 0.0;
+        p.status[sg].iters = 0; p.status[sg].converged = 0; p.status[sg].nxz = 0.0; p.status[sg].pad = 0;
     }
 }
 
@@ -804,6 +804,104 @@ admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1_all, con
 }
 
 
+
+// ---- the same update with the convergence test DEFERRED by one launch (single-problem path) -------------------------
+// The ticket above serialises every iteration on an agent-scope fence, an atomic and a last-arriving workgroup.  Here
+// every workgroup writes its block's ||x-z||^2 into the buffer of the iteration's parity and is done.  The NEXT
+// launch first sums the previous iteration's block norms (every workgroup, identically, with loads that fly together
+// with its partial sums), commits iteration count / norm / convergence (workgroup 0), and if that iteration had
+// converged nobody writes anything -- the iterates stay those of the converged iteration, exactly as with the
+// ticket.  status.pad == 1 marks "one iteration executed, not yet committed"; admm_commit_kernel commits the last
+// iteration of a chunk.  Mat-vec launches issued past the (not yet visible) convergence are harmless.
+__device__ __forceinline__ double pending_norm(const double *__restrict__ bn, int nblk, double *slot) {
+    if (threadIdx.x < 64) {   // lane q sums blocks q, q+64, ...; then the wave's fixed shuffle pattern
+        double part = 0;
+        for (int q = threadIdx.x; q < nblk; q += 64) part += bn[q];
+        const double w = wave_sum(part);
+        if (threadIdx.x == 0) *slot = w;
+    }
+    __syncthreads();
+    return sqrt(*slot);                                               // norm(tmp)   src/lasso.jl:157
+}
+
+__global__ void __launch_bounds__(512)
+admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk,
+                          int ntiles, double *__restrict__ blocknorm_all, int parity) {
+    const int sg = blockIdx.y;
+    AdmmStatus *status = p.status + sg;
+    if (status->converged) return;
+    __shared__ double sh[3 * TS], sq[TS], gs[TS], slot;
+    const double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
+    double *bn_prev = blocknorm_all + ((int64_t)sg * 2 + (parity ^ 1)) * nblk, *bn_cur = blocknorm_all + ((int64_t)sg * 2 + parity) * nblk;
+    const int I = blockIdx.x, i = threadIdx.x & 127;
+    const int64_t li_ = (int64_t)I * TS + i, gi = (int64_t)sg * p.np + li_;
+    const bool row = threadIdx.x < TS, ok = row && li_ < p.n;
+    const double ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;   // in flight together with the partials
+    if (status->pad) {                                               // uniform: commit the previous iteration
+        const double nxz = pending_norm(bn_prev, nblk, &slot);
+        const bool conv = nxz < p.tol;                               //             src/lasso.jl:164
+        if (I == 0 && threadIdx.x == 0) {
+            status->iters += 1;
+            status->nxz = nxz;
+            if (conv) status->converged = 1;
+        }
+        if (conv) return;                                            // every workgroup takes the same decision
+    }
+    const double xi = gather_x4(part1, part2, nblk, I, sh);
+    const double v = xi + ui;
+    double zi = 0.0, d2 = 0.0;
+    if (p.prox_kind == LPVS_PROX_L1) {
+        const double gl = p.mu * p.prox_param;
+        zi = v + (v <= -gl ? gl : (v >= gl ? -gl : -v));
+    } else if (p.prox_kind == LPVS_PROX_L0) {
+        zi = fabs(v) > sqrt(2.0 * p.mu * p.prox_param) ? v : 0.0;
+    } else {  // group: block soft-threshold, norms through LDS
+        const int gl = (int)p.group_len;
+        if (row) sq[i] = v * v;
+        __syncthreads();
+        if (threadIdx.x < TS / gl) {
+            double s2 = 0;
+            for (int q = 0; q < gl; ++q) s2 += sq[threadIdx.x * gl + q];   // sequential, as norm() on the slice
+            double scale = 1.0 - p.prox_param * p.mu / sqrt(s2);           // s2 == 0 -> -inf -> 0
+            if (!(scale > 0)) scale = 0.0;
+            gs[threadIdx.x] = scale;
+        }
+        __syncthreads();
+        if (row) zi = gs[i / gl] * v;
+    }
+    if (row) {
+        if (!ok) zi = 0.0;
+        const double d = xi - zi, un = ui + d;     // src/lasso.jl:154-155
+        p.x[gi] = xi; p.z[gi] = zi; p.u[gi] = un;
+        p.rhs[gi] = ok ? bi + (zi - un) / p.mu : 0.0;
+        d2 = ok ? d * d : 0.0;
+    }
+    const double wsum = wave_sum(d2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bn_cur[I] = sh[0] + sh[1];
+        if (I == 0) status->pad = 1;
+    }
+}
+
+// commits the last executed iteration of a chunk (one workgroup per signal)
+__global__ void __launch_bounds__(64)
+admm_commit_kernel(AdmmParams p, int nblk, double *__restrict__ blocknorm_all, int parity_last) {
+    const int sg = blockIdx.x;
+    AdmmStatus *status = p.status + sg;
+    if (status->converged || !status->pad) return;
+    __shared__ double slot;
+    const double nxz = pending_norm(blocknorm_all + ((int64_t)sg * 2 + parity_last) * nblk, nblk, &slot);
+    if (threadIdx.x == 0) {
+        status->iters += 1;
+        status->nxz = nxz;
+        if (nxz < p.tol) status->converged = 1;
+        status->pad = 0;
+    }
+}
+
 // Small systems of a batch (np <= 1024, e.g. the windows of ls_windowpsd): ONE workgroup per problem does what
 // admm_fused_update_kernel does with nblk workgroups -- thread group g (128 lanes) owns row block g -- so the norm
 // ||x-z|| needs no cross-workgroup ticket (no agent-scope fences, no atomics).  blockDim = 128 * nblk.
@@ -1005,7 +1103,7 @@ int32_t launch_admm_init(const AdmmParams &p, hipStream_t s) {
 
 size_t symv_part_doubles(int64_t np, int64_t ns) {
     const int64_t nblk = np / TS;
-    return ((size_t)(nblk * (nblk + 1) / 2) * TS * 2 + (size_t)nblk + 2) * (size_t)ns + 16;   // part1, part2, block norms, tickets
+    return ((size_t)(nblk * (nblk + 1) / 2) * TS * 2 + 2 * (size_t)nblk + 2) * (size_t)ns + 16;   // part1, part2, block norms (two parities), tickets
 }
 size_t symv_packed_doubles(int64_t np) {
     const int64_t nblk = np / TS;
@@ -1046,13 +1144,12 @@ bool fused_ok(const AdmmParams &p) {
 }
 
 // one ADMM iteration on the packed symmetric form
-static void launch_iteration_sym(const AdmmParams &p, hipStream_t s) {
+static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     const int nblk = (int)(p.np / TS);
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
     const unsigned ns = (unsigned)p.ns;
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
-    unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
     if (p.ns > 1 && !p.mp_f32)
         hipLaunchKernelGGL((symv_tile_multi_kernel<double, 8>), dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     else if (p.mp_f32)
@@ -1061,7 +1158,7 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s) {
     else
         hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     if (fused_ok(p)) {
-        hipLaunchKernelGGL(admm_fused_update_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, ticket);
+        hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1);
     } else {
         hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status);
         hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
@@ -1132,7 +1229,7 @@ int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s
     const bool sym = p.part != nullptr && p.Mp != nullptr;
     for (int64_t i = 0; i < iters; ++i) {
         if (sym) {
-            launch_iteration_sym(p, s);
+            launch_iteration_sym(p, s, (int)i);
         } else {
             launch_symv_raw(p.M, p.np, p.rhs, p.x, p.status, p.ns, s);
             if (p.prox_kind != LPVS_PROX_BALL_L0 && p.n <= 4096) {
@@ -1144,6 +1241,12 @@ int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s
                 hipLaunchKernelGGL(admm_prox_kernel, dim3((unsigned)p.ns), dim3(1024), 0, s, p);
             }
         }
+    }
+    if (sym && iters > 0 && fused_ok(p)) {   // commit the last iteration of the chunk (deferred convergence test)
+        const int nblk = (int)(p.np / TS);
+        const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
+        double *blocknorm = p.part + (size_t)ntiles * TS * 2 * (unsigned)p.ns;
+        hipLaunchKernelGGL(admm_commit_kernel, dim3((unsigned)p.ns), dim3(64), 0, s, p, nblk, blocknorm, (int)((iters - 1) & 1));
     }
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
