@@ -9,7 +9,7 @@ module LPVSpectralAMD
 
 using Printf, LinearAlgebra
 
-export ls_spectral, ls_sparse_spectral, ls_sparse_spectral_lpv, ls_spectral_lpv, ls_windowpsd,
+export ls_spectral, tls_spectral, ls_sparse_spectral, ls_sparse_spectral_lpv, ls_spectral_lpv, ls_windowpsd,
        get_fourier_regressor, check_freq, default_freqs, Windows2, SpectralExt, psd,
        NormL1, NormL0, IndBallL0, GroupL2
 
@@ -61,6 +61,21 @@ function get_fourier_regressor(t::AbstractArray{T}, f::AbstractArray{T}) where T
         fv::Ptr{Float64}, length(fv)::Int64, A::Ptr{Float64}, z::Ref{Int64})::Int32)
     A, zf
 end
+
+# Float32 method (the reference is eltype-generic): same call through the _f32 entry point, Float32 in and out
+function get_fourier_regressor(t::AbstractArray{Float32}, f::AbstractArray{Float32})
+    tv, fv = Vector{Float32}(t), Vector{Float32}(f)
+    z = Ref{Int64}(0)
+    check(@ccall LIB.lpvs_check_freq_f32(fv::Ptr{Float32}, length(fv)::Int64, z::Ref{Int64})::Int32)
+    zf = z[] == 0 ? nothing : Int(z[])
+    A = zeros(Float32, length(tv), zf === nothing ? 2length(fv) : 2length(fv) - 1)
+    GC.@preserve tv fv A check(@ccall LIB.lpvs_fourier_regressor_f32(tv::Ptr{Float32}, length(tv)::Int64,
+        fv::Ptr{Float32}, length(fv)::Int64, A::Ptr{Float32}, z::Ref{Int64})::Int32)
+    A, zf
+end
+# (lpvs_problem_create_{fourier,lpv}_f32, lpvs_admm_init_f32, lpvs_admm_get_f32, lpvs_problem_get_params_f32 and
+#  lpvs_ls_spectral_f32 bind the same way; handles created through them stream a single-precision copy of the matrix
+#  in the ADMM mat-vec.)
 
 # ---- handle wrapper ----------------------------------------------------------------------------
 mutable struct Problem
@@ -148,6 +163,15 @@ end
 function ls_spectral(y, t, f, W::AbstractVector; verbose=false, λ=1e-10)             # src/lsfft.jl:74-80
     p = fourier_problem(y, t, f, W)
     pack(p, solve_ridge(p, λ)), f                         # (A'WA + λI) \ A'Wy
+end
+
+function tls_spectral(y, t, f=default_freqs(t)[1:end-1])                               # src/lsfft.jl:85-99
+    p = fourier_problem(y, t, f, nothing)
+    G = zeros(p.n, p.n); b = zeros(p.n)
+    check(@ccall LIB.lpvs_problem_get_gram_f64(p.h::Ptr{Cvoid}, G::Ptr{Float64}, b::Ptr{Float64})::Int32)
+    H = [G b; b' dot(y, y)]                             # [A y]'[A y]: its smallest eigenvector is the last right singular vector
+    v = eigen(Symmetric(H)).vectors[:, 1]
+    pack(p, -v[1:p.n] ./ v[p.n + 1]), f
 end
 
 function ls_sparse_spectral(y::AbstractArray{T}, t, f=default_freqs(t); init=false, λ=T(1),
