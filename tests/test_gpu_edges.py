@@ -1,0 +1,72 @@
+"""Edge cases of the structured (NUDFT) Gram and of the batched-window engine: single frequencies, slot padding,
+sample counts that straddle the kernel's 16-sample blocks and chunk boundaries, ragged window tails, empty inputs."""
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(w, x):
+    return 1e-12 + 4.5e-16 * np.abs(w).max() * np.abs(x).max()
+
+
+@pytest.mark.parametrize("N,Nf,Nv", [(37, 1, 2), (37, 3, 2), (1000, 7, 3), (8193, 9, 2), (16385, 17, 4)])
+def test_lpv_structured_gram_small_and_ragged_sizes(L, oracle, N, Nf, Nv):
+    rng = np.random.default_rng(N + Nf)
+    X = np.sort(rng.random(N) * 12.0); V = rng.random(N) * 2 - 0.5
+    w = 0.7 + 1.3 * np.arange(Nf)                       # arithmetic progression, not starting at its step
+    y = rng.standard_normal(N)
+    with L.Problem.lpv(y, X, V, w, Nv) as p:
+        G, b = p.get_gram()
+        assert p.timing()["gram_form"] == "ap"
+    Phi = oracle.lpv_regressor(X, V, w, Nv)
+    Go, bo = oracle.gram(Phi, y)
+    assert np.abs(G - Go).max() <= _tol(w, X) * np.abs(Go).max()
+    assert np.abs(b - bo).max() <= 10 * _tol(w, X) * max(np.abs(bo).max(), 1.0)
+
+
+@pytest.mark.parametrize("f", [np.array([0.0]), np.array([0.25]), np.arange(5) / 8.0, np.arange(1, 10) / 20.0])
+def test_fourier_structured_gram_tiny_grids(L, oracle, f):
+    rng = np.random.default_rng(len(f))
+    N = 531
+    t = np.sort(rng.random(N) * 50)
+    y = rng.standard_normal(N)
+    with L.Problem.fourier(y, t, f) as p:
+        G, b = p.get_gram()
+        assert p.timing()["gram_form"] == "ap"
+    A, zf = oracle.get_fourier_regressor(t, f)
+    Go, bo = oracle.gram(A, y)
+    tol = _tol(2 * np.pi * f, t)
+    assert G.shape == Go.shape
+    assert np.abs(G - Go).max() <= tol * np.abs(Go).max()
+    assert np.abs(b - bo).max() <= 10 * tol * max(np.abs(bo).max(), 1.0)
+
+
+def test_batched_windows_ragged_tail_and_overlap(L):
+    """L not a multiple of the hop, overlapping windows, hanning weights: the batched engine (structured per-window Gram)
+    equals the window-by-window loop."""
+    rng = np.random.default_rng(5)
+    Ltot, nw = 5000, 9
+    t = np.arange(Ltot) * 0.5
+    y = np.sin(2 * np.pi * 0.11 * t) + 0.5 * np.sin(2 * np.pi * 0.31 * t) + 0.2 * rng.standard_normal(Ltot)
+    freqs = np.arange(0, 40) / 80.0
+    kw = dict(nw=nw, noverlap=100, window_func=L.hanning, estimator=L.ls_sparse_spectral, λ=0.5, iters=300, tol=0.0,
+              printerval=1000, out=io.StringIO())
+    S1, f1 = L.ls_windowpsd(y, t, freqs, batched=True, **kw)
+    S2, f2 = L.ls_windowpsd(y, t, freqs, batched=False, **kw)
+    assert np.array_equal(f1, f2)
+    assert np.abs(S1 - S2).max() <= 1e-9 * np.abs(S2).max()
+
+
+def test_empty_and_mismatched_inputs_raise(L):
+    e = np.zeros(0)
+    with pytest.raises((ValueError, AssertionError)):
+        L.Problem.lpv(e, e, e, np.array([1.0, 2.0]), 2)
+    with pytest.raises((ValueError, AssertionError)):
+        L.Problem.fourier(e, e, np.array([0.1]))
+    with pytest.raises(AssertionError):
+        L.Problem.lpv(np.zeros(5), np.zeros(4), np.zeros(5), np.array([1.0]), 2)
+    with pytest.raises(ValueError):                       # zero frequency not first, src/lsfft.jl:22
+        L.Problem.fourier(np.zeros(8), np.arange(8.0), np.array([0.1, 0.0]))
