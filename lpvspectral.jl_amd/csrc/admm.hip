@@ -11,6 +11,9 @@
 // can be enqueued without a host round trip and still stop at exactly the reference's iteration.
 #include "lpvs_internal.h"
 
+#include <cstdlib>
+#include <string>
+
 namespace lpvs {
 
 namespace {
@@ -603,6 +606,112 @@ symv_tile_multi_kernel(const T *__restrict__ Mp, const double *__restrict__ rhs_
     }
 }
 
+
+// ---- multi-signal tile product on the matrix cores ------------------------------------------------------------------
+// With ns right-hand sides sharing M the per-signal cross-lane row reductions of symv_tile_multi_kernel, not the memory
+// pipe, bound the kernel (2.9 TB/s at ns = 8).  Here a tile is two small GEMMs on v_mfma_f64_16x16x4_f64:
+//     P1[i][s] = sum_c T[i][c] R_J[c][s]      (A operand = T, 16 rows x 4 cols;  B = R_J)
+//     P2[s][c] = sum_i R_I[i][s] T[i][c]      (A = R_I', B = T, 4 rows x 16 cols)
+// The two products need T in transposed operand layouts, so the tile goes through LDS in four 32-row stages (LDS-DMA,
+// one 1 KiB row per instruction, rows padded by 16 B) and is read from there in either layout: waves 0-1 form P1 of the
+// stage's two 16-row blocks, waves 2-3 accumulate P2 over the stages (four 16-column blocks each).  43 KB of LDS per
+// workgroup: three workgroups per CU keep the memory pipe busy while others multiply (double-buffering the stages
+// inside a workgroup at two workgroups per CU was slower: 1.36 vs 1.24 ms at ns = 8, n = 32768).  Signals are processed eight at a
+// time (the MFMA's 16-wide signal dimension is half used).  Partials have the layout of the scalar kernels, so the
+// update kernels are shared.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int MT_RS = TS + 2;                        // padded row stride of the staged rows (doubles)
+constexpr int MT_NS = 8;                             // signals per pass
+constexpr int MT_ROWS = 32;                          // tile rows per stage
+constexpr size_t kSymvMfmaLds = sizeof(double) * ((size_t)MT_ROWS * MT_RS + (size_t)MT_ROWS * MT_NS + (size_t)TS * MT_NS);
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 3)
+symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
+                      double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    if (status != nullptr) {
+        bool all = true;
+        for (int q = 0; q < ns; ++q) all = all && status[q].converged;
+        if (all) return;
+    }
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *stg = lds;                               // [32][MT_RS]   the current 32 rows of the tile
+    double *ri = stg + MT_ROWS * MT_RS;              // [32][MT_NS]   right-hand sides of row block I, rows of the current stage
+    double *rj = ri + MT_ROWS * MT_NS;               // [128][MT_NS]  right-hand sides of row block J
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const double *src = Mp + (int64_t)t * TS * TS;
+    for (int s0 = 0; s0 < ns; s0 += MT_NS) {
+        const int nsb = ns - s0 < MT_NS ? ns - s0 : MT_NS;
+        f64x4 acc2[4];                               // waves 2-3: P2 blocks, columns 64*(wave-2) + 16*u .., over all stages
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc2[u] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < TS / MT_ROWS; ++q) {
+            __syncthreads();                         // everyone is done with the previous contents of the LDS images
+#pragma unroll
+            for (int r = 0; r < MT_ROWS / 4; ++r) {  // wave w brings rows 8w..8w+7 of the stage: one 1 KiB row per instruction
+                const int row = wave * (MT_ROWS / 4) + r;
+                glds16(src + (int64_t)(MT_ROWS * q + row) * TS + 2 * lane, stg + row * MT_RS);
+            }
+            {   // R_I rows of this stage: 32 x 8 values, one per thread (zero beyond the pass's signals)
+                const int sq = tid / MT_ROWS, i = tid - sq * MT_ROWS;
+                ri[i * MT_NS + sq] = sq < nsb ? rhs_all[(int64_t)(s0 + sq) * np + (int64_t)I * TS + MT_ROWS * q + i] : 0.0;
+            }
+            if (q == 0)
+                for (int e = tid; e < TS * MT_NS; e += 256) {
+                    const int sq = e / TS, i = e - sq * TS;
+                    rj[i * MT_NS + sq] = sq < nsb ? rhs_all[(int64_t)(s0 + sq) * np + (int64_t)J * TS + i] : 0.0;
+                }
+            __syncthreads();                         // DMA landed (vmcnt(0)), staging visible
+            if (wave < 2) {
+                // P1: rows 16*wave .. of this stage, all 128 columns.  A[i = li][k = lk], B[k = lk][j = s = li]
+                f64x4 a0 = (f64x4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+                const double *arow = stg + (16 * wave + li) * MT_RS;
+#pragma unroll 8
+                for (int kk = 0; kk < 32; kk += 2) {
+                    const int c = 4 * kk + lk;
+                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[c], li < MT_NS ? rj[c * MT_NS + li] : 0.0, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[c + 4], li < MT_NS ? rj[(c + 4) * MT_NS + li] : 0.0, a1, 0, 0, 0);
+                }
+                // D: col = lane&15 = s, row = lk + 4*reg
+                if (li < nsb && !(status != nullptr && status[s0 + li].converged)) {
+                    double *p1 = part1_all + (int64_t)(s0 + li) * ntiles * TS + (int64_t)t * TS + MT_ROWS * q + 16 * wave + lk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p1[4 * r] = a0[r] + a1[r];
+                }
+            } else {
+                // P2: columns 64*(wave-2) + 16*u .., the 32 rows of this stage.  A[s = li][k = lk], B[k = lk][j = c = li]
+#pragma unroll
+                for (int kk = 0; kk < MT_ROWS / 4; ++kk) {
+                    const int i = 4 * kk + lk;
+                    const double a = li < MT_NS ? ri[i * MT_NS + li] : 0.0;
+                    const double *brow = stg + i * MT_RS + 64 * (wave - 2) + li;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * u], acc2[u], 0, 0, 0);
+                }
+            }
+        }
+        if (I != J && wave >= 2) {   // P2: D row = s = lk + 4*reg, col = li
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int sgl = lk + 4 * r;
+                    if (sgl < nsb && !(status != nullptr && status[s0 + sgl].converged))
+                        part2_all[(int64_t)(s0 + sgl) * ntiles * TS + (int64_t)t * TS + 64 * (wave - 2) + 16 * u + li] = acc2[u][r];
+                }
+        }
+    }
+}
+
 // Same tile product for a batch of problems that each own their matrix (windows): blockIdx.y = problem.
 __global__ void __launch_bounds__(256)
 symv_tile_batch_kernel(const double *__restrict__ Mp_all, int64_t mp_stride, const double *__restrict__ rhs_all, int64_t np,
@@ -1150,7 +1259,12 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     const unsigned ns = (unsigned)p.ns;
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
-    if (p.ns > 1 && !p.mp_f32)
+    static const bool mfma_multi = [] { const char *e = getenv("LPVS_MULTI_MATVEC"); return !(e && std::string(e) == "valu"); }();
+    if (p.ns > 1 && !p.mp_f32 && mfma_multi) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kSymvMfmaLds);   // per device; cheap
+        hipLaunchKernelGGL(symv_tile_mfma_kernel, dim3(ntiles), dim3(256), kSymvMfmaLds, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
+    } else if (p.ns > 1 && !p.mp_f32)
         hipLaunchKernelGGL((symv_tile_multi_kernel<double, 8>), dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     else if (p.mp_f32)
         hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,

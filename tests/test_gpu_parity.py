@@ -384,8 +384,9 @@ def test_windowpsd_batched_equals_sequential_and_oracle(L, oracle, noverlap, zer
 # ------------------------------------------------------------------ shared-regressor batch (cfg5 engine)
 @pytest.mark.parametrize("Nf,Nv,prox", [(12, 8, "group"), (140, 8, "group"), (140, 8, "ball"), (12, 4, "l1")])
 def test_lpv_multi_equals_single_signal_runs(L, Nf, Nv, prox):
-    """ns signals sharing (X, V, w): one Gram, ns right-hand sides; every column must equal the single-signal
-    solve bit for bit (same kernels, same order), with its own stopping iteration."""
+    """ns signals sharing (X, V, w): one Gram, ns right-hand sides; every column must equal the single-signal solve, with
+    its own stopping iteration: bit for bit on the plain mat-vec path (same kernels, same order); on the tile-packed path
+    the multi-signal product runs on the matrix cores (different summation order): rel-L2 <= 1e-12, identical support."""
     rng = np.random.default_rng(13)
     N, ns = 1500, 3
     X = np.sort(10 * rng.random(N)); V = np.linspace(0, 1, N)
@@ -400,7 +401,10 @@ def test_lpv_multi_equals_single_signal_runs(L, Nf, Nv, prox):
     its = []
     for q in range(ns):
         se = L.ls_sparse_spectral_lpv(Y[:, q].copy(), X, V, w, Nv, proxg=g, **kw)
-        assert np.array_equal(ses[q].x, se.x), (q, rel(ses[q].x, se.x))
+        if n >= 2048:
+            assert rel(ses[q].x, se.x) <= 1e-12 and np.array_equal(np.abs(ses[q].x) > 0, np.abs(se.x) > 0), (q, rel(ses[q].x, se.x))
+        else:
+            assert np.array_equal(ses[q].x, se.x), (q, rel(ses[q].x, se.x))
         its.append(np.count_nonzero(se.x))
     assert (n >= 2048) == (Nf == 140)            # both the packed-symmetric and the plain mat-vec paths are covered
     with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
