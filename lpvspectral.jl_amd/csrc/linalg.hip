@@ -403,9 +403,11 @@ rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, 
     const int wa = wave / RU_WN, wb = wave % RU_WN;
     // XCD-aware: the 8 XCDs are dealt consecutive blocks round-robin; give each a contiguous run of the tile list
     int2 tt;
-    if (band_tile >= 0) {   // band launch (grid = tile rows): the tiles of tile row / tile column band_tile, enumerated directly
-        const int e = blockIdx.x;
-        tt = e <= band_tile ? make_int2(band_tile, e) : make_int2(e, band_tile);
+    if (band_tile >= 0) {   // band launch: the tiles of the band's tile rows / tile columns, enumerated directly
+        const int nr = (int)(np / RU_TM);          // grid = nr per 128-wide slice of the band
+        const int bsl = blockIdx.x / nr, e = blockIdx.x - bsl * nr, bt = band_tile + bsl;
+        if (bsl == 0 && nw > RU_TM && e == band_tile + 1) return;   // tile (band_tile+1, band_tile) belongs to the second slice
+        tt = e <= bt ? make_int2(bt, e) : make_int2(e, bt);
     } else {
         const int bq = ntiles / 8, br = ntiles % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;
         const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
@@ -637,7 +639,10 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     static const bool single_wg_pivot = [] { const char *e = getenv("LPVS_PIVOT"); return !(e && std::string(e) == "sweep64"); }();
     static const bool lookahead_on = [] { const char *e = getenv("LPVS_LOOKAHEAD"); return !(e && e[0] == '0'); }();
     LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rank_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    static const int kw_outer = [] { const char *e = getenv("LPVS_KW"); return (e && atoi(e) == 256) ? 256 : 128; }();
+    // 128-wide pivot blocks (one-workgroup inverse) up to np ~ 12k; beyond, the bulk update is long enough to hide the
+    // 256-wide chain (pivot block by the 64-wide sweep) and the deeper update runs closer to the MFMA peak
+    static const int kw_env = [] { const char *e = getenv("LPVS_KW"); return e ? atoi(e) : 0; }();
+    const int kw_outer = kw_env == 128 || kw_env == 256 ? kw_env : (np >= 12288 ? 256 : 128);
     const bool la = lookahead_on && aux != nullptr && np > kw_outer;
     if (la) LPVS_TRY(aux->ensure());
 
@@ -659,8 +664,8 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
         const int64_t n0 = k0 + kw;
         const int nw = n0 < np ? width(n0) : 0;
         // a 128-wide band is one tile row + one tile column: launch just those (32k early-exit workgroups cost 0.3 ms at np = 32768)
-        const bool direct = which == 1 && nw == RU_TM && RU_TM == RU_TN;
-        hipLaunchKernelGGL(rank_update_kernel, dim3(direct ? (unsigned)(np / RU_TM) : (unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, k0,
+        const bool direct = which == 1 && nw % RU_TM == 0 && nw > 0 && RU_TM == RU_TN;
+        hipLaunchKernelGGL(rank_update_kernel, dim3(direct ? (unsigned)(np / RU_TM * (nw / RU_TM)) : (unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, k0,
                            kw, Ck, Bk, tiles, (int)ht.size(), which, n0, nw, direct ? (int)(n0 / RU_TM) : -1);
     };
 
