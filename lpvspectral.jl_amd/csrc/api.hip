@@ -1299,8 +1299,6 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
     return LPVS_OK;
 }
 
-// ---- window bookkeeping (host integer arithmetic; src/windows.jl:27-36, :57-70) ----------------
-
 // ---- single-precision entry points (src/lasso.jl:85,91,144: the reference is eltype-generic) -------------------------
 // Inputs are widened exactly to double, the assembly / Gram / factorisation run in double (at least as accurate as a
 // Float32 run of the reference), the ADMM mat-vec of large problems streams a single-precision copy of M (half the
@@ -1443,6 +1441,7 @@ int32_t lpvs_ls_spectral_f32(const float *y, const float *t, int64_t N, const fl
     return narrow_out(im_out, o.as<double>() + Nf, Nf, nullptr);
 }
 
+// ---- window bookkeeping (host integer arithmetic; src/windows.jl:27-36, :57-70) ----------------
 int32_t lpvs_window_count(int64_t L, int64_t n, int64_t noverlap, int64_t *count) {
     if (!count) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (noverlap < 0) noverlap = n >> 1;  // src/windows.jl:29
