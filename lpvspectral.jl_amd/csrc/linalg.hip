@@ -636,12 +636,12 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     const std::vector<int2> &ht = ru_tiles(np);   // persistent host copy: the async upload may outlive this call
     LPVS_HIP(hipMemcpyAsync(tiles, ht.data(), sizeof(int2) * ht.size(), hipMemcpyHostToDevice, s));
     const size_t lds = sizeof(double) * 2 * RU_BK * (RU_TM + RU_TN);
-    static const bool single_wg_pivot = [] { const char *e = getenv("LPVS_PIVOT"); return !(e && std::string(e) == "sweep64"); }();
-    static const bool lookahead_on = [] { const char *e = getenv("LPVS_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+    const bool single_wg_pivot = [] { const char *e = getenv("LPVS_PIVOT"); return !(e && std::string(e) == "sweep64"); }();
+    const bool lookahead_on = [] { const char *e = getenv("LPVS_LOOKAHEAD"); return !(e && e[0] == '0'); }();
     LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rank_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // 128-wide pivot blocks (one-workgroup inverse) up to np ~ 12k; beyond, the bulk update is long enough to hide the
     // 256-wide chain (pivot block by the 64-wide sweep) and the deeper update runs closer to the MFMA peak
-    static const int kw_env = [] { const char *e = getenv("LPVS_KW"); return e ? atoi(e) : 0; }();
+    const int kw_env = [] { const char *e = getenv("LPVS_KW"); return e ? atoi(e) : 0; }();
     const int kw_outer = kw_env == 128 || kw_env == 256 ? kw_env : (np >= 12288 ? 256 : 128);
     const bool la = lookahead_on && aux != nullptr && np > kw_outer;
     if (la) LPVS_TRY(aux->ensure());
@@ -709,7 +709,7 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
 static int32_t spd_inverse_impl(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s, SweepAux *aux) {
     if (np % 128 != 0) { set_error("spd_inverse: np=%lld not a multiple of 128", (long long)np); return LPVS_ESTATE; }
     LPVS_HIP(hipMemsetAsync(status_dev, 0, sizeof(int) * (size_t)nbatch, s));
-    static const bool two_level_on = [] { const char *e = getenv("LPVS_FACTOR"); return !(e && std::string(e) == "sweep64"); }();
+    const bool two_level_on = [] { const char *e = getenv("LPVS_FACTOR"); return !(e && std::string(e) == "sweep64"); }();
     if (nbatch == 1 && np >= kTwoLevelMinNp && two_level_on) {
         LPVS_TRY(spd_inverse_two_level(A, np, work, status_dev, s, aux));
     } else {

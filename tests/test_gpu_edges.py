@@ -70,3 +70,22 @@ def test_empty_and_mismatched_inputs_raise(L):
         L.Problem.lpv(np.zeros(5), np.zeros(4), np.zeros(5), np.array([1.0]), 2)
     with pytest.raises(ValueError):                       # zero frequency not first, src/lsfft.jl:22
         L.Problem.fourier(np.zeros(8), np.arange(8.0), np.array([0.1, 0.0]))
+
+
+@pytest.mark.parametrize("knobs", [{}, {"LPVS_KW": "256"}, {"LPVS_KW": "256", "LPVS_LOOKAHEAD": "0"}, {"LPVS_LOOKAHEAD": "0"},
+                                   {"LPVS_PIVOT": "sweep64"}, {"LPVS_FACTOR": "sweep64"}])
+@pytest.mark.parametrize("n", [1024, 2100])
+def test_factorisation_variants_give_the_inverse(L, knobs, n, monkeypatch):
+    """Every factorisation variant (128 / 256-wide outer blocks incl. the ragged last block, with and without look-ahead,
+    one-workgroup or swept pivot block, single-level sweep) returns (G + I/mu)^-1: |M H - I| at rounding level."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n + 50, n))
+    G = A.T @ A
+    b = rng.standard_normal(n)
+    with L.Problem.gram(G, b) as p:
+        M = p.get_inverse(20.0)
+    H = G + 20.0 * np.eye(n)
+    assert np.abs(M @ H - np.eye(n)).max() <= 5e-13
+    assert np.array_equal(M, M.T)
