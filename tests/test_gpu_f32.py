@@ -48,7 +48,7 @@ def test_f32_ls_spectral_and_sparse_fourier(L, oracle):
 
 
 def test_f32_lpv_group_lasso_streams_single_precision_matrix(L, oracle):
-    """n = 2048 takes the tile-packed path, so M is streamed in single precision: measured rel-L2 ~1e-7."""
+    """n = 2048 takes the tile-packed path, so M is streamed in single precision: measured rel-L2 4e-6."""
     rng = np.random.default_rng(21)
     N, Nf, Nv = 5000, 128, 8
     X = np.sort(rng.random(N) * 10 * N / 500).astype(np.float32)
@@ -61,7 +61,7 @@ def test_f32_lpv_group_lasso_streams_single_precision_matrix(L, oracle):
     y64, X64, V64, w64 = (a.astype(np.float64) for a in (y, X, V, w))
     ref = L.ls_sparse_spectral_lpv(y64, X64, V64, w64, Nv, λ=3.0, iters=150, tol=0.0, printerval=1000, out=io.StringIO())
     r = rel(se.x, ref.x)
-    assert r <= 1e-5, r                                     # SURVEY tolerance is 1e-3
+    assert r <= 2e-5, r                                     # measured 4.1e-6; SURVEY tolerance is 1e-3
     assert np.array_equal(np.abs(se.x) > 0, np.abs(ref.x) > 0)
     with L.Problem.lpv(y, X, V, w, Nv) as p:                # the handle reports single-precision bytes per mat-vec
         p.set_prox(L.SlicedSeparableSum.frequency_groups(3.0, Nf, 2 * Nv))
