@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a clean checkout has no built library (the .so files are git-ignored): build it once, as __graft_entry__.build() does
+    so = os.path.join(ROOT, "lpvspectral.jl_amd", "liblpvspectral.so")
+    if not os.path.exists(so) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "lpvspectral.jl_amd", "csrc")])
 
 
 def _have_gpu():
