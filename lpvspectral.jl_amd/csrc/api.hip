@@ -1169,7 +1169,9 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
     const size_t panel_bytes = ap ? 0 : sizeof(double) * (size_t)nrows * (size_t)ld;
     while (!ap && bw > 1 && panel_bytes * (size_t)bw > budget) --bw;
     // structured form: every window is cut into segments of rpcw samples, one workgroup row per segment
-    const int64_t rpcw = ap ? std::min<int64_t>(n, nudft_rows_per_chunk(n * bw, sl.nsl)) : 0;
+    // fixed segment length: the summation order of a window must not depend on how many windows share the pass, so that
+    // window shards (ranks of a node) reproduce the whole run bit for bit
+    const int64_t rpcw = ap ? std::min<int64_t>(n, 4096) : 0;
     const int spw = ap ? (int)ceil_div(n, rpcw) : 0;
     DevBuf Wp;
     const double *Wdev = nullptr;

@@ -147,3 +147,52 @@ def test_group_lasso_kkt_at_convergence_midsize(L, oracle):
     Phi = oracle.lpv_regressor(X.cpu().numpy(), V.cpu().numpy(), w.cpu().numpy(), Nv)
     Go = Phi.T @ Phi
     assert np.abs(G - Go).max() <= 1e-12 * np.abs(Go).max()
+
+
+def test_cfg4_window_shards_reproduce_the_whole(L):
+    """cfg4 shape (windows of 2^16 samples, Nf = 256 with the zero frequency, L1, mu = 1e-4), 48 windows: disjoint window
+    ranges -- what the ranks of a node own -- reproduce the whole run bit for bit, S is the in-order sum of |x_i|^2, and a
+    window solved alone through the single-problem path agrees with its batched solution."""
+    n, nwin, Nf = 1 << 16, 48, 256
+    g = torch.Generator(device="cuda").manual_seed(4)
+    t = torch.arange(nwin * n, dtype=torch.float64, device="cuda")
+    f = np.arange(Nf) / 512.0
+    y = (torch.sin(2 * np.pi * f[33] * t) + 0.5 * torch.sin(2 * np.pi * f[100] * t)
+         + 0.3 * torch.randn(nwin * n, dtype=torch.float64, device="cuda", generator=g))
+    kw = dict(λ=0.2, μ=1e-4, tol=0.0, iters=300)
+    x, S, its = L.windowpsd_sparse_batched(y, t, f, n, 0, None, **kw)
+    assert x.shape == (nwin, Nf) and np.all(its == 300)
+    Sref = np.zeros(Nf)
+    for i in range(nwin):
+        Sref += x[i].real ** 2 + x[i].imag ** 2
+    assert np.array_equal(S, Sref)                                   # window order, src/lsfft.jl:122
+    parts = [L.windowpsd_sparse_batched(y, t, f, n, 0, None, win_lo=lo, win_hi=hi, **kw)[0] for lo, hi in ((0, 17), (17, 40), (40, 48))]
+    assert np.array_equal(np.vstack(parts), x)                       # shards == whole, bit for bit
+    assert int(np.argmax(np.abs(x[5]))) == 33
+    i = 29                                                           # one window alone (single-problem path, np = 512)
+    yi, ti = y[i * n:(i + 1) * n].cpu().numpy(), t[i * n:(i + 1) * n].cpu().numpy()
+    with L.Problem.fourier(yi, ti, f, np.ones(n)) as p:
+        p.set_prox(L.NormL1(0.2))
+        p.admm_init(None, μ=1e-4, tol=0.0, linear_sign=-1)           # Quadratic(Q, +q) as written, src/lasso.jl:119-121
+        p.admm_run(300)
+        xi = p.params(0)
+    assert rel(xi, x[i]) <= 1e-9
+
+
+def test_cfg5_shape_multichannel_equals_single_channel(L):
+    """cfg5 shape (Nf = 1024, Nv = 16 -> n = 32768, IndBallL0(32)) at N = 2^17 rows, 3 channels sharing (X, V): every channel of the
+    multi-signal solve (matrix-core tile product) equals its own single-signal solve (scalar tile product) to summation
+    order, with the same support of 32 coefficients."""
+    import bench
+    N, Nf, Nv, ns = 1 << 17, 1024, 16, 3
+    _, X, V, w = bench.synth_signal(N, Nf, 0, torch.device("cuda"))
+    g = torch.Generator(device="cuda").manual_seed(55)
+    Y = torch.stack([(1 + q) * torch.cos(w[(37 * q + 11) % Nf] * X) * (1 + V) + 0.5 * torch.cos(w[(91 * q + 400) % Nf] * X)
+                     + 0.1 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g) for q in range(ns)], dim=1)
+    kw = dict(proxg=L.IndBallL0(32), iters=40, tol=0.0, μ=0.05, printerval=100000)
+    ses = L.ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, **kw)
+    q = 1
+    se = L.ls_sparse_spectral_lpv(Y[:, q].contiguous(), X, V, w, Nv, **kw)
+    assert np.count_nonzero(se.x) <= 32 and np.count_nonzero(se.x) > 0
+    assert np.array_equal(np.abs(ses[q].x) > 0, np.abs(se.x) > 0)
+    assert rel(ses[q].x, se.x) <= 1e-10
