@@ -1164,7 +1164,9 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         if (bw > nwin) bw = nwin;
         if (bw > 8192) bw = 8192;
     }
-    const GramPlan pl = make_gram_plan(nreg, n, bw);
+    // the sample split of the dense form is chosen for a nominal batch of 64 windows, whatever the shard holds: the
+    // summation order of a window must not depend on how the windows are sharded
+    const GramPlan pl = make_gram_plan(nreg, n, 64);
     const int64_t nrows = ap ? n : pl.ksplit * pl.rows_per_chunk;
     const size_t panel_bytes = ap ? 0 : sizeof(double) * (size_t)nrows * (size_t)ld;
     while (!ap && bw > 1 && panel_bytes * (size_t)bw > budget) --bw;

@@ -196,3 +196,17 @@ def test_cfg5_shape_multichannel_equals_single_channel(L):
     assert np.count_nonzero(se.x) <= 32 and np.count_nonzero(se.x) > 0
     assert np.array_equal(np.abs(ses[q].x) > 0, np.abs(se.x) > 0)
     assert rel(ses[q].x, se.x) <= 1e-10
+
+
+def test_window_shards_reproduce_the_whole_dense_form(L, monkeypatch):
+    """Same sharding invariance on the dense (MFMA panel) batched path, taken for non-uniform frequency grids."""
+    monkeypatch.setenv("LPVS_GRAM_FORM", "panel")
+    n, nwin, Nf = 1 << 13, 23, 64
+    rng = np.random.default_rng(3)
+    t = np.arange(nwin * n, dtype=np.float64)
+    f = np.arange(1, Nf + 1) / 200.0
+    y = np.sin(2 * np.pi * f[20] * t) + 0.3 * rng.standard_normal(nwin * n)
+    kw = dict(λ=0.2, μ=1e-3, tol=0.0, iters=100)
+    x, S, its = L.windowpsd_sparse_batched(y, t, f, n, 0, None, **kw)
+    parts = [L.windowpsd_sparse_batched(y, t, f, n, 0, None, win_lo=lo, win_hi=hi, **kw)[0] for lo, hi in ((0, 1), (1, 12), (12, 23))]
+    assert np.array_equal(np.vstack(parts), x)
