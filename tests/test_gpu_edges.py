@@ -89,3 +89,40 @@ def test_factorisation_variants_give_the_inverse(L, knobs, n, monkeypatch):
     H = G + 20.0 * np.eye(n)
     assert np.abs(M @ H - np.eye(n)).max() <= 5e-13
     assert np.array_equal(M, M.T)
+
+
+@pytest.mark.parametrize("Nf,Nv", [(12, 4), (128, 8)])
+def test_iterates_do_not_depend_on_chunking(L, Nf, Nv):
+    """lpvs_admm_run in one call or in chunks (what printerval / cb do) gives the same iterates bit for bit, on the plain
+    (n < 2048: hipGraph replay) and on the tile-packed (n >= 2048: deferred convergence commit) path; an early stop lands on
+    the same iteration."""
+    rng = np.random.default_rng(Nf)
+    N = 3000
+    X = np.sort(rng.random(N) * 60); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) / 8
+    y = np.cos(w[3] * X) * (1 + V) + 0.1 * rng.standard_normal(N)
+    g = L.SlicedSeparableSum.frequency_groups(2.0, Nf, 2 * Nv)
+    res = []
+    for chunks in ([300], [100, 100, 100], [1, 7, 150, 142]):
+        with L.Problem.lpv(y, X, V, w, Nv) as p:
+            p.set_prox(g)
+            p.admm_init(None, μ=0.05, tol=0.0)
+            for c in chunks:
+                it, nxz, conv = p.admm_run(c)
+            res.append((it, nxz) + p.admm_get())
+    for r in res[1:]:
+        assert r[0] == res[0][0] == 300 and r[1] == res[0][1]
+        for a, b in zip(r[2:], res[0][2:]):
+            assert np.array_equal(a, b)
+    stops = []
+    for chunks in ([4000], [250] * 16):
+        with L.Problem.lpv(y, X, V, w, Nv) as p:
+            p.set_prox(g)
+            p.admm_init(None, μ=0.05, tol=1e-4)
+            for c in chunks:
+                it, nxz, conv = p.admm_run(c)
+                if conv:
+                    break
+            stops.append((it, conv, nxz) + p.admm_get())
+    assert stops[0][1] and stops[1][1] and stops[0][0] == stops[1][0] and stops[0][2] == stops[1][2]
+    assert np.array_equal(stops[0][3], stops[1][3]) and np.array_equal(stops[0][4], stops[1][4])
