@@ -205,6 +205,41 @@ struct EventPair {
 
 using namespace lpvs;
 
+// Streams and events are not free to create and destroy (about 1 ms per handle): handles borrow them from a small
+// per-process cache and give them back idle.
+struct StreamBundle {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    EventPair ev[4];
+    SweepAux aux;
+    ~StreamBundle() {
+        for (auto &e : ev) e.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+static std::mutex g_bundle_mu;
+static std::vector<StreamBundle *> g_bundles;
+static StreamBundle *bundle_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> g(g_bundle_mu);
+        for (size_t i = 0; i < g_bundles.size(); ++i)
+            if (g_bundles[i]->device == device) { StreamBundle *b = g_bundles[i]; g_bundles.erase(g_bundles.begin() + (long)i); return b; }
+    }
+    StreamBundle *b = new (std::nothrow) StreamBundle();
+    if (!b) return nullptr;
+    b->device = device;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete b; return nullptr; }
+    for (auto &e : b->ev) if (e.init() != LPVS_OK) { delete b; return nullptr; }
+    return b;
+}
+static void bundle_release(StreamBundle *b) {
+    if (!b) return;
+    (void)hipStreamSynchronize(b->stream);
+    if (b->aux.side) (void)hipStreamSynchronize(b->aux.side);
+    std::lock_guard<std::mutex> g(g_bundle_mu);
+    if (g_bundles.size() < 8) g_bundles.push_back(b); else delete b;
+}
+
 struct lpvs_problem {
     int kind = 0;  // 0 fourier, 1 lpv, 2 explicit gram
     int device = 0;
@@ -217,8 +252,8 @@ struct lpvs_problem {
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
     // timing (ms) -- see lpvs_problem_get_timing
     double t_basis = 0, t_gram = 0, t_reduce = 0, t_factor = 0, t_admm = 0, gram_launches = 0, gram_flops = 0, admm_iters_timed = 0, gram_form = 0;
-    EventPair ev[4];
-    SweepAux sweep_aux;   // side stream + events of the factorisation's look-ahead
+    EventPair ev[4];          // copies of the bundle's events (owned by `res`)
+    StreamBundle *res = nullptr;   // stream, events and the factorisation's side stream, borrowed from the cache
     bool f32 = false;     // created through an _f32 entry point: the ADMM mat-vec streams a single-precision copy of M
     // launch-bound regime (small n): a chunk of ADMM iterations captured once into a hipGraph and replayed
     hipGraphExec_t admm_graph = nullptr;
@@ -226,8 +261,7 @@ struct lpvs_problem {
     void drop_graph() { if (admm_graph) (void)hipGraphExecDestroy(admm_graph); admm_graph = nullptr; admm_graph_iters = 0; }
     ~lpvs_problem() {
         drop_graph();
-        for (auto &e : ev) e.destroy();
-        if (stream) (void)hipStreamDestroy(stream);
+        bundle_release(res);
     }
 };
 
@@ -247,9 +281,10 @@ int32_t problem_begin(int32_t device, lpvs_problem **out, lpvs_problem **hp) {
     lpvs_problem *h = new (std::nothrow) lpvs_problem();
     if (!h) return LPVS_ENOMEM;
     h->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete h; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return LPVS_EDEVICE; }
-    for (auto &ev : h->ev) { int32_t rc = ev.init(); if (rc != LPVS_OK) { delete h; return rc; } }
+    h->res = bundle_acquire(device);
+    if (!h->res) { delete h; set_error("stream / event creation failed"); return LPVS_EDEVICE; }
+    h->stream = h->res->stream;
+    for (int i = 0; i < 4; ++i) h->ev[i] = h->res->ev[i];
     *hp = h;
     return LPVS_OK;
 }
@@ -288,7 +323,7 @@ int32_t factorize(lpvs_problem *h, double shift) {
     LPVS_HIP(hipEventRecord(h->ev[3].a, h->stream));
     LPVS_HIP(hipMemcpyAsync(h->M.p, h->G.p, sizeof(double) * (size_t)np * (size_t)np, hipMemcpyDeviceToDevice, h->stream));
     LPVS_TRY(launch_add_diag(h->M.as<double>(), np, n, shift, h->stream));
-    LPVS_TRY(spd_inverse_inplace(h->M.as<double>(), np, h->work.as<double>(), h->istat.as<int>(), h->stream, &h->sweep_aux));
+    LPVS_TRY(spd_inverse_inplace(h->M.as<double>(), np, h->work.as<double>(), h->istat.as<int>(), h->stream, &h->res->aux));
     LPVS_HIP(hipEventRecord(h->ev[3].b, h->stream));
     int st = 0;
     LPVS_HIP(hipMemcpyAsync(&st, h->istat.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -366,6 +401,9 @@ const char *lpvs_last_error(void) { return g_err; }
 
 int32_t lpvs_release_cached_memory(void) {
     pool().flush();
+    std::vector<StreamBundle *> idle;
+    { std::lock_guard<std::mutex> g(g_bundle_mu); idle.swap(g_bundles); }
+    for (StreamBundle *b : idle) delete b;           // idle streams / events of destroyed handles
     return LPVS_OK;
 }
 
