@@ -126,3 +126,29 @@ def test_iterates_do_not_depend_on_chunking(L, Nf, Nv):
             stops.append((it, conv, nxz) + p.admm_get())
     assert stops[0][1] and stops[1][1] and stops[0][0] == stops[1][0] and stops[0][2] == stops[1][2]
     assert np.array_equal(stops[0][3], stops[1][3]) and np.array_equal(stops[0][4], stops[1][4])
+
+
+def test_structured_gram_at_the_admission_boundary(L, monkeypatch):
+    """Frequencies that deviate from an arithmetic progression by eps with max|eps| * max|x| just below / above the 1e-7 admission
+    bound: below, the structured form is taken and its first-order correction keeps it within 1e-12 of the dense form (the neglected
+    second order is (eps x)^2 / 2 <= 5e-15); above, the dense form runs."""
+    rng = np.random.default_rng(77)
+    N, Nf, Nv = 4000, 10, 3
+    X = np.sort(rng.random(N) * 50.0); V = rng.random(N)
+    y = rng.standard_normal(N)
+    base = 0.3 + 0.9 * np.arange(Nf)
+    pert = rng.uniform(-1, 1, Nf); pert[0] = pert[-1] = 0.0; pert /= np.abs(pert).max()
+    res = {}
+    for tag, scale in (("below", 0.9e-7 / X.max()), ("above", 3e-7 / X.max())):
+        w = base + scale * pert
+        with L.Problem.lpv(y, X, V, w, Nv) as p:
+            G, b = p.get_gram()
+            form = p.timing()["gram_form"]
+        monkeypatch.setenv("LPVS_GRAM_FORM", "krs")
+        with L.Problem.lpv(y, X, V, w, Nv) as p:
+            Gd, bd = p.get_gram()
+        monkeypatch.delenv("LPVS_GRAM_FORM")
+        res[tag] = (form, np.abs(G - Gd).max() / np.abs(Gd).max(), np.abs(b - bd).max() / np.abs(bd).max())
+    assert res["below"][0] == "ap" and res["above"][0] in ("krs", "kr")
+    assert res["below"][1] <= 1e-12 and res["below"][2] <= 1e-11, res
+    assert res["above"][1] == 0.0
