@@ -168,6 +168,11 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
                            int32_t linear_sign);
 int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, double *nxz,
                       int32_t *converged);
+/* resume (checkpoint / re-entry): after lpvs_admm_init (same mu, tol, prox, linear_sign) install iterates
+ * saved with lpvs_admm_get_f64 from an earlier run -- possibly of another process -- together with the number of
+ * iterations they represent; lpvs_admm_run then continues exactly as the uninterrupted run would (the x-update of
+ * src/lasso.jl:150-151 only needs z and u).  Arrays are n (x ns) in the solver's own order, as lpvs_admm_get_f64 returns. */
+int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *z, const double *u, int64_t iters_done);
 /* per-signal state of a multi-signal handle (lpvs_admm_run reports the slowest signal / the largest ||x-z||) */
 int32_t lpvs_admm_status(lpvs_problem *h, int64_t signal, int64_t *iters_done, double *nxz, int32_t *converged);
 /* iterates in the solver's own (regressor-column) order; any pointer may be NULL */
@@ -248,6 +253,58 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
                                   double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
                                   int32_t linear_sign, int64_t win_lo, int64_t win_hi, int32_t device,
                                   double *x_re, double *x_im, double *S_out, int64_t *iters_out);
+
+/* phase times of the calling thread's last batched-window call (HIP events on the library's stream), out[0..7]:
+ * Gram + rhs ms, inverse ms, ADMM / dense-solve ms, windows, batch mat-vec microseconds per launch (only when the environment
+ * has LPVS_WINDOW_MATVEC_TIMING: 200 extra launches after the last pass), windows of that pass, passes, 1 if structured Gram */
+int32_t lpvs_windowpsd_last_timing(double *out, int32_t n_out);
+
+/* estimator of the batched-window engine */
+#define LPVS_EST_SPARSE 1 /* ls_sparse_spectral(y,t,f,W): Quadratic(Q,q) + ADMM        src/lasso.jl:105-126 */
+#define LPVS_EST_DENSE 2  /* ls_spectral(y,t,f,W): (A'WA + lam I) \ A'Wy               src/lsfft.jl:74-80  */
+
+/* ---- the engine itself: ns signals sharing the sampling points t (Y is L x ns column-major) --------------------------
+ * Every window's Gram A'WA and factorisation are formed ONCE and serve all ns right-hand sides A'W y_s -- the y and u of
+ * ls_windowcsd / ls_cohere (src/lsfft.jl:150-151,184-185 call the estimator twice per window on the same t).
+ *   estimator   LPVS_EST_SPARSE (prox_*, mu, tol, iters, linear_sign as in lpvs_windowpsd_sparse_f64; lam unused) or
+ *               LPVS_EST_DENSE (lam = ridge; the ADMM arguments are ignored)
+ *   x_re, x_im  ns x (win_hi - win_lo) x Nf, signal-major then window-major: fourier2complex of every solution
+ *   iters_out   ns x (win_hi - win_lo) iteration counts (0 for the dense estimator); may be NULL */
+int32_t lpvs_windows_estimate_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap,
+                                  const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam,
+                                  int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
+                                  int32_t linear_sign, int64_t win_lo, int64_t win_hi, int32_t device, double *x_re,
+                                  double *x_im, int64_t *iters_out);
+
+/* ---- the same engine driven over several devices by ONE host process (SURVEY.md section 8(e) "Process model") --------
+ * The k windows are split into contiguous ranges over `ngpus` devices (devices[r], or 0..ngpus-1 when devices == NULL;
+ * ngpus <= 0: every visible device); one host thread, stream and engine pass per device, no data-path collective; the
+ * per-window coefficients are gathered with ONE RCCL all-gather over xGMI (librccl.so.1 is bound at run time, only when
+ * ngpus > 1) and returned for ALL k windows: x_re / x_im are ns x k x Nf, iters_out ns x k.  The caller accumulates
+ * |x|^2 (src/lsfft.jl:122) or xy conj(xu) (:152, :187-189) in window order.  Window shards reproduce the single-device
+ * run bit for bit (fixed segment lengths, one admission decision for the structured Gram).  Arguments may be host or
+ * device pointers; device arguments are staged through the host once. */
+int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap,
+                                        const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam,
+                                        int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
+                                        int64_t iters, int32_t linear_sign, const int32_t *devices, int32_t ngpus, double *x_re,
+                                        double *x_im, int64_t *iters_out);
+
+/* ---- ls_windowcsd / ls_cohere on the engine                                              src/lsfft.jl:140-156, :176-193
+ * Accumulators over the windows [win_lo, win_hi) in window order (NOT yet normalised: ls_windowcsd returns Syu / k,
+ * ls_cohere |Syu|^2 / (Suu Syy)):  Syu += xy .* conj.(xu),  Syy += abs2.(xy),  Suu += abs2.(xu).  Any output may be NULL;
+ * x_re / x_im (2 x nwin x Nf: xy of every window, then xu) and iters_out (2 x nwin) are optional. */
+int32_t lpvs_windowcsd_f64(const double *y, const double *u, const double *t, int64_t L, int64_t n, int64_t noverlap,
+                           const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam, int32_t prox_kind,
+                           double prox_param, int64_t group_len, double mu, double tol, int64_t iters, int32_t linear_sign,
+                           int64_t win_lo, int64_t win_hi, int32_t device, double *Syu_re, double *Syu_im, double *Syy,
+                           double *Suu, double *x_re, double *x_im, int64_t *iters_out);
+
+/* ---- storage of the inverse the ADMM mat-vec streams (after lpvs_admm_init) ------------------------------------------
+ * *kind = 0 full symmetric doubles (n < 2048), 1 tile-packed lower triangle in doubles, 2 in floats (_f32 handles),
+ * 3 in 6-byte elements (float head + 16-bit tail = 40 significant bits; the default of _f64 handles with one right-hand side,
+ * LPVS_M_STORAGE=f64 selects 1) */
+int32_t lpvs_admm_matvec_kind(lpvs_problem *h, int32_t *kind);
 
 #ifdef __cplusplus
 }

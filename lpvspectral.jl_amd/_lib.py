@@ -20,6 +20,7 @@ LPVS_EDEVICE, LPVS_EUNSUPPORTED, LPVS_ENUMERIC, LPVS_ESTATE = -5, -6, -7, -8
 
 PROX_L1, PROX_L0, PROX_BALL_L0, PROX_GROUP_L2 = 1, 2, 3, 4
 LINEAR_LEAST_SQUARES, LINEAR_QUADRATIC_AS_WRITTEN = 1, -1
+EST_SPARSE, EST_DENSE = 1, 2
 
 
 class DeviceError(RuntimeError):
@@ -64,6 +65,15 @@ SIGNATURES = {
     "lpvs_problem_set_prox": (_I32, [_P, _I32, _F64, _I64]),
     "lpvs_admm_init_f64": (_I32, [_P, _P, _F64, _F64, _I32]),
     "lpvs_admm_run": (_I32, [_P, _I64, _PI64, C.POINTER(_F64), C.POINTER(_I32)]),
+    "lpvs_admm_set_state_f64": (_I32, [_P, _P, _P, _P, _I64]),
+    "lpvs_admm_matvec_kind": (_I32, [_P, C.POINTER(_I32)]),
+    "lpvs_windowpsd_last_timing": (_I32, [_P, _I32]),
+    "lpvs_windows_estimate_f64": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
+                                          _I64, _I64, _I32, _P, _P, _P]),
+    "lpvs_windows_estimate_multi_f64": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
+                                                _P, _I32, _P, _P, _P]),
+    "lpvs_windowcsd_f64": (_I32, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
+                                   _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "lpvs_lpv_ranges_f64": (_I32, [_P, _P, _I64, _P]),
     "lpvs_problem_create_lpv_rows_f64": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I32, C.POINTER(_P)]),
     "lpvs_problem_device_gram_f64": (_I32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),

@@ -47,6 +47,14 @@ def abs2(x):
     return x.real * x.real + x.imag * x.imag if np.iscomplexobj(x) else x * x
 
 
+def _mul_conj(a, b):
+    """``a .* conj.(b)`` evaluated as Julia does (four real products, no fused multiply-add): numpy's own complex multiply may
+    contract to FMAs on some CPUs, and then ``ls_cohere(y, y) == 1`` (test/runtests.jl:207-208) holds only approximately."""
+    a, b = np.asarray(a), np.asarray(b)
+    ar, ai, br, bi = a.real, a.imag, b.real, b.imag
+    return (ar * br + ai * bi) + 1j * (ai * br - ar * bi)
+
+
 def reshape_params(x, Nf):
     """src/utilities.jl:77: params as an [Nω × Nv] matrix."""
     return np.reshape(np.asarray(x), (int(Nf), -1), order="F")
@@ -145,6 +153,13 @@ def fourier2complex(x, zerofreq):
     out[0] = x[0]
     out[1:] = x[1:n + 1] + 1j * x[n + 1:]
     return out
+
+
+def _host_qr_ridge(A, y, lam):
+    """``[A; λI] \\ [y; 0]`` by LAPACK on the host -- the reference's own route (``real_complex_bs`` / ``fourier_solve``,
+    src/utilities.jl:49-60) for the cases the device normal equations reject as singular to working precision."""
+    n = A.shape[1]
+    return np.linalg.lstsq(np.vstack([A, lam * np.eye(n)]), np.concatenate([np.asarray(y, dtype=np.float64), np.zeros(n)]), rcond=None)[0]
 
 
 # --------------------------------------------------------------------------- device problem handle
@@ -336,6 +351,12 @@ class Problem:
         check(lib().lpvs_admm_run(self._h, int(max_iters), C.byref(it), C.byref(nxz), C.byref(conv)))
         return int(it.value), float(nxz.value), bool(conv.value)
 
+    def admm_set_state(self, x, z, u, iters=0):
+        """Resume: install iterates saved by :meth:`admm_get` (after :meth:`admm_init` with the same parameters)."""
+        arrs = [np.asfortranarray(np.asarray(a, dtype=np.float64)) for a in (x, z, u)]
+        assert all(a.size == self.n * self.ns for a in arrs), "x, z, u have the wrong length"
+        check(lib().lpvs_admm_set_state_f64(self._h, out_ptr(arrs[0]), out_ptr(arrs[1]), out_ptr(arrs[2]), int(iters)))
+
     def admm_get(self):
         shape = self.n if self.ns == 1 else (self.n, self.ns)
         x, z, u = (np.zeros(shape, order="F", dtype=np.float32 if self.f32 else np.float64) for _ in range(3))
@@ -348,6 +369,19 @@ class Problem:
         us, nbytes = C.c_double(0), C.c_double(0)
         check(lib().lpvs_admm_time_matvec(self._h, int(reps), C.byref(us), C.byref(nbytes)))
         return float(us.value), float(nbytes.value)
+
+    def matvec_info(self):
+        """Kernel / storage of the inverse the ADMM mat-vec of this handle streams (after :meth:`admm_init`)."""
+        k = C.c_int32(0)
+        check(lib().lpvs_admm_matvec_kind(self._h, C.byref(k)))
+        np_ = -(-self.n // 128) * 128
+        return {0: dict(kernel="symv_kernel", storage="full symmetric f64", bytes_formula="8 B x np^2"),
+                1: dict(kernel="symv_tile_kernel<double>", storage="tile-packed lower triangle, f64 (8 B)",
+                        bytes_formula="8 B x np(np+128)/2 (np = %d)" % np_),
+                2: dict(kernel="symv_tile_kernel<float>", storage="tile-packed lower triangle, f32 (4 B)",
+                        bytes_formula="4 B x np(np+128)/2 (np = %d)" % np_),
+                3: dict(kernel="symv_tile_split_kernel", storage="tile-packed lower triangle, float head + 16-bit tail (6 B, 40 significant bits)",
+                        bytes_formula="6 B x np(np+128)/2 (np = %d; the 8-byte form would be %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2))}[int(k.value)]
 
     def admm_status(self, signal=0):
         it, nxz, conv = C.c_int64(0), C.c_double(0), C.c_int32(0)
@@ -441,6 +475,10 @@ def ls_spectral(y, t, f=None, W=None, λ=1e-10, verbose=False, device=0):
         re, im = np.zeros(Nf, dtype=dt), np.zeros(Nf, dtype=dt)
         fn = lib().lpvs_ls_spectral_f32 if f32 else lib().lpvs_ls_spectral_f64
         check(fn(py, pt, N, pf, Nf, float(λ), int(device), out_ptr(re), out_ptr(im)))
+        if verbose:                                                  # src/lsfft.jl:65: cond(A'A), from the device Gram
+            with Problem.fourier(y, t, f, None, device=device) as prob:
+                G, _ = prob.get_gram()
+            log.info("Condition number: %s\n", round(float(np.linalg.cond(G)), 2))
         return (re + 1j * im).astype(np.complex64 if f32 else np.complex128), _host(f)
     with Problem.fourier(y, t, f, W, device=device) as prob:
         x = prob.solve_ridge(λ)
@@ -484,9 +522,13 @@ def ls_sparse_spectral(y, t, f=None, W=None, init=False, λ=1.0, proxg=None, dev
     proxg = NormL1(λ) if proxg is None else proxg
     with Problem.fourier(y, t, f, W, device=device) as prob:
         x0 = None
-        if init:  # fourier_solve(A,y,zerofreq,λ), src/lasso.jl:92,112
+        if init:  # fourier_solve(A,y,zerofreq,λ), src/lasso.jl:92,112 -- UNWEIGHTED in both methods (:112 ignores W)
             zf = check_freq(f)
-            p = prob.pack(prob.solve_ridge(λ * λ))
+            if W is None:
+                p = prob.pack(prob.solve_ridge(λ * λ))               # the handle's own Gram is the unweighted one
+            else:
+                p = ls_spectral(y, t, f, λ=λ, device=device)[0]
+            p = np.asarray(p, dtype=np.complex128)
             x0 = np.concatenate([p.real, p.imag[1:] if zf else p.imag])  # src/lasso.jl:93-97
         sign = _lib.LINEAR_LEAST_SQUARES if W is None else _lib.LINEAR_QUADRATIC_AS_WRITTEN
         _admm_on_problem(prob, x0, proxg, sign, **kwargs)
@@ -577,17 +619,31 @@ def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, devi
     w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
     Nv = int(Nv)
     Yh = _host(Y)
+    def ridge(prob):
+        try:
+            return prob.solve_ridge(λ * λ)
+        except _lib.NumericError as e:
+            # (G + λ²I) is singular to working precision (e.g. more unknowns than samples with the default λ = 1e-8): the
+            # normal equations cannot reproduce the reference there, its QR of [Ar; λI] can.  Same route, host LAPACK, on
+            # the regressor the device kernel materialises (src/utilities.jl:49-54).
+            log.info("ls_spectral_lpv: %s; solving [A; λI] \\ [Y; 0] by QR on the host", e)
+            Phi = lpv_regressor(X, V, w, Nv, normalize, coulomb, permuted=True)
+            return _host_qr_ridge(Phi, Yh, λ)
+
     if not covariance:
         with Problem.lpv(Y, X, V, w, Nv, normalize, coulomb, device=device) as prob:
-            params = prob.pack(prob.solve_ridge(λ * λ))
+            params = prob.pack(ridge(prob))
         return SpectralExt(Y, X, V, w, Nv, λ, coulomb, normalize, params, None)
     Y2 = np.stack([Yh, np.ones_like(Yh)], axis=1)
     with Problem.lpv_multi(Y2, X, V, w, Nv, normalize, coulomb, device=device) as prob:
-        x = prob.solve_ridge(λ * λ)                      # first right-hand side = Y
+        x = ridge(prob)                                  # first right-hand side = Y
         params = prob.pack(x)
         G, _ = prob.get_gram()
         B = prob.get_rhs()
-        Minv = prob.get_inverse(λ)
+        try:
+            Minv = prob.get_inverse(λ)
+        except _lib.NumericError:
+            Minv = np.linalg.inv(G + λ * np.eye(G.shape[0]))   # inv(AA'AA + λI) as the reference evaluates it (:253)
         Nf, nb = prob.Nf, prob.nb
     N = len(Yh)
     e2 = float(x @ (G @ x) - 2.0 * (B[:, 0] @ x) + Yh @ Yh)         # ‖AA·x − Y‖²
@@ -633,27 +689,150 @@ def windowpsd_sparse_batched(y, t, freqs, n, noverlap=-1, W=None, proxg=None, λ
     return (xre + 1j * xim)[:nwin], S, its[:nwin]
 
 
+def windowpsd_last_timing():
+    """Phase times (HIP events) of this thread's last batched-window call."""
+    o = np.zeros(8)
+    check(lib().lpvs_windowpsd_last_timing(out_ptr(o), 8))
+    d = dict(gram_rhs_ms=o[0], inverse_ms=o[1], solve_ms=o[2], windows=int(o[3]), passes=int(o[6]), structured_gram=bool(o[7]))
+    if o[4] > 0:
+        d["matvec_us_per_iteration"] = float(o[4]); d["matvec_windows"] = int(o[5])
+    return d
+
+
+def _engine_args(estimator, kwargs, nreg):
+    """Map the reference's estimator + kwargs onto the engine's arguments, or None when that combination has no batched
+    form (user-supplied estimator, callback, init=true, IndBallL0, unknown keywords -> the reference's sequential loop)."""
+    kw = dict(kwargs)
+    kw.pop("device", None)
+    if estimator is ls_spectral:                                       # 4-argument weighted method, src/lsfft.jl:74-80
+        if kw.pop("verbose", False) or set(kw) - {"λ"}:
+            return None
+        return dict(estimator=_lib.EST_DENSE, lam=float(kw.get("λ", 1e-10)), prox=(_lib.PROX_L1, 0.0, 0), μ=0.05, tol=0.0, iters=0,
+                    sign=_lib.LINEAR_LEAST_SQUARES)
+    if estimator is ls_sparse_spectral:                                # 4-argument weighted method, src/lasso.jl:105-126
+        if kw.get("cb") is not None or kw.get("init", False) or set(kw) - {"λ", "proxg", "μ", "tol", "iters", "printerval", "cb", "init", "out"}:
+            return None
+        pg = kw.get("proxg")
+        pg = NormL1(kw.get("λ", 1.0)) if pg is None else pg
+        if not hasattr(pg, "device_params") or isinstance(pg, IndBallL0):
+            return None
+        μ = kw.get("μ", 0.05)
+        assert 0 <= μ <= 1, "μ should be ≤ 1"                          # src/lasso.jl:143
+        return dict(estimator=_lib.EST_SPARSE, lam=0.0, prox=pg.device_params(nreg), μ=float(μ), tol=float(kw.get("tol", 1e-5)),
+                    iters=int(kw.get("iters", 10000)), sign=_lib.LINEAR_QUADRATIC_AS_WRITTEN)
+    return None
+
+
+def windows_estimate(Y, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None, device=0):
+    """The batched-window engine (``lpvs_windows_estimate_f64``): ``Y`` is a list of signals sharing ``t``; returns
+    ``x[ns][nwin][Nf]`` complex and the iteration counts ``[ns][nwin]``."""
+    Ys = [as_f64(y) for y in Y]
+    ns, Ly = len(Ys), Ys[0][2]
+    assert all(e[2] == Ly for e in Ys), "signals must have the same length"
+    kt, pt, Lt = as_f64(t)
+    kf, pf, Nf = as_f64(freqs)
+    kw, pw, nW = as_f64(W)
+    assert Ly == Lt, "y and t has to be the same length"
+    assert W is None or nW == n, "W must have one weight per window sample"
+    k = C.c_int64(0)
+    check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
+    win_hi = int(k.value) if win_hi is None else int(win_hi)
+    nwin = win_hi - int(win_lo)
+    dev_in = all(_lib.is_device_array(y) for y in Y)
+    if ns == 1:
+        keep, pY = Ys[0][0], Ys[0][1]
+    elif dev_in:
+        import torch
+        keep = torch.stack([y.reshape(-1) for y in Y]).contiguous()   # [ns][L] row-major == L x ns column-major
+        pY = C.c_void_p(keep.data_ptr())
+    else:
+        keep = np.ascontiguousarray(np.stack([_host(y) for y in Y]))
+        pY = out_ptr(keep)
+    xre, xim = np.zeros((ns, max(nwin, 1), Nf)), np.zeros((ns, max(nwin, 1), Nf))
+    its = np.zeros((ns, max(nwin, 1)), dtype=np.int64)
+    kind, param, glen = eng["prox"]
+    check(lib().lpvs_windows_estimate_f64(pY, ns, pt, Ly, int(n), int(noverlap), pw, pf, Nf, int(eng["estimator"]), float(eng["lam"]),
+                                          int(kind), float(param), int(glen), float(eng["μ"]), float(eng["tol"]), int(eng["iters"]),
+                                          int(eng["sign"]), int(win_lo), win_hi, int(device), out_ptr(xre), out_ptr(xim), out_ptr(its)))
+    return (xre + 1j * xim)[:, :nwin], its[:, :nwin]
+
+
+def windows_estimate_multi(Y, t, freqs, n, noverlap, W, eng, ngpus=0, devices=None):
+    """``lpvs_windows_estimate_multi_f64``: ALL windows, split into contiguous ranges over ``ngpus`` devices driven by
+    this one process (a host thread per device), the coefficients gathered by one RCCL all-gather.  Same return value as
+    :func:`windows_estimate` over the full window range."""
+    Ys = [np.ascontiguousarray(_host(y)) for y in Y]
+    ns, Ly = len(Ys), len(Ys[0])
+    assert all(len(e) == Ly for e in Ys), "signals must have the same length"
+    keep = np.ascontiguousarray(np.stack(Ys))
+    th = np.ascontiguousarray(_host(t)); fh = np.ascontiguousarray(_host(freqs))
+    Wh = None if W is None else np.ascontiguousarray(_host(W))
+    assert Ly == len(th), "y and t has to be the same length"
+    k = C.c_int64(0)
+    check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
+    k, Nf = int(k.value), len(fh)
+    dv = None if devices is None else np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+    if dv is not None:
+        ngpus = len(dv)
+    xre, xim = np.zeros((ns, max(k, 1), Nf)), np.zeros((ns, max(k, 1), Nf))
+    its = np.zeros((ns, max(k, 1)), dtype=np.int64)
+    kind, param, glen = eng["prox"]
+    check(lib().lpvs_windows_estimate_multi_f64(out_ptr(keep), ns, out_ptr(th), Ly, int(n), int(noverlap), None if Wh is None else out_ptr(Wh),
+                                                out_ptr(fh), Nf, int(eng["estimator"]), float(eng["lam"]), int(kind), float(param), int(glen),
+                                                float(eng["μ"]), float(eng["tol"]), int(eng["iters"]), int(eng["sign"]),
+                                                None if dv is None else out_ptr(dv), int(ngpus), out_ptr(xre), out_ptr(xim), out_ptr(its)))
+    return (xre + 1j * xim)[:, :k], its[:, :k]
+
+
+def windowcsd_batched(y, u, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None, device=0):
+    """``lpvs_windowcsd_f64``: the accumulators ``(Syu, Syy, Suu)`` over the windows ``[win_lo, win_hi)`` in window order
+    (one Gram / factorisation per window, two right-hand sides), plus the per-window ``xy, xu``."""
+    ky, py, Ly = as_f64(y)
+    ku, pu, Lu = as_f64(u)
+    kt, pt, Lt = as_f64(t)
+    kf, pf, Nf = as_f64(freqs)
+    kw, pw, nW = as_f64(W)
+    assert Ly == Lu == Lt, "y, u and t has to be the same length"
+    assert W is None or nW == n, "W must have one weight per window sample"
+    k = C.c_int64(0)
+    check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
+    win_hi = int(k.value) if win_hi is None else int(win_hi)
+    nwin = win_hi - int(win_lo)
+    sre, sim, syy, suu = (np.zeros(Nf) for _ in range(4))
+    xre, xim = np.zeros((2, max(nwin, 1), Nf)), np.zeros((2, max(nwin, 1), Nf))
+    kind, param, glen = eng["prox"]
+    check(lib().lpvs_windowcsd_f64(py, pu, pt, Ly, int(n), int(noverlap), pw, pf, Nf, int(eng["estimator"]), float(eng["lam"]), int(kind),
+                                   float(param), int(glen), float(eng["μ"]), float(eng["tol"]), int(eng["iters"]), int(eng["sign"]),
+                                   int(win_lo), win_hi, int(device), out_ptr(sre), out_ptr(sim), out_ptr(syy), out_ptr(suu), out_ptr(xre),
+                                   out_ptr(xim), None))
+    x = (xre + 1j * xim)[:, :nwin]
+    return sre + 1j * sim, syy, suu, x[0], x[1]
+
+
 def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimator=None, batched=True, **kwargs):
     """``ls_windowpsd(y,t,freqs; nw, noverlap, window_func, estimator=ls_spectral, kwargs...)``
     (src/lsfft.jl:112-126) -> ``(S, freqs)``.  ``estimator`` is any callable ``(y,t,f,W; kw...) -> (x, f)``
     (plugin boundary #1); it is always called with the window vector, as in the reference (:121).
 
-    With ``estimator=ls_sparse_spectral`` (this package's) and no per-iteration callback the windows are solved
-    as ONE device batch (``windowpsd_sparse_batched``; per-iteration progress lines are not printed);
-    ``batched=False`` forces the reference's sequential loop."""
+    With this package's ``ls_spectral`` / ``ls_sparse_spectral`` as the estimator (and no per-iteration callback) the windows
+    are solved as ONE device batch (per-iteration progress lines are not printed); ``batched=False`` forces the reference's
+    sequential loop."""
     estimator = ls_spectral if estimator is None else estimator
-    yh = y
-    n = len(yh) // nw                                               # :113
+    n = len(y) // nw                                                # :113
     if freqs is None:
         freqs = default_freqs(t, n=n)                               # :114
     windows = Windows2(y, t, n, noverlap, window_func)              # :115
     k = len(windows)                                                # :116
-    pg = kwargs.get("proxg")
-    if (batched and estimator is ls_sparse_spectral and k > 0 and kwargs.get("cb") is None and not kwargs.get("init", False)
-            and (pg is None or (hasattr(pg, "device_params") and not isinstance(pg, IndBallL0)))):
-        kw = {a: kwargs[a] for a in ("λ", "proxg", "μ", "tol", "iters") if a in kwargs}
-        kw.setdefault("tol", 1e-5); kw.setdefault("iters", 10000); kw.setdefault("μ", 0.05)
-        _, S, _ = windowpsd_sparse_batched(y, t, freqs, n, windows.noverlap, windows.W, device=kwargs.get("device", 0), **kw)
+    ngpus = kwargs.pop("ngpus", 1)                                  # extension: devices driven by this process (0 = all visible)
+    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and k > 0 and not is_f32(y)) else None
+    if eng is not None:
+        if ngpus != 1:
+            x, _ = windows_estimate_multi([y], t, freqs, n, windows.noverlap, windows.W, eng, ngpus=ngpus)
+        else:
+            x, _ = windows_estimate([y], t, freqs, n, windows.noverlap, windows.W, eng, device=kwargs.get("device", 0))
+        S = np.zeros(len(freqs))
+        for i in range(k):
+            S += abs2(x[0, i])                                      # :122, window order
         return S / k ** 2, freqs                                    # :125
     S = np.zeros(len(freqs))
     for yi, ti in windows:                                          # :120
@@ -662,25 +841,38 @@ def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimato
     return S / k ** 2, freqs                                        # :125
 
 
-def ls_windowcsd(y, u, t, freqs=None, nw=10, noverlap=-1, window_func=rect, estimator=None, **kwargs):
+def ls_windowcsd(y, u, t, freqs=None, nw=10, noverlap=-1, window_func=rect, estimator=None, batched=True, **kwargs):
     """``ls_windowcsd(y,u,t,freqs; nw, noverlap, window_func, estimator=ls_spectral)`` (src/lsfft.jl:140-156):
-    cross spectral density, ``S += xy .* conj(xu)`` over the windows, returned as ``S/nw``."""
+    cross spectral density, ``S += xy .* conj(xu)`` over the windows, returned as ``S/nw`` (the recomputed window count).
+
+    Batched on the device engine as :func:`ls_windowpsd` is: one Gram and one factorisation per window serve both signals."""
     estimator = ls_spectral if estimator is None else estimator
     n = len(y) // nw
     if freqs is None:
         freqs = default_freqs(t, n=n)
-    S = np.zeros(len(freqs), dtype=np.complex128)
     wy = Windows2(y, t, n, noverlap, window_func)
     wu = Windows2(u, t, n, noverlap, window_func)
     k = len(wy)
+    ngpus = kwargs.pop("ngpus", 1)
+    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and k > 0 and not is_f32(y)) else None
+    if eng is not None and ngpus != 1:
+        x, _ = windows_estimate_multi([y, u], t, freqs, n, wy.noverlap, wy.W, eng, ngpus=ngpus)
+        S = np.zeros(len(freqs), dtype=np.complex128)
+        for i in range(k):
+            S = S + _mul_conj(x[0, i], x[1, i])                     # :152, window order
+        return S / k, freqs
+    if eng is not None:
+        Syu, _, _, _, _ = windowcsd_batched(y, u, t, freqs, n, wy.noverlap, wy.W, eng, device=kwargs.get("device", 0))
+        return Syu / k, freqs
+    S = np.zeros(len(freqs), dtype=np.complex128)
     for (yi, ti), (ui, _) in zip(wy, wu):
         xy = estimator(yi, ti, freqs, wy.W, **kwargs)[0]
         xu = estimator(ui, ti, freqs, wu.W, **kwargs)[0]
-        S = S + np.asarray(xy) * np.conj(np.asarray(xu))
+        S = S + _mul_conj(xy, xu)                                 # src/lsfft.jl:152
     return S / k, freqs
 
 
-def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, **kwargs):
+def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, batched=True, **kwargs):
     """``ls_cohere(y,u,t,freqs; nw, noverlap, estimator=ls_spectral)`` (src/lsfft.jl:176-193): magnitude-squared
     coherence over Hann-weighted windows (``Windows3(y,t,u,n,noverlap,hanning)``, :182)."""
     from .windows import hanning
@@ -688,13 +880,25 @@ def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, **kwargs)
     n = len(y) // nw
     if freqs is None:
         freqs = default_freqs(t, n=n)
+    windows = Windows3(y, t, u, n, noverlap, hanning)
+    ngpus = kwargs.pop("ngpus", 1)
+    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and len(windows) > 0 and not is_f32(y)) else None
+    if eng is not None and ngpus != 1:
+        x, _ = windows_estimate_multi([y, u], t, freqs, n, windows.noverlap, windows.W, eng, ngpus=ngpus)
+        Syy, Suu = np.zeros(len(freqs)), np.zeros(len(freqs))
+        Syu = np.zeros(len(freqs), dtype=np.complex128)
+        for i in range(x.shape[1]):                                 # :183-190, window order
+            Syu += _mul_conj(x[0, i], x[1, i]); Syy += abs2(x[0, i]); Suu += abs2(x[1, i])
+        return abs2(Syu) / (Suu * Syy), freqs
+    if eng is not None:
+        Syu, Syy, Suu, _, _ = windowcsd_batched(y, u, t, freqs, n, windows.noverlap, windows.W, eng, device=kwargs.get("device", 0))
+        return abs2(Syu) / (Suu * Syy), freqs                       # :191
     Syy, Suu = np.zeros(len(freqs)), np.zeros(len(freqs))
     Syu = np.zeros(len(freqs), dtype=np.complex128)
-    windows = Windows3(y, t, u, n, noverlap, hanning)
     for yi, ti, ui in windows:
         xy = np.asarray(estimator(yi, ti, freqs, windows.W, **kwargs)[0])
         xu = np.asarray(estimator(ui, ti, freqs, windows.W, **kwargs)[0])
-        Syu += xy * np.conj(xu)
+        Syu += _mul_conj(xy, xu)
         Syy += abs2(xy)
         Suu += abs2(xu)
     return abs2(Syu) / (Suu * Syy), freqs

@@ -78,6 +78,21 @@ admm_init_kernel(AdmmParams p) {
     }
 }
 
+// re-entry from saved iterates (x, z, u already copied in): next right-hand side and iteration count
+__global__ void __launch_bounds__(256)
+admm_restate_kernel(AdmmParams p, long long iters) {
+    const int sg = blockIdx.y;
+    const int64_t o = (int64_t)sg * p.np;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.np; i += (int64_t)gridDim.x * 256) {
+        const bool ok = i < p.n;
+        if (!ok) { p.x[o + i] = 0.0; p.z[o + i] = 0.0; p.u[o + i] = 0.0; }
+        p.rhs[o + i] = ok ? p.b[o + i] + (p.z[o + i] - p.u[o + i]) / p.mu : 0.0;   // b + (z-u)/mu, as the update kernels write it
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        p.status[sg].iters = iters; p.status[sg].converged = 0; p.status[sg].nxz = 0.0; p.status[sg].pad = 0;
+    }
+}
+
 // ---- prox_g + dual update + residual norm + next rhs: ONE workgroup of 1024 threads ----------
 __device__ double block_sum_1024(double v, double *sh) {
     v = wave_sum(v);
@@ -532,6 +547,136 @@ symv_tile_kernel(const T *__restrict__ Mp, const double *__restrict__ rhs_all, i
 }
 
 
+// ---- 6-byte ("split") storage of the packed inverse ----------------------------------------------------------------
+// The mat-vec is HBM-bound on the bytes of M, and M = (G + I/mu)^-1 comes out of the block sweep with a normwise error of
+// ~1e-12 (|M H - I|_max = 2e-13 at n = 8192, tools/factor_check.py): the trailing 13 bits of its doubles carry no
+// information.  An element is stored as the 48 leading bits of its double, rounded to nearest at bit 13, in two parts:
+//   head = those bits down to bit 29 as a FLOAT (sign, exponent, 23 mantissa bits: exactly the double with its low 29 bits
+//          cleared, which is always a float for |M| in [2^-120, 2^127]; smaller magnitudes are flushed to 0),
+//   tail = the next 16 mantissa bits (bits 28..13 of the double) as an unsigned short.
+// 40 significant bits, relative error <= 2^-40 = 9.1e-13 per element -- below the accuracy M has anyway -- in 6 bytes
+// instead of 8: 25 % fewer bytes per iteration.  Decoding is exact and costs three VALU instructions per element:
+// v_cvt_f64_f32 (whose low dword has only its top 3 bits set), extract the tail, v_lshl_or_b32 into that low dword.
+//   tile layout (98304 B): head[128][128] float, then tail[128][128] uint16 with the columns of a row permuted so that the
+//   8 tails a lane needs are one 16-byte load: position 8c + 4h + k holds column 64h + 4c + k  (c < 16, h < 2, k < 4).
+// Lane (g = lane >> 4, c = lane & 15) of wave w owns rows 32w + 4rg + g (rg < 8) and columns {4c+k, 64+4c+k}: per row group
+// two float4 and one uint4 load (every instruction covers whole 128-byte lines): 24 loads = 384 bytes in flight per lane;
+// three workgroups per CU keep ~290 KB in flight per CU (the 8-byte kernel: two workgroups, 262 KB).  Single right-hand
+// side only (multi-signal handles keep doubles for the matrix-core tile product).
+constexpr size_t kSplitTileBytes = (size_t)TS * TS * 6;
+
+__device__ __forceinline__ double split_decode(float head, unsigned int tail16) {
+    const double d = (double)head;
+    return __hiloint2double(__double2hiint(d), (int)((tail16 << 13) | (unsigned int)__double2loint(d)));
+}
+// an SSA value the optimiser cannot look through: keeps `up ? a[k] : a[k+cnt]` from becoming a dynamically indexed array
+// access (which the backend then lowers to an 8-way select chain per value)
+__device__ __forceinline__ double opaque(double v) { asm volatile("" : "+v"(v)); return v; }
+
+__global__ void __launch_bounds__(256)
+pack_tiles_split_kernel(const double *__restrict__ M, int64_t np, unsigned char *__restrict__ Mp) {
+    int I, J;
+    tile_index(blockIdx.x, I, J);
+    const double *src = M + (int64_t)I * TS * np + (int64_t)J * TS;
+    float *head = reinterpret_cast<float *>(Mp + (size_t)blockIdx.x * kSplitTileBytes);
+    unsigned short *tail = reinterpret_cast<unsigned short *>(Mp + (size_t)blockIdx.x * kSplitTileBytes + (size_t)TS * TS * 4);
+    for (int e = threadIdx.x; e < TS * TS; e += 256) {
+        const int r = e >> 7, col = e & 127;
+        const double m = src[(int64_t)r * np + col];
+        unsigned long long B = (unsigned long long)__double_as_longlong(m);
+        B = (B + (1ull << 12)) & ~((1ull << 13) - 1);                    // round to nearest at bit 13 (carries run into the exponent)
+        float h = (float)__longlong_as_double((long long)(B & ~((1ull << 29) - 1)));   // exact: 23 mantissa bits left
+        unsigned int q = (unsigned int)(B >> 13) & 0xffffu;
+        if (!(fabs(m) >= 0x1p-120) || !(fabs(m) < 0x1p127)) { h = (float)m; q = 0; }   // outside the float range (never for an inverse): plain float
+        head[e] = h;
+        tail[r * TS + 8 * ((col & 63) >> 2) + 4 * (col >> 6) + (col & 3)] = (unsigned short)q;
+    }
+}
+
+template <int MINW>
+__global__ void __launch_bounds__(256, MINW)
+symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs, int64_t np, int ntiles,
+                       double *__restrict__ part1, double *__restrict__ part2, const AdmmStatus *status) {
+    if (status != nullptr && status[0].converged) return;
+    __shared__ double sI[TS], sJ[TS], sT[4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const unsigned char *tile = Mp + (size_t)t * kSplitTileBytes;
+    const float *head = reinterpret_cast<const float *>(tile) + (wave * 32 + g) * TS + 4 * c;
+    const unsigned short *tail = reinterpret_cast<const unsigned short *>(tile + (size_t)TS * TS * 4) + (wave * 32 + g) * TS + 8 * c;
+    float4 ha[8], hb[8];
+    uint4 lq[8];
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        ha[rg] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
+        hb[rg] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
+        lq[rg] = *reinterpret_cast<const uint4 *>(tail + rg * 4 * TS);
+    }
+    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+    __syncthreads();
+    double rj[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+    double tc[8], v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        const double ri = sI[wave * 32 + 4 * rg + g];
+        const float hh[8] = {ha[rg].x, ha[rg].y, ha[rg].z, ha[rg].w, hb[rg].x, hb[rg].y, hb[rg].z, hb[rg].w};
+        const unsigned int qq[8] = {lq[rg].x & 0xffffu, lq[rg].x >> 16, lq[rg].y & 0xffffu, lq[rg].y >> 16,
+                                    lq[rg].z & 0xffffu, lq[rg].z >> 16, lq[rg].w & 0xffffu, lq[rg].w >> 16};
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const double m0 = split_decode(hh[k], qq[k]), m1 = split_decode(hh[k + 1], qq[k + 1]);
+            tc[k] = fma(m0, ri, tc[k]);
+            tc[k + 1] = fma(m1, ri, tc[k + 1]);
+            a0 = fma(m0, rj[k], a0);
+            a1 = fma(m1, rj[k + 1], a1);
+        }
+        v[rg] = a0 + a1;
+    }
+    // row sums: halving butterfly over the 16 column lanes (after the step with mask m a lane keeps the row groups whose
+    // bit matches its own), then the last pair
+#pragma unroll
+    for (int m = 8, cnt = 4; m >= 2; m >>= 1, cnt >>= 1) {
+        const bool up = (c & m) != 0;
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const double lo_ = opaque(v[k]), hi_ = opaque(v[k + cnt]);
+            v[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1, 64);
+    if ((c & 1) == 0) {
+        const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
+        part1[(int64_t)t * TS + wave * 32 + 4 * rg + g] = v[0];
+    }
+    if (I != J) {
+        // column sums: over the wave's four row lanes g (masks 32, 16), then over the four waves through LDS
+#pragma unroll
+        for (int m = 32, cnt = 4; m >= 16; m >>= 1, cnt >>= 1) {
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int k = 0; k < cnt; ++k) {
+                const double lo_ = opaque(tc[k]), hi_ = opaque(tc[k + cnt]);
+                tc[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+            }
+        }
+        const int col = ((lane & 32) ? 64 : 0) + 4 * c + ((lane & 16) ? 2 : 0);
+        sT[wave][col] = tc[0]; sT[wave][col + 1] = tc[1];
+        __syncthreads();
+        if (threadIdx.x < TS)
+            part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+    }
+}
+
+
 // Several right-hand sides sharing M (multichannel problems): same tile product, but the right-hand sides of up to NSB
 // signals are staged together and the column sums of all of them are reduced together -- two barriers per block of
 // signals instead of three per signal (the barriers, not the arithmetic, kept the memory pipe idle between tiles).
@@ -712,55 +857,66 @@ symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ 
     }
 }
 
-// Same tile product for a batch of problems that each own their matrix (windows): blockIdx.y = problem.
+// Same tile product for a batch of problems that each own their matrix (windows): blockIdx.y = matrix; a matrix serves
+// nrhs right-hand sides (problems nrhs*blockIdx.y ..; e.g. the two signals of ls_windowcsd share a window's Gram), the tile
+// is read once and applied to each of them.
 __global__ void __launch_bounds__(256)
 symv_tile_batch_kernel(const double *__restrict__ Mp_all, int64_t mp_stride, const double *__restrict__ rhs_all, int64_t np,
-                       int ntiles, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
-    const int sg = blockIdx.y;
-    if (status[sg].converged) return;
+                       int ntiles, int nrhs, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    const int mat = blockIdx.y;
+    {
+        bool all = status != nullptr;
+        for (int r = 0; r < nrhs && all; ++r) all = status[mat * nrhs + r].converged != 0;
+        if (all) return;
+    }
     __shared__ double sI[TS], sJ[TS], sT[4][TS];
     const int t = blockIdx.x;
     int I, J;
     tile_index(t, I, J);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double2 *base = reinterpret_cast<const double2 *>(Mp_all + (int64_t)sg * mp_stride + (int64_t)t * TS * TS + wave * 32 * TS) + lane;
+    const double2 *base = reinterpret_cast<const double2 *>(Mp_all + (int64_t)mat * mp_stride + (int64_t)t * TS * TS + wave * 32 * TS) + lane;
     double2 m[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) m[r] = base[r * (TS / 2)];
-    const double *rhs = rhs_all + (int64_t)sg * np;
-    double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
-    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
-    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
-    __syncthreads();
-    const double rj0 = sJ[2 * lane], rj1 = sJ[2 * lane + 1];
-    double t0 = 0, t1 = 0, v[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        const double ri = sI[wave * 32 + r];
-        t0 = fma(m[r].x, ri, t0);
-        t1 = fma(m[r].y, ri, t1);
-        v[r] = fma(m[r].x, rj0, m[r].y * rj1);
-    }
-#pragma unroll
-    for (int w = 32, cnt = 16; w >= 2; w >>= 1, cnt >>= 1) {
-        const bool hi = (lane & w) != 0;
-#pragma unroll
-        for (int k = 0; k < cnt; ++k) {
-            const double send = hi ? v[k] : v[k + cnt];
-            const double keep = hi ? v[k + cnt] : v[k];
-            v[k] = keep + __shfl_xor(send, w, 64);
-        }
-    }
-    v[0] += __shfl_xor(v[0], 1, 64);
-    if ((lane & 1) == 0) {
-        const int row = ((lane & 32) ? 16 : 0) + ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
-        part1[(int64_t)t * TS + wave * 32 + row] = v[0];
-    }
-    if (I != J) {
-        sT[wave][2 * lane] = t0; sT[wave][2 * lane + 1] = t1;
+    for (int rr = 0; rr < nrhs; ++rr) {
+        const int sg = mat * nrhs + rr;
+        if (status != nullptr && status[sg].converged) continue;   // uniform
+        const double *rhs = rhs_all + (int64_t)sg * np;
+        double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
+        if (rr > 0) __syncthreads();   // previous right-hand side's readers are done with sI / sJ / sT
+        if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+        else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
         __syncthreads();
-        if (threadIdx.x < TS)
-            part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+        const double rj0 = sJ[2 * lane], rj1 = sJ[2 * lane + 1];
+        double t0 = 0, t1 = 0, v[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const double ri = sI[wave * 32 + r];
+            t0 = fma(m[r].x, ri, t0);
+            t1 = fma(m[r].y, ri, t1);
+            v[r] = fma(m[r].x, rj0, m[r].y * rj1);
+        }
+#pragma unroll
+        for (int w = 32, cnt = 16; w >= 2; w >>= 1, cnt >>= 1) {
+            const bool hi = (lane & w) != 0;
+#pragma unroll
+            for (int k = 0; k < cnt; ++k) {
+                const double send = hi ? v[k] : v[k + cnt];
+                const double keep = hi ? v[k + cnt] : v[k];
+                v[k] = keep + __shfl_xor(send, w, 64);
+            }
+        }
+        v[0] += __shfl_xor(v[0], 1, 64);
+        if ((lane & 1) == 0) {
+            const int row = ((lane & 32) ? 16 : 0) + ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
+            part1[(int64_t)t * TS + wave * 32 + row] = v[0];
+        }
+        if (I != J) {
+            sT[wave][2 * lane] = t0; sT[wave][2 * lane + 1] = t1;
+            __syncthreads();
+            if (threadIdx.x < TS)
+                part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+        }
     }
 }
 
@@ -920,8 +1076,10 @@ admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1_all, con
 // launch first sums the previous iteration's block norms (every workgroup, identically, with loads that fly together
 // with its partial sums), commits iteration count / norm / convergence (workgroup 0), and if that iteration had
 // converged nobody writes anything -- the iterates stay those of the converged iteration, exactly as with the
-// ticket.  status.pad == 1 marks "one iteration executed, not yet committed"; admm_commit_kernel commits the last
-// iteration of a chunk.  Mat-vec launches issued past the (not yet visible) convergence are harmless.
+// ticket.  Whether a previous iteration is pending is known to the HOST (every launch of a chunk but the first has
+// one), so it is a kernel argument: no workgroup reads a flag that another workgroup of the same launch writes.
+// admm_commit_kernel commits the last iteration of a chunk.  Mat-vec launches issued past the (not yet visible)
+// convergence are harmless.
 __device__ __forceinline__ double pending_norm(const double *__restrict__ bn, int nblk, double *slot) {
     if (threadIdx.x < 64) {   // lane q sums blocks q, q+64, ...; then the wave's fixed shuffle pattern
         double part = 0;
@@ -935,9 +1093,11 @@ __device__ __forceinline__ double pending_norm(const double *__restrict__ bn, in
 
 __global__ void __launch_bounds__(512)
 admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk,
-                          int ntiles, double *__restrict__ blocknorm_all, int parity) {
+                          int ntiles, double *__restrict__ blocknorm_all, int parity, int commit_prev) {
     const int sg = blockIdx.y;
     AdmmStatus *status = p.status + sg;
+    // `converged` is written by workgroup 0 of a launch only when that launch's commit finds convergence, and then
+    // every workgroup of the launch (whether it reads the flag before or after that write) returns without writing.
     if (status->converged) return;
     __shared__ double sh[3 * TS], sq[TS], gs[TS], slot;
     const double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
@@ -946,7 +1106,7 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     const int64_t li_ = (int64_t)I * TS + i, gi = (int64_t)sg * p.np + li_;
     const bool row = threadIdx.x < TS, ok = row && li_ < p.n;
     const double ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;   // in flight together with the partials
-    if (status->pad) {                                               // uniform: commit the previous iteration
+    if (commit_prev) {                                               // uniform (host-known): commit the previous iteration
         const double nxz = pending_norm(bn_prev, nblk, &slot);
         const bool conv = nxz < p.tol;                               //             src/lasso.jl:164
         if (I == 0 && threadIdx.x == 0) {
@@ -989,10 +1149,7 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = wsum;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        bn_cur[I] = sh[0] + sh[1];
-        if (I == 0) status->pad = 1;
-    }
+    if (threadIdx.x == 0) bn_cur[I] = sh[0] + sh[1];
 }
 
 // commits the last executed iteration of a chunk (one workgroup per signal)
@@ -1000,14 +1157,13 @@ __global__ void __launch_bounds__(64)
 admm_commit_kernel(AdmmParams p, int nblk, double *__restrict__ blocknorm_all, int parity_last) {
     const int sg = blockIdx.x;
     AdmmStatus *status = p.status + sg;
-    if (status->converged || !status->pad) return;
+    if (status->converged) return;   // otherwise the chunk's last iteration is pending (the host launches this only after >= 1 iteration)
     __shared__ double slot;
     const double nxz = pending_norm(blocknorm_all + ((int64_t)sg * 2 + parity_last) * nblk, nblk, &slot);
     if (threadIdx.x == 0) {
         status->iters += 1;
         status->nxz = nxz;
         if (nxz < p.tol) status->converged = 1;
-        status->pad = 0;
     }
 }
 
@@ -1090,7 +1246,7 @@ symv_batch_kernel(AdmmBatch p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= p.np) return;
-    const double2 *m2 = reinterpret_cast<const double2 *>(p.M + ((int64_t)q * p.np + row) * p.np);
+    const double2 *m2 = reinterpret_cast<const double2 *>(p.M + ((int64_t)(q / p.nrhs) * p.np + row) * p.np);
     const double2 *r2 = reinterpret_cast<const double2 *>(p.rhs + (int64_t)q * p.np);
     double acc = 0;
     const int64_t nv = p.np / 2;
@@ -1186,9 +1342,10 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
         double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
         double *blocknorm = part2 + (size_t)ntiles * TS * ns;
         unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
+        const int nrhs = p.nrhs > 0 ? p.nrhs : 1;
         for (int64_t i = 0; i < iters; ++i) {
-            hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
-                               (int)ntiles, part1, part2, p.status);
+            hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
+                               (int)ntiles, nrhs, part1, part2, p.status);
             if (nblk <= 8)
                 hipLaunchKernelGGL(admm_window_update_kernel, dim3(ns), dim3((unsigned)(TS * nblk)), 0, s, q, part1, part2, nblk, (int)ntiles);
             else
@@ -1204,8 +1361,73 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
     return LPVS_OK;
 }
 
+// the batch mat-vec alone, `reps` times (benchmark instrumentation; iterates are not modified)
+int32_t launch_admm_batch_matvec_only(const AdmmBatch &p, int reps, hipStream_t s) {
+    if (p.Mp == nullptr || p.part == nullptr) { set_error("batch mat-vec timing needs the tile-packed form"); return LPVS_ESTATE; }
+    const int nblk = (int)(p.np / TS);
+    const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), ns = (unsigned)p.nbatch;
+    const int nrhs = p.nrhs > 0 ? p.nrhs : 1;
+    double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
+                           (int)ntiles, nrhs, part1, part2, (const AdmmStatus *)nullptr);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+// ---- dense (ridge) estimator on a batch of windows: out = A v per problem, matrix of problem q = A_all[q / nrhs] ----------
+__global__ void __launch_bounds__(256)
+batch_matvec_kernel(const double *__restrict__ A_all, int64_t np, int nrhs, const double *__restrict__ v_all, double *__restrict__ out_all) {
+    const int q = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= np) return;
+    const double2 *m2 = reinterpret_cast<const double2 *>(A_all + ((int64_t)(q / nrhs) * np + row) * np);
+    const double2 *r2 = reinterpret_cast<const double2 *>(v_all + (int64_t)q * np);
+    double acc = 0;
+    for (int64_t j = lane; j < np / 2; j += 64) {
+        const double2 m = m2[j], v = r2[j];
+        acc = fma(m.x, v.x, acc);
+        acc = fma(m.y, v.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out_all[(int64_t)q * np + row] = acc;
+}
+__global__ void __launch_bounds__(256)
+batch_ridge_residual_kernel(const double *__restrict__ b, const double *__restrict__ Gx, const double *__restrict__ x, double ridge, int64_t n,
+                            int64_t np, double *__restrict__ r) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, o = (int64_t)blockIdx.y * np + i;
+    if (i < np) r[o] = i < n ? b[o] - fma(ridge, x[o], Gx[o]) : 0.0;
+}
+__global__ void __launch_bounds__(256)
+batch_vec_add_kernel(double *__restrict__ x, const double *__restrict__ d, int64_t np) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, o = (int64_t)blockIdx.y * np + i;
+    if (i < np) x[o] += d[o];
+}
+
+// x = M b refined `steps` times against H = Q + ridge I, for nprob problems (problem q uses matrices q / nrhs); t1, t2 scratch
+int32_t launch_batch_ridge_solve(const double *Q, const double *M, int64_t np, int64_t n, int nprob, int nrhs, const double *b, double ridge,
+                                 int steps, double *x, double *t1, double *t2, hipStream_t s) {
+    const dim3 gm((unsigned)ceil_div(np, 4), (unsigned)nprob), gv((unsigned)ceil_div(np, 256), (unsigned)nprob);
+    hipLaunchKernelGGL(batch_matvec_kernel, gm, dim3(256), 0, s, M, np, nrhs, b, x);
+    for (int k = 0; k < steps; ++k) {
+        hipLaunchKernelGGL(batch_matvec_kernel, gm, dim3(256), 0, s, Q, np, nrhs, (const double *)x, t1);
+        hipLaunchKernelGGL(batch_ridge_residual_kernel, gv, dim3(256), 0, s, b, (const double *)t1, (const double *)x, ridge, n, np, t2);
+        hipLaunchKernelGGL(batch_matvec_kernel, gm, dim3(256), 0, s, M, np, nrhs, (const double *)t2, t1);
+        hipLaunchKernelGGL(batch_vec_add_kernel, gv, dim3(256), 0, s, x, (const double *)t1, np);
+    }
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s) {
     hipLaunchKernelGGL(admm_init_kernel, dim3((unsigned)ceil_div(p.np, 256), (unsigned)p.ns), dim3(256), 0, s, p);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_admm_restate(const AdmmParams &p, int64_t iters, hipStream_t s) {
+    hipLaunchKernelGGL(admm_restate_kernel, dim3((unsigned)ceil_div(p.np, 256), (unsigned)p.ns), dim3(256), 0, s, p, (long long)iters);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -1240,6 +1462,13 @@ int32_t launch_cvt_f64_f32(const double *src, float *dst, int64_t count, hipStre
     return LPVS_OK;
 }
 
+int32_t launch_pack_tiles_split(const double *M, int64_t np, unsigned char *Mp, hipStream_t s) {
+    const int nblk = (int)(np / TS);
+    hipLaunchKernelGGL(pack_tiles_split_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, M, np, Mp);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s) {
     const int nblk = (int)(np / TS);
     hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, M, np, Mp);
@@ -1252,6 +1481,13 @@ bool fused_ok(const AdmmParams &p) {
     return p.prox_kind == LPVS_PROX_GROUP_L2 && p.group_len <= TS && TS % p.group_len == 0 && p.n % p.group_len == 0;
 }
 
+static void launch_split(const unsigned char *Mp, const double *rhs, int64_t np, unsigned ntiles, double *part1, double *part2,
+                         const AdmmStatus *status, hipStream_t s) {
+    static const int wgs = [] { const char *e = getenv("LPVS_SPLIT_WGS"); return e ? atoi(e) : 3; }();   // experiment knob
+    if (wgs == 2) hipLaunchKernelGGL(symv_tile_split_kernel<2>, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
+    else hipLaunchKernelGGL(symv_tile_split_kernel<3>, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
+}
+
 // one ADMM iteration on the packed symmetric form
 static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     const int nblk = (int)(p.np / TS);
@@ -1260,19 +1496,21 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
     static const bool mfma_multi = [] { const char *e = getenv("LPVS_MULTI_MATVEC"); return !(e && std::string(e) == "valu"); }();
-    if (p.ns > 1 && !p.mp_f32 && mfma_multi) {
+    if (p.ns > 1 && !p.mp_f32 && !p.mp_split && mfma_multi) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kSymvMfmaLds);   // per device; cheap
         hipLaunchKernelGGL(symv_tile_mfma_kernel, dim3(ntiles), dim3(256), kSymvMfmaLds, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
-    } else if (p.ns > 1 && !p.mp_f32)
+    } else if (p.ns > 1 && !p.mp_f32 && !p.mp_split)
         hipLaunchKernelGGL((symv_tile_multi_kernel<double, 8>), dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     else if (p.mp_f32)
         hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,
                            (int)ntiles, part1, part2, p.status);
+    else if (p.mp_split)
+        launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, ntiles, part1, part2, p.status, s);
     else
         hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     if (fused_ok(p)) {
-        hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1);
+        hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0);
     } else {
         hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status);
         hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
@@ -1312,6 +1550,38 @@ int32_t launch_rect_matvec(const double *A, int64_t rows, int64_t cols, int64_t 
     return LPVS_OK;
 }
 
+// r = b - (G x + ridge x)  (Gx supplied) on the first n entries, 0 on the pad;   x += d
+__global__ void __launch_bounds__(256)
+ridge_residual_kernel(const double *__restrict__ b, const double *__restrict__ Gx, const double *__restrict__ x, double ridge, int64_t n,
+                      int64_t np, double *__restrict__ r) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < np) r[i] = i < n ? b[i] - fma(ridge, x[i], Gx[i]) : 0.0;
+}
+__global__ void __launch_bounds__(256)
+vec_add_kernel(double *__restrict__ x, const double *__restrict__ d, int64_t np) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < np) x[i] += d[i];
+}
+
+// x = M b followed by `steps` rounds of iterative refinement against H = G + ridge I (M is H^-1 up to the sweep's rounding;
+// the normal equations square cond(A), so the explicit inverse alone loses about cond(H) * eps):  x += M (b - H x);
+// on return t2 holds the final residual b - H x
+int32_t launch_ridge_solve_refined(const double *G, const double *M, int64_t np, int64_t n, const double *b, double ridge, int steps,
+                                   double *x, double *t1, double *t2, hipStream_t s) {
+    launch_symv_raw(M, np, b, x, nullptr, 1, s);
+    const unsigned nb = (unsigned)ceil_div(np, 256);
+    for (int k = 0; k < steps; ++k) {
+        launch_symv_raw(G, np, x, t1, nullptr, 1, s);                                     // t1 = G x
+        hipLaunchKernelGGL(ridge_residual_kernel, dim3(nb), dim3(256), 0, s, b, t1, x, ridge, n, np, t2);   // t2 = b - H x
+        launch_symv_raw(M, np, t2, t1, nullptr, 1, s);                                    // t1 = M r
+        hipLaunchKernelGGL(vec_add_kernel, dim3(nb), dim3(256), 0, s, x, t1, np);
+    }
+    launch_symv_raw(G, np, x, t1, nullptr, 1, s);                                         // final residual left in t2
+    hipLaunchKernelGGL(ridge_residual_kernel, dim3(nb), dim3(256), 0, s, b, t1, x, ridge, n, np, t2);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s) {
     launch_symv_raw(M, np, rhs, x, nullptr, 1, s);
     LPVS_HIP(hipGetLastError());
@@ -1328,6 +1598,8 @@ int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
             if (p.mp_f32)
                 hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np,
                                    p.ns, (int)ntiles, part1, part2, (const AdmmStatus *)nullptr);
+            else if (p.mp_split)
+                launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, ntiles, part1, part2, nullptr, s);
             else
                 hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2,
                                    (const AdmmStatus *)nullptr);
@@ -1349,7 +1621,7 @@ int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s
             if (p.prox_kind != LPVS_PROX_BALL_L0 && p.n <= 4096) {
                 // small problems: the light 256-thread kernel (no 128 KiB LDS image) has the shorter latency
                 AdmmBatch q{p.M, p.np, p.n, p.ns, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len,
-                            p.status, nullptr, nullptr};
+                            p.status, nullptr, nullptr, 1};
                 hipLaunchKernelGGL(admm_batch_prox_kernel, dim3((unsigned)p.ns), dim3(256), 0, s, q);
             } else {
                 hipLaunchKernelGGL(admm_prox_kernel, dim3((unsigned)p.ns), dim3(1024), 0, s, p);

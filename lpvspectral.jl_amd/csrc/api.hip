@@ -201,6 +201,14 @@ struct EventPair {
     double ms() const { float t = 0; if (hipEventElapsedTime(&t, a, b) != hipSuccess) { (void)hipGetLastError(); return 0; } return t; }
 };
 
+// Declared AFTER the temporaries of a scope (so destroyed BEFORE them): on an early error return the stream is drained
+// before the temporaries' blocks go back to the process-wide cache, where another handle's stream could pick them up.
+struct DrainOnExit {
+    hipStream_t s;
+    explicit DrainOnExit(hipStream_t s_) : s(s_) {}
+    ~DrainOnExit() { (void)hipStreamSynchronize(s); }
+};
+
 }  // namespace lpvs
 
 using namespace lpvs;
@@ -248,6 +256,8 @@ struct lpvs_problem {
     int64_t ns = 1;   // signals sharing the regressor (right-hand sides); state vectors are [ns][np]
     DevBuf G, b, M, x, z, u, rhs, bs, scratch, status, work, istat, part, Mp;
     bool M_valid = false; double M_shift = 0;
+    bool Mp_valid = false;   // Mp is the packed copy of the CURRENT M (cleared whenever M is recomputed or G changes)
+    int Mp_mode = 0;         // storage of Mp: kMpF64 / kMpF32 / kMpSplit (see make_params)
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
     // timing (ms) -- see lpvs_problem_get_timing
@@ -314,10 +324,34 @@ int32_t copy_state_in(lpvs_problem *h, void *dev, const double *src) {
     return LPVS_OK;
 }
 
+// storage of the tile-packed inverse streamed by the ADMM mat-vec of large problems
+enum { kMpNone = 0, kMpF64 = 1, kMpF32 = 2, kMpSplit = 3 };
+// LPVS_M_STORAGE = split (default) | f64: how a double-precision handle stores the tile-packed inverse its mat-vec streams.
+// split = float head + 16-bit tail (6 bytes, 40 significant bits, admm.hip); _f32 handles always stream floats; handles with
+// several right-hand sides keep doubles (their tile product runs on the matrix cores from LDS-DMA staged double tiles).
+int mp_mode_for(const lpvs_problem *h) {
+    if (h->np < kSymmetricMinNp) return kMpNone;
+    if (h->f32) return kMpF32;
+    if (h->ns > 1) return kMpF64;
+    const char *e = getenv("LPVS_M_STORAGE");
+    return (e && std::string(e) == "split") ? kMpSplit : kMpF64;
+}
+
+AdmmParams make_params(const lpvs_problem *h) {
+    const bool sym = h->np >= kSymmetricMinNp;
+    AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
+                 h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
+                 h->scratch.as<double>(), h->part.as<double>(), sym ? h->Mp.as<double>() : nullptr, (int)h->ns};
+    p.mp_f32 = sym && h->Mp_mode == kMpF32 ? 1 : 0;
+    p.mp_split = sym && h->Mp_mode == kMpSplit ? 1 : 0;
+    return p;
+}
+
 // M = (G + shift I)^-1 on the padded np x np system (pad diagonal = 1), cached by shift.
 int32_t factorize(lpvs_problem *h, double shift) {
     if (h->M_valid && h->M_shift == shift) return LPVS_OK;
     const int64_t np = h->np, n = h->n;
+    h->Mp_valid = false;
     if (!h->M.p) LPVS_TRY(h->M.alloc(sizeof(double) * (size_t)np * (size_t)np));
     if (!h->work.p) LPVS_TRY(h->work.alloc(spd_inverse_work_bytes(np)));
     LPVS_HIP(hipEventRecord(h->ev[3].a, h->stream));
@@ -358,6 +392,7 @@ static int32_t create_panel_problem(lpvs_problem *h, const double *y, const doub
     LPVS_TRY(alloc_state(h));
 
     DevBuf P, Wp, slab, scr;
+    DrainOnExit drain(s);
     LPVS_TRY(P.alloc(sizeof(double) * (size_t)Npad * (size_t)ld));
     if (Npad > N) LPVS_HIP(hipMemsetAsync(P.as<double>() + N * ld, 0, sizeof(double) * (size_t)(Npad - N) * (size_t)ld, s));
     const double *Wdev = nullptr;
@@ -579,6 +614,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         double lo, hi, am, gamma; std::vector<double> vc;
         DevBuf K, KK, dvc, part, tab, tabb;
         ApSlotsDev sd;
+        DrainOnExit drain(s);
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
         if (ranges) { lo = ranges[0]; hi = ranges[1]; am = ranges[2]; }
         else LPVS_TRY(device_minmax(dV.p, N, &lo, &hi, &am, s));
@@ -620,6 +656,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     const int64_t Npad = pl.ksplit * pl.rows_per_chunk;
 
     DevBuf T, K, KK, G3, slab, scr; int64_t ldk;
+    DrainOnExit drain(s);
     LPVS_HIP(hipEventRecord(h->ev[0].a, s));
     LPVS_TRY(build_lpv_tables(dX.p, dV.p, N, Npad, dw.p, Nf, Nv, normalize, coulomb, T, K, &ldk, s, ranges));
     if (krs) {
@@ -701,7 +738,7 @@ int32_t lpvs_problem_device_gram_f64(lpvs_problem *h, double **G_dev, double **b
 
 int32_t lpvs_problem_gram_modified(lpvs_problem *h) {
     if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
-    h->M_valid = false; h->inited = false;
+    h->M_valid = false; h->Mp_valid = false; h->inited = false;
     h->drop_graph();
     return LPVS_OK;
 }
@@ -740,6 +777,7 @@ int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_
             LPVS_HIP(hipMemsetAsync(h->b.p, 0, h->b.bytes, s));
             LPVS_TRY(alloc_state(h));
             ApSlotsDev sd; DevBuf part, tab, tabb;
+            DrainOnExit drain(s);
             LPVS_HIP(hipEventRecord(h->ev[0].a, s));
             LPVS_TRY(sd.upload(sl, s));
             LPVS_HIP(hipEventRecord(h->ev[0].b, s));
@@ -865,7 +903,23 @@ int32_t lpvs_problem_solve_ridge_f64(lpvs_problem *h, double ridge, double *x_ou
     LPVS_HIP(hipSetDevice(h->device));
     h->inited = false;  // M is re-used
     LPVS_TRY(factorize(h, ridge));
-    LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->b.as<double>(), h->scratch.as<double>(), h->stream));
+    // two rounds of iterative refinement against G + ridge I: the normal equations square cond(A) and the reference solves
+    // the same systems by SVD / QR (src/utilities.jl:49-60), so the explicit inverse alone would lose cond(G) * eps
+    LPVS_TRY(launch_ridge_solve_refined(h->G.as<double>(), h->M.as<double>(), h->np, h->n, h->b.as<double>(), ridge, 2,
+                                        h->scratch.as<double>(), h->rhs.as<double>(), h->z.as<double>(), h->stream));
+    // fail loudly instead of returning a meaningless solution when G + ridge I is singular to working precision (the
+    // reference's QR / SVD of [A; lam I] still works there: the host wrapper then takes that route)
+    std::vector<double> hr((size_t)h->n), hb((size_t)h->n);
+    LPVS_TRY(copy_from_device(hr.data(), h->z.p, sizeof(double) * (size_t)h->n, h->stream));
+    LPVS_TRY(copy_from_device(hb.data(), h->b.p, sizeof(double) * (size_t)h->n, h->stream));
+    double r2 = 0, b2 = 0;
+    for (int64_t i = 0; i < h->n; ++i) { r2 += hr[i] * hr[i]; b2 += hb[i] * hb[i]; }
+    if (!(r2 <= 1e-18 * b2) && b2 > 0) {
+        h->M_valid = false;
+        set_error("normal equations (G + %.3g I) x = b are too ill-conditioned for the device solve (relative residual %.3g after refinement)",
+                  ridge, std::sqrt(r2 / b2));
+        return LPVS_ENUMERIC;
+    }
     return copy_from_device(x_out, h->scratch.p, sizeof(double) * (size_t)h->n, h->stream);
 }
 
@@ -887,12 +941,15 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     LPVS_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     h->drop_graph();
-    const bool had_M = h->M_valid && h->M_shift == 1.0 / mu && h->Mp.p != nullptr;
-    LPVS_TRY(factorize(h, 1.0 / mu));
-    if (h->np >= kSymmetricMinNp && !had_M) {   // tile-packed lower triangle for the half-traffic mat-vec
-        if (!h->Mp.p) LPVS_TRY(h->Mp.alloc((h->f32 ? sizeof(float) : sizeof(double)) * symv_packed_doubles(h->np)));
-        if (h->f32) LPVS_TRY(launch_pack_tiles_f32(h->M.as<double>(), h->np, h->Mp.as<float>(), s));
+    LPVS_TRY(factorize(h, 1.0 / mu));            // no-op when M is cached for this shift; clears Mp_valid otherwise
+    const int mode = mp_mode_for(h);
+    if (h->np >= kSymmetricMinNp && (!h->Mp_valid || h->Mp_mode != mode)) {   // tile-packed lower triangle for the half-traffic mat-vec
+        const size_t elt = mode == kMpF32 ? 4 : (mode == kMpSplit ? 6 : 8);
+        if (!h->Mp.p || h->Mp.bytes < elt * symv_packed_doubles(h->np)) LPVS_TRY(h->Mp.alloc(elt * symv_packed_doubles(h->np)));
+        if (mode == kMpF32) LPVS_TRY(launch_pack_tiles_f32(h->M.as<double>(), h->np, h->Mp.as<float>(), s));
+        else if (mode == kMpSplit) LPVS_TRY(launch_pack_tiles_split(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), s));
         else LPVS_TRY(launch_pack_tiles(h->M.as<double>(), h->np, h->Mp.as<double>(), s));
+        h->Mp_valid = true; h->Mp_mode = mode;
     }
     LPVS_HIP(hipMemsetAsync(h->part.p, 0, h->part.bytes, s));   // zero the ticket / block norms
     h->mu = mu; h->tol = tol; h->sign = linear_sign;
@@ -905,13 +962,25 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     LPVS_HIP(hipStreamSynchronize(s));
     if (linear_sign < 0) for (auto &q : hb) q = -q;
     LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
-    AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
-                 h->rhs.as<double>(), mu, tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
-                 h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr, (int)h->ns};
-    p.mp_f32 = h->f32 ? 1 : 0;
+    const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_init(p, s));
     LPVS_HIP(hipStreamSynchronize(s));
     h->inited = true;
+    return LPVS_OK;
+}
+
+int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *z, const double *u, int64_t iters_done) {
+    if (!h || !x || !z || !u) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (!h->inited) { set_error("lpvs_admm_set_state before lpvs_admm_init"); return LPVS_ESTATE; }
+    if (iters_done < 0) { set_error("iters_done must be >= 0"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    LPVS_TRY(copy_state_in(h, h->x.p, x));
+    LPVS_TRY(copy_state_in(h, h->z.p, z));
+    LPVS_TRY(copy_state_in(h, h->u.p, u));
+    const AdmmParams p = make_params(h);
+    LPVS_TRY(launch_admm_restate(p, iters_done, s));
+    LPVS_HIP(hipStreamSynchronize(s));
     return LPVS_OK;
 }
 
@@ -920,10 +989,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     if (!h->inited) { set_error("lpvs_admm_run before lpvs_admm_init"); return LPVS_ESTATE; }
     LPVS_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
-                 h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
-                 h->scratch.as<double>(), h->part.as<double>(), h->np >= kSymmetricMinNp ? h->Mp.as<double>() : nullptr, (int)h->ns};
-    p.mp_f32 = h->f32 ? 1 : 0;
+    const AdmmParams p = make_params(h);
     const size_t ns = (size_t)h->ns;
     std::vector<AdmmStatus> st0(ns), st(ns);
     LPVS_HIP(hipMemcpyAsync(st0.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
@@ -974,6 +1040,14 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     return LPVS_OK;
 }
 
+/* 0: full symmetric matrix (plain mat-vec, n < 2048), 1: tile-packed doubles, 2: tile-packed floats, 3: tile-packed split */
+int32_t lpvs_admm_matvec_kind(lpvs_problem *h, int32_t *kind) {
+    if (!h || !kind) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (!h->inited) { set_error("lpvs_admm_matvec_kind before lpvs_admm_init"); return LPVS_ESTATE; }
+    *kind = h->np >= kSymmetricMinNp ? h->Mp_mode : kMpNone;
+    return LPVS_OK;
+}
+
 int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_launch, double *bytes_per_launch) {
     if (!h || !us_per_launch) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited) { set_error("lpvs_admm_time_matvec before lpvs_admm_init"); return LPVS_ESTATE; }
@@ -981,17 +1055,15 @@ int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_laun
     LPVS_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const bool sym = h->np >= kSymmetricMinNp;
-    AdmmParams p{h->M.as<double>(), h->np, h->n, h->bs.as<double>(), h->x.as<double>(), h->z.as<double>(), h->u.as<double>(),
-                 h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
-                 h->scratch.as<double>(), h->part.as<double>(), sym ? h->Mp.as<double>() : nullptr, (int)h->ns};
-    p.mp_f32 = h->f32 ? 1 : 0;
+    const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_matvec_only(p, 3, s));   // warm
     LPVS_HIP(hipEventRecord(h->ev[1].a, s));
     LPVS_TRY(launch_admm_matvec_only(p, reps, s));
     LPVS_HIP(hipEventRecord(h->ev[1].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     *us_per_launch = h->ev[1].ms() * 1e3 / reps;
-    if (bytes_per_launch) *bytes_per_launch = (sym && h->f32 ? sizeof(float) : sizeof(double)) * (double)(sym ? symv_packed_doubles(h->np) : (size_t)h->np * (size_t)h->np);
+    const double elt = !sym ? 8.0 : (h->Mp_mode == kMpF32 ? 4.0 : (h->Mp_mode == kMpSplit ? 6.0 : 8.0));
+    if (bytes_per_launch) *bytes_per_launch = elt * (double)(sym ? symv_packed_doubles(h->np) : (size_t)h->np * (size_t)h->np);
     return LPVS_OK;
 }
 
@@ -1116,6 +1188,7 @@ int32_t lpvs_ls_spectral_f64(const double *y, const double *t, int64_t N, const 
     LPVS_TRY(alloc_state(h));
     LPVS_HIP(hipMemcpyAsync(h->b.p, dy.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));   // right-hand side = y
     DevBuf D, slab, xo;
+    DrainOnExit drain(s);
     LPVS_TRY(D.alloc(sizeof(double) * (size_t)rows * (size_t)ldn));
     LPVS_TRY(launch_fourier_dual_panel(dt.p, N, df.p, Nf, (int)zf, D.as<double>(), ldn, rows, s));
     LPVS_TRY(slab.alloc(pl.slab_bytes));
@@ -1141,31 +1214,52 @@ int32_t lpvs_ls_spectral_f64(const double *y, const double *t, int64_t N, const 
 }
 
 // ---- batched windows ------------------------------------------------------------------------------------
-int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,
-                                  const double *freqs, int64_t Nf, int32_t prox_kind, double prox_param, int64_t group_len,
-                                  double mu, double tol, int64_t iters, int32_t linear_sign, int64_t win_lo, int64_t win_hi,
-                                  int32_t device, double *x_re, double *x_im, double *S_out, int64_t *iters_out) {
+// One engine behind ls_windowpsd / ls_windowcsd / ls_cohere (src/lsfft.jl:112-193): all windows [win_lo, win_hi) of
+// Windows2 / Windows3 (src/windows.jl:27-36, :94-103) are solved together; `ns` signals sharing t (the y and u of the
+// cross-spectral drivers) share every window's Gram and factorisation and differ only in the right-hand side.
+}  // extern "C"
+
+namespace {
+
+// phase times (ms) of the calling thread's last engine call: [0] Gram + rhs, [1] inverse (+ pack), [2] ADMM iterations or dense
+// solves, [3] windows, [4] batch mat-vec microseconds per launch (LPVS_WINDOW_MATVEC_TIMING=1 only, last pass), [5] windows of
+// that pass, [6] passes, [7] 1 if the structured Gram was used
+thread_local double g_win_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+// sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations) is called in window order, signals innermost
+template <class Sink>
+int32_t windows_engine(const WinJob &a, Sink sink) {
     int64_t k = 0;
-    LPVS_TRY(lpvs_window_count(L, n, noverlap, &k));
-    if (noverlap < 0) noverlap = n >> 1;
+    LPVS_TRY(lpvs_window_count(a.L, a.n, a.noverlap, &k));
+    const int64_t n = a.n, Nf = a.Nf, ns = a.ns;
+    const int64_t noverlap = a.noverlap < 0 ? n >> 1 : a.noverlap;
+    const int64_t win_lo = a.win_lo, win_hi = a.win_hi;
+    const bool sparse = a.estimator == LPVS_EST_SPARSE;
+    if (a.estimator != LPVS_EST_SPARSE && a.estimator != LPVS_EST_DENSE) { set_error("unknown estimator %d", a.estimator); return LPVS_EARGUMENT; }
+    if (ns < 1 || ns > 64) { set_error("number of signals %lld outside [1, 64]", (long long)ns); return LPVS_EARGUMENT; }
     if (win_lo < 0 || win_hi > k || win_lo > win_hi) { set_error("window range [%lld,%lld) outside [0,%lld)", (long long)win_lo, (long long)win_hi, (long long)k); return LPVS_EARGUMENT; }
-    if (!(mu >= 0 && mu <= 1)) { set_error("μ should be ≤ 1"); return LPVS_EASSERT; }
-    if (mu == 0) { set_error("mu = 0 makes the x-update singular"); return LPVS_ENUMERIC; }
-    if (prox_kind != LPVS_PROX_L1 && prox_kind != LPVS_PROX_L0 && prox_kind != LPVS_PROX_GROUP_L2) { set_error("prox kind %d is not batched", prox_kind); return LPVS_EUNSUPPORTED; }
-    if (prox_kind == LPVS_PROX_GROUP_L2 && group_len <= 0) { set_error("group_len must be positive"); return LPVS_EARGUMENT; }
-    if (linear_sign != 1 && linear_sign != -1) { set_error("linear_sign must be +1 or -1"); return LPVS_EARGUMENT; }
+    const double mu = a.mu, tol = a.tol;
+    if (sparse) {
+        if (!(mu >= 0 && mu <= 1)) { set_error("μ should be ≤ 1"); return LPVS_EASSERT; }
+        if (mu == 0) { set_error("mu = 0 makes the x-update singular"); return LPVS_ENUMERIC; }
+        if (a.prox_kind != LPVS_PROX_L1 && a.prox_kind != LPVS_PROX_L0 && a.prox_kind != LPVS_PROX_GROUP_L2) { set_error("prox kind %d is not batched", a.prox_kind); return LPVS_EUNSUPPORTED; }
+        if (a.prox_kind == LPVS_PROX_GROUP_L2 && a.group_len <= 0) { set_error("group_len must be positive"); return LPVS_EARGUMENT; }
+        if (a.linear_sign != 1 && a.linear_sign != -1) { set_error("linear_sign must be +1 or -1"); return LPVS_EARGUMENT; }
+    }
     int64_t zf = 0;
-    LPVS_TRY(lpvs_check_freq_f64(freqs, Nf, &zf));
+    LPVS_TRY(lpvs_check_freq_f64(a.freqs, Nf, &zf));
+    for (double &v : g_win_timing) v = 0;
     const int64_t nwin = win_hi - win_lo;
     if (nwin == 0) return LPVS_OK;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
-    if (device < 0 || device >= count) { set_error("device %d out of range", device); return LPVS_EDEVICE; }
-    LPVS_HIP(hipSetDevice(device));
-    hipStream_t s = nullptr;
-    struct StreamGuard { hipStream_t s = nullptr; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } sg;
-    LPVS_HIP(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
-    s = sg.s;
+    if (a.device < 0 || a.device >= count) { set_error("device %d out of range", a.device); return LPVS_EDEVICE; }
+    LPVS_HIP(hipSetDevice(a.device));
+    StreamBundle *res = bundle_acquire(a.device);
+    if (!res) { set_error("stream / event creation failed"); return LPVS_EDEVICE; }
+    struct BundleGuard { StreamBundle *b; ~BundleGuard() { bundle_release(b); } } bg{res};
+    hipStream_t s = res->stream;
+    EventPair *ev = res->ev;
 
     const int64_t nreg = zf ? 2 * Nf - 1 : 2 * Nf, np = round_up(nreg, 128), ld = round_up(nreg, 256);
     // sub-batch: the k-major regressor panels of one pass stay under a budget (default 48 GiB of the 288 GB)
@@ -1175,11 +1269,11 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
     if (bw < 1) bw = 1;
     if (bw > nwin) bw = nwin;
     if (bw > 8192) bw = 8192;
-    // the part of y, t this call touches
-    const int64_t step = n - noverlap, s0 = win_lo * step, s1 = (win_hi - 1) * step + n;
-    DevArg dy, dt, df;
-    LPVS_TRY(dy.set(y, L, s)); LPVS_TRY(dt.set(t, L, s)); LPVS_TRY(df.set(freqs, Nf, s));
-    (void)s0; (void)s1;
+    const int64_t step = n - noverlap;
+    std::vector<DevArg> dys((size_t)ns);
+    DevArg dt, df;
+    for (int64_t q = 0; q < ns; ++q) LPVS_TRY(dys[(size_t)q].set(a.ys[q], a.L, s));
+    LPVS_TRY(dt.set(a.t, a.L, s)); LPVS_TRY(df.set(a.freqs, Nf, s));
     // structured Gram (nudft.hip) when T(2pi)*freqs is an arithmetic progression: no regressor panels at all
     ApSlots sl;
     {
@@ -1187,17 +1281,18 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         const std::string form = form_env ? form_env : "auto";
         if (form == "auto" || form == "ap") {
             std::vector<double> hw;
-            LPVS_TRY(fetch_host(hw, freqs, Nf));
+            LPVS_TRY(fetch_host(hw, a.freqs, Nf));
             for (auto &v : hw) v = 6.283185307179586 * v;
-            double tlo, thi, tam;
-            LPVS_TRY(device_minmax(dt.p, L, &tlo, &thi, &tam, s));
+            double tlo, thi, tam = a.t_absmax;
+            if (!(tam >= 0)) LPVS_TRY(device_minmax(dt.p, a.L, &tlo, &thi, &tam, s));
             sl = make_ap_slots(hw, tam);
             if (form == "ap" && !sl.ok) { set_error("LPVS_GRAM_FORM=ap but 2*pi*freqs is not an arithmetic progression (max|eps|*max|t| = %.3g)", sl.emax * tam); return LPVS_EARGUMENT; }
         }
     }
     const bool ap = sl.ok;
-    if (ap) {   // windows per pass bounded by the matrices (M, packed M, work): 32 GiB
-        bw = (int64_t)(((size_t)32 << 30) / (sizeof(double) * (size_t)np * (size_t)np * 2));
+    const int nmat = sparse ? 2 : 3;   // resident np x np matrices per window: M, packed M (sparse) / Q, M, work (dense)
+    if (ap) {   // windows per pass bounded by the matrices: 32 GiB
+        bw = (int64_t)(((size_t)32 << 30) / (sizeof(double) * (size_t)np * (size_t)np * (size_t)nmat));
         if (bw < 1) bw = 1;
         if (bw > nwin) bw = nwin;
         if (bw > 8192) bw = 8192;
@@ -1208,22 +1303,24 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
     const int64_t nrows = ap ? n : pl.ksplit * pl.rows_per_chunk;
     const size_t panel_bytes = ap ? 0 : sizeof(double) * (size_t)nrows * (size_t)ld;
     while (!ap && bw > 1 && panel_bytes * (size_t)bw > budget) --bw;
-    // structured form: every window is cut into segments of rpcw samples, one workgroup row per segment
-    // fixed segment length: the summation order of a window must not depend on how many windows share the pass, so that
-    // window shards (ranks of a node) reproduce the whole run bit for bit
+    // structured form: every window is cut into segments of rpcw samples, one workgroup row per segment; the segment length
+    // is fixed: the summation order of a window must not depend on how many windows share the pass, so that window shards
+    // (ranks of a node) reproduce the whole run bit for bit
     const int64_t rpcw = ap ? std::min<int64_t>(n, 4096) : 0;
     const int spw = ap ? (int)ceil_div(n, rpcw) : 0;
     DevBuf Wp;
     const double *Wdev = nullptr;
-    if (W != nullptr) {
+    if (a.W != nullptr) {
         LPVS_TRY(Wp.alloc(sizeof(double) * (size_t)nrows));
         LPVS_HIP(hipMemsetAsync(Wp.p, 0, Wp.bytes, s));
-        LPVS_TRY(copy_to_device(Wp.p, W, sizeof(double) * (size_t)n, s));
+        LPVS_TRY(copy_to_device(Wp.p, a.W, sizeof(double) * (size_t)n, s));
         Wdev = Wp.as<double>();
     }
     PhaseTrace tr(s);
-    DevBuf P, slab, M, bvec, x, z, u, rhs, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb;
+    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb;
     ApSlotsDev sd;
+    DrainOnExit drain(s);
+    const int64_t nprob_max = bw * ns;
     if (ap) {
         LPVS_TRY(sd.upload(sl, s));
         LPVS_TRY(seg.alloc(sizeof(int64_t) * 3 * (size_t)bw * (size_t)spw));
@@ -1234,30 +1331,37 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
         LPVS_TRY(P.alloc(panel_bytes * (size_t)bw));
         LPVS_TRY(slab.alloc(pl.slab_bytes * (size_t)bw));
     }
-    LPVS_TRY(part.alloc(sizeof(double) * symv_part_doubles(np, bw)));
-    LPVS_TRY(Mp.alloc(sizeof(double) * symv_packed_doubles(np) * (size_t)bw));
     LPVS_TRY(M.alloc(sizeof(double) * (size_t)np * (size_t)np * (size_t)bw));
-    const size_t vb = sizeof(double) * (size_t)np * (size_t)bw;
+    if (sparse) {
+        LPVS_TRY(part.alloc(sizeof(double) * symv_part_doubles(np, nprob_max)));
+        LPVS_TRY(Mp.alloc(sizeof(double) * symv_packed_doubles(np) * (size_t)bw));
+        LPVS_TRY(status.alloc(sizeof(AdmmStatus) * (size_t)nprob_max));
+    } else {
+        LPVS_TRY(Q.alloc(sizeof(double) * (size_t)np * (size_t)np * (size_t)bw));
+    }
+    const size_t vb = sizeof(double) * (size_t)np * (size_t)nprob_max;
     LPVS_TRY(bvec.alloc(vb)); LPVS_TRY(x.alloc(vb)); LPVS_TRY(z.alloc(vb)); LPVS_TRY(u.alloc(vb)); LPVS_TRY(rhs.alloc(vb));
-    LPVS_TRY(status.alloc(sizeof(AdmmStatus) * (size_t)bw)); LPVS_TRY(istat.alloc(sizeof(int) * (size_t)bw));
+    LPVS_TRY(istat.alloc(sizeof(int) * (size_t)bw));
     LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)bw));
     LPVS_TRY(offs.alloc(sizeof(int64_t) * (size_t)bw));
     if (!ap) LPVS_TRY(scr.alloc(rhs_scratch_bytes(n, nreg) * (size_t)bw));
 
     tr.mark("alloc");
     std::vector<int64_t> hseg((size_t)3 * (size_t)bw * (size_t)spw);
-    std::vector<double> S((size_t)Nf, 0.0), zh((size_t)np * (size_t)bw), re((size_t)Nf), im((size_t)Nf);
+    std::vector<double> zh((size_t)np * (size_t)nprob_max), re((size_t)Nf), im((size_t)Nf);
     std::vector<int64_t> hoff((size_t)bw);
-    std::vector<AdmmStatus> hst((size_t)bw);
+    std::vector<AdmmStatus> hst((size_t)nprob_max);
     std::vector<int> hist_((size_t)bw);
-    std::vector<double> xre_h, xim_h;
-    const bool out_dev_re = is_device_ptr(x_re), out_dev_im = is_device_ptr(x_im);
-    if (out_dev_re || out_dev_im) { xre_h.resize((size_t)nwin * Nf); xim_h.resize((size_t)nwin * Nf); }
+    const bool want_mv = sparse && getenv("LPVS_WINDOW_MATVEC_TIMING") != nullptr;
+    g_win_timing[3] = (double)nwin; g_win_timing[7] = ap ? 1 : 0;
 
     for (int64_t w0 = 0; w0 < nwin; w0 += bw) {
         const int nb_ = (int)((nwin - w0 < bw) ? nwin - w0 : bw);
+        const int nprob = nb_ * (int)ns;
         for (int q = 0; q < nb_; ++q) hoff[q] = (win_lo + w0 + q) * step;           // arraysplit offsets, src/windows.jl:33
         LPVS_HIP(hipMemcpyAsync(offs.p, hoff.data(), sizeof(int64_t) * (size_t)nb_, hipMemcpyHostToDevice, s));
+        double *G = sparse ? M.as<double>() : Q.as<double>();                      // where the window Grams are assembled
+        LPVS_HIP(hipEventRecord(ev[0].a, s));
         if (ap) {
             for (int q = 0; q < nb_; ++q)
                 for (int c = 0; c < spw; ++c) {
@@ -1267,78 +1371,214 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
                     e[2] = hoff[q];
                 }
             LPVS_TRY(copy_to_device(seg.p, hseg.data(), sizeof(int64_t) * 3 * (size_t)nb_ * (size_t)spw, s));
-            LPVS_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
+            LPVS_HIP(hipMemsetAsync(G, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
             LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
             LPVS_TRY(launch_nudft_windows(dt.p, nullptr, Wdev, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, seg.as<int64_t>(), nb_, spw,
                                           npart.as<double>(), tab.as<double>(), s));
-            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.nf8, (int)zf, nreg, M.as<double>(), np, nb_, sl.nsl * 4,
+            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.nf8, (int)zf, nreg, G, np, nb_, sl.nsl * 4,
                                                 np * np, s));                                       // Q = A'WA   src/lasso.jl:119
             tr.mark("gram (structured)");
-            LPVS_TRY(launch_nudft_windows(dt.p, dy.p, Wdev, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, seg.as<int64_t>(), nb_, spw,
-                                          npart.as<double>(), tabb.as<double>(), s));
-            LPVS_TRY(launch_ap_rhs_fourier(tabb.as<double>(), sd.eps.as<double>(), Nf, (int)zf, bvec.as<double>(), nb_, sl.nf8 * 4, np, s));   // q = A'Wy   :120
+            for (int64_t q = 0; q < ns; ++q) {   // q_s = A'W y_s for every signal sharing the window   :120
+                LPVS_TRY(launch_nudft_windows(dt.p, dys[(size_t)q].p, Wdev, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, seg.as<int64_t>(),
+                                              nb_, spw, npart.as<double>(), tabb.as<double>(), s));
+                LPVS_TRY(launch_ap_rhs_fourier(tabb.as<double>(), sd.eps.as<double>(), Nf, (int)zf, bvec.as<double>() + q * np, nb_, sl.nf8 * 4, ns * np, s));
+            }
         } else {
             LPVS_TRY(launch_window_panels(dt.p, offs.as<int64_t>(), nb_, n, nrows, df.p, Nf, (int)zf, P.as<double>(), ld, s));
             tr.mark("panels");
             LPVS_TRY(launch_gram_panel_batch(pl, nb_, P.as<double>(), nrows * ld, ld, Wdev, slab.as<double>(), s));
             tr.mark("gram");
-            LPVS_HIP(hipMemsetAsync(M.p, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
+            LPVS_HIP(hipMemsetAsync(G, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
             LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
-            LPVS_TRY(launch_gram_reduce_batch(pl, nb_, slab.as<double>(), M.as<double>(), np, s));     // Q = A'WA   src/lasso.jl:119
-            LPVS_TRY(launch_rhs_panel_batch(nb_, P.as<double>(), nrows * ld, ld, nreg, Wdev, dy.p, offs.as<int64_t>(), n, bvec.as<double>(), np,
-                                            scr.as<double>(), scr.bytes, s));                          // q = A'Wy   src/lasso.jl:120
+            LPVS_TRY(launch_gram_reduce_batch(pl, nb_, slab.as<double>(), G, np, s));                  // Q = A'WA   src/lasso.jl:119
+            for (int64_t q = 0; q < ns; ++q)
+                LPVS_TRY(launch_rhs_panel_batch(nb_, P.as<double>(), nrows * ld, ld, nreg, Wdev, dys[(size_t)q].p, offs.as<int64_t>(), n,
+                                                bvec.as<double>() + q * np, ns * np, scr.as<double>(), scr.bytes, s));   // q = A'Wy   :120
         }
-        if (linear_sign < 0) {  // Quadratic(Q, +q): the x-update's linear term is -q
-            LPVS_HIP(hipMemcpyAsync(zh.data(), bvec.p, sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyDeviceToHost, s));
+        LPVS_HIP(hipEventRecord(ev[0].b, s));
+        if (sparse && a.linear_sign < 0) {  // Quadratic(Q, +q): the x-update's linear term is -q
+            LPVS_HIP(hipMemcpyAsync(zh.data(), bvec.p, sizeof(double) * (size_t)np * (size_t)nprob, hipMemcpyDeviceToHost, s));
             LPVS_HIP(hipStreamSynchronize(s));
-            for (size_t i = 0; i < (size_t)np * (size_t)nb_; ++i) zh[i] = -zh[i];
-            LPVS_HIP(hipMemcpyAsync(bvec.p, zh.data(), sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyHostToDevice, s));
+            for (size_t i = 0; i < (size_t)np * (size_t)nprob; ++i) zh[i] = -zh[i];
+            LPVS_HIP(hipMemcpyAsync(bvec.p, zh.data(), sizeof(double) * (size_t)np * (size_t)nprob, hipMemcpyHostToDevice, s));
             LPVS_HIP(hipStreamSynchronize(s));
         }
         tr.mark("reduce+rhs");
-        LPVS_TRY(launch_add_diag_batch(M.as<double>(), np, nreg, 1.0 / mu, nb_, s));
+        LPVS_HIP(hipEventRecord(ev[1].a, s));
+        if (!sparse) LPVS_HIP(hipMemcpyAsync(M.p, Q.p, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, hipMemcpyDeviceToDevice, s));
+        const double shift = sparse ? 1.0 / mu : a.lam;       // (Q + I/mu) for the ADMM x-update; (A'WA + lam I) of src/lsfft.jl:77
+        LPVS_TRY(launch_add_diag_batch(M.as<double>(), np, nreg, shift, nb_, s));
         LPVS_TRY(spd_inverse_inplace_batch(M.as<double>(), np, nb_, work.as<double>(), istat.as<int>(), s));
         LPVS_HIP(hipMemcpyAsync(hist_.data(), istat.p, sizeof(int) * (size_t)nb_, hipMemcpyDeviceToHost, s));
         LPVS_HIP(hipStreamSynchronize(s));
         for (int q = 0; q < nb_; ++q)
-            if (hist_[q] != 0) { set_error("window %lld: (Q + I/mu) is not positive definite", (long long)(win_lo + w0 + q)); return LPVS_ENUMERIC; }
+            if (hist_[q] != 0) { set_error("window %lld: (Q + %.3g I) is not positive definite", (long long)(win_lo + w0 + q), shift); return LPVS_ENUMERIC; }
         tr.mark("inverse");
-        LPVS_TRY(launch_pack_tiles_batch(M.as<double>(), np, nb_, Mp.as<double>(), s));
-        LPVS_HIP(hipMemsetAsync(part.p, 0, part.bytes, s));   // tickets / block norms
-        AdmmBatch ab{M.as<double>(), np, nreg, nb_, bvec.as<double>(), x.as<double>(), z.as<double>(), u.as<double>(), rhs.as<double>(),
-                     mu, tol, prox_kind, prox_param, group_len, status.as<AdmmStatus>(), part.as<double>(), Mp.as<double>()};
-        LPVS_TRY(launch_admm_batch_init(ab, s));
-        for (int64_t done = 0; done < iters;) {   // chunks: stop early once every window of the batch has converged
-            const int64_t chunk = iters - done < 256 ? iters - done : 256;
-            LPVS_TRY(launch_admm_batch_iterations(ab, chunk, s));
-            done += chunk;
-            LPVS_HIP(hipMemcpyAsync(hst.data(), status.p, sizeof(AdmmStatus) * (size_t)nb_, hipMemcpyDeviceToHost, s));
-            LPVS_HIP(hipStreamSynchronize(s));
-            bool all = true;
-            for (int q = 0; q < nb_; ++q) all = all && hst[q].converged;
-            if (all) break;
+        const double *sol = nullptr;
+        if (sparse) {
+            LPVS_TRY(launch_pack_tiles_batch(M.as<double>(), np, nb_, Mp.as<double>(), s));
+            LPVS_HIP(hipEventRecord(ev[1].b, s));
+            LPVS_HIP(hipMemsetAsync(part.p, 0, part.bytes, s));   // tickets / block norms
+            AdmmBatch ab{M.as<double>(), np, nreg, nprob, bvec.as<double>(), x.as<double>(), z.as<double>(), u.as<double>(), rhs.as<double>(),
+                         mu, tol, a.prox_kind, a.prox_param, a.group_len, status.as<AdmmStatus>(), part.as<double>(), Mp.as<double>(), (int)ns};
+            LPVS_HIP(hipEventRecord(ev[2].a, s));
+            LPVS_TRY(launch_admm_batch_init(ab, s));
+            for (int64_t done = 0; done < a.iters;) {   // chunks: stop early once every problem of the batch has converged
+                const int64_t chunk = a.iters - done < 256 ? a.iters - done : 256;
+                LPVS_TRY(launch_admm_batch_iterations(ab, chunk, s));
+                done += chunk;
+                LPVS_HIP(hipMemcpyAsync(hst.data(), status.p, sizeof(AdmmStatus) * (size_t)nprob, hipMemcpyDeviceToHost, s));
+                LPVS_HIP(hipStreamSynchronize(s));
+                bool all = true;
+                for (int q = 0; q < nprob; ++q) all = all && hst[q].converged;
+                if (all) break;
+            }
+            if (a.iters <= 0) {
+                LPVS_HIP(hipMemcpyAsync(hst.data(), status.p, sizeof(AdmmStatus) * (size_t)nprob, hipMemcpyDeviceToHost, s));
+                LPVS_HIP(hipStreamSynchronize(s));
+            }
+            LPVS_HIP(hipEventRecord(ev[2].b, s));
+            if (want_mv && w0 + nb_ >= nwin) {
+                LPVS_TRY(launch_admm_batch_matvec_only(ab, 3, s));
+                LPVS_HIP(hipEventRecord(ev[3].a, s));
+                LPVS_TRY(launch_admm_batch_matvec_only(ab, 200, s));
+                LPVS_HIP(hipEventRecord(ev[3].b, s));
+                LPVS_HIP(hipStreamSynchronize(s));
+                g_win_timing[4] = ev[3].ms() * 1e3 / 200; g_win_timing[5] = nb_;
+            }
+            tr.mark("admm");
+            sol = z.as<double>();
+        } else {
+            LPVS_HIP(hipEventRecord(ev[1].b, s));
+            LPVS_HIP(hipEventRecord(ev[2].a, s));
+            // x = (A'WA + lam I)^-1 A'W y, refined twice against the window's own Gram (src/lsfft.jl:77)
+            LPVS_TRY(launch_batch_ridge_solve(Q.as<double>(), M.as<double>(), np, nreg, nprob, (int)ns, bvec.as<double>(), a.lam, 2, x.as<double>(),
+                                              z.as<double>(), u.as<double>(), s));
+            LPVS_HIP(hipEventRecord(ev[2].b, s));
+            for (int q = 0; q < nprob; ++q) hst[q] = AdmmStatus{0, 1, 0, 0.0};
+            tr.mark("ridge solves");
+            sol = x.as<double>();
         }
-        tr.mark("admm");
-        LPVS_HIP(hipMemcpyAsync(zh.data(), z.p, sizeof(double) * (size_t)np * (size_t)nb_, hipMemcpyDeviceToHost, s));
+        LPVS_HIP(hipMemcpyAsync(zh.data(), sol, sizeof(double) * (size_t)np * (size_t)nprob, hipMemcpyDeviceToHost, s));
         LPVS_HIP(hipStreamSynchronize(s));
-        for (int q = 0; q < nb_; ++q) {
-            const double *c = zh.data() + (size_t)q * (size_t)np;           // fourier2complex, src/utilities.jl:62-73
-            if (!zf) for (int64_t i = 0; i < Nf; ++i) { re[i] = c[i]; im[i] = c[Nf + i]; }
-            else { re[0] = c[0]; im[0] = 0.0; for (int64_t i = 1; i < Nf; ++i) { re[i] = c[i]; im[i] = c[Nf + i - 1]; } }
-            for (int64_t i = 0; i < Nf; ++i) S[i] += re[i] * re[i] + im[i] * im[i];   // S .+= abs2.(x), window order   src/lsfft.jl:122
-            double *dre = out_dev_re ? xre_h.data() : x_re, *dim_ = out_dev_im ? xim_h.data() : x_im;
-            if (dre) memcpy(dre + (size_t)(w0 + q) * Nf, re.data(), sizeof(double) * (size_t)Nf);
-            if (dim_) memcpy(dim_ + (size_t)(w0 + q) * Nf, im.data(), sizeof(double) * (size_t)Nf);
-            if (iters_out) iters_out[w0 + q] = hst[q].iters;
-        }
-    }
-    if (out_dev_re && x_re) LPVS_HIP(hipMemcpy(x_re, xre_h.data(), sizeof(double) * xre_h.size(), hipMemcpyHostToDevice));
-    if (out_dev_im && x_im) LPVS_HIP(hipMemcpy(x_im, xim_h.data(), sizeof(double) * xim_h.size(), hipMemcpyHostToDevice));
-    if (S_out) {
-        if (is_device_ptr(S_out)) { LPVS_HIP(hipMemcpy(S_out, S.data(), sizeof(double) * (size_t)Nf, hipMemcpyHostToDevice)); }
-        else memcpy(S_out, S.data(), sizeof(double) * (size_t)Nf);
+        g_win_timing[0] += ev[0].ms(); g_win_timing[1] += ev[1].ms(); g_win_timing[2] += ev[2].ms(); g_win_timing[6] += 1;
+        for (int q = 0; q < nb_; ++q)
+            for (int64_t sg = 0; sg < ns; ++sg) {
+                const double *c = zh.data() + ((size_t)q * (size_t)ns + (size_t)sg) * (size_t)np;   // fourier2complex, src/utilities.jl:62-73
+                if (!zf) for (int64_t i = 0; i < Nf; ++i) { re[i] = c[i]; im[i] = c[Nf + i]; }
+                else { re[0] = c[0]; im[0] = 0.0; for (int64_t i = 1; i < Nf; ++i) { re[i] = c[i]; im[i] = c[Nf + i - 1]; } }
+                sink(w0 + q, sg, re.data(), im.data(), (int64_t)hst[(size_t)q * (size_t)ns + (size_t)sg].iters);
+            }
     }
     return LPVS_OK;
+}
+
+// host-side output staging: results are assembled on the host and copied out once (outputs may be device pointers)
+struct HostOut {
+    double *user = nullptr; std::vector<double> stage; bool dev = false;
+    void init(double *p, size_t count) { user = p; dev = p && is_device_ptr(p); if (dev) stage.assign(count, 0.0); }
+    double *ptr() { return dev ? stage.data() : user; }
+    int32_t finish() {
+        if (dev) LPVS_HIP(hipMemcpy(user, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice));
+        return LPVS_OK;
+    }
+};
+
+}  // namespace
+
+namespace lpvs {
+int32_t windows_engine_run(const WinJob &job, const WinSink &sink) { return windows_engine(job, sink); }
+void windows_last_timing(double *out8) { for (int i = 0; i < 8; ++i) out8[i] = g_win_timing[i]; }
+void windows_set_timing(const double *in8) { for (int i = 0; i < 8; ++i) g_win_timing[i] = in8[i]; }
+}  // namespace lpvs
+
+extern "C" {
+
+int32_t lpvs_windowpsd_last_timing(double *out, int32_t n_out) {
+    if (!out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    for (int i = 0; i < n_out && i < 8; ++i) out[i] = g_win_timing[i];
+    return LPVS_OK;
+}
+
+int32_t lpvs_windows_estimate_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,
+                                  const double *freqs, int64_t Nf, int32_t estimator, double lam, int32_t prox_kind, double prox_param,
+                                  int64_t group_len, double mu, double tol, int64_t iters, int32_t linear_sign, int64_t win_lo,
+                                  int64_t win_hi, int32_t device, double *x_re, double *x_im, int64_t *iters_out) {
+    if (!Y || !t || !freqs || ns < 1) { set_error("NULL argument or ns < 1"); return LPVS_EARGUMENT; }
+    std::vector<const double *> ys((size_t)ns);
+    for (int64_t q = 0; q < ns; ++q) ys[(size_t)q] = Y + q * L;
+    const WinJob job{ys.data(), ns, t, L, n, noverlap, W, freqs, Nf, estimator, lam, prox_kind, prox_param, group_len, mu, tol, iters, linear_sign,
+                     win_lo, win_hi, device};
+    const int64_t nwin = win_hi > win_lo ? win_hi - win_lo : 0;
+    HostOut ore, oim;
+    ore.init(x_re, (size_t)(ns * nwin * Nf)); oim.init(x_im, (size_t)(ns * nwin * Nf));
+    double *pre = ore.ptr(), *pim = oim.ptr();
+    LPVS_TRY(windows_engine(job, [&](int64_t w, int64_t sg, const double *re, const double *im, int64_t its) {
+        if (pre) memcpy(pre + (size_t)(sg * nwin + w) * (size_t)Nf, re, sizeof(double) * (size_t)Nf);
+        if (pim) memcpy(pim + (size_t)(sg * nwin + w) * (size_t)Nf, im, sizeof(double) * (size_t)Nf);
+        if (iters_out) iters_out[sg * nwin + w] = its;
+    }));
+    LPVS_TRY(ore.finish());
+    return oim.finish();
+}
+
+int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,
+                                  const double *freqs, int64_t Nf, int32_t prox_kind, double prox_param, int64_t group_len,
+                                  double mu, double tol, int64_t iters, int32_t linear_sign, int64_t win_lo, int64_t win_hi,
+                                  int32_t device, double *x_re, double *x_im, double *S_out, int64_t *iters_out) {
+    const double *ys[1] = {y};
+    const WinJob job{ys, 1, t, L, n, noverlap, W, freqs, Nf, LPVS_EST_SPARSE, 0.0, prox_kind, prox_param, group_len, mu, tol, iters, linear_sign,
+                     win_lo, win_hi, device};
+    const int64_t nwin = win_hi > win_lo ? win_hi - win_lo : 0;
+    HostOut ore, oim, oS;
+    ore.init(x_re, (size_t)(nwin * Nf)); oim.init(x_im, (size_t)(nwin * Nf)); oS.init(S_out, (size_t)Nf);
+    double *pre = ore.ptr(), *pim = oim.ptr(), *pS = oS.ptr();
+    if (pS) for (int64_t i = 0; i < Nf; ++i) pS[i] = 0.0;
+    LPVS_TRY(windows_engine(job, [&](int64_t w, int64_t, const double *re, const double *im, int64_t its) {
+        if (pS) for (int64_t i = 0; i < Nf; ++i) pS[i] += re[i] * re[i] + im[i] * im[i];   // S .+= abs2.(x), window order   src/lsfft.jl:122
+        if (pre) memcpy(pre + (size_t)w * (size_t)Nf, re, sizeof(double) * (size_t)Nf);
+        if (pim) memcpy(pim + (size_t)w * (size_t)Nf, im, sizeof(double) * (size_t)Nf);
+        if (iters_out) iters_out[w] = its;
+    }));
+    LPVS_TRY(ore.finish()); LPVS_TRY(oim.finish());
+    return oS.finish();
+}
+
+// ls_windowcsd / ls_cohere accumulators (src/lsfft.jl:140-156, :176-193): per window xy and xu from ONE Gram and ONE
+// factorisation with two right-hand sides;  Syu += xy .* conj.(xu),  Syy += abs2.(xy),  Suu += abs2.(xu)  in window order
+// (four real products per complex product, no fused multiply-add -- as Julia evaluates it).
+int32_t lpvs_windowcsd_f64(const double *y, const double *u, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,
+                           const double *freqs, int64_t Nf, int32_t estimator, double lam, int32_t prox_kind, double prox_param,
+                           int64_t group_len, double mu, double tol, int64_t iters, int32_t linear_sign, int64_t win_lo, int64_t win_hi,
+                           int32_t device, double *Syu_re, double *Syu_im, double *Syy, double *Suu, double *x_re, double *x_im,
+                           int64_t *iters_out) {
+    if (!y || !u) { set_error("NULL signal"); return LPVS_EARGUMENT; }
+    const double *ys[2] = {y, u};
+    const WinJob job{ys, 2, t, L, n, noverlap, W, freqs, Nf, estimator, lam, prox_kind, prox_param, group_len, mu, tol, iters, linear_sign,
+                     win_lo, win_hi, device};
+    const int64_t nwin = win_hi > win_lo ? win_hi - win_lo : 0;
+    HostOut ore, oim, o1, o2, o3, o4;
+    ore.init(x_re, (size_t)(2 * nwin * Nf)); oim.init(x_im, (size_t)(2 * nwin * Nf));
+    o1.init(Syu_re, (size_t)Nf); o2.init(Syu_im, (size_t)Nf); o3.init(Syy, (size_t)Nf); o4.init(Suu, (size_t)Nf);
+    double *pre = ore.ptr(), *pim = oim.ptr(), *a1 = o1.ptr(), *a2 = o2.ptr(), *a3 = o3.ptr(), *a4 = o4.ptr();
+    for (double *p : {a1, a2, a3, a4}) if (p) for (int64_t i = 0; i < Nf; ++i) p[i] = 0.0;
+    std::vector<double> yr((size_t)Nf), yi((size_t)Nf);
+    LPVS_TRY(windows_engine(job, [&](int64_t w, int64_t sg, const double *re, const double *im, int64_t its) {
+        if (pre) memcpy(pre + (size_t)(sg * nwin + w) * (size_t)Nf, re, sizeof(double) * (size_t)Nf);
+        if (pim) memcpy(pim + (size_t)(sg * nwin + w) * (size_t)Nf, im, sizeof(double) * (size_t)Nf);
+        if (iters_out) iters_out[sg * nwin + w] = its;
+        if (sg == 0) { memcpy(yr.data(), re, sizeof(double) * (size_t)Nf); memcpy(yi.data(), im, sizeof(double) * (size_t)Nf); return; }
+        for (int64_t i = 0; i < Nf; ++i) {
+            const double ar = yr[i], ai = yi[i], br = re[i], bi = im[i];
+            if (a1) a1[i] += ar * br + ai * bi;            // Re xy conj(xu)
+            if (a2) a2[i] += ai * br - ar * bi;            // Im xy conj(xu)
+            if (a3) a3[i] += ar * ar + ai * ai;
+            if (a4) a4[i] += br * br + bi * bi;
+        }
+    }));
+    LPVS_TRY(ore.finish()); LPVS_TRY(oim.finish());
+    LPVS_TRY(o1.finish()); LPVS_TRY(o2.finish()); LPVS_TRY(o3.finish());
+    return o4.finish();
 }
 
 // ---- single-precision entry points (src/lasso.jl:85,91,144: the reference is eltype-generic) -------------------------

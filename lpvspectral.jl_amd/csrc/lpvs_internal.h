@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 
 #include "../../include/lpvspectral.h"
@@ -179,16 +180,18 @@ struct AdmmParams {
     const double *Mp;  // tile-packed lower triangle of M (symv_packed_doubles(np)), or nullptr
     int ns;            // right-hand sides sharing M (signals of a shared-regressor batch); vectors are [ns][np]
     int mp_f32 = 0;    // Mp holds float (the _f32 entry points: M is streamed in single precision, arithmetic stays double)
+    int mp_split = 0;  // Mp holds 6-byte elements (float head + 16-bit tail, 40 significant bits; see admm.hip)
 };
 size_t symv_part_doubles(int64_t np, int64_t ns = 1);
 size_t symv_packed_doubles(int64_t np);
 int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s);
 int32_t launch_pack_tiles_f32(const double *M, int64_t np, float *Mp, hipStream_t s);
+int32_t launch_pack_tiles_split(const double *M, int64_t np, unsigned char *Mp, hipStream_t s);   // 6 * symv_packed_doubles(np) bytes
 // element conversions for the _f32 entry points (device buffers)
 int32_t launch_cvt_f32_f64(const float *src, double *dst, int64_t count, hipStream_t s);
 int32_t launch_cvt_f64_f32(const double *src, float *dst, int64_t count, hipStream_t s);
 constexpr int64_t kSymmetricMinNp = 2048;  // below this the iteration is launch-latency bound: plain mat-vec
-// batch of nbatch independent problems of one shape: arrays are [nbatch][np] (matrices [nbatch][np][np])
+// batch of nbatch independent problems of one shape: arrays are [nbatch][np]; matrices [nbatch / nrhs][np][np]
 struct AdmmBatch {
     const double *M;
     int64_t np, n;
@@ -201,19 +204,44 @@ struct AdmmBatch {
     int64_t group_len;
     AdmmStatus *status;   // [nbatch]
     double *part;         // symv_part_doubles(np, nbatch) doubles, zeroed before the first iteration (or nullptr)
-    const double *Mp;     // [nbatch] tile-packed lower triangles (or nullptr: plain mat-vec)
+    const double *Mp;     // [nbatch / nrhs] tile-packed lower triangles (or nullptr: plain mat-vec)
+    int nrhs = 1;         // problems per matrix: problem q uses matrix q / nrhs (signals sharing a window's Gram)
 };
+int32_t launch_admm_batch_matvec_only(const AdmmBatch &p, int reps, hipStream_t s);
+int32_t launch_batch_ridge_solve(const double *Q, const double *M, int64_t np, int64_t n, int nprob, int nrhs, const double *b, double ridge,
+                                 int steps, double *x, double *t1, double *t2, hipStream_t s);
 int32_t launch_pack_tiles_batch(const double *M, int64_t np, int nbatch, double *Mp, hipStream_t s);
 int32_t launch_admm_batch_init(const AdmmBatch &p, hipStream_t s);
 int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s);
 int32_t launch_admm_init(const AdmmParams &p, hipStream_t s);              // z=x, u=0, rhs, status=0
 int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s);
+// resume: x, z, u hold saved iterates; recompute the next right-hand side, set the iteration count, clear the flags
+int32_t launch_admm_restate(const AdmmParams &p, int64_t iters, hipStream_t s);
 // the mat-vec kernel alone, `reps` times (x is recomputed from the current rhs; nothing else changes)
 int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s);
 int32_t launch_rect_matvec(const double *A, int64_t rows, int64_t cols, int64_t ld, const double *v, double *out, hipStream_t s);
 int32_t launch_fourier_dual_panel(const double *t, int64_t N, const double *f, int64_t Nf, int zerofreq, double *D, int64_t ldn,
                                   int64_t nrows, hipStream_t s);
+// x = M b refined against H = G + ridge I:  x += M (b - H x), `steps` times (t1, t2: np doubles of scratch)
+int32_t launch_ridge_solve_refined(const double *G, const double *M, int64_t np, int64_t n, const double *b, double ridge, int steps,
+                                   double *x, double *t1, double *t2, hipStream_t s);
 // x = Minv * rhs_in (one GEMV; ridge solves)
 int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s);
+
+// ---- batched-window engine (api.hip) ------------------------------------------------------------------------------
+struct WinJob {
+    const double *const *ys; int64_t ns;          // ns signals sharing the sampling points t
+    const double *t; int64_t L, n, noverlap;
+    const double *W, *freqs; int64_t Nf;
+    int estimator; double lam;                    // LPVS_EST_SPARSE / LPVS_EST_DENSE (ridge lam)
+    int prox_kind; double prox_param; int64_t group_len; double mu, tol; int64_t iters; int linear_sign;
+    int64_t win_lo, win_hi; int device;
+    double t_absmax = -1.0;                       // max|t| over the WHOLE record when (t, L) is only a span of it (< 0: compute)
+};
+// sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations): window order, signals innermost
+typedef std::function<void(int64_t, int64_t, const double *, const double *, int64_t)> WinSink;
+int32_t windows_engine_run(const WinJob &job, const WinSink &sink);
+void windows_last_timing(double *out8);           // the calling thread's last engine call
+void windows_set_timing(const double *in8);
 
 }  // namespace lpvs

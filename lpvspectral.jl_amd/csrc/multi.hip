@@ -1,0 +1,227 @@
+// multi.hip -- one host process driving several MI355X of a node ("Process model").
+//
+// The windows of ls_windowpsd / ls_windowcsd / ls_cohere (the loop of src/lsfft.jl:120-123, :149-153, :183-190) are
+// independent: contiguous window ranges go to the devices, one host thread + stream + engine pass per device, no
+// data-path collective.  The per-window coefficients of all shards are then gathered with ONE RCCL all-gather over xGMI
+// (equal-size slots; a few MB, latency-bound) so that device devices[0] holds every window, and are read back once; the
+// caller accumulates |x|^2 / xy conj(xu) in window order, as the reference does.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): the library has no link-time dependency on it, a single-device
+// build of the host language needs none, and a process that already carries an RCCL (PyTorch-ROCm bundles one) keeps one
+// copy.  ngpus = 1 does not touch RCCL.
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "lpvs_internal.h"
+
+namespace lpvs {
+namespace {
+
+// the handful of RCCL entry points used (signatures of rccl.h 2.x; ncclDouble = 8, ncclSuccess = 0)
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t s) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd; }
+};
+
+Rccl &rccl() {
+    static Rccl r = [] {
+        Rccl q;
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *nm : names) if (!q.lib) q.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);   // one already in the process?
+        for (const char *nm : names) if (!q.lib) q.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (!q.lib) q.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (q.lib) {
+            q.CommInitAll = reinterpret_cast<decltype(q.CommInitAll)>(dlsym(q.lib, "ncclCommInitAll"));
+            q.CommDestroy = reinterpret_cast<decltype(q.CommDestroy)>(dlsym(q.lib, "ncclCommDestroy"));
+            q.AllGather = reinterpret_cast<decltype(q.AllGather)>(dlsym(q.lib, "ncclAllGather"));
+            q.GroupStart = reinterpret_cast<decltype(q.GroupStart)>(dlsym(q.lib, "ncclGroupStart"));
+            q.GroupEnd = reinterpret_cast<decltype(q.GroupEnd)>(dlsym(q.lib, "ncclGroupEnd"));
+            q.GetErrorString = reinterpret_cast<decltype(q.GetErrorString)>(dlsym(q.lib, "ncclGetErrorString"));
+        }
+        return q;
+    }();
+    return r;
+}
+
+// communicators are expensive to create (hundreds of ms): kept per device list for the life of the process
+std::mutex g_comm_mu;
+std::map<std::vector<int>, std::vector<void *>> g_comms;
+
+int32_t comms_for(const std::vector<int> &devs, std::vector<void *> **out) {
+    std::lock_guard<std::mutex> g(g_comm_mu);
+    auto it = g_comms.find(devs);
+    if (it == g_comms.end()) {
+        Rccl &R = rccl();
+        if (!R.ok()) { const char *de = dlerror(); set_error("ngpus > 1 needs RCCL for the final gather, and librccl.so.1 could not be loaded: %s", de ? de : "symbols missing"); return LPVS_EDEVICE; }
+        std::vector<void *> c(devs.size(), nullptr);
+        const int rc = R.CommInitAll(c.data(), (int)devs.size(), devs.data());
+        if (rc != 0) { set_error("ncclCommInitAll over %zu devices failed: %s", devs.size(), R.GetErrorString ? R.GetErrorString(rc) : "?"); return LPVS_EDEVICE; }
+        it = g_comms.emplace(devs, std::move(c)).first;
+    }
+    *out = &it->second;
+    return LPVS_OK;
+}
+
+struct Shard {
+    int device = 0;
+    int64_t lo = 0, hi = 0;
+    std::vector<double> host;      // slot image: [window][signal][2 Nf + 1] (re, im, iterations)
+    DevBuf send, recv;
+    hipStream_t stream = nullptr;
+    int32_t rc = LPVS_OK;
+    std::string err;
+    double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+}  // namespace
+}  // namespace lpvs
+
+using namespace lpvs;
+
+extern "C" {
+
+int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap,
+                                        const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam,
+                                        int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
+                                        int32_t linear_sign, const int32_t *devices, int32_t ngpus, double *x_re, double *x_im,
+                                        int64_t *iters_out) {
+    if (!Y || !t || !freqs || ns < 1 || Nf < 1) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    if (ngpus <= 0) ngpus = count;                               // all visible devices
+    if (ngpus > count && devices == nullptr) { set_error("ngpus = %d but %d device(s) visible", ngpus, count); return LPVS_EDEVICE; }
+    std::vector<int> devs((size_t)ngpus);
+    bool shared = false;
+    for (int r = 0; r < ngpus; ++r) {
+        devs[(size_t)r] = devices ? devices[r] : r;
+        if (devs[(size_t)r] < 0 || devs[(size_t)r] >= count) { set_error("device %d out of range [0,%d)", devs[(size_t)r], count); return LPVS_EDEVICE; }
+        for (int q = 0; q < r; ++q)
+            if (devs[(size_t)q] == devs[(size_t)r]) {
+                // rehearsal on a box with fewer GPUs than shards (tests): shards may share a device, and then the gather cannot be
+                // an RCCL collective (one rank per device) -- the shard images are taken from the host staging instead
+                if (getenv("LPVS_MULTI_ALLOW_SHARED_DEVICE") == nullptr) { set_error("device %d listed twice", devs[(size_t)r]); return LPVS_EARGUMENT; }
+                shared = true;
+            }
+    }
+    // LPVS_MULTI_FORCE_RCCL: also a single device goes through the (one-rank) all-gather -- exercises the RCCL binding on a 1-GPU box
+    const bool use_rccl = !shared && (ngpus > 1 || getenv("LPVS_MULTI_FORCE_RCCL") != nullptr);
+    int64_t k = 0;
+    LPVS_TRY(lpvs_window_count(L, n, noverlap, &k));
+    if (k == 0) return LPVS_OK;
+    // arguments that live on a device are staged through the host once: every device thread uploads what it needs
+    std::vector<double> hY, ht, hW, hf;
+    auto host_of = [&](const double *p, int64_t cnt, std::vector<double> &stage) -> const double * {
+        if (!p || !is_device_ptr(p)) return p;
+        stage.resize((size_t)cnt);
+        if (hipMemcpy(stage.data(), p, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return stage.data();
+    };
+    const double *Yh = host_of(Y, L * ns, hY), *th = host_of(t, L, ht), *Wh = host_of(W, n, hW), *fh = host_of(freqs, Nf, hf);
+    if (!Yh || !th || !fh || (W && !Wh)) { set_error("staging of device arguments failed"); return LPVS_EDEVICE; }
+    double tam = 0;
+    for (int64_t i = 0; i < L; ++i) { const double a = th[i] < 0 ? -th[i] : th[i]; if (a > tam) tam = a; }   // one admission decision for all shards
+
+    const int64_t cap = (k + ngpus - 1) / ngpus;                 // equal-size slots keep the gather a single all-gather
+    const size_t per_win = (size_t)ns * (size_t)(2 * Nf + 1), slot = (size_t)cap * per_win;
+    std::vector<Shard> sh((size_t)ngpus);
+    std::vector<const double *> ys((size_t)ns);
+    for (int64_t q = 0; q < ns; ++q) ys[(size_t)q] = Yh + q * L;
+    const int64_t base = k / ngpus, rem = k % ngpus;
+    for (int r = 0; r < ngpus; ++r) {
+        Shard &S = sh[(size_t)r];
+        S.device = devs[(size_t)r];
+        S.lo = r * base + (r < rem ? r : rem);
+        S.hi = S.lo + base + (r < rem ? 1 : 0);
+        S.host.assign(slot, 0.0);
+    }
+    auto work = [&](int r) {
+        Shard &S = sh[(size_t)r];
+        if (hipSetDevice(S.device) != hipSuccess) { (void)hipGetLastError(); S.rc = LPVS_EDEVICE; S.err = "hipSetDevice failed"; return; }
+        WinJob job{ys.data(), ns, th, L, n, noverlap, Wh, fh, Nf, estimator, lam, prox_kind, prox_param, group_len, mu, tol, iters, linear_sign,
+                   S.lo, S.hi, S.device};
+        job.t_absmax = tam;
+        double *img = S.host.data();
+        S.rc = windows_engine_run(job, [&](int64_t w, int64_t sg, const double *re, const double *im, int64_t its) {
+            double *e = img + ((size_t)w * (size_t)ns + (size_t)sg) * (size_t)(2 * Nf + 1);
+            memcpy(e, re, sizeof(double) * (size_t)Nf);
+            memcpy(e + Nf, im, sizeof(double) * (size_t)Nf);
+            e[2 * Nf] = (double)its;
+        });
+        if (S.rc != LPVS_OK) { S.err = lpvs_last_error(); return; }
+        windows_last_timing(S.timing);
+        if (use_rccl) {   // the shard's slot goes to its device for the gather
+            if ((S.rc = S.send.alloc(sizeof(double) * slot)) != LPVS_OK || (S.rc = S.recv.alloc(sizeof(double) * slot * (size_t)ngpus)) != LPVS_OK) { S.err = lpvs_last_error(); return; }
+            if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipMemcpyAsync(S.send.p, img, sizeof(double) * slot, hipMemcpyHostToDevice, S.stream) != hipSuccess ||
+                hipStreamSynchronize(S.stream) != hipSuccess) { (void)hipGetLastError(); S.rc = LPVS_EDEVICE; S.err = "upload of the shard's coefficients failed"; }
+        }
+    };
+    if (ngpus == 1) work(0);
+    else {
+        std::vector<std::thread> th_;
+        for (int r = 0; r < ngpus; ++r) th_.emplace_back(work, r);
+        for (auto &q : th_) q.join();
+    }
+    struct Cleanup { std::vector<Shard> &s; ~Cleanup() { for (auto &S : s) if (S.stream) { (void)hipSetDevice(S.device); (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); } } } cleanup{sh};
+    for (auto &S : sh) if (S.rc != LPVS_OK) { set_error("device %d (windows [%lld,%lld)): %s", S.device, (long long)S.lo, (long long)S.hi, S.err.c_str()); return S.rc; }
+    {   // timing of the call = the slowest shard's phases
+        double tmax[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (auto &S : sh) for (int i = 0; i < 8; ++i) if (S.timing[i] > tmax[i]) tmax[i] = S.timing[i];
+        tmax[3] = (double)k;
+        windows_set_timing(tmax);
+    }
+    std::vector<double> all;
+    const double *img_all = nullptr;
+    if (use_rccl) {
+        std::vector<void *> *comms = nullptr;
+        LPVS_TRY(comms_for(devs, &comms));
+        Rccl &R = rccl();
+        int rc = R.GroupStart();
+        for (int r = 0; r < ngpus && rc == 0; ++r) {
+            LPVS_HIP(hipSetDevice(sh[(size_t)r].device));
+            rc = R.AllGather(sh[(size_t)r].send.p, sh[(size_t)r].recv.p, slot, 8 /* ncclDouble */, (*comms)[(size_t)r], sh[(size_t)r].stream);
+        }
+        const int rc2 = R.GroupEnd();
+        if (rc != 0 || rc2 != 0) { set_error("RCCL all-gather of the window coefficients failed: %s", R.GetErrorString ? R.GetErrorString(rc ? rc : rc2) : "?"); return LPVS_EDEVICE; }
+        for (auto &S : sh) { LPVS_HIP(hipSetDevice(S.device)); LPVS_HIP(hipStreamSynchronize(S.stream)); }
+        all.resize(slot * (size_t)ngpus);
+        LPVS_HIP(hipSetDevice(sh[0].device));
+        LPVS_HIP(hipMemcpy(all.data(), sh[0].recv.p, sizeof(double) * all.size(), hipMemcpyDeviceToHost));   // devices[0] holds every window
+        img_all = all.data();
+    }
+    // unpack in window order: x_re / x_im are ns x k x Nf (signal-major), iters_out ns x k
+    const bool dre = x_re && is_device_ptr(x_re), dim_ = x_im && is_device_ptr(x_im);
+    std::vector<double> sre, sim;
+    if (dre) sre.resize((size_t)(ns * k * Nf));
+    if (dim_) sim.resize((size_t)(ns * k * Nf));
+    double *pre = dre ? sre.data() : x_re, *pim = dim_ ? sim.data() : x_im;
+    for (int r = 0; r < ngpus; ++r) {
+        const Shard &S = sh[(size_t)r];
+        const double *img = use_rccl ? img_all + (size_t)r * slot : S.host.data();
+        for (int64_t w = S.lo; w < S.hi; ++w)
+            for (int64_t sg = 0; sg < ns; ++sg) {
+                const double *e = img + ((size_t)(w - S.lo) * (size_t)ns + (size_t)sg) * (size_t)(2 * Nf + 1);
+                if (pre) memcpy(pre + (size_t)(sg * k + w) * (size_t)Nf, e, sizeof(double) * (size_t)Nf);
+                if (pim) memcpy(pim + (size_t)(sg * k + w) * (size_t)Nf, e + Nf, sizeof(double) * (size_t)Nf);
+                if (iters_out) iters_out[sg * k + w] = (int64_t)e[2 * Nf];
+            }
+    }
+    if (dre) LPVS_HIP(hipMemcpy(x_re, sre.data(), sizeof(double) * sre.size(), hipMemcpyHostToDevice));
+    if (dim_) LPVS_HIP(hipMemcpy(x_im, sim.data(), sizeof(double) * sim.size(), hipMemcpyHostToDevice));
+    return LPVS_OK;
+}
+
+}  // extern "C"

@@ -419,3 +419,67 @@ def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimato
         x = est(yi, ti, freqs, windows.W, **kw)[0]
         S += np.abs(x) ** 2
     return S / k ** 2, freqs
+
+
+class Windows3(Windows2):
+    """src/windows.jl:86-110: three arrays split alike."""
+    def __init__(self, y, t, v, n=None, noverlap=-1, window_func=rect):
+        super().__init__(y, t, n, noverlap, window_func)
+        self.v = np.asarray(v)
+        assert len(self.v) == len(self.y), "y, t and v has to be the same length"
+
+    def __iter__(self):
+        for o in self.offsets:
+            yield self.y[o:o + self.n], self.t[o:o + self.n], self.v[o:o + self.n]
+
+
+def _mul_conj(a, b):
+    """a .* conj.(b) as Julia evaluates it: four real products, no fused multiply-add."""
+    ar, ai, br, bi = np.real(a), np.imag(a), np.real(b), np.imag(b)
+    return (ar * br + ai * bi) + 1j * (ai * br - ar * bi)
+
+
+def _abs2(x):
+    return np.real(x) * np.real(x) + np.imag(x) * np.imag(x)
+
+
+def _default_estimator(yi, ti, f, W, **k_):
+    return ls_spectral(yi, ti, f, W, **k_)
+
+
+def ls_windowcsd(y, u, t, freqs=None, nw=10, noverlap=-1, window_func=rect, estimator=None, **kw):
+    """src/lsfft.jl:140-156: S += xy .* conj.(xu) over zip(Windows2(y,t,..), Windows2(u,t,..)); returns S ./ nw, freqs with
+    nw = length(windowsy) (recomputed, :146)."""
+    y, u, t = _f64(y), _f64(u), _f64(t)
+    n = len(y) // nw
+    if freqs is None:
+        freqs = default_freqs(t, n=n)
+    wy = Windows2(y, t, n, noverlap, window_func)
+    wu = Windows2(u, t, n, noverlap, window_func)
+    k = len(wy)
+    est = estimator if estimator is not None else _default_estimator
+    S = np.zeros(len(freqs), dtype=np.complex128)
+    for (yi, ti), (ui, _) in zip(wy, wu):
+        xy = est(yi, ti, freqs, wy.W, **kw)[0]
+        xu = est(ui, ti, freqs, wu.W, **kw)[0]
+        S = S + _mul_conj(xy, xu)
+    return S / k, freqs
+
+
+def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, **kw):
+    """src/lsfft.jl:176-193: Windows3(y,t,u,n,noverlap,hanning); Sch = abs2.(Syu) ./ (Suu .* Syy)."""
+    y, u, t = _f64(y), _f64(u), _f64(t)
+    n = len(y) // nw
+    if freqs is None:
+        freqs = default_freqs(t, n=n)
+    est = estimator if estimator is not None else _default_estimator
+    Syy, Suu = np.zeros(len(freqs)), np.zeros(len(freqs))
+    Syu = np.zeros(len(freqs), dtype=np.complex128)
+    windows = Windows3(y, t, u, n, noverlap, hanning)
+    for yi, ti, ui in windows:
+        xy = est(yi, ti, freqs, windows.W, **kw)[0]
+        xu = est(ui, ti, freqs, windows.W, **kw)[0]
+        Syu += _mul_conj(xy, xu)
+        Syy += _abs2(xy)
+        Suu += _abs2(xu)
+    return _abs2(Syu) / (Suu * Syy), freqs

@@ -1,0 +1,109 @@
+"""Regression tests for defects found in review (GPU only): stale packed inverse after gram_modified, weighted
+``init=true`` start, conditioning of the ridge solves, resume re-entry."""
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def _spd_problem(n, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((3 * n // 2, n)) / np.sqrt(n)
+    xs = np.zeros(n); xs[rng.choice(n, 9, replace=False)] = rng.standard_normal(9) * 3
+    y = A @ xs + 0.01 * rng.standard_normal(A.shape[0])
+    return A.T @ A, A.T @ y
+
+
+def test_gram_modified_then_refactorise_repacks_the_inverse(L, oracle):
+    """admm_init(mu) -> edit G in place -> gram_modified -> get_inverse(1/mu) (refactorises M) -> admm_init(mu): the
+    tile-packed copy streamed by the mat-vec must be rebuilt from the NEW inverse (it used to be kept)."""
+    n, mu = 2176, 0.05                                            # >= 2048: tile-packed path; not a multiple of 128
+    G, b = _spd_problem(n, 5)
+    with L.Problem.gram(G, b) as p:
+        p.set_prox(L.NormL1(0.5))
+        p.admm_init(None, μ=mu, tol=0.0)
+        p.admm_run(5)
+        Gd, bd = p.device_gram()
+        Gd.mul_(2.0)                                              # in-place edit of the resident Gram
+        import torch
+        torch.cuda.synchronize()
+        p.gram_modified()
+        Minv = p.get_inverse(1.0 / mu)                            # refactorises for the shift admm_init will ask for
+        assert np.abs(Minv @ (2.0 * G + np.eye(n) / mu) - np.eye(n)).max() <= 1e-9
+        p.admm_init(None, μ=mu, tol=0.0)
+        p.admm_run(40)
+        x, z, u = p.admm_get()
+    ro = oracle.admm_gram(2.0 * G, b, oracle.NormL1(0.5), iters=40, tol=0.0, mu=mu)
+    assert rel(z, ro["z"]) <= 1e-9 and rel(x, ro["x"]) <= 1e-9 and np.array_equal(z != 0, ro["z"] != 0)
+
+
+def test_weighted_init_starts_from_the_unweighted_solution(L, oracle):
+    """src/lasso.jl:112: the weighted method initialises with fourier_solve(A, y, zerofreq, lam) -- W is not used there."""
+    rng = np.random.default_rng(31)
+    N = 600
+    t = np.sort(rng.random(N)) * N
+    f = np.arange(0, 40) / 100.0
+    y = 0.4 + 1.5 * np.sin(2 * np.pi * f[7] * t) + 0.6 * np.cos(2 * np.pi * f[23] * t) + 0.1 * rng.standard_normal(N)
+    W = L.hanning(N) + 0.05
+    for Wi in (None, W):
+        x, _ = L.ls_sparse_spectral(y, t, f, Wi, init=True, λ=0.5, iters=7, tol=0.0, μ=0.05, printerval=1000, out=io.StringIO())
+        xo, _, ro = oracle.ls_sparse_spectral(y, t, f, Wi, init=True, lam=0.5, iters=7, tol=0.0, mu=0.05)
+        assert rel(x, xo) <= 1e-6, (Wi is None, rel(x, xo))      # few iterations: the start still matters
+
+
+def test_ridge_solves_on_ill_conditioned_lpv_bases(L, oracle):
+    """Overlapping normalised Gaussian bases: cond(G) = cond(A)^2 is large.  (i) moderately ill-conditioned, tall: the
+    refined device solve agrees with the reference's QR route; (ii) more unknowns than samples at the default lam = 1e-8:
+    (G + 1e-16 I) is singular to working precision, the device solve says so and the wrapper takes the host QR route."""
+    rng = np.random.default_rng(0)
+    N = 2500
+    X = np.sort(10 * rng.random(N)); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * np.arange(2, 26, 2.0)
+    Y = 2 * V ** 2 * np.cos(w[0] * X) + 3 * np.exp(-10 * (V - 0.5) ** 2) * np.cos(w[9] * X) + 0.1 * rng.standard_normal(N)
+    Nv = 24                                                        # 576 unknowns, heavily overlapping activations
+    Ar = oracle.lpv_regressor(X, V, w, Nv, permuted=False)
+    c = np.linalg.cond(Ar)
+    assert c > 1e4
+    lam = 1e-4
+    se = L.ls_spectral_lpv(Y, X, V, w, Nv, λ=lam, covariance=False)
+    xo = oracle.ls_spectral_lpv(Y, X, V, w, Nv, lam=lam)
+    # compare through the fitted signal (the coefficients of a nearly collinear basis are not individually determined)
+    xr = np.concatenate([se.x.real, se.x.imag]); xor = np.concatenate([xo.real, xo.imag])
+    assert rel(Ar @ xr, Ar @ xor) <= 1e-7, (c, rel(Ar @ xr, Ar @ xor))
+    # (ii) fat system, default lam
+    Ns = 400
+    se2 = L.ls_spectral_lpv(Y[:Ns], X[:Ns], V[:Ns], w, 50)         # n = 1200 > N = 400, lam = 1e-8
+    xo2 = oracle.ls_spectral_lpv(Y[:Ns], X[:Ns], V[:Ns], w, 50)
+    Ar2 = oracle.lpv_regressor(X[:Ns], V[:Ns], w, 50, permuted=False)
+    f1 = Ar2 @ np.concatenate([se2.x.real, se2.x.imag]); f2 = Ar2 @ np.concatenate([xo2.real, xo2.imag])
+    assert rel(f1, f2) <= 1e-6                                     # the same fit as the reference's route (lstsq of [Ar; lam I])
+    assert se2.Σ is not None and se2.Σ.shape == (2400, 2400)
+
+
+def test_resume_from_saved_state_continues_bit_for_bit(L):
+    """SURVEY section 5 (checkpoint / resume): x, z, u and the iteration count read back from one handle and installed into
+    a fresh one continue the run bit for bit, including the stopping iteration."""
+    n, mu = 2304, 0.05
+    G, b = _spd_problem(n, 9)
+    with L.Problem.gram(G, b) as p:
+        p.set_prox(L.NormL1(0.3))
+        p.admm_init(None, μ=mu, tol=1e-7)
+        p.admm_run(60)
+        x1, z1, u1 = p.admm_get()
+        it_full, nxz_full, conv_full = p.admm_run(5000)
+        xf, zf, uf = p.admm_get()
+    assert conv_full and it_full > 60
+    with L.Problem.gram(G, b) as q:
+        q.set_prox(L.NormL1(0.3))
+        q.admm_init(None, μ=mu, tol=1e-7)
+        q.admm_set_state(x1, z1, u1, iters=60)
+        it, nxz, conv = q.admm_run(5000)
+        xr, zr, ur = q.admm_get()
+    assert (it, conv) == (it_full, conv_full) and nxz == nxz_full
+    assert np.array_equal(zr, zf) and np.array_equal(xr, xf) and np.array_equal(ur, uf)

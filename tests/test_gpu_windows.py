@@ -1,0 +1,165 @@
+"""The batched-window engine behind ls_windowpsd / ls_windowcsd / ls_cohere (src/lsfft.jl:112-193) against the CPU oracle's
+restatement of those drivers: ns signals share every window's Gram and factorisation.  GPU only.
+
+Tolerances: dense estimator (normal equations on both sides) rel <= 1e-8; sparse estimator vs the oracle's faithful CG form
+rel <= 1e-6 (CG's own tolerance), identical support and stopping iterations vs the single-window device path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def two_signals(Lh, seed, zero):
+    rng = np.random.default_rng(seed)
+    t = np.cumsum(0.5 + rng.random(Lh))                       # non-equidistant
+    f = np.arange(0 if zero else 1, 40) / 100.0
+    common = 1.5 * np.sin(2 * np.pi * 0.11 * t)
+    y = common + 0.7 * np.cos(2 * np.pi * 0.29 * t + 0.4) + 0.1 * rng.standard_normal(Lh) + (0.5 if zero else 0)
+    u = 0.8 * common + 0.5 * np.sin(2 * np.pi * 0.21 * t + 1.0) + 0.1 * rng.standard_normal(Lh)
+    return y, u, t, f
+
+
+def test_known_answers_through_the_engine(L):
+    """test/runtests.jl:203-208 on the batched path (default estimator = ls_spectral, the weighted 4-argument method)."""
+    t = np.arange(1000) * 0.1
+    y = np.sin(2 * np.pi * t)
+    x, freqs = L.ls_windowcsd(y, y, t, noverlap=0)
+    a = np.abs(x)
+    assert abs(a.max() - 2.0 * len(freqs)) < 1e-4 and a.argmax() + 1 == 11
+    c, _ = L.ls_cohere(y, y, t)
+    assert np.all(c == 1)
+    S, fr = L.ls_windowpsd(y, t, noverlap=0)
+    assert S.argmax() + 1 == 13 and len(fr) == 63
+    S16, _ = L.ls_windowpsd(y, t, nw=16, noverlap=0)
+    assert np.abs(S16).argmax() + 1 == 7
+    rng = np.random.default_rng(0)
+    c, _ = L.ls_cohere(y, y + 0.5 * rng.standard_normal(1000), t, nw=8, noverlap=-1)
+    assert abs(c.max() - 1.0) < 0.15 and abs(int(c.argmax()) + 1 - 14) <= 1 and c.mean() < 0.25     # :210-213
+
+
+@pytest.mark.parametrize("noverlap,zero", [(0, True), (100, False), (-1, False)])
+def test_csd_cohere_psd_dense_estimator_vs_oracle(L, oracle, noverlap, zero):
+    y, u, t, f = two_signals(4000, 8, zero)
+    kw = dict(nw=8, noverlap=noverlap)
+    S, _ = L.ls_windowcsd(y, u, t, f, window_func=L.hanning, λ=1e-3, **kw)
+    So, _ = oracle.ls_windowcsd(y, u, t, f, window_func=oracle.hanning, lam=1e-3, **kw)
+    assert rel(S, So) <= 1e-8, rel(S, So)
+    Sseq, _ = L.ls_windowcsd(y, u, t, f, window_func=L.hanning, λ=1e-3, batched=False, **kw)
+    assert rel(S, Sseq) <= 1e-10
+    c, _ = L.ls_cohere(y, u, t, f, λ=1e-3, **kw)
+    co, _ = oracle.ls_cohere(y, u, t, f, lam=1e-3, **kw)
+    assert rel(c, co) <= 1e-7 and 0 <= c.min() and c.max() <= 1 + 1e-12
+    assert abs(f[int(np.argmax(c))] - 0.11) <= 0.011          # the shared component
+    P, _ = L.ls_windowpsd(y, t, f, window_func=L.hanning, λ=1e-3, **kw)
+    Po, _ = oracle.ls_windowpsd(y, t, f, window_func=oracle.hanning, lam=1e-3, **kw)
+    assert rel(P, Po) <= 1e-8
+
+
+@pytest.mark.parametrize("noverlap,zero", [(0, True), (100, False)])
+def test_csd_cohere_sparse_estimator_vs_oracle(L, oracle, noverlap, zero):
+    y, u, t, f = two_signals(4000, 9, zero)
+    kw = dict(nw=8, noverlap=noverlap)
+    est = dict(λ=0.5, μ=0.05, tol=1e-9, iters=3000)
+    oest = dict(lam=0.5, mu=0.05, tol=1e-9, iters=3000)
+    osp = lambda yy, tt, ff, W, **k: oracle.ls_sparse_spectral(yy, tt, ff, W, **k)
+    S, _ = L.ls_windowcsd(y, u, t, f, window_func=L.hanning, estimator=L.ls_sparse_spectral, **est, **kw)
+    So, _ = oracle.ls_windowcsd(y, u, t, f, window_func=oracle.hanning, estimator=osp, **oest, **kw)
+    assert rel(S, So) <= 1e-6, rel(S, So)
+    assert np.array_equal(S != 0, So != 0)
+    c, _ = L.ls_cohere(y, u, t, f, estimator=L.ls_sparse_spectral, **est, **kw)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        co, _ = oracle.ls_cohere(y, u, t, f, estimator=osp, **oest, **kw)
+    assert np.array_equal(np.isnan(c), np.isnan(co))            # 0/0 where neither signal has the frequency, as in the reference
+    ok = ~np.isnan(co)
+    assert ok.sum() >= 1 and rel(c[ok], co[ok]) <= 1e-6
+    # sequential device path (the reference's loop calling the 4-argument estimator twice per window)
+    Sseq, _ = L.ls_windowcsd(y, u, t, f, window_func=L.hanning, estimator=L.ls_sparse_spectral, batched=False, printerval=100000, **est, **kw)
+    assert rel(S, Sseq) <= 1e-12
+
+
+def test_engine_shared_gram_equals_separate_runs_and_shards(L):
+    """ns = 3 signals through one engine call == three single-signal calls, bit for bit (same kernels, same order); disjoint
+    window ranges reproduce the whole; accumulators are the in-order sums of the per-window products."""
+    rng = np.random.default_rng(12)
+    Lh, n, noverlap = 6000, 750, 250
+    t = np.cumsum(0.5 + rng.random(Lh))
+    f = np.arange(0, 48) / 120.0
+    Y = [np.sin(2 * np.pi * f[5 + 7 * q] * t + q) + 0.2 * rng.standard_normal(Lh) for q in range(3)]
+    W = L.hanning(n)
+    eng_s = dict(estimator=1, lam=0.0, prox=(1, 0.4, 0), μ=0.05, tol=1e-8, iters=2000, sign=-1)
+    eng_d = dict(estimator=2, lam=1e-4, prox=(1, 0.0, 0), μ=0.05, tol=0.0, iters=0, sign=1)
+    for eng in (eng_s, eng_d):
+        x3, it3 = L.windows_estimate(Y, t, f, n, noverlap, W, eng)
+        k = x3.shape[1]
+        assert x3.shape == (3, k, len(f)) and k == (Lh - n) // (n - noverlap) + 1
+        for q in range(3):
+            x1, it1 = L.windows_estimate([Y[q]], t, f, n, noverlap, W, eng)
+            assert np.array_equal(x1[0], x3[q]) and np.array_equal(it1[0], it3[q])
+        if eng is eng_s:
+            assert len(set(it3.ravel())) > 1 and it3.max() < 2000            # every problem stops at its own iteration
+        Syu, Syy, Suu, xy, xu = L.windowcsd_batched(Y[0], Y[1], t, f, n, noverlap, W, eng)
+        assert np.array_equal(xy, x3[0]) and np.array_equal(xu, x3[1])
+        acc = np.zeros(len(f), dtype=complex); ayy = np.zeros(len(f)); auu = np.zeros(len(f))
+        for i in range(k):
+            a, b = xy[i], xu[i]
+            acc = acc + ((a.real * b.real + a.imag * b.imag) + 1j * (a.imag * b.real - a.real * b.imag))
+            ayy += a.real * a.real + a.imag * a.imag
+            auu += b.real * b.real + b.imag * b.imag
+        assert np.array_equal(Syu, acc) and np.array_equal(Syy, ayy) and np.array_equal(Suu, auu)
+        parts = [L.windowcsd_batched(Y[0], Y[1], t, f, n, noverlap, W, eng, win_lo=lo, win_hi=hi) for lo, hi in ((0, 3), (3, 4), (4, k))]
+        assert np.array_equal(np.vstack([p_[3] for p_ in parts]), xy) and np.array_equal(np.vstack([p_[4] for p_ in parts]), xu)
+    tm = L.windowpsd_last_timing()
+    assert tm["windows"] == k - 4 and tm["passes"] >= 1
+
+
+def test_engine_sparse_matches_single_window_handles(L):
+    """One window of the sparse engine (two right-hand sides) against the single-problem handle path with the same
+    Quadratic(Q, +q) convention: identical stopping iteration, coefficients to summation order."""
+    y, u, t, f = two_signals(3000, 3, True)
+    n, W = 1000, L.hanning(1000)
+    eng = dict(estimator=1, lam=0.0, prox=(1, 0.5, 0), μ=0.05, tol=1e-9, iters=3000, sign=-1)
+    x, its = L.windows_estimate([y, u], t, f, n, 0, W, eng)
+    for q, sig in enumerate((y, u)):
+        for i in range(3):
+            with L.Problem.fourier(sig[i * n:(i + 1) * n], t[i * n:(i + 1) * n], f, W) as p:
+                p.set_prox(L.NormL1(0.5))
+                p.admm_init(None, μ=0.05, tol=1e-9, linear_sign=-1)
+                it, _, conv = p.admm_run(3000)
+                xi = p.params(0)
+            assert conv and it == its[q, i]
+            assert rel(x[q, i], xi) <= 1e-12
+
+
+def test_multi_device_driver_shards_reproduce_single_device(L, monkeypatch):
+    """lpvs_windows_estimate_multi_f64 (one host process, a thread per device shard).  On the 1-GPU box the shards share the
+    device (rehearsal switch): 3 ragged shards of 7 windows == the single-device engine, bit for bit; and the single-rank
+    RCCL all-gather (forced) exercises the run-time binding of librccl and returns the same bytes."""
+    rng = np.random.default_rng(21)
+    Lh, n, noverlap = 5600, 800, 0
+    t = np.cumsum(0.5 + rng.random(Lh))
+    f = np.arange(1, 40) / 100.0
+    Y = [np.sin(2 * np.pi * f[9] * t) + 0.2 * rng.standard_normal(Lh), np.cos(2 * np.pi * f[9] * t + 0.3) + 0.2 * rng.standard_normal(Lh)]
+    W = L.hanning(n)
+    for eng in (dict(estimator=1, lam=0.0, prox=(1, 0.4, 0), μ=0.05, tol=1e-8, iters=1500, sign=-1),
+                dict(estimator=2, lam=1e-4, prox=(1, 0.0, 0), μ=0.05, tol=0.0, iters=0, sign=1)):
+        x1, it1 = L.windows_estimate(Y, t, f, n, noverlap, W, eng)
+        assert x1.shape[1] == 7
+        monkeypatch.setenv("LPVS_MULTI_ALLOW_SHARED_DEVICE", "1")
+        x3, it3 = L.windows_estimate_multi(Y, t, f, n, noverlap, W, eng, devices=[0, 0, 0])
+        monkeypatch.delenv("LPVS_MULTI_ALLOW_SHARED_DEVICE")
+        assert np.array_equal(x3, x1) and np.array_equal(it3, it1)
+        xa, ita = L.windows_estimate_multi(Y, t, f, n, noverlap, W, eng, ngpus=1)
+        assert np.array_equal(xa, x1) and np.array_equal(ita, it1)
+        monkeypatch.setenv("LPVS_MULTI_FORCE_RCCL", "1")
+        xr, itr = L.windows_estimate_multi(Y, t, f, n, noverlap, W, eng, ngpus=1)
+        monkeypatch.delenv("LPVS_MULTI_FORCE_RCCL")
+        assert np.array_equal(xr, x1) and np.array_equal(itr, it1)
+    with pytest.raises(ValueError):
+        L.windows_estimate_multi(Y, t, f, n, noverlap, W, eng, devices=[0, 0])       # duplicates need the rehearsal switch
+    S1, _ = L.ls_windowcsd(Y[0], Y[1], t, f, nw=7, noverlap=0, window_func=L.hanning, λ=1e-4)
+    S2, _ = L.ls_windowcsd(Y[0], Y[1], t, f, nw=7, noverlap=0, window_func=L.hanning, λ=1e-4, ngpus=0)   # all visible devices
+    assert np.array_equal(S1, S2)

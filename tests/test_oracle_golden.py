@@ -80,6 +80,24 @@ def test_ls_windowpsd_known_answer(oracle, case):
     assert np.abs(S).argmax() + 1 == case["argmax"]
 
 
+def test_ls_windowcsd_and_cohere_known_answers(oracle):
+    """test/runtests.jl:203-213: csd peak (2 length(freqs), 11); cohere(y, y) == 1 everywhere; with noise the mean coherence
+    stays below 0.25 and the maximum sits next to the signal's frequency (the reference's own draw is Julia's RNG)."""
+    g = GOLD["ls_windowcsd"]
+    t = _t()
+    y = np.sin(2 * np.pi * t)
+    x, fr = oracle.ls_windowcsd(y, y, t, nw=g["nw"], noverlap=g["noverlap"])
+    a = np.abs(x)
+    assert abs(a.max() - 2.0 * len(fr)) < g["atol"] and a.argmax() + 1 == g["findmax_abs"][1]
+    c, _ = oracle.ls_cohere(y, y, t)
+    assert np.all(c == GOLD["ls_cohere_self"]["all_equal"])
+    rng = np.random.default_rng(0)
+    c, _ = oracle.ls_cohere(y, y + 0.5 * rng.standard_normal(len(y)), t, nw=8, noverlap=-1)
+    assert abs(c.max() - 1.0) < 0.15 and abs(int(c.argmax()) + 1 - 14) <= 1 and c.mean() < 0.25
+    W3 = oracle.Windows3(np.arange(1, 101), np.arange(1, 101), np.arange(1, 101), 10, 1)          # test/runtests.jl:48-62
+    assert len(W3) == 11 and np.array_equal(list(W3)[1][2], np.arange(10, 20))
+
+
 def _lpv_signal(N, seed):
     rng = np.random.default_rng(seed)
     X = np.sort(10 * rng.random(N))

@@ -21,7 +21,12 @@ for k, d in sorted(res.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WR
     rows.append({"kernel": k, "launches": nf, "fetch_raw_bytes_per_launch": d["FETCH_SIZE"] * 1024 / nf,
                  "fetch_corrected_bytes_per_launch": 2 * d["FETCH_SIZE"] * 1024 / nf,
                  "write_bytes_per_launch": d["WRITE_SIZE"] * 1024 / nw})
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+stamp = hashlib.sha256(open(os.path.join(root, "lpvspectral.jl_amd", "csrc", "admm.hip"), "rb").read()).hexdigest()[:16]
+rows.insert(0, {"kernel": "__meta__", "admm_hip_sha16": stamp, "command": "bench.py --steps 1 --warmup 0 --iters 20 (tools/collect_pmc.sh)"})
 json.dump(rows, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+rows = rows[1:]
 for r in rows[:12]:
     print("%-28s launches %5d  fetch(raw) %10.1f MB  fetch(x2) %10.1f MB  write %10.1f MB" % (
         r["kernel"], r["launches"], r["fetch_raw_bytes_per_launch"] / 1e6, r["fetch_corrected_bytes_per_launch"] / 1e6, r["write_bytes_per_launch"] / 1e6))
