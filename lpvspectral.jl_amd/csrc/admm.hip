@@ -71,7 +71,7 @@ admm_init_kernel(AdmmParams p) {
         p.x[o + i] = xi;
         p.z[o + i] = xi;                                    // z = copy(x)      src/lasso.jl:146
         p.u[o + i] = 0.0;                                   // u = zeros        src/lasso.jl:147
-        p.rhs[o + i] = ok ? p.b[o + i] + (xi - 0.0) / p.mu : 0.0;  // b + (z-u)/mu
+        p.rhs[o + i] = ok ? (p.xb ? (xi - 0.0) / p.mu : p.b[o + i] + (xi - 0.0) / p.mu) : 0.0;  // b + (z-u)/mu (offset form: (z-u)/mu)
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         p.status[sg].iters = 0; p.status[sg].converged = 0; p.status[sg].nxz = 0.0; p.status[sg].pad = 0;
@@ -86,7 +86,8 @@ admm_restate_kernel(AdmmParams p, long long iters) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.np; i += (int64_t)gridDim.x * 256) {
         const bool ok = i < p.n;
         if (!ok) { p.x[o + i] = 0.0; p.z[o + i] = 0.0; p.u[o + i] = 0.0; }
-        p.rhs[o + i] = ok ? p.b[o + i] + (p.z[o + i] - p.u[o + i]) / p.mu : 0.0;   // b + (z-u)/mu, as the update kernels write it
+        const double v = (p.z[o + i] - p.u[o + i]) / p.mu;
+        p.rhs[o + i] = ok ? (p.xb ? v : p.b[o + i] + v) : 0.0;   // b + (z-u)/mu, as the update kernels write it
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         p.status[sg].iters = iters; p.status[sg].converged = 0; p.status[sg].nxz = 0.0; p.status[sg].pad = 0;
@@ -289,11 +290,12 @@ admm_prox_kernel(AdmmParams p) {
     double *__restrict__ R = p.rhs + so;
     double ss = 0;  // sum (x-z)^2 over this thread's elements
 
+    const bool offset_form = p.xb != nullptr;   // x = xb + M (z-u)/mu: the right-hand side carries no b
     auto finish = [&](int64_t i, double xi, double ui, double bi, double zi) {
         const double d = xi - zi;              // tmp = x - z            src/lasso.jl:154
         const double un = ui + d;              // u += tmp               src/lasso.jl:155
         Z[i] = zi; U[i] = un;
-        R[i] = bi + (zi - un) / mu;            // next x-update: b + (z-u)/mu
+        R[i] = offset_form ? (zi - un) / mu : bi + (zi - un) / mu;   // next x-update: b + (z-u)/mu
         ss = fma(d, d, ss);
     };
 
@@ -560,9 +562,18 @@ symv_tile_kernel(const T *__restrict__ Mp, const double *__restrict__ rhs_all, i
 //   tile layout (98304 B): head[128][128] float, then tail[128][128] uint16 with the columns of a row permuted so that the
 //   8 tails a lane needs are one 16-byte load: position 8c + 4h + k holds column 64h + 4c + k  (c < 16, h < 2, k < 4).
 // Lane (g = lane >> 4, c = lane & 15) of wave w owns rows 32w + 4rg + g (rg < 8) and columns {4c+k, 64+4c+k}: per row group
-// two float4 and one uint4 load (every instruction covers whole 128-byte lines): 24 loads = 384 bytes in flight per lane;
-// three workgroups per CU keep ~290 KB in flight per CU (the 8-byte kernel: two workgroups, 262 KB).  Single right-hand
-// side only (multi-signal handles keep doubles for the matrix-core tile product).
+// two float4 and one uint4 load (every instruction covers whole 128-byte lines): 24 loads = 384 bytes in flight per lane,
+// two workgroups per CU (three would need <= 168 registers and spill: measured 38.3 us against 30.4 us per launch at
+// np = 8192, i.e. 6.7 TB/s of 6-byte elements; the 8-byte kernel: 41.6 us, 6.56 TB/s).  Single right-hand side only
+// (multi-signal handles keep doubles for the matrix-core tile product).
+//
+// ACCURACY.  A reduced-precision copy of M must not multiply the large constant vector b: the rounding of the small
+// eigenvalues of M (the large ones of G) would be amplified by cond(G + I/mu) -- measured 5.3e-9 rel-L2 in z after 2000
+// iterations at the cfg3 size (9e-9 at n = 32768), above the 1e-9 parity bound.  So the x-update runs in OFFSET FORM
+// (AdmmParams::xb): xb = M b once from the full-precision inverse, and per iteration x = xb + M~ (z-u)/mu.  Near the
+// solution (z-u)/mu = x/mu - subgradient, so |dM (z-u)/mu| <= 2^-40 |M| |x| / mu <= 2^-40 |x|: no amplification.
+// Measured with the offset form: 1.2e-10 rel-L2 in z against the 8-byte storage at cfg3 (2000 iterations), 6e-11 against
+// the CPU oracle at n = 2176 (300 iterations; the 8-byte storage: 8e-13), identical supports and stopping iterations.
 constexpr size_t kSplitTileBytes = (size_t)TS * TS * 6;
 
 __device__ __forceinline__ double split_decode(float head, unsigned int tail16) {
@@ -593,8 +604,7 @@ pack_tiles_split_kernel(const double *__restrict__ M, int64_t np, unsigned char 
     }
 }
 
-template <int MINW>
-__global__ void __launch_bounds__(256, MINW)
+__global__ void __launch_bounds__(256, 2)
 symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs, int64_t np, int ntiles,
                        double *__restrict__ part1, double *__restrict__ part2, const AdmmStatus *status) {
     if (status != nullptr && status[0].converged) return;
@@ -980,12 +990,15 @@ __device__ __forceinline__ double gather_x4(const double *__restrict__ part1, co
 
 __global__ void __launch_bounds__(256)
 symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, int ntiles, int64_t np,
-                   double *__restrict__ x, const AdmmStatus *status) {
+                   double *__restrict__ x, const AdmmStatus *status, const double *__restrict__ xb) {
     const int sg = blockIdx.y;
     if (status != nullptr && status[sg].converged) return;
     __shared__ double sh[TS];
     const double s = gather_x(part1 + (int64_t)sg * ntiles * TS, part2 + (int64_t)sg * ntiles * TS, nblk, blockIdx.x, sh);
-    if (threadIdx.x < TS) x[(int64_t)sg * np + (int64_t)blockIdx.x * TS + threadIdx.x] = s;
+    if (threadIdx.x < TS) {
+        const int64_t gi = (int64_t)sg * np + (int64_t)blockIdx.x * TS + threadIdx.x;
+        x[gi] = xb ? xb[gi] + s : s;
+    }
 }
 
 // ---- fused: gather x from the tile partials + prox_g + dual update + next rhs, one workgroup per
@@ -1105,7 +1118,8 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     const int I = blockIdx.x, i = threadIdx.x & 127;
     const int64_t li_ = (int64_t)I * TS + i, gi = (int64_t)sg * p.np + li_;
     const bool row = threadIdx.x < TS, ok = row && li_ < p.n;
-    const double ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;   // in flight together with the partials
+    const bool offset_form = p.xb != nullptr;                       // x = xb + M (z-u)/mu
+    const double ui = ok ? p.u[gi] : 0.0, bi = ok ? (offset_form ? p.xb[gi] : p.b[gi]) : 0.0;   // in flight together with the partials
     if (commit_prev) {                                               // uniform (host-known): commit the previous iteration
         const double nxz = pending_norm(bn_prev, nblk, &slot);
         const bool conv = nxz < p.tol;                               //             src/lasso.jl:164
@@ -1116,7 +1130,8 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
         }
         if (conv) return;                                            // every workgroup takes the same decision
     }
-    const double xi = gather_x4(part1, part2, nblk, I, sh);
+    double xi = gather_x4(part1, part2, nblk, I, sh);
+    if (offset_form) xi += bi;                                       // (bi holds xb here)
     const double v = xi + ui;
     double zi = 0.0, d2 = 0.0;
     if (p.prox_kind == LPVS_PROX_L1) {
@@ -1142,7 +1157,7 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
         if (!ok) zi = 0.0;
         const double d = xi - zi, un = ui + d;     // src/lasso.jl:154-155
         p.x[gi] = xi; p.z[gi] = zi; p.u[gi] = un;
-        p.rhs[gi] = ok ? bi + (zi - un) / p.mu : 0.0;
+        p.rhs[gi] = ok ? (offset_form ? (zi - un) / p.mu : bi + (zi - un) / p.mu) : 0.0;
         d2 = ok ? d * d : 0.0;
     }
     const double wsum = wave_sum(d2);
@@ -1483,9 +1498,7 @@ bool fused_ok(const AdmmParams &p) {
 
 static void launch_split(const unsigned char *Mp, const double *rhs, int64_t np, unsigned ntiles, double *part1, double *part2,
                          const AdmmStatus *status, hipStream_t s) {
-    static const int wgs = [] { const char *e = getenv("LPVS_SPLIT_WGS"); return e ? atoi(e) : 3; }();   // experiment knob
-    if (wgs == 2) hipLaunchKernelGGL(symv_tile_split_kernel<2>, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
-    else hipLaunchKernelGGL(symv_tile_split_kernel<3>, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
+    hipLaunchKernelGGL(symv_tile_split_kernel, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
 }
 
 // one ADMM iteration on the packed symmetric form
@@ -1512,7 +1525,7 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     if (fused_ok(p)) {
         hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0);
     } else {
-        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status);
+        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb);
         hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
     }
 }

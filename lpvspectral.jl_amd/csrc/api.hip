@@ -258,6 +258,7 @@ struct lpvs_problem {
     bool M_valid = false; double M_shift = 0;
     bool Mp_valid = false;   // Mp is the packed copy of the CURRENT M (cleared whenever M is recomputed or G changes)
     int Mp_mode = 0;         // storage of Mp: kMpF64 / kMpF32 / kMpSplit (see make_params)
+    DevBuf xb; bool offset_form = false;   // xb = M * (signed b), computed at admm_init from the full-precision M (AdmmParams::xb)
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
     // timing (ms) -- see lpvs_problem_get_timing
@@ -334,7 +335,7 @@ int mp_mode_for(const lpvs_problem *h) {
     if (h->f32) return kMpF32;
     if (h->ns > 1) return kMpF64;
     const char *e = getenv("LPVS_M_STORAGE");
-    return (e && std::string(e) == "split") ? kMpSplit : kMpF64;
+    return (e && std::string(e) == "f64") ? kMpF64 : kMpSplit;
 }
 
 AdmmParams make_params(const lpvs_problem *h) {
@@ -344,6 +345,7 @@ AdmmParams make_params(const lpvs_problem *h) {
                  h->scratch.as<double>(), h->part.as<double>(), sym ? h->Mp.as<double>() : nullptr, (int)h->ns};
     p.mp_f32 = sym && h->Mp_mode == kMpF32 ? 1 : 0;
     p.mp_split = sym && h->Mp_mode == kMpSplit ? 1 : 0;
+    p.xb = sym && h->offset_form ? h->xb.as<double>() : nullptr;
     return p;
 }
 
@@ -962,6 +964,12 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     LPVS_HIP(hipStreamSynchronize(s));
     if (linear_sign < 0) for (auto &q : hb) q = -q;
     LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
+    // reduced-precision copies of M (split, f32) are only ever applied to (z-u)/mu: x = xb + M~ (z-u)/mu, xb = M b in full precision
+    h->offset_form = h->np >= kSymmetricMinNp && h->ns == 1 && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpF32) && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
+    if (h->offset_form) {
+        if (!h->xb.p) LPVS_TRY(h->xb.alloc(sizeof(double) * (size_t)h->np));
+        LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->bs.as<double>(), h->xb.as<double>(), s));
+    }
     const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_init(p, s));
     LPVS_HIP(hipStreamSynchronize(s));

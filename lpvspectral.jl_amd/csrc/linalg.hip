@@ -393,10 +393,12 @@ panel_gemm_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, i
 // A[Ri][Rj] += sum_c Ck[c][Ri] Bk[c][Rj] (Ck = -C') on the lower triangle, skipping pivot rows / columns.  The
 // accumulators start from the tile of A itself (its loads fly while the first stage lands), so the epilogue is
 // stores only and the read-modify-write latency is not exposed.
-// which = 0: every tile; 1: only tiles inside the next pivot band [n0, n0+nw); 2: every tile outside it.
+// which = 0: every tile; 1: only tiles inside the next pivot band [n0, n0+nw); 2: every tile outside it;
+//         3: only tiles inside the SECOND next band [n1, n1+nw1) and outside the next one; 4: every tile outside both.
 __global__ void __launch_bounds__(RU_THREADS, 2)
 rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, int kw, const double *__restrict__ Ck,
-                   const double *__restrict__ Bk, const int2 *__restrict__ tiles, int ntiles, int which, int64_t n0, int nw, int band_tile) {
+                   const double *__restrict__ Bk, const int2 *__restrict__ tiles, int ntiles, int which, int64_t n0, int nw, int band_tile,
+                   int64_t n1, int nw1) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -406,7 +408,8 @@ rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, 
     if (band_tile >= 0) {   // band launch: the tiles of the band's tile rows / tile columns, enumerated directly
         const int nr = (int)(np / RU_TM);          // grid = nr per 128-wide slice of the band
         const int bsl = blockIdx.x / nr, e = blockIdx.x - bsl * nr, bt = band_tile + bsl;
-        if (bsl == 0 && nw > RU_TM && e == band_tile + 1) return;   // tile (band_tile+1, band_tile) belongs to the second slice
+        const int bwidth = which == 3 ? nw1 : nw;                   // width of the band being enumerated
+        if (bsl == 0 && bwidth > RU_TM && e == band_tile + 1) return;   // tile (band_tile+1, band_tile) belongs to the second slice
         tt = e <= bt ? make_int2(bt, e) : make_int2(e, bt);
     } else {
         const int bq = ntiles / 8, br = ntiles % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;
@@ -421,7 +424,12 @@ rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, 
         if (in_band(r, k0, kw) || in_band(c, k0, kw)) return true;
         if (which != 0) {
             const bool next = in_band(r, n0, nw) || in_band(c, n0, nw);
-            if ((which == 1) != next) return true;
+            if (which <= 2) { if ((which == 1) != next) return true; }
+            else {
+                if (next) return true;
+                const bool second = nw1 > 0 && (in_band(r, n1, nw1) || in_band(c, n1, nw1));
+                if ((which == 3) != second) return true;
+            }
         }
         return false;
     };
@@ -569,7 +577,7 @@ size_t spd_inverse_work_bytes(int64_t np) {
     size_t d = sweep64_work_doubles(np);
     if (np >= kTwoLevelMinNp) {
         const int64_t ldp = round_up(np, RU_TN);
-        const size_t two = (size_t)(4 * KW * ldp + KW * KW) + sweep64_work_doubles(KW) + ru_tile_capacity(np);   // int2 = one double
+        const size_t two = (size_t)(6 * KW * ldp + KW * KW) + sweep64_work_doubles(KW) + ru_tile_capacity(np);   // int2 = one double
         if (two > d) d = two;
     }
     return sizeof(double) * d;
@@ -614,6 +622,7 @@ int32_t SweepAux::ensure() {
     LPVS_HIP(hipEventCreateWithFlags(&panel, hipEventDisableTiming));
     LPVS_HIP(hipEventCreateWithFlags(&rest, hipEventDisableTiming));
     LPVS_HIP(hipEventCreateWithFlags(&band, hipEventDisableTiming));
+    LPVS_HIP(hipEventCreateWithFlags(&second, hipEventDisableTiming));
     return LPVS_OK;
 }
 SweepAux::~SweepAux() {
@@ -621,6 +630,7 @@ SweepAux::~SweepAux() {
     if (panel) (void)hipEventDestroy(panel);
     if (rest) (void)hipEventDestroy(rest);
     if (band) (void)hipEventDestroy(band);
+    if (second) (void)hipEventDestroy(second);
 }
 
 // Step k of the outer sweep:  chain_k = { P = inv(A_kk); Bk = A[:,k]; Ck = -(Bk' P)'; A[:,k] = C; A_kk = -P },
@@ -630,8 +640,8 @@ SweepAux::~SweepAux() {
 // MFMA-bound bulk update.
 static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *status_dev, hipStream_t s, SweepAux *aux) {
     const int64_t ldp = round_up(np, RU_TN);
-    double *panelbuf[2] = {work, work + 2 * KW * ldp};   // {Bk, Ck} x 2
-    double *P = work + 4 * KW * ldp, *inner = P + KW * KW;
+    double *panelbuf[3] = {work, work + 2 * KW * ldp, work + 4 * KW * ldp};   // {Bk, Ck} x 3 (depth-2 look-ahead rotates three)
+    double *P = work + 6 * KW * ldp, *inner = P + KW * KW;
     int2 *tiles = reinterpret_cast<int2 *>(inner + sweep64_work_doubles(KW));
     const std::vector<int2> &ht = ru_tiles(np);   // persistent host copy: the async upload may outlive this call
     LPVS_HIP(hipMemcpyAsync(tiles, ht.data(), sizeof(int2) * ht.size(), hipMemcpyHostToDevice, s));
@@ -663,10 +673,15 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
         const int kw = width(k0);
         const int64_t n0 = k0 + kw;
         const int nw = n0 < np ? width(n0) : 0;
+        const int64_t n1 = n0 + nw;
+        const int nw1 = (nw > 0 && n1 < np) ? width(n1) : 0;
         // a 128-wide band is one tile row + one tile column: launch just those (32k early-exit workgroups cost 0.3 ms at np = 32768)
-        const bool direct = which == 1 && nw % RU_TM == 0 && nw > 0 && RU_TM == RU_TN;
-        hipLaunchKernelGGL(rank_update_kernel, dim3(direct ? (unsigned)(np / RU_TM * (nw / RU_TM)) : (unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, k0,
-                           kw, Ck, Bk, tiles, (int)ht.size(), which, n0, nw, direct ? (int)(n0 / RU_TM) : -1);
+        const bool direct1 = which == 1 && nw % RU_TM == 0 && nw > 0 && RU_TM == RU_TN;
+        const bool direct3 = which == 3 && nw1 % RU_TM == 0 && nw1 > 0 && RU_TM == RU_TN;
+        const unsigned grid = direct1 ? (unsigned)(np / RU_TM * (nw / RU_TM)) : (direct3 ? (unsigned)(np / RU_TM * (nw1 / RU_TM)) : (unsigned)ht.size());
+        const int band_tile = direct1 ? (int)(n0 / RU_TM) : (direct3 ? (int)(n1 / RU_TM) : -1);
+        hipLaunchKernelGGL(rank_update_kernel, dim3(grid), dim3(RU_THREADS), lds, st, A, np, ldp, k0,
+                           kw, Ck, Bk, tiles, (int)ht.size(), which, n0, nw, band_tile, n1, nw1);
     };
 
     if (!la) {
@@ -682,6 +697,41 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     LPVS_HIP(hipStreamWaitEvent(side, aux->rest, 0));
     chain(0, panelbuf[0], panelbuf[0] + KW * ldp, side);
     LPVS_HIP(hipEventRecord(aux->panel, side));
+    // measured at np = 8192: 18.4 -> 17.8 ms; neutral at 16384, slightly slower at 4096 (5.6 -> 5.8 ms): used from np = 6144
+    const bool depth2 = np >= 6144 && [] { const char *e = getenv("LPVS_LOOKAHEAD"); return !(e && e[0] == '1'); }();   // LPVS_LOOKAHEAD=1: depth one
+    if (depth2) {
+        // Depth-2 look-ahead.  With depth one the main stream alternates  band_k | bulk_k  (the band of step k, which the next
+        // pivot chain waits for, runs alone on the chip and two event hand-overs sit between consecutive bulks: 57 of 286 us
+        // per step at np = 8192; profiles/r02_factor_timeline.txt).  Here the side stream owns everything the pivot chains need
+        // and never blocks the bulk (the second-band launch costs the main stream 38 us, so the step shrinks to 278 us only):
+        //   side:  band_k (tile row / column k+1, needs panel_k and second_{k-1})  ->  chain_{k+1}  ->  panel_{k+1}
+        //   main:  bulk_k = { second band (tile row / column k+2) -> event second_k ;  everything else }   (needs panel_k)
+        // band_k's tiles received the updates of steps < k as the "second band" of step k-1; the side stream may run a whole
+        // step ahead, so the panels rotate through three buffers (chain_{k+1} writes while bulk_{k-1} may still read its own).
+        int cur = 0;
+        for (int64_t k0 = 0; k0 < np; k0 += kw_outer, cur = (cur + 1) % 3) {
+            double *Bk = panelbuf[cur], *Ck = Bk + KW * ldp;
+            const int64_t n0 = k0 + width(k0);
+            const bool next = n0 < np;
+            LPVS_HIP(hipStreamWaitEvent(s, aux->panel, 0));     // panel k (captured before the side stream re-records the event)
+            if (next) {
+                if (k0 > 0) LPVS_HIP(hipStreamWaitEvent(side, aux->second, 0));   // second band of step k-1 = this step's band tiles
+                update(k0, Bk, Ck, 1, side);
+                double *Bn = panelbuf[(cur + 1) % 3];
+                chain(n0, Bn, Bn + KW * ldp, side);
+                LPVS_HIP(hipEventRecord(aux->panel, side));
+                if (n0 + width(n0) < np) update(k0, Bk, Ck, 3, s);
+                LPVS_HIP(hipEventRecord(aux->second, s));
+                update(k0, Bk, Ck, 4, s);
+            } else {
+                update(k0, Bk, Ck, 0, s);
+            }
+            LPVS_HIP(hipGetLastError());
+        }
+        LPVS_HIP(hipEventRecord(aux->rest, side));              // the side stream has nothing pending when the caller goes on
+        LPVS_HIP(hipStreamWaitEvent(s, aux->rest, 0));
+        return LPVS_OK;
+    }
     int cur = 0;
     for (int64_t k0 = 0; k0 < np; k0 += kw_outer, cur ^= 1) {
         double *Bk = panelbuf[cur], *Ck = Bk + KW * ldp;

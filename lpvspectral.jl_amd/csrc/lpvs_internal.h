@@ -145,7 +145,7 @@ int32_t launch_ap_rhs(const double *tab, const double *eps, int64_t Nf, int64_t 
 // (high-priority) stream while the bulk of the current trailing update runs on the caller's stream.
 struct SweepAux {
     hipStream_t side = nullptr;
-    hipEvent_t panel = nullptr, rest = nullptr, band = nullptr;
+    hipEvent_t panel = nullptr, rest = nullptr, band = nullptr, second = nullptr;
     int32_t ensure();
     ~SweepAux();
 };
@@ -181,6 +181,10 @@ struct AdmmParams {
     int ns;            // right-hand sides sharing M (signals of a shared-regressor batch); vectors are [ns][np]
     int mp_f32 = 0;    // Mp holds float (the _f32 entry points: M is streamed in single precision, arithmetic stays double)
     int mp_split = 0;  // Mp holds 6-byte elements (float head + 16-bit tail, 40 significant bits; see admm.hip)
+    // offset form of the x-update (single-problem tile-packed path): x = xb + M (z-u)/mu with xb = M b computed once from
+    // the full-precision inverse; the per-iteration product then never multiplies the large constant vector b by the
+    // reduced-precision copy of M (its rounding would otherwise be amplified by cond(G + I/mu)).  nullptr: x = M (b + (z-u)/mu).
+    const double *xb = nullptr;
 };
 size_t symv_part_doubles(int64_t np, int64_t ns = 1);
 size_t symv_packed_doubles(int64_t np);

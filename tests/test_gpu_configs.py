@@ -217,7 +217,9 @@ def test_cfg5_fullshape_eight_channels_invariants(L):
         p1.admm_init(None, μ=mu, tol=0.0)
         p1.admm_run(31)
         xs, zs, us = p1.admm_get()
-    assert np.array_equal(zs != 0, z2[:, q] != 0) and rel(zs, z2[:, q]) <= 1e-10
+    r1 = rel(zs, z2[:, q])
+    print(f"cfg5 shape n=32768, 31 iterations: single-signal path (6-byte storage of M, offset form) vs multi-signal path (doubles, matrix cores): rel-L2(z) = {r1:.3e}")
+    assert np.array_equal(zs != 0, z2[:, q] != 0) and r1 <= 1e-9
 
 
 # ------------------------------------------------------------------ per-iteration iterates with tol > 0 on the fused path

@@ -83,7 +83,7 @@ def test_ridge_solves_on_ill_conditioned_lpv_bases(L, oracle):
     Ar2 = oracle.lpv_regressor(X[:Ns], V[:Ns], w, 50, permuted=False)
     f1 = Ar2 @ np.concatenate([se2.x.real, se2.x.imag]); f2 = Ar2 @ np.concatenate([xo2.real, xo2.imag])
     assert rel(f1, f2) <= 1e-6                                     # the same fit as the reference's route (lstsq of [Ar; lam I])
-    assert se2.Σ is not None and se2.Σ.shape == (2400, 2400)
+    assert se2.Σ is not None and se2.Σ.shape == (1200, 1200)
 
 
 def test_resume_from_saved_state_continues_bit_for_bit(L):
