@@ -573,7 +573,7 @@ symv_tile_kernel(const T *__restrict__ Mp, const double *__restrict__ rhs_all, i
 // (AdmmParams::xb): xb = M b once from the full-precision inverse, and per iteration x = xb + M~ (z-u)/mu.  Near the
 // solution (z-u)/mu = x/mu - subgradient, so |dM (z-u)/mu| <= 2^-40 |M| |x| / mu <= 2^-40 |x|: no amplification.
 // Measured with the offset form: 1.2e-10 rel-L2 in z against the 8-byte storage at cfg3 (2000 iterations), 6e-11 against
-// the CPU oracle at n = 2176 (300 iterations; the 8-byte storage: 8e-13), identical supports and stopping iterations.
+// an exact-solve CPU run of the same ADMM at n = 2176 (300 iterations; the 8-byte storage: 8e-13), identical supports and stopping iterations.
 constexpr size_t kSplitTileBytes = (size_t)TS * TS * 6;
 
 __device__ __forceinline__ double split_decode(float head, unsigned int tail16) {
