@@ -771,20 +771,22 @@ symv_tile_multi_kernel(const T *__restrict__ Mp, const double *__restrict__ rhs_
 // one 1 KiB row per instruction, rows padded by 16 B) and is read from there in either layout: waves 0-1 form P1 of the
 // stage's two 16-row blocks, waves 2-3 accumulate P2 over the stages (four 16-column blocks each).  43 KB of LDS per
 // workgroup: three workgroups per CU keep the memory pipe busy while others multiply (double-buffering the stages
-// inside a workgroup at two workgroups per CU was slower: 1.36 vs 1.24 ms at ns = 8, n = 32768).  Signals are processed eight at a
-// time (the MFMA's 16-wide signal dimension is half used).  Partials have the layout of the scalar kernels, so the
-// update kernels are shared.
+// inside a workgroup at two workgroups per CU was slower: 1.36 vs 1.24 ms at ns = 8, n = 32768).  Signals are processed eight
+// (ns <= 8: the MFMA's 16-wide signal dimension is half used) or sixteen at a time (no padding: the tile product costs the
+// same matrix-pipe time for twice the signals).  Partials have the layout of the scalar kernels, so the update kernels
+// are shared.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int MT_RS = TS + 2;                        // padded row stride of the staged rows (doubles)
-constexpr int MT_NS = 8;                             // signals per pass
 constexpr int MT_ROWS = 32;                          // tile rows per stage
-constexpr size_t kSymvMfmaLds = sizeof(double) * ((size_t)MT_ROWS * MT_RS + (size_t)MT_ROWS * MT_NS + (size_t)TS * MT_NS);
+// NS = signals per pass: 8 (half of the MFMA's 16-wide signal dimension is padding) or 16 (none); LDS 43 / 53 KB
+template <int NS> constexpr size_t symv_mfma_lds() { return sizeof(double) * ((size_t)MT_ROWS * MT_RS + (size_t)MT_ROWS * NS + (size_t)TS * NS); }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+template <int NS>
 __global__ void __launch_bounds__(256, 3)
 symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
                       double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
@@ -795,8 +797,8 @@ symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ 
     }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *stg = lds;                               // [32][MT_RS]   the current 32 rows of the tile
-    double *ri = stg + MT_ROWS * MT_RS;              // [32][MT_NS]   right-hand sides of row block I, rows of the current stage
-    double *rj = ri + MT_ROWS * MT_NS;               // [128][MT_NS]  right-hand sides of row block J
+    double *ri = stg + MT_ROWS * MT_RS;              // [32][NS]      right-hand sides of row block I, rows of the current stage
+    double *rj = ri + MT_ROWS * NS;                  // [128][NS]     right-hand sides of row block J
     const int t = blockIdx.x;
     int I, J;
     tile_index(t, I, J);
@@ -804,11 +806,12 @@ symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const double *src = Mp + (int64_t)t * TS * TS;
-    for (int s0 = 0; s0 < ns; s0 += MT_NS) {
-        const int nsb = ns - s0 < MT_NS ? ns - s0 : MT_NS;
+    for (int s0 = 0; s0 < ns; s0 += NS) {
+        const int nsb = ns - s0 < NS ? ns - s0 : NS;
         f64x4 acc2[4];                               // waves 2-3: P2 blocks, columns 64*(wave-2) + 16*u .., over all stages
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc2[u] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
         for (int q = 0; q < TS / MT_ROWS; ++q) {
             __syncthreads();                         // everyone is done with the previous contents of the LDS images
 #pragma unroll
@@ -816,14 +819,14 @@ symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ 
                 const int row = wave * (MT_ROWS / 4) + r;
                 glds16(src + (int64_t)(MT_ROWS * q + row) * TS + 2 * lane, stg + row * MT_RS);
             }
-            {   // R_I rows of this stage: 32 x 8 values, one per thread (zero beyond the pass's signals)
-                const int sq = tid / MT_ROWS, i = tid - sq * MT_ROWS;
-                ri[i * MT_NS + sq] = sq < nsb ? rhs_all[(int64_t)(s0 + sq) * np + (int64_t)I * TS + MT_ROWS * q + i] : 0.0;
+            for (int e = tid; e < MT_ROWS * NS; e += 256) {   // R_I rows of this stage: 32 x NS values (zero beyond the pass's signals)
+                const int sq = e / MT_ROWS, i = e - sq * MT_ROWS;
+                ri[i * NS + sq] = sq < nsb ? rhs_all[(int64_t)(s0 + sq) * np + (int64_t)I * TS + MT_ROWS * q + i] : 0.0;
             }
             if (q == 0)
-                for (int e = tid; e < TS * MT_NS; e += 256) {
+                for (int e = tid; e < TS * NS; e += 256) {
                     const int sq = e / TS, i = e - sq * TS;
-                    rj[i * MT_NS + sq] = sq < nsb ? rhs_all[(int64_t)(s0 + sq) * np + (int64_t)J * TS + i] : 0.0;
+                    rj[i * NS + sq] = sq < nsb ? rhs_all[(int64_t)(s0 + sq) * np + (int64_t)J * TS + i] : 0.0;
                 }
             __syncthreads();                         // DMA landed (vmcnt(0)), staging visible
             if (wave < 2) {
@@ -833,8 +836,8 @@ symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ 
 #pragma unroll 8
                 for (int kk = 0; kk < 32; kk += 2) {
                     const int c = 4 * kk + lk;
-                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[c], li < MT_NS ? rj[c * MT_NS + li] : 0.0, a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[c + 4], li < MT_NS ? rj[(c + 4) * MT_NS + li] : 0.0, a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[c], li < NS ? rj[c * NS + li] : 0.0, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[c + 4], li < NS ? rj[(c + 4) * NS + li] : 0.0, a1, 0, 0, 0);
                 }
                 // D: col = lane&15 = s, row = lk + 4*reg
                 if (li < nsb && !(status != nullptr && status[s0 + li].converged)) {
@@ -847,7 +850,7 @@ symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ 
 #pragma unroll
                 for (int kk = 0; kk < MT_ROWS / 4; ++kk) {
                     const int i = 4 * kk + lk;
-                    const double a = li < MT_NS ? ri[i * MT_NS + li] : 0.0;
+                    const double a = li < NS ? ri[i * NS + li] : 0.0;
                     const double *brow = stg + i * MT_RS + 64 * (wave - 2) + li;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * u], acc2[u], 0, 0, 0);
@@ -858,7 +861,7 @@ symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ 
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < NS / 4; ++r) {
                     const int sgl = lk + 4 * r;
                     if (sgl < nsb && !(status != nullptr && status[s0 + sgl].converged))
                         part2_all[(int64_t)(s0 + sgl) * ntiles * TS + (int64_t)t * TS + 64 * (wave - 2) + 16 * u + li] = acc2[u][r];
@@ -1120,6 +1123,16 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     const bool row = threadIdx.x < TS, ok = row && li_ < p.n;
     const bool offset_form = p.xb != nullptr;                       // x = xb + M (z-u)/mu
     const double ui = ok ? p.u[gi] : 0.0, bi = ok ? (offset_form ? p.xb[gi] : p.b[gi]) : 0.0;   // in flight together with the partials
+    // the first 16 tile partials of this thread's quarter of the row block are requested BEFORE the pending norm is summed:
+    // the norm's loads, reduction and barrier then overlap the partials' memory latency instead of preceding it
+    const int gq = threadIdx.x >> 7;
+    const int per = (nblk + 3) / 4, e0 = gq * per, e1 = e0 + per < nblk ? e0 + per : nblk;
+    auto at = [&](int e) -> const double * {
+        return e <= I ? part1 + ((int64_t)I * (I + 1) / 2 + e) * TS + i : part2 + ((int64_t)e * (e + 1) / 2 + I) * TS + i;
+    };
+    double pre[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pre[q] = e0 + q < e1 ? *at(e0 + q) : 0.0;
     if (commit_prev) {                                               // uniform (host-known): commit the previous iteration
         const double nxz = pending_norm(bn_prev, nblk, &slot);
         const bool conv = nxz < p.tol;                               //             src/lasso.jl:164
@@ -1130,7 +1143,24 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
         }
         if (conv) return;                                            // every workgroup takes the same decision
     }
-    double xi = gather_x4(part1, part2, nblk, I, sh);
+    double xi;
+    {   // same summation order as gather_x4: the quarter's contributions in order, then the four quarters in order
+        double sacc = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc += pre[q];                 // (entries past e1 are +0.0: they do not change the sum's bits)
+        int e = e0 + 16;
+        for (; e + 16 <= e1; e += 16) {
+            double a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = *at(e + q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sacc += a[q];
+        }
+        for (; e < e1; ++e) sacc += *at(e);
+        if (gq > 0) sh[(gq - 1) * TS + i] = sacc;
+        __syncthreads();
+        xi = gq == 0 ? ((sacc + sh[i]) + sh[TS + i]) + sh[2 * TS + i] : 0.0;
+    }
     if (offset_form) xi += bi;                                       // (bi holds xb here)
     const double v = xi + ui;
     double zi = 0.0, d2 = 0.0;
@@ -1509,10 +1539,14 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
     static const bool mfma_multi = [] { const char *e = getenv("LPVS_MULTI_MATVEC"); return !(e && std::string(e) == "valu"); }();
-    if (p.ns > 1 && !p.mp_f32 && !p.mp_split && mfma_multi) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)kSymvMfmaLds);   // per device; cheap
-        hipLaunchKernelGGL(symv_tile_mfma_kernel, dim3(ntiles), dim3(256), kSymvMfmaLds, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
+    if (p.ns > 8 && !p.mp_f32 && !p.mp_split && mfma_multi) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)symv_mfma_lds<16>());   // per device; cheap
+        hipLaunchKernelGGL(symv_tile_mfma_kernel<16>, dim3(ntiles), dim3(256), symv_mfma_lds<16>(), s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
+    } else if (p.ns > 1 && !p.mp_f32 && !p.mp_split && mfma_multi) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)symv_mfma_lds<8>());
+        hipLaunchKernelGGL(symv_tile_mfma_kernel<8>, dim3(ntiles), dim3(256), symv_mfma_lds<8>(), s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     } else if (p.ns > 1 && !p.mp_f32 && !p.mp_split)
         hipLaunchKernelGGL((symv_tile_multi_kernel<double, 8>), dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
     else if (p.mp_f32)

@@ -537,6 +537,13 @@ struct ApSlots {
     std::vector<double> eps, om_hi, om_lo, omr_hi, omr_lo;
     ApStep step{};
 };
+// Single-precision callers (_f32 entry points): the frequency grid is a progression rounded to FLOATS, so its residuals are up
+// to 2^-24 |w| and |eps| max|x| reaches 0.2 rad at the cfg3 size -- far beyond the double-precision admission bound.  But a
+// Float32 run of the reference evaluates fl32(w x) itself, a phase error of up to 2^-24 |w x|: snapping w to the exact
+// progression its floats were rounded from stays inside that error.  While an _f32 constructor runs, residuals up to
+// 2^-23 max|w| (one float ulp) are admitted and dropped.
+static thread_local bool g_f32_admission = false;
+
 static ApSlots make_ap_slots(const std::vector<double> &hw, double xam) {
     ApSlots sl;
     const int64_t Nf = (int64_t)hw.size();
@@ -546,7 +553,15 @@ static ApSlots make_ap_slots(const std::vector<double> &hw, double xam) {
         sl.eps[f] = (double)((long double)hw[f] - (a0 + (long double)f * D));
         sl.emax = std::fmax(sl.emax, std::fabs(sl.eps[f]));
     }
+    double wam = 0;
+    for (double v : hw) wam = std::fmax(wam, std::fabs(v));
     sl.ok = std::isfinite(sl.emax) && std::isfinite(xam) && sl.emax * xam <= 1e-7;   // second-order term (eps x)^2/2 <= 5e-15
+    if (!sl.ok && g_f32_admission && std::isfinite(sl.emax) && std::isfinite(xam) && sl.emax <= 0x1p-23 * wam) {
+        // large residual phases: snapped grid, NO first-order term -- G is then exactly the Gram of the regressor at the snapped
+        // frequencies (positive semidefinite by construction), which a first-order expansion with |eps x| ~ 0.2 would not guarantee
+        sl.ok = true;
+        if (sl.emax * xam > 3e-3) for (auto &e : sl.eps) e = 0.0;   // small residual phases keep the first-order term (error (eps x)^2/2 <= 5e-6)
+    }
     if (!sl.ok) return sl;
     sl.nf8 = round_up(Nf, 8); sl.s8 = round_up(2 * Nf - 1, 8); sl.nsl = sl.nf8 + sl.s8;
     auto split = [](long double v, double &hi, double &lo) { hi = (double)v; lo = (double)(v - (long double)hi); };
@@ -1673,6 +1688,7 @@ int32_t lpvs_problem_create_fourier_f32(const float *y, const float *t, int64_t 
     LPVS_HIP(hipSetDevice(device));
     WideArg dy, dt, df, dW;
     LPVS_TRY(dy.set(y, N, nullptr)); LPVS_TRY(dt.set(t, N, nullptr)); LPVS_TRY(df.set(f, Nf, nullptr)); LPVS_TRY(dW.set(W, N, nullptr));
+    struct Admit { Admit() { g_f32_admission = true; } ~Admit() { g_f32_admission = false; } } admit;
     LPVS_TRY(lpvs_problem_create_fourier_f64(dy.p, dt.p, N, df.p, Nf, dW.p, device, out));
     (*out)->f32 = true;
     return LPVS_OK;
@@ -1685,6 +1701,7 @@ int32_t lpvs_problem_create_lpv_f32(const float *y, const float *X, const float 
     LPVS_HIP(hipSetDevice(device));
     WideArg dy, dX, dV, dw;
     LPVS_TRY(dy.set(y, N, nullptr)); LPVS_TRY(dX.set(X, N, nullptr)); LPVS_TRY(dV.set(V, N, nullptr)); LPVS_TRY(dw.set(w, Nf, nullptr));
+    struct Admit { Admit() { g_f32_admission = true; } ~Admit() { g_f32_admission = false; } } admit;
     LPVS_TRY(lpvs_problem_create_lpv_f64(dy.p, dX.p, dV.p, N, dw.p, Nf, Nv, normalize, coulomb, device, out));
     (*out)->f32 = true;
     return LPVS_OK;

@@ -39,7 +39,7 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(os.environ.get("LPVS_ORACLE_SO") or build())   # LPVS_ORACLE_SO: e.g. the sanitizer build (tests)
         _LIB.lpvo_check_freq.restype = C.c_int64
         _LIB.lpvo_admm_ls.restype = C.c_int64
         _LIB.lpvo_admm_quadratic.restype = C.c_int64

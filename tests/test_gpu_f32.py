@@ -75,3 +75,36 @@ def test_f32_lpv_group_lasso_streams_single_precision_matrix(L, oracle):
         us, nbytes = p.time_matvec(20)
         x, z, u = p.admm_get()
     assert nbytes == 4 * (2048 * (2048 + 128) // 2) and x.dtype == np.float32
+
+
+def test_f32_float_grid_takes_the_structured_gram(L, oracle):
+    """A frequency grid stored in floats is a progression only up to float rounding (residual phases |eps x| far above the
+    double-precision admission bound).  _f32 handles admit it: the grid is snapped to the exact progression its floats were
+    rounded from -- a phase change of at most 2^-24 |w x|, which is what a Float32 run of the reference commits in
+    fl32(w x) anyway.  Checked against the fp64 oracle evaluated ON THE SNAPPED GRID (float I/O tolerance), and against
+    the un-snapped grid with the tolerance the snapping implies."""
+    import io
+    rng = np.random.default_rng(41)
+    N, Nf, Nv = 3000, 16, 4
+    X = np.sort(rng.random(N) * 5000).astype(np.float32)              # |eps x| up to 157 * 6e-8 * 5000 = 0.05 rad: snap regime
+    V = np.linspace(0, 1, N).astype(np.float32)
+    w = (2 * np.pi * (np.arange(Nf) + 1.0) * 25 / Nf).astype(np.float32)
+    y = (2 * V ** 2 * np.cos(w[3].astype(np.float64) * X) + np.cos(w[11].astype(np.float64) * X + 0.4) + 0.1 * rng.standard_normal(N)).astype(np.float32)
+    with L.Problem.lpv(y, X, V, w, Nv) as p:
+        assert p.timing()["gram_form"] == "ap" and p.f32
+    with L.Problem.lpv(y.astype(np.float64), X.astype(np.float64), V.astype(np.float64), w.astype(np.float64), Nv) as p:
+        assert p.timing()["gram_form"] == "krs"                      # the same grid through the _f64 entry point: not admitted
+    se = L.ls_sparse_spectral_lpv(y, X, V, w, Nv, λ=3.0, iters=200, tol=0.0, printerval=1000, out=io.StringIO())
+    y64, X64, V64, w64 = (a.astype(np.float64) for a in (y, X, V, w))
+    wl = w64.astype(np.longdouble)
+    snapped = np.asarray(wl[0] + np.arange(Nf, dtype=np.longdouble) * (wl[-1] - wl[0]) / (Nf - 1), dtype=np.float64)
+    assert 1e-6 < np.abs(snapped - w64).max() * X64.max() < 0.2
+    def run(wg):
+        Phi = oracle.lpv_regressor(X64, V64, wg, Nv)
+        Go, bo = oracle.gram(Phi, y64)
+        ro = oracle.admm_gram(Go, bo, oracle.GroupL2(3.0, 2 * Nv), iters=200, tol=0.0, mu=0.05)
+        return oracle.lpv_unpermute(ro["z"], Nf, Nv)
+    xs, xu = run(snapped), run(w64)
+    assert rel(se.x, xs) <= 2e-5, rel(se.x, xs)                       # float I/O only
+    assert np.array_equal(np.abs(se.x) > 0, np.abs(xs) > 0)
+    print(f"f32 float grid: rel-L2 vs oracle on the snapped grid {rel(se.x, xs):.2e}; the snapping itself moves the oracle by {rel(xs, xu):.2e}")

@@ -173,3 +173,43 @@ def test_prox_operators(oracle):
 def test_admm_mu_assert(oracle):
     with pytest.raises(AssertionError):
         oracle.admm_gram(np.eye(3), np.ones(3), oracle.NormL1(1.0), mu=1.5)
+
+
+def test_oracle_under_address_and_ub_sanitizer():
+    """SURVEY section 5 (race detection / sanitizers): the C restatement, built with -fsanitize=address,undefined
+    (oracle/Makefile), runs a tour of its entry points -- regressors, prox operators, both ADMM forms, windows -- in a
+    subprocess; any heap overflow / UB report fails the run.  (GPU sanitizers are not available on the pool.)"""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+    subprocess.check_call(["make", "-s", "-C", odir, "liblpvs_oracle_asan.so"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from oracle import oracle as o
+        rng = np.random.default_rng(0)
+        t = np.sort(rng.random(300)) * 300; f = np.arange(0, 17) / 40.0
+        y = np.sin(2 * np.pi * f[5] * t) + 0.1 * rng.standard_normal(300)
+        A, zf = o.get_fourier_regressor(t, f)
+        G, b = o.gram(A, y, np.ones(300))
+        for g in (o.NormL1(0.5), o.NormL0(0.5), o.IndBallL0(3), o.GroupL2(0.5, 3)):
+            r1 = o.admm_gram(G, b, g, iters=40, tol=1e-9)
+            r2 = o.admm_ls(A, y, g, iters=40, tol=1e-9)
+            assert np.linalg.norm(r1["z"] - r2["z"]) <= 1e-6 * max(np.linalg.norm(r1["z"]), 1.0)
+        o.admm_quadratic(G, b, o.NormL1(0.5), iters=20)
+        X = np.sort(rng.random(200)) * 10; V = rng.random(200)
+        Phi = o.lpv_regressor(X, V, 2 * np.pi * np.arange(1, 5.0), 3)
+        Phi2 = o.lpv_regressor(X, V, 2 * np.pi * np.arange(1, 5.0), 3, True, True, False)
+        o.ls_sparse_spectral_lpv(y[:200], X, V, 2 * np.pi * np.arange(1, 5.0), 3, lam=2.0, iters=30)
+        W = o.Windows2(np.arange(1.0, 101), np.arange(1.0, 101), 10, 1)
+        assert np.array_equal(o.mapwindows(lambda yt: -yt[0], W), -np.arange(1.0, 101))
+        o.ls_cohere(y, y + 0.1, t, f, nw=3)
+        print("asan tour ok")
+    """ % root)
+    env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
+               LPVS_ORACLE_SO=os.path.join(odir, "liblpvs_oracle_asan.so"), OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "asan tour ok" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-4000:]
