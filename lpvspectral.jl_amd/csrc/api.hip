@@ -530,10 +530,16 @@ int32_t lpvs_lpv_regressor_f64(const double *X, const double *V, int64_t N, cons
 // Slot tables of the structured Gram (nudft.hip) for frequencies w_f = a + f*D + eps_f: exact progressions in
 // double-double, each family padded to a multiple of 8:
 //   [0, nf8): m*D (differences), [nf8, nf8+s8): 2a + s*D (sums); the right-hand side uses a + f*D, f < nf8.
+// MERGED layout: when 2a is (up to rounding) an integer multiple j0 < Nf of D -- default_freqs (a = 0), the README grid
+// w = D*(1..Nf) (a = D) -- the sum frequencies (j0 + s) D are multiples of D like the differences, so ONE progression
+// j*D, j = 0 .. j0+2Nf-2 serves both families: 2Nf-1+j0 slots instead of 3Nf-1 (a third less work); the sum of (f, f') is
+// slot s0 + f + f' with s0 = j0, and the rounding residual delta = 2a - j0*D joins the first-order correction.
 struct ApSlots {
     bool ok = false;
     double emax = 0;
     int64_t nf8 = 0, s8 = 0, nsl = 0;
+    int64_t s0 = 0;        // slot of the sum frequency 2a (split layout: nf8; merged: j0)
+    double delta = 0;      // merged layout: 2a - j0*D
     std::vector<double> eps, om_hi, om_lo, omr_hi, omr_lo;
     ApStep step{};
 };
@@ -565,9 +571,28 @@ static ApSlots make_ap_slots(const std::vector<double> &hw, double xam) {
     if (!sl.ok) return sl;
     sl.nf8 = round_up(Nf, 8); sl.s8 = round_up(2 * Nf - 1, 8); sl.nsl = sl.nf8 + sl.s8;
     auto split = [](long double v, double &hi, double &lo) { hi = (double)v; lo = (double)(v - (long double)hi); };
-    sl.om_hi.resize((size_t)sl.nsl); sl.om_lo.resize((size_t)sl.nsl); sl.omr_hi.resize((size_t)sl.nf8); sl.omr_lo.resize((size_t)sl.nf8);
-    for (int64_t m = 0; m < sl.nf8; ++m) split((long double)m * D, sl.om_hi[m], sl.om_lo[m]);
-    for (int64_t q = 0; q < sl.s8; ++q) split(2.0L * a0 + (long double)q * D, sl.om_hi[sl.nf8 + q], sl.om_lo[sl.nf8 + q]);
+    sl.omr_hi.resize((size_t)sl.nf8); sl.omr_lo.resize((size_t)sl.nf8);
+    sl.s0 = sl.nf8;
+    bool merged = false;
+    static const bool merge_on = [] { const char *e = getenv("LPVS_AP_SLOTS"); return !(e && std::string(e) == "split"); }();
+    if (merge_on && Nf > 1 && D != 0.0L) {
+        const long double j0r = 2.0L * a0 / D;
+        const long long j0 = llroundl(j0r);
+        const long double delta = 2.0L * a0 - (long double)j0 * D;
+        if (j0 >= 0 && j0 < Nf && std::fabs((double)delta) * xam <= 1e-7) {
+            merged = true;
+            sl.s0 = j0; sl.delta = (double)delta;
+            sl.nsl = round_up(j0 + 2 * Nf - 1, 8);
+            sl.s8 = sl.nsl;
+        }
+    }
+    sl.om_hi.resize((size_t)sl.nsl); sl.om_lo.resize((size_t)sl.nsl);
+    if (merged) {
+        for (int64_t j = 0; j < sl.nsl; ++j) split((long double)j * D, sl.om_hi[j], sl.om_lo[j]);
+    } else {
+        for (int64_t m = 0; m < sl.nf8; ++m) split((long double)m * D, sl.om_hi[m], sl.om_lo[m]);
+        for (int64_t q = 0; q < sl.s8; ++q) split(2.0L * a0 + (long double)q * D, sl.om_hi[sl.nf8 + q], sl.om_lo[sl.nf8 + q]);
+    }
     for (int64_t f = 0; f < sl.nf8; ++f) split(a0 + (long double)f * D, sl.omr_hi[f], sl.omr_lo[f]);
     for (int b = 0; b < 8; ++b) split((long double)b * D, sl.step.hi[b], sl.step.lo[b]);
     return sl;
@@ -650,7 +675,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)nf8 * (size_t)nb * 4));
         LPVS_HIP(hipEventRecord(h->ev[1].a, s));
         LPVS_TRY(launch_nudft(dX.p, nullptr, N, KK.as<double>(), P, (int)P, sd.hi.as<double>(), sd.lo.as<double>(), (int)nsl, step, part.as<double>(), tab.as<double>(), s));
-        LPVS_TRY(launch_ap_assemble(tab.as<double>(), sd.eps.as<double>(), Nf, nf8, nb, h->n, h->G.as<double>(), h->np, s));
+        LPVS_TRY(launch_ap_assemble(tab.as<double>(), sd.eps.as<double>(), Nf, sl.s0, sl.delta, nb, h->n, h->G.as<double>(), h->np, s));
         LPVS_HIP(hipEventRecord(h->ev[1].b, s));
         LPVS_HIP(hipEventRecord(h->ev[2].a, s));
         for (int64_t q = 0; q < ns; ++q) {   // b_q = Phi' y_q: Nf slots a + f*D, weights y K_j, first-order eps correction
@@ -804,7 +829,7 @@ int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_
             const double *Wd = W ? dW.p : nullptr;               // A' diag(W) A and A' (W .* y), src/lasso.jl:119-120
             LPVS_HIP(hipEventRecord(h->ev[1].a, s));
             LPVS_TRY(launch_nudft(dt.p, nullptr, N, Wd, 1, 1, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, part.as<double>(), tab.as<double>(), s));
-            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.nf8, (int)zf, h->n, h->G.as<double>(), h->np, 1, 0, 0, s));
+            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.s0, sl.delta, (int)zf, h->n, h->G.as<double>(), h->np, 1, 0, 0, s));
             LPVS_HIP(hipEventRecord(h->ev[1].b, s));
             LPVS_HIP(hipEventRecord(h->ev[2].a, s));
             LPVS_TRY(launch_nudft(dt.p, dy.p, N, Wd, 1, 1, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, part.as<double>(), tabb.as<double>(), s));
@@ -1398,7 +1423,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
             LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
             LPVS_TRY(launch_nudft_windows(dt.p, nullptr, Wdev, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, seg.as<int64_t>(), nb_, spw,
                                           npart.as<double>(), tab.as<double>(), s));
-            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.nf8, (int)zf, nreg, G, np, nb_, sl.nsl * 4,
+            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.s0, sl.delta, (int)zf, nreg, G, np, nb_, sl.nsl * 4,
                                                 np * np, s));                                       // Q = A'WA   src/lasso.jl:119
             tr.mark("gram (structured)");
             for (int64_t q = 0; q < ns; ++q) {   // q_s = A'W y_s for every signal sharing the window   :120

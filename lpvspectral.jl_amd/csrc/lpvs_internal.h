@@ -130,12 +130,13 @@ int32_t launch_nudft(const double *x, const double *y, int64_t N, const double *
 int32_t launch_nudft_windows(const double *x, const double *y, const double *Wt, const double *om_hi, const double *om_lo, int nslots,
                              const ApStep &step, const int64_t *seg_dev, int nwin, int segs_per_window, double *partial, double *tab,
                              hipStream_t s);
-int32_t launch_ap_assemble_fourier(const double *tab, const double *eps, int64_t Nf, int64_t s0, int zf, int64_t n, double *G, int64_t ldg,
-                                   int nbatch, int64_t tab_stride, int64_t g_stride, hipStream_t s);
+// s0 = slot of the sum frequency 2a (sum of (f, f') = slot s0 + f + f'), delta = residual of 2a against that slot
+int32_t launch_ap_assemble_fourier(const double *tab, const double *eps, int64_t Nf, int64_t s0, double delta, int zf, int64_t n, double *G,
+                                   int64_t ldg, int nbatch, int64_t tab_stride, int64_t g_stride, hipStream_t s);
 int32_t launch_ap_rhs_fourier(const double *tab, const double *eps, int64_t Nf, int zf, double *b, int nbatch, int64_t tab_stride,
                               int64_t b_stride, hipStream_t s);
-int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t s0, int64_t nb, int64_t n, double *G, int64_t ldg,
-                           hipStream_t s);
+int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t s0, double delta, int64_t nb, int64_t n, double *G,
+                           int64_t ldg, hipStream_t s);
 int32_t launch_ap_rhs(const double *tab, const double *eps, int64_t Nf, int64_t nb, double *b, hipStream_t s);
 
 // ---- dense symmetric inverse (linalg.hip) ------------------------------------------------

@@ -263,7 +263,7 @@ nudft_reduce_kernel(const double *__restrict__ part_all, int nchunks, int64_t co
 // k = a - Nf + zf (zf = 1 when the zero frequency is present and has no sine column), dd = 1/sqrt(2 Nf).
 // One activation "pair" (weight W_n or 1).  blockIdx.z = problem of a batch.
 __global__ void __launch_bounds__(256)
-ap_assemble_fourier_kernel(const double *__restrict__ tab_all, const double *__restrict__ eps, int Nf, int s0, int zf, double scale,
+ap_assemble_fourier_kernel(const double *__restrict__ tab_all, const double *__restrict__ eps, int Nf, int s0, double delta, int zf, double scale,
                            int64_t n, double *__restrict__ G_all, int64_t ldg, int64_t tab_stride, int64_t g_stride) {
     const int64_t ga = blockIdx.y;
     const int64_t gb = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -273,7 +273,7 @@ ap_assemble_fourier_kernel(const double *__restrict__ tab_all, const double *__r
     const int ca = ga >= Nf, cb = gb >= Nf;
     const int ka = ca ? (int)ga - Nf + zf : (int)ga, kb = cb ? (int)gb - Nf + zf : (int)gb;
     const int hi = ka >= kb ? ka : kb, lo = ka >= kb ? kb : ka;
-    const double dm = eps[hi] - eps[lo], dp = eps[ka] + eps[kb];
+    const double dm = eps[hi] - eps[lo], dp = (eps[ka] + eps[kb]) + delta;
     const double *tm = tab + (int64_t)(hi - lo) * 4;
     const double *tp = tab + (int64_t)(s0 + ka + kb) * 4;
     const double cm = fma(-dm, tm[3], tm[0]);
@@ -305,7 +305,7 @@ ap_rhs_fourier_kernel(const double *__restrict__ tab_all, const double *__restri
 // G[a][b] = G[b][a], a >= b, from the slot tables tab[slot][q][4]; slots 0..Nf-1 are the differences m = f-f',
 // slots s0..s0+2Nf-2 the sums s = f+f' (s0 = Nf rounded up to a multiple of 8).
 __global__ void __launch_bounds__(256)
-ap_assemble_kernel(const double *__restrict__ tab, const double *__restrict__ eps, int Nf, int s0, int nb, int P, int64_t n,
+ap_assemble_kernel(const double *__restrict__ tab, const double *__restrict__ eps, int Nf, int s0, double delta, int nb, int P, int64_t n,
                    double *__restrict__ G, int64_t ldg) {
     const int64_t ga = blockIdx.y;
     const int64_t gb = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -317,7 +317,7 @@ ap_assemble_kernel(const double *__restrict__ tab, const double *__restrict__ ep
     if (ja > jb) { const int t = ja; ja = jb; jb = t; }
     const int q = ja * nb - ja * (ja - 1) / 2 + (jb - ja);
     const int m = fa - fb, s = fa + fb;                     // fa >= fb because a >= b
-    const double dm = eps[fa] - eps[fb], dp = eps[fa] + eps[fb];
+    const double dm = eps[fa] - eps[fb], dp = (eps[fa] + eps[fb]) + delta;
     const double *tm = tab + ((int64_t)m * P + q) * 4;
     const double *tp = tab + ((int64_t)(s0 + s) * P + q) * 4;
     const double cm = fma(-dm, tm[3], tm[0]), sm = fma(dm, tm[2], tm[1]);   // first order in the residuals
@@ -402,10 +402,10 @@ int32_t launch_nudft_windows(const double *x, const double *y, const double *Wt,
     return nudft_impl(x, y, 0, Wt, 1, 1, om_hi, om_lo, nslots, step, partial, tab, seg_dev, (unsigned)(nwin * segs_per_window), (unsigned)nwin, s);
 }
 
-int32_t launch_ap_assemble_fourier(const double *tab, const double *eps, int64_t Nf, int64_t s0, int zf, int64_t n, double *G, int64_t ldg,
-                                   int nbatch, int64_t tab_stride, int64_t g_stride, hipStream_t s) {
+int32_t launch_ap_assemble_fourier(const double *tab, const double *eps, int64_t Nf, int64_t s0, double delta, int zf, int64_t n, double *G,
+                                   int64_t ldg, int nbatch, int64_t tab_stride, int64_t g_stride, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(n, 256), (unsigned)n, (unsigned)nbatch);
-    hipLaunchKernelGGL(ap_assemble_fourier_kernel, grid, dim3(256), 0, s, tab, eps, (int)Nf, (int)s0, zf, 1.0 / (double)(2 * Nf), n, G, ldg,
+    hipLaunchKernelGGL(ap_assemble_fourier_kernel, grid, dim3(256), 0, s, tab, eps, (int)Nf, (int)s0, delta, zf, 1.0 / (double)(2 * Nf), n, G, ldg,
                        tab_stride, g_stride);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
@@ -419,11 +419,11 @@ int32_t launch_ap_rhs_fourier(const double *tab, const double *eps, int64_t Nf, 
     return LPVS_OK;
 }
 
-int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t s0, int64_t nb, int64_t n, double *G, int64_t ldg,
-                           hipStream_t s) {
+int32_t launch_ap_assemble(const double *tab, const double *eps, int64_t Nf, int64_t s0, double delta, int64_t nb, int64_t n, double *G,
+                           int64_t ldg, hipStream_t s) {
     const int P = (int)(nb * (nb + 1) / 2);
     dim3 grid((unsigned)ceil_div(n, 256), (unsigned)n);
-    hipLaunchKernelGGL(ap_assemble_kernel, grid, dim3(256), 0, s, tab, eps, (int)Nf, (int)s0, (int)nb, P, n, G, ldg);
+    hipLaunchKernelGGL(ap_assemble_kernel, grid, dim3(256), 0, s, tab, eps, (int)Nf, (int)s0, delta, (int)nb, P, n, G, ldg);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
