@@ -278,13 +278,15 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         return None
     tm["matvec_us_per_iteration"] = tm_mv.get("matvec_us_per_iteration")
     tm["matvec_windows"] = tm_mv.get("matvec_windows")
-    np_, ntile_bytes = 512, 8 * (512 * (512 + 128) // 2)
+    elt = 8 if os.environ.get("LPVS_M_STORAGE") == "f64" else 6      # bytes per stored element of the packed inverses (admm.hip)
+    np_, ntile_bytes = 512, elt * (512 * (512 + 128) // 2)
     mv_us = tm.get("matvec_us_per_iteration")
     roof = None
     if mv_us:
         nmv = tm.get("matvec_windows") or (hi - lo)
         achieved = nmv * ntile_bytes / (mv_us * 1e-6) * 1e-9
-        roof = {"bound": "hbm", "kernel": "symv_tile_batch_kernel (one tile-packed (Q + I/mu)^-1 per window, all windows of the shard per launch)",
+        roof = {"bound": "hbm", "kernel": ("symv_tile_split_batch_kernel" if elt == 6 else "symv_tile_batch_kernel") +
+                          " (one tile-packed (Q + I/mu)^-1 per window in %d-byte elements, all windows of the shard per launch)" % elt,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": nmv * ntile_bytes, "launch_us": mv_us, "windows_per_launch": nmv, "launches_per_step": iters,
                 "note": "HIP events around 200 back-to-back launches of the batch mat-vec on the library's stream (rank 0's shard)"}

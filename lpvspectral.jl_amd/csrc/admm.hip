@@ -588,6 +588,8 @@ __global__ void __launch_bounds__(256)
 pack_tiles_split_kernel(const double *__restrict__ M, int64_t np, unsigned char *__restrict__ Mp) {
     int I, J;
     tile_index(blockIdx.x, I, J);
+    M += (int64_t)blockIdx.y * np * np;                                  // blockIdx.y = problem of a batch
+    Mp += (size_t)blockIdx.y * gridDim.x * kSplitTileBytes;
     const double *src = M + (int64_t)I * TS * np + (int64_t)J * TS;
     float *head = reinterpret_cast<float *>(Mp + (size_t)blockIdx.x * kSplitTileBytes);
     unsigned short *tail = reinterpret_cast<unsigned short *>(Mp + (size_t)blockIdx.x * kSplitTileBytes + (size_t)TS * TS * 4);
@@ -604,30 +606,26 @@ pack_tiles_split_kernel(const double *__restrict__ M, int64_t np, unsigned char 
     }
 }
 
-__global__ void __launch_bounds__(256, 2)
-symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs, int64_t np, int ntiles,
-                       double *__restrict__ part1, double *__restrict__ part2, const AdmmStatus *status) {
-    if (status != nullptr && status[0].converged) return;
-    __shared__ double sI[TS], sJ[TS], sT[4][TS];
-    const int t = blockIdx.x;
-    int I, J;
-    tile_index(t, I, J);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const unsigned char *tile = Mp + (size_t)t * kSplitTileBytes;
+// raw registers of one lane's share of a split tile (8 row groups: two float4 heads, one uint4 of tails)
+struct SplitRaw { float4 ha[8], hb[8]; uint4 lq[8]; };
+
+__device__ __forceinline__ void split_load(const unsigned char *tile, int wave, int g, int c, SplitRaw &w) {
     const float *head = reinterpret_cast<const float *>(tile) + (wave * 32 + g) * TS + 4 * c;
     const unsigned short *tail = reinterpret_cast<const unsigned short *>(tile + (size_t)TS * TS * 4) + (wave * 32 + g) * TS + 8 * c;
-    float4 ha[8], hb[8];
-    uint4 lq[8];
 #pragma unroll
     for (int rg = 0; rg < 8; ++rg) {
-        ha[rg] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
-        hb[rg] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
-        lq[rg] = *reinterpret_cast<const uint4 *>(tail + rg * 4 * TS);
+        w.ha[rg] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
+        w.hb[rg] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
+        w.lq[rg] = *reinterpret_cast<const uint4 *>(tail + rg * 4 * TS);
     }
-    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
-    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
-    __syncthreads();
+}
+
+// one right-hand side against the tile held in `w`: sI / sJ hold the right-hand side's blocks I and J (already visible),
+// part1 / part2 point at this tile's 128 partials; sT is scratch.  All 256 threads of the workgroup call it.
+__device__ __forceinline__ void split_tile_product(const SplitRaw &w, const double *sI, const double *sJ, double (*sT)[TS], bool offdiag,
+                                                   double *__restrict__ part1, double *__restrict__ part2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
     double rj[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
@@ -637,9 +635,9 @@ symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__res
 #pragma unroll
     for (int rg = 0; rg < 8; ++rg) {
         const double ri = sI[wave * 32 + 4 * rg + g];
-        const float hh[8] = {ha[rg].x, ha[rg].y, ha[rg].z, ha[rg].w, hb[rg].x, hb[rg].y, hb[rg].z, hb[rg].w};
-        const unsigned int qq[8] = {lq[rg].x & 0xffffu, lq[rg].x >> 16, lq[rg].y & 0xffffu, lq[rg].y >> 16,
-                                    lq[rg].z & 0xffffu, lq[rg].z >> 16, lq[rg].w & 0xffffu, lq[rg].w >> 16};
+        const float hh[8] = {w.ha[rg].x, w.ha[rg].y, w.ha[rg].z, w.ha[rg].w, w.hb[rg].x, w.hb[rg].y, w.hb[rg].z, w.hb[rg].w};
+        const unsigned int qq[8] = {w.lq[rg].x & 0xffffu, w.lq[rg].x >> 16, w.lq[rg].y & 0xffffu, w.lq[rg].y >> 16,
+                                    w.lq[rg].z & 0xffffu, w.lq[rg].z >> 16, w.lq[rg].w & 0xffffu, w.lq[rg].w >> 16};
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
@@ -665,9 +663,9 @@ symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__res
     v[0] += __shfl_xor(v[0], 1, 64);
     if ((c & 1) == 0) {
         const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
-        part1[(int64_t)t * TS + wave * 32 + 4 * rg + g] = v[0];
+        part1[wave * 32 + 4 * rg + g] = v[0];
     }
-    if (I != J) {
+    if (offdiag) {
         // column sums: over the wave's four row lanes g (masks 32, 16), then over the four waves through LDS
 #pragma unroll
         for (int m = 32, cnt = 4; m >= 16; m >>= 1, cnt >>= 1) {
@@ -682,7 +680,53 @@ symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__res
         sT[wave][col] = tc[0]; sT[wave][col + 1] = tc[1];
         __syncthreads();
         if (threadIdx.x < TS)
-            part2[(int64_t)t * TS + threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+            part2[threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs, int64_t np, int ntiles,
+                       double *__restrict__ part1, double *__restrict__ part2, const AdmmStatus *status) {
+    if (status != nullptr && status[0].converged) return;
+    __shared__ double sI[TS], sJ[TS], sT[4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    SplitRaw w;
+    split_load(Mp + (size_t)t * kSplitTileBytes, wave, lane >> 4, lane & 15, w);
+    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+    __syncthreads();
+    split_tile_product(w, sI, sJ, sT, I != J, part1 + (int64_t)t * TS, part2 + (int64_t)t * TS);
+}
+
+// the same for a batch of problems that each own their matrix (windows): blockIdx.y = matrix, serving nrhs right-hand sides
+__global__ void __launch_bounds__(256, 2)
+symv_tile_split_batch_kernel(const unsigned char *__restrict__ Mp_all, size_t mp_stride, const double *__restrict__ rhs_all, int64_t np,
+                             int ntiles, int nrhs, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    const int mat = blockIdx.y;
+    {
+        bool all = status != nullptr;
+        for (int r = 0; r < nrhs && all; ++r) all = status[mat * nrhs + r].converged != 0;
+        if (all) return;
+    }
+    __shared__ double sI[TS], sJ[TS], sT[4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    SplitRaw w;
+    split_load(Mp_all + (size_t)mat * mp_stride + (size_t)t * kSplitTileBytes, wave, lane >> 4, lane & 15, w);
+    for (int rr = 0; rr < nrhs; ++rr) {
+        const int sg = mat * nrhs + rr;
+        if (status != nullptr && status[sg].converged) continue;   // uniform
+        const double *rhs = rhs_all + (int64_t)sg * np;
+        if (rr > 0) __syncthreads();   // previous right-hand side's readers are done with sI / sJ / sT
+        if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+        else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+        __syncthreads();
+        split_tile_product(w, sI, sJ, sT, I != J, part1_all + ((int64_t)sg * ntiles + t) * TS, part2_all + ((int64_t)sg * ntiles + t) * TS);
     }
 }
 
@@ -1021,8 +1065,10 @@ admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1_all, con
     const int I = blockIdx.x, i = threadIdx.x & 127;
     const int64_t li_ = (int64_t)I * TS + i, gi = (int64_t)sg * p.np + li_;
     const bool row = threadIdx.x < TS, ok = row && li_ < p.n;
-    const double ui = ok ? p.u[gi] : 0.0, bi = ok ? p.b[gi] : 0.0;   // in flight together with the partials
-    const double xi = gather_x4(part1, part2, nblk, I, sh);
+    const bool offset_form = p.xb != nullptr;
+    const double ui = ok ? p.u[gi] : 0.0, bi = ok ? (offset_form ? p.xb[gi] : p.b[gi]) : 0.0;   // in flight together with the partials
+    double xi = gather_x4(part1, part2, nblk, I, sh);
+    if (offset_form) xi += bi;                                   // (bi holds xb here)
     const double v = xi + ui;
     double zi = 0.0, d2 = 0.0;
     if (p.prox_kind == LPVS_PROX_L1) {
@@ -1048,7 +1094,7 @@ admm_fused_update_kernel(AdmmParams p, const double *__restrict__ part1_all, con
         if (!ok) zi = 0.0;
         const double d = xi - zi, un = ui + d;     // src/lasso.jl:154-155
         p.x[gi] = xi; p.z[gi] = zi; p.u[gi] = un;
-        p.rhs[gi] = ok ? bi + (zi - un) / p.mu : 0.0;
+        p.rhs[gi] = ok ? (offset_form ? (zi - un) / p.mu : bi + (zi - un) / p.mu) : 0.0;
         d2 = ok ? d * d : 0.0;
     }
     // block sum of d2: the two row waves reduce by shuffles (fixed pattern -> reproducible)
@@ -1233,6 +1279,8 @@ admm_window_update_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     double xi = a[0];
 #pragma unroll
     for (int e = 1; e < 8; ++e) xi += a[e];                    // fixed order: tile column 0, 1, ...
+    const bool offset_form = p.xb != nullptr;                  // x = xb + M~ (z-u)/mu (reduced-precision copy of M, see the split kernel)
+    if (offset_form) xi += ok ? p.xb[gi] : 0.0;
     const double v = xi + ui;
     double zi = 0.0;
     if (p.prox_kind == LPVS_PROX_L1) {
@@ -1257,7 +1305,7 @@ admm_window_update_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     if (!ok) zi = 0.0;
     const double d = xi - zi, un = ui + d;                       // src/lasso.jl:154-155
     p.x[gi] = xi; p.z[gi] = zi; p.u[gi] = un;
-    p.rhs[gi] = ok ? bi + (zi - un) / p.mu : 0.0;
+    p.rhs[gi] = ok ? (offset_form ? (zi - un) / p.mu : bi + (zi - un) / p.mu) : 0.0;
     const double w = wave_sum(ok ? d * d : 0.0);
     if ((threadIdx.x & 63) == 0) wsum_s[threadIdx.x >> 6] = w;
     __syncthreads();
@@ -1279,7 +1327,7 @@ admm_batch_init_kernel(AdmmBatch p) {
     if (i < p.np) {
         const int64_t o = (int64_t)q * p.np + i;
         p.x[o] = 0.0; p.z[o] = 0.0; p.u[o] = 0.0;
-        p.rhs[o] = i < p.n ? p.b[o] : 0.0;         // b + (z-u)/mu with z = u = 0
+        p.rhs[o] = (i < p.n && p.xb == nullptr) ? p.b[o] : 0.0;   // b + (z-u)/mu with z = u = 0 (offset form: (z-u)/mu alone)
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { p.status[q].iters = 0; p.status[q].converged = 0; p.status[q].nxz = 0.0; }
 }
@@ -1381,6 +1429,7 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
     // prox can be fused; AdmmParams with ns = nbatch has the layout the fused update kernel expects
     AdmmParams q{p.M, p.np, p.n, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len, p.status,
                  nullptr, p.part, p.Mp, p.nbatch};
+    q.xb = p.xb;
     if (p.Mp != nullptr && p.part != nullptr && fused_ok(q)) {
         const int nblk = (int)(p.np / TS);
         const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), ns = (unsigned)p.nbatch;
@@ -1389,8 +1438,12 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
         unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
         const int nrhs = p.nrhs > 0 ? p.nrhs : 1;
         for (int64_t i = 0; i < iters; ++i) {
-            hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
-                               (int)ntiles, nrhs, part1, part2, p.status);
+            if (p.mp_split)
+                hipLaunchKernelGGL(symv_tile_split_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp),
+                                   (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, nrhs, part1, part2, p.status);
+            else
+                hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
+                                   (int)ntiles, nrhs, part1, part2, p.status);
             if (nblk <= 8)
                 hipLaunchKernelGGL(admm_window_update_kernel, dim3(ns), dim3((unsigned)(TS * nblk)), 0, s, q, part1, part2, nblk, (int)ntiles);
             else
@@ -1413,9 +1466,14 @@ int32_t launch_admm_batch_matvec_only(const AdmmBatch &p, int reps, hipStream_t 
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), ns = (unsigned)p.nbatch;
     const int nrhs = p.nrhs > 0 ? p.nrhs : 1;
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
-    for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
-                           (int)ntiles, nrhs, part1, part2, (const AdmmStatus *)nullptr);
+    for (int i = 0; i < reps; ++i) {
+        if (p.mp_split)
+            hipLaunchKernelGGL(symv_tile_split_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp),
+                               (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, nrhs, part1, part2, (const AdmmStatus *)nullptr);
+        else
+            hipLaunchKernelGGL(symv_tile_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, p.Mp, (int64_t)ntiles * TS * TS, p.rhs, p.np,
+                               (int)ntiles, nrhs, part1, part2, (const AdmmStatus *)nullptr);
+    }
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -1503,6 +1561,25 @@ int32_t launch_cvt_f32_f64(const float *src, double *dst, int64_t count, hipStre
 int32_t launch_cvt_f64_f32(const double *src, float *dst, int64_t count, hipStream_t s) {
     if (count <= 0) return LPVS_OK;
     hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, src, dst, count);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+bool admm_batch_uses_tiles(const AdmmBatch &p) {
+    AdmmParams q{p.M, p.np, p.n, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len, p.status,
+                 nullptr, p.part, p.Mp, p.nbatch};
+    return fused_ok(q);
+}
+
+int32_t launch_batch_matvec(const double *A, int64_t np, int nprob, int nrhs, const double *v, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(batch_matvec_kernel, dim3((unsigned)ceil_div(np, 4), (unsigned)nprob), dim3(256), 0, s, A, np, nrhs, v, out);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+int32_t launch_pack_tiles_split_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, hipStream_t s) {
+    const int nblk = (int)(np / TS);
+    hipLaunchKernelGGL(pack_tiles_split_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2), (unsigned)nbatch), dim3(256), 0, s, M, np, Mp);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

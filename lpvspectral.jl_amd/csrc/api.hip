@@ -1365,7 +1365,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         Wdev = Wp.as<double>();
     }
     PhaseTrace tr(s);
-    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb;
+    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, xb, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb;
     ApSlotsDev sd;
     DrainOnExit drain(s);
     const int64_t nprob_max = bw * ns;
@@ -1389,6 +1389,8 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     }
     const size_t vb = sizeof(double) * (size_t)np * (size_t)nprob_max;
     LPVS_TRY(bvec.alloc(vb)); LPVS_TRY(x.alloc(vb)); LPVS_TRY(z.alloc(vb)); LPVS_TRY(u.alloc(vb)); LPVS_TRY(rhs.alloc(vb));
+    const bool split_storage = sparse && [] { const char *e = getenv("LPVS_M_STORAGE"); return !(e && std::string(e) == "f64"); }();
+    if (split_storage) LPVS_TRY(xb.alloc(vb));
     LPVS_TRY(istat.alloc(sizeof(int) * (size_t)bw));
     LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)bw));
     LPVS_TRY(offs.alloc(sizeof(int64_t) * (size_t)bw));
@@ -1464,11 +1466,20 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         tr.mark("inverse");
         const double *sol = nullptr;
         if (sparse) {
-            LPVS_TRY(launch_pack_tiles_batch(M.as<double>(), np, nb_, Mp.as<double>(), s));
-            LPVS_HIP(hipEventRecord(ev[1].b, s));
-            LPVS_HIP(hipMemsetAsync(part.p, 0, part.bytes, s));   // tickets / block norms
             AdmmBatch ab{M.as<double>(), np, nreg, nprob, bvec.as<double>(), x.as<double>(), z.as<double>(), u.as<double>(), rhs.as<double>(),
                          mu, tol, a.prox_kind, a.prox_param, a.group_len, status.as<AdmmStatus>(), part.as<double>(), Mp.as<double>(), (int)ns};
+            // 6-byte storage of the packed inverses + offset form of the x-update, as for the single problems (admm.hip); only
+            // where the tile-packed path runs at all (LPVS_M_STORAGE=f64: doubles)
+            const bool split = split_storage && admm_batch_uses_tiles(ab);
+            if (split) {
+                LPVS_TRY(launch_pack_tiles_split_batch(M.as<double>(), np, nb_, Mp.as<unsigned char>(), s));
+                LPVS_TRY(launch_batch_matvec(M.as<double>(), np, nprob, (int)ns, bvec.as<double>(), xb.as<double>(), s));   // xb = M b, full precision
+                ab.xb = xb.as<double>(); ab.mp_split = 1;
+            } else {
+                LPVS_TRY(launch_pack_tiles_batch(M.as<double>(), np, nb_, Mp.as<double>(), s));
+            }
+            LPVS_HIP(hipEventRecord(ev[1].b, s));
+            LPVS_HIP(hipMemsetAsync(part.p, 0, part.bytes, s));   // tickets / block norms
             LPVS_HIP(hipEventRecord(ev[2].a, s));
             LPVS_TRY(launch_admm_batch_init(ab, s));
             for (int64_t done = 0; done < a.iters;) {   // chunks: stop early once every problem of the batch has converged

@@ -211,7 +211,12 @@ struct AdmmBatch {
     double *part;         // symv_part_doubles(np, nbatch) doubles, zeroed before the first iteration (or nullptr)
     const double *Mp;     // [nbatch / nrhs] tile-packed lower triangles (or nullptr: plain mat-vec)
     int nrhs = 1;         // problems per matrix: problem q uses matrix q / nrhs (signals sharing a window's Gram)
+    const double *xb = nullptr;   // offset form: x = xb + M~ (z-u)/mu, xb = M b per problem ([nbatch][np]); nullptr: classic
+    int mp_split = 0;     // Mp holds 6-byte elements (float head + 16-bit tail)
 };
+bool admm_batch_uses_tiles(const AdmmBatch &p);   // will launch_admm_batch_iterations take the tile-packed path for this batch?
+int32_t launch_batch_matvec(const double *A, int64_t np, int nprob, int nrhs, const double *v, double *out, hipStream_t s);   // out_q = A[q / nrhs] v_q
+int32_t launch_pack_tiles_split_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, hipStream_t s);
 int32_t launch_admm_batch_matvec_only(const AdmmBatch &p, int reps, hipStream_t s);
 int32_t launch_batch_ridge_solve(const double *Q, const double *M, int64_t np, int64_t n, int nprob, int nrhs, const double *b, double ridge,
                                  int steps, double *x, double *t1, double *t2, hipStream_t s);

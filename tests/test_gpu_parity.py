@@ -360,21 +360,28 @@ def test_windowpsd_batched_equals_sequential_and_oracle(L, oracle, noverlap, zer
     W = L.hanning(n)
     kw = dict(λ=0.5, μ=0.05, tol=1e-9, iters=3000)
     xb, Sb, its = L.windowpsd_sparse_batched(y, t, f, n, noverlap, W, **kw)
+    os.environ["LPVS_M_STORAGE"] = "f64"
+    try:
+        xb8, Sb8, its8 = L.windowpsd_sparse_batched(y, t, f, n, noverlap, W, **kw)
+    finally:
+        del os.environ["LPVS_M_STORAGE"]
+    assert np.array_equal(its8, its)
     k = len(L.Windows2(y, t, n, noverlap))
     assert xb.shape == (k, len(f)) and its.shape == (k,)
     S_seq = np.zeros(len(f))
     for i, (yi, ti) in enumerate(L.Windows2(y, t, n, noverlap)):
         xs, _ = L.ls_sparse_spectral(yi, ti, f, W, printerval=100000, **kw)       # sequential device path
         xo, _, ro = oracle.ls_sparse_spectral(yi, ti, f, W, lam=0.5, mu=0.05, tol=1e-9, iters=3000)
-        assert rel(xb[i], xs) <= 1e-12 and rel(xb[i], xo) <= 1e-6
+        assert rel(xb[i], xs) <= 1e-9 and rel(xb[i], xo) <= 1e-6    # batch: 6-byte copy of the inverse (offset form); handle path: doubles
+        assert rel(xb8[i], xs) <= 1e-12                             # with doubles in the batch too only the summation order differs
         assert its[i] == ro["iters"] and np.array_equal(xb[i] != 0, xo != 0)
         S_seq += np.abs(xs) ** 2
-    assert rel(Sb, S_seq) <= 1e-12
+    assert rel(Sb, S_seq) <= 1e-9 and rel(Sb8, S_seq) <= 1e-12
     # the drop-in driver uses the batch and divides by k^2 (src/lsfft.jl:125)
     S1, _ = L.ls_windowpsd(y, t, f, nw=Lh // n, noverlap=noverlap, window_func=L.hanning, estimator=L.ls_sparse_spectral, **kw)
     S2, _ = L.ls_windowpsd(y, t, f, nw=Lh // n, noverlap=noverlap, window_func=L.hanning, estimator=L.ls_sparse_spectral, batched=False,
                            printerval=100000, **kw)
-    assert rel(S1, Sb / k ** 2) <= 1e-14 and rel(S1, S2) <= 1e-12
+    assert rel(S1, Sb / k ** 2) <= 1e-14 and rel(S1, S2) <= 1e-9
     # sharding: two disjoint window ranges reproduce the whole, bit for bit
     xa, Sa, _ = L.windowpsd_sparse_batched(y, t, f, n, noverlap, W, win_lo=0, win_hi=k // 2, **kw)
     xc, Sc, _ = L.windowpsd_sparse_batched(y, t, f, n, noverlap, W, win_lo=k // 2, win_hi=k, **kw)

@@ -78,7 +78,7 @@ def test_csd_cohere_sparse_estimator_vs_oracle(L, oracle, noverlap, zero):
     assert ok.sum() >= 1 and rel(c[ok], co[ok]) <= 1e-6
     # sequential device path (the reference's loop calling the 4-argument estimator twice per window)
     Sseq, _ = L.ls_windowcsd(y, u, t, f, window_func=L.hanning, estimator=L.ls_sparse_spectral, batched=False, printerval=100000, **est, **kw)
-    assert rel(S, Sseq) <= 1e-12
+    assert rel(S, Sseq) <= 1e-9                                 # engine: 6-byte copy of the inverses; handles of this size: doubles
 
 
 def test_engine_shared_gram_equals_separate_runs_and_shards(L):
@@ -116,13 +116,17 @@ def test_engine_shared_gram_equals_separate_runs_and_shards(L):
     assert tm["windows"] == k - 4 and tm["passes"] >= 1
 
 
-def test_engine_sparse_matches_single_window_handles(L):
+def test_engine_sparse_matches_single_window_handles(L, monkeypatch):
     """One window of the sparse engine (two right-hand sides) against the single-problem handle path with the same
     Quadratic(Q, +q) convention: identical stopping iteration, coefficients to summation order."""
     y, u, t, f = two_signals(3000, 3, True)
     n, W = 1000, L.hanning(1000)
     eng = dict(estimator=1, lam=0.0, prox=(1, 0.5, 0), μ=0.05, tol=1e-9, iters=3000, sign=-1)
     x, its = L.windows_estimate([y, u], t, f, n, 0, W, eng)
+    monkeypatch.setenv("LPVS_M_STORAGE", "f64")                      # doubles in the engine too: only the summation order differs
+    x8, its8 = L.windows_estimate([y, u], t, f, n, 0, W, eng)
+    monkeypatch.delenv("LPVS_M_STORAGE")
+    assert np.array_equal(its8, its)
     for q, sig in enumerate((y, u)):
         for i in range(3):
             with L.Problem.fourier(sig[i * n:(i + 1) * n], t[i * n:(i + 1) * n], f, W) as p:
@@ -131,7 +135,7 @@ def test_engine_sparse_matches_single_window_handles(L):
                 it, _, conv = p.admm_run(3000)
                 xi = p.params(0)
             assert conv and it == its[q, i]
-            assert rel(x[q, i], xi) <= 1e-12
+            assert rel(x[q, i], xi) <= 1e-9 and rel(x8[q, i], xi) <= 1e-12
 
 
 def test_multi_device_driver_shards_reproduce_single_device(L, monkeypatch):
