@@ -83,6 +83,9 @@ SIGNATURES = {
     "lpvs_lpv_regressor_f32": (_I32, [_P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P]),
     "lpvs_problem_create_fourier_f32": (_I32, [_P, _P, _I64, _P, _I64, _P, _I32, C.POINTER(_P)]),
     "lpvs_problem_create_lpv_f32": (_I32, [_P, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.POINTER(_P)]),
+    "lpvs_problem_create_lpv_multi_f32": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.POINTER(_P)]),
+    "lpvs_windows_estimate_f32": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
+                                          _I64, _I64, _I32, _P, _P, _P]),
     "lpvs_admm_init_f32": (_I32, [_P, _P, _F64, _F64, _I32]),
     "lpvs_admm_get_f32": (_I32, [_P, _P, _P, _P]),
     "lpvs_problem_get_params_f32": (_I32, [_P, _I32, _P, _P]),

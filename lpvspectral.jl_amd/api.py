@@ -213,6 +213,19 @@ class Problem:
     @classmethod
     def lpv_multi(cls, Y, X, V, w, Nv, normalize=True, coulomb=False, device=0):
         """``Y`` is N x ns (one column per signal / channel) sharing ``X, V, w``: one Gram, ns right-hand sides."""
+        if is_f32(Y) and not _lib.is_device_array(Y):            # Float32 records: the _f32 entry point (float I/O, double arithmetic)
+            Yh = np.asfortranarray(np.asarray(Y, dtype=np.float32))
+            N, ns = Yh.shape
+            kx, px, Nx = as_f32(np.asarray(X, dtype=np.float32))
+            kv, pv, Nvv = as_f32(np.asarray(V, dtype=np.float32))
+            kw, pw, Nf = as_f32(np.asarray(w, dtype=np.float32))
+            assert N == Nx == Nvv, "Y, X and V has to have the same number of samples"
+            h = C.c_void_p()
+            check(lib().lpvs_problem_create_lpv_multi_f32(out_ptr(Yh), int(ns), px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)),
+                                                          int(device), C.byref(h)))
+            p = cls(h, "lpv")
+            p.Nf, p.nb, p.ns, p.f32 = Nf, (2 * Nv if coulomb else Nv), int(ns), True
+            return p
         if _lib.is_device_array(Y):
             assert Y.dim() == 2
             ns, N = Y.shape[1], Y.shape[0]
@@ -726,6 +739,23 @@ def _engine_args(estimator, kwargs, nreg):
 def windows_estimate(Y, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None, device=0):
     """The batched-window engine (``lpvs_windows_estimate_f64``): ``Y`` is a list of signals sharing ``t``; returns
     ``x[ns][nwin][Nf]`` complex and the iteration counts ``[ns][nwin]``."""
+    if all(is_f32(y) and not _lib.is_device_array(y) for y in Y):      # Float32 records: lpvs_windows_estimate_f32
+        keep = np.ascontiguousarray(np.stack([np.asarray(y, dtype=np.float32) for y in Y]))
+        ns, Ly = keep.shape
+        th = np.ascontiguousarray(np.asarray(_host(t), dtype=np.float32)); fh = np.ascontiguousarray(np.asarray(_host(freqs), dtype=np.float32))
+        Wh = None if W is None else np.ascontiguousarray(np.asarray(_host(W), dtype=np.float32))
+        assert Ly == len(th), "y and t has to be the same length"
+        k = C.c_int64(0)
+        check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
+        win_hi = int(k.value) if win_hi is None else int(win_hi)
+        nwin, Nf = win_hi - int(win_lo), len(fh)
+        xre, xim = np.zeros((ns, max(nwin, 1), Nf), dtype=np.float32), np.zeros((ns, max(nwin, 1), Nf), dtype=np.float32)
+        its = np.zeros((ns, max(nwin, 1)), dtype=np.int64)
+        kind, param, glen = eng["prox"]
+        check(lib().lpvs_windows_estimate_f32(out_ptr(keep), ns, out_ptr(th), Ly, int(n), int(noverlap), None if Wh is None else out_ptr(Wh), out_ptr(fh), Nf,
+                                              int(eng["estimator"]), float(eng["lam"]), int(kind), float(param), int(glen), float(eng["μ"]), float(eng["tol"]),
+                                              int(eng["iters"]), int(eng["sign"]), int(win_lo), win_hi, int(device), out_ptr(xre), out_ptr(xim), out_ptr(its)))
+        return (xre + 1j * xim).astype(np.complex64)[:, :nwin], its[:, :nwin]
     Ys = [as_f64(y) for y in Y]
     ns, Ly = len(Ys), Ys[0][2]
     assert all(e[2] == Ly for e in Ys), "signals must have the same length"
@@ -824,7 +854,7 @@ def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimato
     windows = Windows2(y, t, n, noverlap, window_func)              # :115
     k = len(windows)                                                # :116
     ngpus = kwargs.pop("ngpus", 1)                                  # extension: devices driven by this process (0 = all visible)
-    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and k > 0 and not is_f32(y)) else None
+    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and k > 0) else None
     if eng is not None:
         if ngpus != 1:
             x, _ = windows_estimate_multi([y], t, freqs, n, windows.noverlap, windows.W, eng, ngpus=ngpus)
@@ -854,7 +884,7 @@ def ls_windowcsd(y, u, t, freqs=None, nw=10, noverlap=-1, window_func=rect, esti
     wu = Windows2(u, t, n, noverlap, window_func)
     k = len(wy)
     ngpus = kwargs.pop("ngpus", 1)
-    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and k > 0 and not is_f32(y)) else None
+    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and k > 0) else None
     if eng is not None and ngpus != 1:
         x, _ = windows_estimate_multi([y, u], t, freqs, n, wy.noverlap, wy.W, eng, ngpus=ngpus)
         S = np.zeros(len(freqs), dtype=np.complex128)
@@ -882,7 +912,7 @@ def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, batched=T
         freqs = default_freqs(t, n=n)
     windows = Windows3(y, t, u, n, noverlap, hanning)
     ngpus = kwargs.pop("ngpus", 1)
-    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and len(windows) > 0 and not is_f32(y)) else None
+    eng = _engine_args(estimator, kwargs, 2 * len(freqs)) if (batched and len(windows) > 0) else None
     if eng is not None and ngpus != 1:
         x, _ = windows_estimate_multi([y, u], t, freqs, n, windows.noverlap, windows.W, eng, ngpus=ngpus)
         Syy, Suu = np.zeros(len(freqs)), np.zeros(len(freqs))

@@ -1743,6 +1743,40 @@ int32_t lpvs_problem_create_lpv_f32(const float *y, const float *X, const float 
     return LPVS_OK;
 }
 
+int32_t lpvs_problem_create_lpv_multi_f32(const float *Y, int64_t ns, const float *X, const float *V, int64_t N, const float *w, int64_t Nf,
+                                          int64_t Nv, int32_t normalize, int32_t coulomb, int32_t device, lpvs_problem **out) {
+    if (!Y || !X || !V || !w || N <= 0 || Nf <= 0 || ns <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    LPVS_HIP(hipSetDevice(device));
+    WideArg dY, dX, dV, dw;
+    LPVS_TRY(dY.set(Y, N * ns, nullptr)); LPVS_TRY(dX.set(X, N, nullptr)); LPVS_TRY(dV.set(V, N, nullptr)); LPVS_TRY(dw.set(w, Nf, nullptr));
+    struct Admit { Admit() { g_f32_admission = true; } ~Admit() { g_f32_admission = false; } } admit;
+    LPVS_TRY(lpvs_problem_create_lpv_multi_f64(dY.p, ns, dX.p, dV.p, N, dw.p, Nf, Nv, normalize, coulomb, device, out));
+    (*out)->f32 = true;   // float I/O through the _f32 accessors; several right-hand sides keep the double matrix stream (matrix cores)
+    return LPVS_OK;
+}
+
+// the batched-window engine for Float32 callers: float in / out, double arithmetic (float time stamps and frequencies are widened
+// exactly; a float frequency grid is snapped to the progression it was rounded from, as in the other _f32 constructors)
+int32_t lpvs_windows_estimate_f32(const float *Y, int64_t ns, const float *t, int64_t L, int64_t n, int64_t noverlap, const float *W,
+                                  const float *freqs, int64_t Nf, int32_t estimator, double lam, int32_t prox_kind, double prox_param,
+                                  int64_t group_len, double mu, double tol, int64_t iters, int32_t linear_sign, int64_t win_lo,
+                                  int64_t win_hi, int32_t device, float *x_re, float *x_im, int64_t *iters_out) {
+    if (!Y || !t || !freqs || ns < 1 || L <= 0 || Nf <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    LPVS_HIP(hipSetDevice(device));
+    WideArg dY, dt, dW, df;
+    LPVS_TRY(dY.set(Y, L * ns, nullptr)); LPVS_TRY(dt.set(t, L, nullptr)); LPVS_TRY(dW.set(W, n, nullptr)); LPVS_TRY(df.set(freqs, Nf, nullptr));
+    const int64_t nwin = win_hi > win_lo ? win_hi - win_lo : 0;
+    const int64_t cnt = ns * nwin * Nf;
+    DevBuf o; LPVS_TRY(o.alloc(sizeof(double) * (size_t)(cnt > 0 ? cnt : 1) * 2));
+    struct Admit { Admit() { g_f32_admission = true; } ~Admit() { g_f32_admission = false; } } admit;
+    LPVS_TRY(lpvs_windows_estimate_f64(dY.p, ns, dt.p, L, n, noverlap, dW.p, df.p, Nf, estimator, lam, prox_kind, prox_param, group_len, mu, tol,
+                                       iters, linear_sign, win_lo, win_hi, device, o.as<double>(), o.as<double>() + cnt, iters_out));
+    LPVS_TRY(narrow_out(x_re, o.as<double>(), cnt, nullptr));
+    return narrow_out(x_im, o.as<double>() + cnt, cnt, nullptr);
+}
+
 int32_t lpvs_admm_init_f32(lpvs_problem *h, const float *x0, double mu, double tol, int32_t linear_sign) {
     if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
     LPVS_HIP(hipSetDevice(h->device));

@@ -108,3 +108,36 @@ def test_f32_float_grid_takes_the_structured_gram(L, oracle):
     assert rel(se.x, xs) <= 2e-5, rel(se.x, xs)                       # float I/O only
     assert np.array_equal(np.abs(se.x) > 0, np.abs(xs) > 0)
     print(f"f32 float grid: rel-L2 vs oracle on the snapped grid {rel(se.x, xs):.2e}; the snapping itself moves the oracle by {rel(xs, xu):.2e}")
+
+
+def test_f32_multi_signal_and_window_engine_entry_points(L, oracle):
+    """lpvs_problem_create_lpv_multi_f32 and lpvs_windows_estimate_f32: float in / out, double arithmetic, against the fp64
+    oracle on the widened inputs."""
+    import io
+    rng = np.random.default_rng(51)
+    N, Nf, Nv, ns = 1500, 12, 4, 3
+    X = np.sort(rng.random(N) * 10).astype(np.float32); V = np.linspace(0, 1, N).astype(np.float32)
+    w = (2 * np.pi * (np.arange(Nf) + 1.0) * 2).astype(np.float32)
+    Y = np.stack([np.cos(w[(3 * q + 1) % Nf].astype(np.float64) * X) * (1 + q * V) + 0.05 * rng.standard_normal(N) for q in range(ns)], axis=1).astype(np.float32)
+    ses = L.ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, λ=2.0, iters=150, tol=0.0, printerval=1000, out=io.StringIO())
+    X64, V64, w64 = (a.astype(np.float64) for a in (X, V, w))
+    Phi = oracle.lpv_regressor(X64, V64, w64, Nv)
+    for q in range(ns):
+        Go, bo = oracle.gram(Phi, Y[:, q].astype(np.float64))
+        ro = oracle.admm_gram(Go, bo, oracle.GroupL2(2.0, 2 * Nv), iters=150, tol=0.0, mu=0.05)
+        xo = oracle.lpv_unpermute(ro["z"], Nf, Nv)
+        assert ses[q].x.dtype == np.complex64 and rel(ses[q].x, xo) <= 2e-5 and np.array_equal(np.abs(ses[q].x) > 0, np.abs(xo) > 0)
+    # windows: csd of two float records with the dense and the sparse estimator
+    Lh = 4000
+    t = np.cumsum(0.5 + rng.random(Lh)).astype(np.float32)
+    f = (np.arange(1, 33) / 80.0).astype(np.float32)
+    t64, f64 = t.astype(np.float64), f.astype(np.float64)
+    y = (np.sin(2 * np.pi * f64[8] * t64) + 0.1 * rng.standard_normal(Lh)).astype(np.float32)
+    u = (0.7 * np.sin(2 * np.pi * f64[8] * t64 + 0.5) + 0.1 * rng.standard_normal(Lh)).astype(np.float32)
+    S, _ = L.ls_windowcsd(y, u, t, f, nw=8, noverlap=0, λ=1e-3)
+    So, _ = oracle.ls_windowcsd(y.astype(np.float64), u.astype(np.float64), t64, f64, nw=8, noverlap=0, lam=1e-3)
+    assert rel(S, So) <= 1e-4, rel(S, So)                          # float outputs of the engine, double accumulation over the windows
+    Ss, _ = L.ls_windowpsd(y, t, f, nw=8, noverlap=0, estimator=L.ls_sparse_spectral, λ=0.5, μ=0.05, tol=1e-9, iters=2000)
+    Sso, _ = oracle.ls_windowpsd(y.astype(np.float64), t64, f64, nw=8, noverlap=0,
+                                 estimator=lambda yy, tt, ff, W, **k: oracle.ls_sparse_spectral(yy, tt, ff, W, **k), lam=0.5, mu=0.05, tol=1e-9, iters=2000)
+    assert rel(Ss, Sso) <= 1e-4 and int(np.argmax(Ss)) == 8
