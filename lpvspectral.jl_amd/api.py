@@ -388,6 +388,10 @@ class Problem:
         k = C.c_int32(0)
         check(lib().lpvs_admm_matvec_kind(self._h, C.byref(k)))
         np_ = -(-self.n // 128) * 128
+        if self.ns > 1 and int(k.value) in (1, 3):
+            elt = 8 if int(k.value) == 1 else 6
+            return dict(kernel="symv_tile_mfma_ws_kernel", storage="tile-packed lower triangle, %s" % ("f64 (8 B)" if elt == 8 else "float head + 16-bit tail (6 B, 40 significant bits)"),
+                        bytes_formula="%d B x np(np+128)/2 (np = %d), streamed once per 16 signals" % (elt, np_))
         return {0: dict(kernel="symv_kernel", storage="full symmetric f64", bytes_formula="8 B x np^2"),
                 1: dict(kernel="symv_tile_kernel<double>", storage="tile-packed lower triangle, f64 (8 B)",
                         bytes_formula="8 B x np(np+128)/2 (np = %d)" % np_),

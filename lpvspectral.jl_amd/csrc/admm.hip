@@ -13,6 +13,7 @@
 
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 namespace lpvs {
 
@@ -580,6 +581,20 @@ __device__ __forceinline__ double split_decode(float head, unsigned int tail16) 
     const double d = (double)head;
     return __hiloint2double(__double2hiint(d), (int)((tail16 << 13) | (unsigned int)__double2loint(d)));
 }
+// the same with the shift-or as ONE instruction (the compiler otherwise masks after shifting and ors separately): on gfx950
+// every vector instruction of a wave that shares a SIMD with fp64 MFMAs costs the matrix pipe ~7 cycles
+__device__ __forceinline__ double split_decode_lo(float head, unsigned int pair) {   // tail = low half of `pair`
+    const double d = (double)head;
+    unsigned int lo = (unsigned int)__double2loint(d), t = pair & 0xffffu;
+    asm("v_lshl_or_b32 %0, %1, 13, %0" : "+v"(lo) : "v"(t));
+    return __hiloint2double(__double2hiint(d), (int)lo);
+}
+__device__ __forceinline__ double split_decode_hi(float head, unsigned int pair) {   // tail = high half of `pair`
+    const double d = (double)head;
+    unsigned int lo = (unsigned int)__double2loint(d), t = pair >> 16;
+    asm("v_lshl_or_b32 %0, %1, 13, %0" : "+v"(lo) : "v"(t));
+    return __hiloint2double(__double2hiint(d), (int)lo);
+}
 // an SSA value the optimiser cannot look through: keeps `up ? a[k] : a[k+cnt]` from becoming a dynamically indexed array
 // access (which the backend then lowers to an 8-way select chain per value)
 __device__ __forceinline__ double opaque(double v) { asm volatile("" : "+v"(v)); return v; }
@@ -910,6 +925,311 @@ symv_tile_mfma_kernel(const double *__restrict__ Mp, const double *__restrict__ 
                     if (sgl < nsb && !(status != nullptr && status[s0 + sgl].converged))
                         part2_all[(int64_t)(s0 + sgl) * ntiles * TS + (int64_t)t * TS + 64 * (wave - 2) + 16 * u + li] = acc2[u][r];
                 }
+        }
+    }
+}
+
+// ---- the multi-signal tile product, wave-specialised and streamed (6-byte or 8-byte packed copy) --------------------------
+// What bounds symv_tile_mfma_kernel (measured at n = 32768, ns = 8: 1.02 ms per launch, 4.2 TB/s of 8-byte tiles):
+//   * the 16.8 M v_mfma_f64_16x16x4_f64 of a launch need 0.52 ms of the matrix pipe (its 66 TFLOP/s issue ceiling);
+//   * on gfx950 the fp64 MFMA and the vector ALU exclude each other: every VALU instruction issued by ANY wave of the SIMD
+//     costs the matrix pipe ~7 cycles (measured by adding dummy v_add_u32 to a co-resident wave: +7.1 cycles of MFMA time
+//     each; scalar instructions are free).  Address arithmetic, selects for the padded signal lanes, LDS-DMA bookkeeping and
+//     the decode of 6-byte elements all bill the matrix pipe;
+//   * waves that alternate "stage a tile slice" / "multiply" between barriers leave either pipe idle half of the time, and
+//     co-resident workgroups fall into step instead of filling each other's gaps.
+// Here ONE 512-thread workgroup per CU is persistent (tiles t = blockIdx.x, += gridDim.x) and split into roles:
+//   waves 4-7, LOADERS: global -> registers (a ring of D 32-row stages in flight per CU: ~100 KB) -> decode -> the LDS
+//     image of the NEXT stage (double-buffered); all addresses are a scalar base plus a loop-invariant lane offset, so the
+//     only vector instructions left are the three per element of the 6-byte decode;
+//   waves 0-3, MFMA (one per SIMD): waves 0-1 form P1 of the stage's two 16-row blocks, waves 2-3 accumulate P2 over the
+//     tile's four stages; operands come from LDS with immediate offsets (no selects: the right-hand-side images always hold
+//     16 signal columns; columns beyond ns hold signal ns-1 again and their results are not stored).
+// One barrier per stage.  Signals are processed 16 per pass; the last pass of ns > 16 re-covers the last 16 signals.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (a native vector: stays in registers where HIP's uint4 struct did not)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int WS_NS = 16;                            // signal columns of the LDS images = the MFMA's N
+constexpr size_t symv_ws_lds() { return sizeof(double) * 2 * ((size_t)MT_ROWS * MT_RS + (size_t)MT_ROWS * WS_NS + (size_t)TS * WS_NS); }
+
+struct StreamVisit { int t, pass, I, J; };          // one (tile, signal pass): four 32-row stages
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_f64(double v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    const u32x2 w = {(unsigned int)__double2loint(v), (unsigned int)__double2hiint(v)};
+    __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, voffset, soffset, 0);
+}
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(512, 1)
+symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
+                         double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    if (status != nullptr) {
+        bool all = true;
+        for (int q = 0; q < ns; ++q) all = all && status[q].converged;
+        if (all) return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int NS = WS_NS, NQ = TS / MT_ROWS;
+    static_assert(NQ == 4, "a tile is four stages: ring slot = stage, LDS parity = stage & 1");
+    constexpr unsigned kStgB = MT_ROWS * MT_RS * 8, kRiB = MT_ROWS * NS * 8, kRjB = TS * NS * 8;   // bytes of one image
+    unsigned char *stg = lds_raw;                    // [2][32][MT_RS]   32 rows of a tile, by stage parity
+    unsigned char *ri = stg + 2 * kStgB;             // [2][32][16]      right-hand sides of row block I, rows of the stage
+    unsigned char *rj = ri + 2 * kRiB;               // [2][128][16]     right-hand sides of row block J, by visit parity
+    constexpr size_t kTileBytes = SPLIT ? kSplitTileBytes : (size_t)TS * TS * 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ltid = tid & 255;                      // index within the role's four waves
+    const int li = lane & 15, lk = lane >> 4;
+    const int G = gridDim.x;
+    // Step q of a tile is its stage (q + q0) & 3 with q0 = blockIdx.x & 3, so that workgroups advancing in near lockstep do
+    // not all ask for the same quarter of their (power-of-two sized) tiles at the same time.
+    const int q0 = blockIdx.x & (NQ - 1);
+    const int npass = (ns + NS - 1) / NS, nvalid = ns < NS ? ns : NS, s0max = ns > NS ? ns - NS : 0;
+    if ((int)blockIdx.x >= ntiles) return;
+    auto next = [&](StreamVisit v) -> StreamVisit {  // scalar only; t >= ntiles after the workgroup's last visit
+        if (++v.pass == npass) {
+            v.pass = 0;
+            v.t += G;
+            v.J += G;                                // t = I(I+1)/2 + J, 0 <= J <= I
+            while (v.J > v.I) { v.J -= v.I + 1; ++v.I; }
+        }
+        return v;
+    };
+    auto s0_of = [&](const StreamVisit &v) -> int { const int s0 = v.pass * NS; return s0 < s0max ? s0 : s0max; };
+    StreamVisit cv{(int)blockIdx.x, 0, 0, 0};        // the visit being multiplied
+    tile_index(cv.t, cv.I, cv.J);
+    cv.I = __builtin_amdgcn_readfirstlane(cv.I); cv.J = __builtin_amdgcn_readfirstlane(cv.J);
+    int tp = 0;                                      // parity of the visit count
+
+    if (wave >= 4) {
+        // ---- loader waves.  Thread (r = ltid >> 4, c = ltid & 15) owns rows r and r + 16 of a stage:
+        //   split:  two 16-byte pieces of heads (columns 4c.., 64+4c..) and one of tails per row (pack_tiles_split_kernel's layout)
+        //   double: four 16-byte pieces per row (columns 32j + 2c, 2c+1)
+        const int r = ltid >> 4, c = ltid & 15;
+        constexpr int NRAW = SPLIT ? 6 : 8, RI = MT_ROWS * NS / 256, RJ = TS * NS / 256;
+        u32x4 raw[NQ][NRAW];                          // ring slot = step of the tile
+        double pri[NQ][RI], prj[RJ];                 // (the J slice travels with step 0)
+        // loop-invariant lane offsets (bytes)
+        const int lo_a = SPLIT ? r * (TS * 4) + c * 16 : r * (TS * 8) + c * 16;   // heads (split) / doubles
+        const int lo_t = r * (TS * 2) + c * 16;                                    // tails (split)
+        int go_ri[RI], go_rj[RJ];
+        unsigned wo_ri[RI], wo_rj[RJ];
+#pragma unroll
+        for (int k = 0; k < RI; ++k) {
+            const int e = ltid + 256 * k, sq = e >> 5, i = e & 31;
+            go_ri[k] = (int)(((int64_t)(sq < ns ? sq : ns - 1) * np + i) * 8);
+            wo_ri[k] = (i * NS + sq) * 8;
+        }
+#pragma unroll
+        for (int k = 0; k < RJ; ++k) {
+            const int e = ltid + 256 * k, sq = e >> 7, i = e & 127;
+            go_rj[k] = (int)(((int64_t)(sq < ns ? sq : ns - 1) * np + i) * 8);
+            wo_rj[k] = (i * NS + sq) * 8;
+        }
+        const unsigned wo_stg = SPLIT ? (r * MT_RS + 4 * c) * 8 : (r * MT_RS + 2 * c) * 8;
+        // Every load of a step is unconditional (past the last visit an earlier one is requested again): a load under a
+        // branch, or registers that differ between two paths into the loop, make the compiler wait for the prefetch right
+        // where it was issued.  Buffer loads: scalar descriptor + scalar offset + loop-invariant lane offset.
+        auto fetch = [&](auto qc, const StreamVisit &v) {
+            constexpr int Q = decltype(qc)::value;
+            const int qp = (Q + q0) & (NQ - 1);
+            const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Mp + (size_t)v.t * kTileBytes), 0, (int)kTileBytes, 0x00020000);
+            if constexpr (SPLIT) {
+                const int oh = qp * (MT_ROWS * TS * 4), ot = TS * TS * 4 + qp * (MT_ROWS * TS * 2);
+                raw[Q][0] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a, oh, 0);
+                raw[Q][1] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + 256, oh, 0);
+                raw[Q][2] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_t, ot, 0);
+                raw[Q][3] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a, oh + 16 * TS * 4, 0);
+                raw[Q][4] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + 256, oh + 16 * TS * 4, 0);
+                raw[Q][5] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_t, ot + 16 * TS * 2, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        raw[Q][4 * k + j] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + j * 256, qp * (MT_ROWS * TS * 8) + k * (16 * TS * 8), 0);
+            }
+            const int s0 = s0_of(v);
+            const int64_t left = (int64_t)(ns - s0) * np * 8;
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rhs_all + (int64_t)s0 * np), 0,
+                                                                              (int)(left < 0x7fffffff ? left : 0x7fffffff), 0x00020000);
+            const int oI = (v.I * TS + MT_ROWS * qp) * 8;
+#pragma unroll
+            for (int k = 0; k < RI; ++k) pri[Q][k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, go_ri[k], oI, 0));
+            if constexpr (Q == 0) {
+                const int oJ = v.J * TS * 8;
+#pragma unroll
+                for (int k = 0; k < RJ; ++k) prj[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, go_rj[k], oJ, 0));
+            }
+        };
+        auto put = [&](auto qc, int vtp) {           // step's registers -> the LDS images of parity Q & 1 (J slice: visit parity)
+            constexpr int Q = decltype(qc)::value;
+            constexpr unsigned par = Q & 1;
+            unsigned char *sp = stg + par * kStgB + wo_stg;
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const u32x4 ha = raw[Q][3 * k], hb = raw[Q][3 * k + 1], lq = raw[Q][3 * k + 2];
+                    f64x2 *row = reinterpret_cast<f64x2 *>(sp + k * (16 * MT_RS * 8));
+                    row[0] = (f64x2){split_decode_lo(__uint_as_float(ha.x), lq.x), split_decode_hi(__uint_as_float(ha.y), lq.x)};
+                    row[1] = (f64x2){split_decode_lo(__uint_as_float(ha.z), lq.y), split_decode_hi(__uint_as_float(ha.w), lq.y)};
+                    row[32] = (f64x2){split_decode_lo(__uint_as_float(hb.x), lq.z), split_decode_hi(__uint_as_float(hb.y), lq.z)};
+                    row[33] = (f64x2){split_decode_lo(__uint_as_float(hb.z), lq.w), split_decode_hi(__uint_as_float(hb.w), lq.w)};
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4 *>(sp + k * (16 * MT_RS * 8) + j * 256) = raw[Q][4 * k + j];
+            }
+#pragma unroll
+            for (int k = 0; k < RI; ++k) *reinterpret_cast<double *>(ri + par * kRiB + wo_ri[k]) = pri[Q][k];
+            if constexpr (Q == 0) {
+                unsigned char *rjp = rj + vtp * kRjB;
+#pragma unroll
+                for (int k = 0; k < RJ; ++k) *reinterpret_cast<double *>(rjp + wo_rj[k]) = prj[k];
+            }
+        };
+        using std::integral_constant;
+        StreamVisit v1 = next(cv);                   // the visit after the current one; `src` = the visit the ring is refilled from
+        // prologue: the first visit's four steps in flight, step 0 staged, slot 0 refilled from the next visit
+        fetch(integral_constant<int, 0>{}, cv);
+        fetch(integral_constant<int, 1>{}, cv);
+        fetch(integral_constant<int, 2>{}, cv);
+        fetch(integral_constant<int, 3>{}, cv);
+        put(integral_constant<int, 0>{}, 0);
+        fetch(integral_constant<int, 0>{}, v1.t < ntiles ? v1 : cv);
+        __syncthreads();
+#pragma unroll 1
+        for (;;) {
+            // while the MFMA waves multiply step q of the current visit, stage step q + 1 and refill its slot from the next visit
+            const StreamVisit src = v1.t < ntiles ? v1 : cv;
+            put(integral_constant<int, 1>{}, tp); fetch(integral_constant<int, 1>{}, src); __syncthreads();
+            put(integral_constant<int, 2>{}, tp); fetch(integral_constant<int, 2>{}, src); __syncthreads();
+            put(integral_constant<int, 3>{}, tp); fetch(integral_constant<int, 3>{}, src); __syncthreads();
+            const StreamVisit v2 = next(v1);
+            if (v1.t < ntiles) put(integral_constant<int, 0>{}, tp ^ 1);
+            fetch(integral_constant<int, 0>{}, v2.t < ntiles ? v2 : cv);
+            __syncthreads();
+            if (v1.t >= ntiles) break;
+            cv = v1; v1 = v2; tp ^= 1;
+        }
+        return;
+    }
+
+    // ---- MFMA waves: loop-invariant lane offsets (bytes)
+    const bool p1 = wave < 2;
+    const unsigned a_lane = p1 ? ((16 * wave + li) * MT_RS + lk) * 8 : (lk * NS + li) * 8;                 // P1: A = tile rows; P2: A = ri
+    const unsigned b_lane = p1 ? (lk * NS + li) * 8 : (lk * MT_RS + 64 * (wave - 2) + li) * 8;             // P1: B = rj;        P2: B = tile rows
+    // partials: buffer stores, a lane whose signal is beyond the pass's valid ones gets an out-of-range offset (store dropped)
+    const int s_lane = p1 ? (li < nvalid ? (int)(((int64_t)li * ntiles * TS + 16 * wave + lk) * 8) : (int)0x80000000u)     // part1: [signal li][tile][row lk + 4k]
+                          : (int)(((int64_t)lk * ntiles * TS + 64 * (wave - 2) + li) * 8);                                   // part2: [signal lk + 4k][tile][col 16u + li]
+    const int64_t pass_bytes = (int64_t)nvalid * ntiles * TS * 8;
+    const int part_records = (int)(pass_bytes < 0x7fffffff ? pass_bytes : 0x7fffffff);
+    f64x4 acc2[4];                                   // waves 2-3: P2 blocks, columns 64*(wave-2) + 16*u .., over the tile's stages
+    __syncthreads();                                 // step 0 of the first visit staged
+    // One continuous software pipeline over the steps: a step's 32 MFMAs run as four groups of eight, each group's operands
+    // read from LDS while the previous group multiplies.  The step's barrier sits BEFORE its last group (whose operands are in
+    // registers by then: nobody reads the step's LDS images after it), and the next step's first operands are requested
+    // right after it, so the matrix pipe does not drain at step boundaries.
+    if (p1) {
+        // P1: rows 16*wave .. of a stage, all 128 columns.  A[i = li][k = lk], B[k = lk][j = s = li]
+        double A[2][8], B[2][8];
+        auto load = [&](auto gc, unsigned par, int vtp, int buf) {      // operands of group G of the stage with parity par
+            constexpr int g = decltype(gc)::value;
+            const unsigned char *ap = stg + par * kStgB + a_lane, *bp = rj + vtp * kRjB + b_lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                A[buf][j] = *reinterpret_cast<const double *>(ap + 32 * (8 * g + j));
+                B[buf][j] = *reinterpret_cast<const double *>(bp + 4 * NS * 8 * (8 * g + j));
+            }
+        };
+        using std::integral_constant;
+        load(integral_constant<int, 0>{}, 0, 0, 0);
+        auto step = [&](auto qc, int next_tp) {
+            constexpr int Q = decltype(qc)::value;
+            constexpr unsigned par = Q & 1;
+            f64x4 a0 = (f64x4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            auto mul = [&](int buf) {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j], B[buf][j], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j + 1], B[buf][j + 1], a1, 0, 0, 0);
+                }
+            };
+            load(integral_constant<int, 1>{}, par, tp, 1); __builtin_amdgcn_sched_barrier(0); mul(0); __builtin_amdgcn_sched_barrier(0);
+            load(integral_constant<int, 2>{}, par, tp, 0); __builtin_amdgcn_sched_barrier(0); mul(1); __builtin_amdgcn_sched_barrier(0);
+            load(integral_constant<int, 3>{}, par, tp, 1); __builtin_amdgcn_sched_barrier(0); mul(0); __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                         // the next step is staged; this step's images are free
+            load(integral_constant<int, 0>{}, par ^ 1, next_tp, 0); __builtin_amdgcn_sched_barrier(0); mul(1); __builtin_amdgcn_sched_barrier(0);
+            // D: col = li = s, row = lk + 4*reg   (a converged signal's partials are never read)
+            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part1_all + (int64_t)s0_of(cv) * ntiles * TS, 0, part_records, 0x00020000);
+            const int so = (cv.t * TS + MT_ROWS * ((Q + q0) & (NQ - 1))) * 8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) store_f64(a0[k] + a1[k], pr, s_lane + 32 * k, so);
+        };
+#pragma unroll 1
+        for (;;) {
+            step(integral_constant<int, 0>{}, tp);
+            step(integral_constant<int, 1>{}, tp);
+            step(integral_constant<int, 2>{}, tp);
+            step(integral_constant<int, 3>{}, tp ^ 1);
+            cv = next(cv);
+            if (cv.t >= ntiles) break;
+            tp ^= 1;
+        }
+    } else {
+        // P2: columns 64*(wave-2) + 16*u .., the 32 rows of a stage.  A[s = li][k = lk], B[k = lk][j = c = li]
+        double A[2][2], B[2][8];
+        auto load = [&](auto gc, unsigned par, int buf) {
+            constexpr int g = decltype(gc)::value;
+            const unsigned char *ap = ri + par * kRiB + a_lane, *bp = stg + par * kStgB + b_lane;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                A[buf][j] = *reinterpret_cast<const double *>(ap + 4 * NS * 8 * (2 * g + j));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) B[buf][4 * j + u] = *reinterpret_cast<const double *>(bp + 4 * MT_RS * 8 * (2 * g + j) + 128 * u);
+            }
+        };
+        using std::integral_constant;
+        load(integral_constant<int, 0>{}, 0, 0);
+        auto step = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            constexpr unsigned par = Q & 1;
+            auto mul = [&](int buf, bool first) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const f64x4 cin = (first && j == 0) ? (f64x4){0.0, 0.0, 0.0, 0.0} : acc2[u];   // a tile's first product starts the sums
+                        acc2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j], B[buf][4 * j + u], cin, 0, 0, 0);
+                    }
+            };
+            load(integral_constant<int, 1>{}, par, 1); __builtin_amdgcn_sched_barrier(0); mul(0, Q == 0); __builtin_amdgcn_sched_barrier(0);
+            load(integral_constant<int, 2>{}, par, 0); __builtin_amdgcn_sched_barrier(0); mul(1, false); __builtin_amdgcn_sched_barrier(0);
+            load(integral_constant<int, 3>{}, par, 1); __builtin_amdgcn_sched_barrier(0); mul(0, false); __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                         // the next step is staged; this step's images are free
+            load(integral_constant<int, 0>{}, par ^ 1, 0); __builtin_amdgcn_sched_barrier(0); mul(1, false); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (Q == NQ - 1) {             // P2 of the tile is complete: D row = s = lk + 4*reg, col = li
+                if (cv.I != cv.J) {
+                    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part2_all + (int64_t)s0_of(cv) * ntiles * TS, 0, part_records, 0x00020000);
+#pragma unroll
+                    for (int k = 0; k < NS / 4; ++k) {
+                        const int so = (int)(((int64_t)4 * k * ntiles + cv.t) * TS * 8);   // (beyond the pass's valid signals: out of range, dropped)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) store_f64(acc2[u][k], pr, s_lane + 128 * u, so);
+                    }
+                }
+            }
+        };
+#pragma unroll 1
+        for (;;) {
+            step(integral_constant<int, 0>{});
+            step(integral_constant<int, 1>{});
+            step(integral_constant<int, 2>{});
+            step(integral_constant<int, 3>{});
+            cv = next(cv);
+            if (cv.t >= ntiles) break;
         }
     }
 }
@@ -1608,6 +1928,60 @@ static void launch_split(const unsigned char *Mp, const double *rhs, int64_t np,
     hipLaunchKernelGGL(symv_tile_split_kernel, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
 }
 
+// persistent grid of the wave-specialised multi-signal kernel: one workgroup per CU, evened out over the rounds so that
+// every workgroup walks the same number of tiles (+-1)
+static unsigned stream_grid(unsigned ntiles) {
+    static const unsigned slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        return (unsigned)cus;
+    }();
+    const unsigned rounds = (ntiles + slots - 1) / slots;
+    return (ntiles + rounds - 1) / rounds;
+}
+
+template <bool SPLIT>
+static void launch_mfma_stream(const AdmmParams &p, unsigned ntiles, double *part1, double *part2, const AdmmStatus *status, hipStream_t s) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_ws_kernel<SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)symv_ws_lds());   // per device; cheap
+    hipLaunchKernelGGL((symv_tile_mfma_ws_kernel<SPLIT>), dim3(stream_grid(ntiles)), dim3(512), symv_ws_lds(), s,
+                       reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
+}
+
+// the mat-vec of one iteration on the packed symmetric form (tile partials -> part1 / part2)
+static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hipStream_t s) {
+    const int nblk = (int)(p.np / TS);
+    const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
+    const unsigned ns = (unsigned)p.ns;
+    double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
+    // multi-signal handles: stream (default: persistent, register-staged MFMA kernel), dma (LDS-DMA staged MFMA kernel, 8-byte
+    // storage only), valu (no matrix cores)
+    static const int multi = [] {
+        const char *e = getenv("LPVS_MULTI_MATVEC");
+        return !e ? 2 : (std::string(e) == "valu" ? 0 : (std::string(e) == "dma" ? 1 : 2));
+    }();
+    if (p.ns > 1 && !p.mp_f32 && (p.mp_split || multi == 2)) {
+        if (p.mp_split) launch_mfma_stream<true>(p, ntiles, part1, part2, status, s);
+        else launch_mfma_stream<false>(p, ntiles, part1, part2, status, s);
+    } else if (p.ns > 8 && !p.mp_f32 && multi == 1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)symv_mfma_lds<16>());   // per device; cheap
+        hipLaunchKernelGGL(symv_tile_mfma_kernel<16>, dim3(ntiles), dim3(256), symv_mfma_lds<16>(), s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
+    } else if (p.ns > 1 && !p.mp_f32 && multi == 1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)symv_mfma_lds<8>());
+        hipLaunchKernelGGL(symv_tile_mfma_kernel<8>, dim3(ntiles), dim3(256), symv_mfma_lds<8>(), s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
+    } else if (p.ns > 1 && !p.mp_f32)
+        hipLaunchKernelGGL((symv_tile_multi_kernel<double, 8>), dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
+    else if (p.mp_f32)
+        hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,
+                           (int)ntiles, part1, part2, status);
+    else if (p.mp_split)
+        launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, ntiles, part1, part2, status, s);
+    else
+        hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
+}
+
 // one ADMM iteration on the packed symmetric form
 static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     const int nblk = (int)(p.np / TS);
@@ -1615,24 +1989,7 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     const unsigned ns = (unsigned)p.ns;
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
-    static const bool mfma_multi = [] { const char *e = getenv("LPVS_MULTI_MATVEC"); return !(e && std::string(e) == "valu"); }();
-    if (p.ns > 8 && !p.mp_f32 && !p.mp_split && mfma_multi) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)symv_mfma_lds<16>());   // per device; cheap
-        hipLaunchKernelGGL(symv_tile_mfma_kernel<16>, dim3(ntiles), dim3(256), symv_mfma_lds<16>(), s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
-    } else if (p.ns > 1 && !p.mp_f32 && !p.mp_split && mfma_multi) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)symv_mfma_lds<8>());
-        hipLaunchKernelGGL(symv_tile_mfma_kernel<8>, dim3(ntiles), dim3(256), symv_mfma_lds<8>(), s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
-    } else if (p.ns > 1 && !p.mp_f32 && !p.mp_split)
-        hipLaunchKernelGGL((symv_tile_multi_kernel<double, 8>), dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
-    else if (p.mp_f32)
-        hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,
-                           (int)ntiles, part1, part2, p.status);
-    else if (p.mp_split)
-        launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, ntiles, part1, part2, p.status, s);
-    else
-        hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, p.status);
+    launch_sym_matvec(p, p.status, s);
     if (fused_ok(p)) {
         hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0);
     } else {
@@ -1706,8 +2063,8 @@ int32_t launch_ridge_solve_refined(const double *G, const double *M, int64_t np,
     return LPVS_OK;
 }
 
-int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s) {
-    launch_symv_raw(M, np, rhs, x, nullptr, 1, s);
+int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s, int ns) {
+    launch_symv_raw(M, np, rhs, x, nullptr, ns, s);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -1716,17 +2073,7 @@ int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
     const bool sym = p.part != nullptr && p.Mp != nullptr;
     for (int i = 0; i < reps; ++i) {
         if (sym) {
-            const int nblk = (int)(p.np / TS);
-            const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
-            double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * (unsigned)p.ns;
-            if (p.mp_f32)
-                hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np,
-                                   p.ns, (int)ntiles, part1, part2, (const AdmmStatus *)nullptr);
-            else if (p.mp_split)
-                launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, ntiles, part1, part2, nullptr, s);
-            else
-                hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2,
-                                   (const AdmmStatus *)nullptr);
+            launch_sym_matvec(p, nullptr, s);
         } else {
             launch_symv_raw(p.M, p.np, p.rhs, p.x, nullptr, p.ns, s);
         }

@@ -328,12 +328,11 @@ int32_t copy_state_in(lpvs_problem *h, void *dev, const double *src) {
 // storage of the tile-packed inverse streamed by the ADMM mat-vec of large problems
 enum { kMpNone = 0, kMpF64 = 1, kMpF32 = 2, kMpSplit = 3 };
 // LPVS_M_STORAGE = split (default) | f64: how a double-precision handle stores the tile-packed inverse its mat-vec streams.
-// split = float head + 16-bit tail (6 bytes, 40 significant bits, admm.hip); _f32 handles always stream floats; handles with
-// several right-hand sides keep doubles (their tile product runs on the matrix cores from LDS-DMA staged double tiles).
+// split = float head + 16-bit tail (6 bytes, 40 significant bits, admm.hip); _f32 handles always stream floats.  Handles with
+// several right-hand sides decode the same 6-byte tiles on the way into the LDS image their matrix-core tile product reads.
 int mp_mode_for(const lpvs_problem *h) {
     if (h->np < kSymmetricMinNp) return kMpNone;
     if (h->f32) return kMpF32;
-    if (h->ns > 1) return kMpF64;
     const char *e = getenv("LPVS_M_STORAGE");
     return (e && std::string(e) == "f64") ? kMpF64 : kMpSplit;
 }
@@ -1005,10 +1004,10 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     if (linear_sign < 0) for (auto &q : hb) q = -q;
     LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
     // reduced-precision copies of M (split, f32) are only ever applied to (z-u)/mu: x = xb + M~ (z-u)/mu, xb = M b in full precision
-    h->offset_form = h->np >= kSymmetricMinNp && h->ns == 1 && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpF32) && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
+    h->offset_form = h->np >= kSymmetricMinNp && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpF32) && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
     if (h->offset_form) {
-        if (!h->xb.p) LPVS_TRY(h->xb.alloc(sizeof(double) * (size_t)h->np));
-        LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->bs.as<double>(), h->xb.as<double>(), s));
+        if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
+        LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->bs.as<double>(), h->xb.as<double>(), s, (int)h->ns));   // every signal's M b
     }
     const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_init(p, s));

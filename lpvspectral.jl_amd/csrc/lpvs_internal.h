@@ -236,7 +236,7 @@ int32_t launch_fourier_dual_panel(const double *t, int64_t N, const double *f, i
 int32_t launch_ridge_solve_refined(const double *G, const double *M, int64_t np, int64_t n, const double *b, double ridge, int steps,
                                    double *x, double *t1, double *t2, hipStream_t s);
 // x = Minv * rhs_in (one GEMV; ridge solves)
-int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s);
+int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, hipStream_t s, int ns = 1);   // x[q] = M rhs[q], q < ns
 
 // ---- batched-window engine (api.hip) ------------------------------------------------------------------------------
 struct WinJob {

@@ -91,6 +91,24 @@ def test_factorisation_variants_give_the_inverse(L, knobs, n, monkeypatch):
     assert np.array_equal(M, M.T)
 
 
+@pytest.mark.parametrize("knobs", [{}, {"LPVS_LOOKAHEAD": "1"}, {"LPVS_KW": "256"}])
+def test_deep_lookahead_factorisation_gives_the_inverse(L, knobs, monkeypatch):
+    """np >= 6144 takes the depth-2 look-ahead schedule (three panel buffers, second band of the trailing update); a ragged
+    size just above that threshold must agree with the depth-one schedule and with the definition of the inverse."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    n = 6200
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n + 50, n))
+    G = A.T @ A
+    b = rng.standard_normal(n)
+    with L.Problem.gram(G, b) as p:
+        M = p.get_inverse(20.0)
+    H = G + 20.0 * np.eye(n)
+    assert np.abs(M @ H - np.eye(n)).max() <= 5e-12
+    assert np.array_equal(M, M.T)
+
+
 @pytest.mark.parametrize("Nf,Nv", [(12, 4), (128, 8)])
 def test_iterates_do_not_depend_on_chunking(L, Nf, Nv):
     """lpvs_admm_run in one call or in chunks (what printerval / cb do) gives the same iterates bit for bit, on the plain
