@@ -371,19 +371,27 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         p.admm_init(None, μ=MU, tol=0.0)
         mv_us, mv_bytes = p.time_matvec(300)
         mv_info = p.matvec_info()
-    # the same mat-vec with the inverse stored in doubles (LPVS_M_STORAGE=f64), for the record: not on the timed path
-    alt = None
-    if args.dtype == "f64" and mv_info["kernel"] == "symv_tile_split_kernel":
-        os.environ["LPVS_M_STORAGE"] = "f64"
-        try:
-            with L.Problem.lpv(y, X, V, w, NV, True, False, device=local) as p:
-                p.set_prox(L.SlicedSeparableSum.frequency_groups(LAMBDA, len(w), 2 * NV))
-                p.admm_init(None, μ=MU, tol=0.0)
-                a_us, a_bytes = p.time_matvec(300)
-                alt = {"kernel": p.matvec_info()["kernel"], "launch_us": a_us, "bytes_per_launch": a_bytes,
-                       "achieved_GBps": a_bytes / (a_us * 1e-6) * 1e-9, "frac_of_hbm_peak": a_bytes / (a_us * 1e-6) * 1e-9 / HBM_PEAK_GBS}
-        finally:
-            del os.environ["LPVS_M_STORAGE"]
+    # the same mat-vec with the inverse stored in doubles (LPVS_M_STORAGE=f64) and in uniform 6-byte elements (=split), for the
+    # record: not on the timed path
+    alt, alt6 = None, None
+    if args.dtype == "f64" and mv_info["kernel"] in ("symv_tile_split_kernel", "symv_tile_mixed_kernel"):
+        for st in ("f64", "split"):
+            if st == "split" and mv_info["kernel"] == "symv_tile_split_kernel":
+                continue
+            os.environ["LPVS_M_STORAGE"] = st
+            try:
+                with L.Problem.lpv(y, X, V, w, NV, True, False, device=local) as p:
+                    p.set_prox(L.SlicedSeparableSum.frequency_groups(LAMBDA, len(w), 2 * NV))
+                    p.admm_init(None, μ=MU, tol=0.0)
+                    a_us, a_bytes = p.time_matvec(300)
+                    rec = {"kernel": p.matvec_info()["kernel"], "launch_us": a_us, "bytes_per_launch": a_bytes,
+                           "achieved_GBps": a_bytes / (a_us * 1e-6) * 1e-9, "frac_of_hbm_peak": a_bytes / (a_us * 1e-6) * 1e-9 / HBM_PEAK_GBS}
+                    if st == "f64":
+                        alt = rec
+                    else:
+                        alt6 = rec
+            finally:
+                del os.environ["LPVS_M_STORAGE"]
     # ... and the whole step with that storage (a few untimed-for-`value` solves), so that both end-to-end rates are on the record
     alt_step = None
     if alt is not None and not rowsh:
@@ -443,7 +451,7 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         "roofline": {"bound": "hbm", "kernel": mv_info["kernel"] + " (ADMM mat-vec with the tile-packed lower triangle of (G + I/mu)^-1)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": mv_bytes,
-                     "launch_us": mv_us, "launches_per_step": iters, "share_of_step": mv_share, "same_matvec_with_8_byte_storage": alt,
+                     "launch_us": mv_us, "launches_per_step": iters, "share_of_step": mv_share, "same_matvec_with_8_byte_storage": alt, "same_matvec_with_uniform_6_byte_storage": alt6,
                      "note": "algorithmic bytes = %s; M is read once per iteration; duration = HIP events around 300 back-to-back launches on "
                              "the library's stream" % mv_info["bytes_formula"]},
         "gram_general_path": general,

@@ -311,8 +311,10 @@ int32_t lpvs_windowcsd_f64(const double *y, const double *u, const double *t, in
 
 /* ---- storage of the inverse the ADMM mat-vec streams (after lpvs_admm_init) ------------------------------------------
  * *kind = 0 full symmetric doubles (n < 2048), 1 tile-packed lower triangle in doubles, 2 in floats (_f32 handles),
- * 3 in 6-byte elements (float head + 16-bit tail = 40 significant bits; the default of _f64 handles with one right-hand side,
- * LPVS_M_STORAGE=f64 selects 1) */
+ * 3 in 6-byte elements (float head + 16-bit tail = 40 significant bits; _f64 handles with several right-hand sides, or
+ * LPVS_M_STORAGE=split), 4 mixed: as 3, but tiles whose entries are all small against max|M| are 36-bit fixed point with a
+ * per-row step (the default of _f64 handles with one right-hand side; lpvs_admm_time_matvec reports the bytes a launch reads);
+ * LPVS_M_STORAGE=f64 selects 1 */
 int32_t lpvs_admm_matvec_kind(lpvs_problem *h, int32_t *kind);
 
 #ifdef __cplusplus

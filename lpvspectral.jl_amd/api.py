@@ -397,6 +397,9 @@ class Problem:
                         bytes_formula="8 B x np(np+128)/2 (np = %d)" % np_),
                 2: dict(kernel="symv_tile_kernel<float>", storage="tile-packed lower triangle, f32 (4 B)",
                         bytes_formula="4 B x np(np+128)/2 (np = %d)" % np_),
+                4: dict(kernel="symv_tile_mixed_kernel", storage="tile-packed lower triangle, mixed: float head + 16-bit tail (6 B, 40 significant bits) "
+                                                                 "for the diagonal tiles, 36-bit fixed point with per-row steps (4.53 B) for tiles of small entries",
+                        bytes_formula="98304 B per 6-byte tile, 74240 B per fixed-point tile (np = %d; 8-byte form %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2)),
                 3: dict(kernel="symv_tile_split_kernel", storage="tile-packed lower triangle, float head + 16-bit tail (6 B, 40 significant bits)",
                         bytes_formula="6 B x np(np+128)/2 (np = %d; the 8-byte form would be %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2))}[int(k.value)]
 

@@ -11,6 +11,7 @@
 // can be enqueued without a host round trip and still stop at exactly the reference's iteration.
 #include "lpvs_internal.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <string>
 #include <type_traits>
@@ -621,6 +622,206 @@ pack_tiles_split_kernel(const double *__restrict__ M, int64_t np, unsigned char 
     }
 }
 
+// ---- 36-bit fixed-point tiles (mixed storage of the single-signal packed inverse) -------------------------------------
+// M = (G + I/mu)^-1 of the LPV / Fourier problems is strongly diagonally dominant: at cfg3 the largest entry of an
+// off-diagonal tile is 2^-9.4 .. 2^-10.7 of the diagonal's.  The error of the product M~ v is then dominated by the rounding
+// of the LARGE entries (diagonal tiles, 2^-41 relative); the small entries' 40 significant bits are ~10 bits more absolute
+// precision than is ever felt.  A tile whose rows are all small is therefore stored as 36-bit fixed point against a per-row
+// power-of-two step:   element = q * step[row],  q = 16 * hi32 + nibble  (two's complement, |q| < 2^35),
+//   stored biased, q + 2^35 = 16 * hi + nibble with hi an unsigned dword;
+//   tile slot (same 98304-byte stride): hi[128][128] uint32 (65536 B), nibbles (8192 B), step[128] float (512 B) = 74240 B.
+// Measured on cfg3's inverse (tools/quant_study.py): |dM v| / |x| = 3.9e-13 with these tiles against 3.2e-13 with 40-bit
+// elements everywhere (32-bit fixed point: 3.8e-12).  Eligibility is decided per tile when packing: every row's step must be
+// <= 2^-44 * max|M| * sqrt(8192 / np) (the fixed-point errors of a row add up over ~np entries); diagonal tiles and tiles
+// that fail keep the 6-byte float-head format, so a matrix without this structure loses nothing.  tile type: 0 = float head
+// + 16-bit tail, 1 = fixed point.  Decoding: v_bfe_u32, v_alignbit_b32, v_lshl_or_b32, one v_add_f64 (exact integer in a double);
+// the row step multiplies the row sum once and the row's right-hand-side value once (for the transposed product).
+// Layouts follow the lane ownership of the split kernel (lane (g, c) of wave w: rows 32w + 4rg + g, columns 4c+k, 64+4c+k):
+//   nibbles: dword (w*64 + lane)*8 + rg holds the row group's 8 nibbles, nibble k at bits 4k (k < 4: column 4c+k, else 64+4c+k-4)
+//   steps:   float (w*4 + g)*8 + rg = step of row 32w + 4rg + g
+constexpr size_t kFixHeadBytes = (size_t)TS * TS * 4, kFixNibBytes = (size_t)TS * TS / 2;
+
+// The common tail of the single-signal tile products: v[rg] = the lane's partial row sums of its 8 row groups (rows 32w + 4rg + g),
+// tc[k] = its partial column sums of its 8 columns; row sums by a halving butterfly over the 16 column lanes, column sums over the
+// wave's four row lanes and then over the four waves through LDS.  All 256 threads call it.
+__device__ __forceinline__ void tile_reduce_store(double (&v)[8], double (&tc)[8], double (*sT)[TS], bool offdiag,
+                                                  double *__restrict__ part1, double *__restrict__ part2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 8, cnt = 4; m >= 2; m >>= 1, cnt >>= 1) {
+        const bool up = (c & m) != 0;
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const double lo_ = opaque(v[k]), hi_ = opaque(v[k + cnt]);
+            v[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1, 64);
+    if ((c & 1) == 0) {
+        const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
+        part1[wave * 32 + 4 * rg + g] = v[0];
+    }
+    if (offdiag) {
+#pragma unroll
+        for (int m = 32, cnt = 4; m >= 16; m >>= 1, cnt >>= 1) {
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int k = 0; k < cnt; ++k) {
+                const double lo_ = opaque(tc[k]), hi_ = opaque(tc[k + cnt]);
+                tc[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+            }
+        }
+        const int col = ((lane & 32) ? 64 : 0) + 4 * c + ((lane & 16) ? 2 : 0);
+        sT[wave][col] = tc[0]; sT[wave][col + 1] = tc[1];
+        __syncthreads();
+        if (threadIdx.x < TS)
+            part2[threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+absmax_kernel(const double *__restrict__ M, int64_t count, unsigned long long *__restrict__ out) {
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) m = fmax(m, fabs(M[i]));
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) m = fmax(m, __shfl_xor(m, w, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));   // positive doubles order like integers
+}
+
+// mixed packing of ONE matrix: tile blockIdx.x -> float-head format or fixed point; types[blockIdx.x] says which
+__global__ void __launch_bounds__(256)
+pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char *__restrict__ Mp, unsigned char *__restrict__ types,
+                        const unsigned long long *__restrict__ absmax_bits, double step_scale) {
+    int I, J;
+    tile_index(blockIdx.x, I, J);
+    const double *src = M + (int64_t)I * TS * np + (int64_t)J * TS;
+    unsigned char *slot = Mp + (size_t)blockIdx.x * kSplitTileBytes;
+    __shared__ float rowstep[TS];
+    __shared__ int bad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) bad = (I == J);
+    __syncthreads();
+    if (I != J) {
+        const double limit = __longlong_as_double((long long)*absmax_bits) * step_scale;     // largest admissible step
+        for (int r = wave; r < TS; r += 4) {
+            double m = fmax(fabs(src[(int64_t)r * np + lane]), fabs(src[(int64_t)r * np + 64 + lane]));
+#pragma unroll
+            for (int w = 32; w >= 1; w >>= 1) m = fmax(m, __shfl_xor(m, w, 64));
+            if (lane == 0) {
+                int e = 0;
+                (void)frexp(m, &e);                                   // m < 2^e
+                const double st = ldexp(1.0, e - 35);
+                rowstep[r] = m > 0.0 ? (float)st : 0x1p-100f;
+                if (m > 0.0 && (!(st <= limit) || e - 35 < -120)) atomicOr(&bad, 1);
+            }
+        }
+    }
+    __syncthreads();
+    const bool fixed = !bad;
+    if (threadIdx.x == 0) types[blockIdx.x] = fixed ? 1 : 0;
+    if (!fixed) {
+        float *head = reinterpret_cast<float *>(slot);
+        unsigned short *tail = reinterpret_cast<unsigned short *>(slot + (size_t)TS * TS * 4);
+        for (int e = threadIdx.x; e < TS * TS; e += 256) {
+            const int r = e >> 7, col = e & 127;
+            const double m = src[(int64_t)r * np + col];
+            unsigned long long B = (unsigned long long)__double_as_longlong(m);
+            B = (B + (1ull << 12)) & ~((1ull << 13) - 1);                    // round to nearest at bit 13 (carries run into the exponent)
+            float h = (float)__longlong_as_double((long long)(B & ~((1ull << 29) - 1)));   // exact: 23 mantissa bits left
+            unsigned int q = (unsigned int)(B >> 13) & 0xffffu;
+            if (!(fabs(m) >= 0x1p-120) || !(fabs(m) < 0x1p127)) { h = (float)m; q = 0; }   // outside the float range (never for an inverse): plain float
+            head[e] = h;
+            tail[r * TS + 8 * ((col & 63) >> 2) + 4 * (col >> 6) + (col & 3)] = (unsigned short)q;
+        }
+        return;
+    }
+    unsigned int *hi = reinterpret_cast<unsigned int *>(slot);
+    unsigned int *nib = reinterpret_cast<unsigned int *>(slot + kFixHeadBytes);
+    float *steps = reinterpret_cast<float *>(slot + kFixHeadBytes + kFixNibBytes);
+    // thread = (wave w, lane (g, c)): the eight row groups of its rows, eight columns each
+    const int g = lane >> 4, c = lane & 15;
+    for (int rg = 0; rg < 8; ++rg) {
+        const int r = wave * 32 + 4 * rg + g;
+        const double inv = 1.0 / (double)rowstep[r];                 // power of two: exact
+        unsigned int word = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int col = k < 4 ? 4 * c + k : 64 + 4 * c + (k - 4);
+            double qd = rint(src[(int64_t)r * np + col] * inv);
+            qd = fmin(fmax(qd, -0x1p35 + 1.0), 0x1p35 - 1.0);
+            const unsigned long long q = (unsigned long long)((long long)qd + (1ll << 35));   // biased: 0 < q < 2^36
+            hi[r * TS + col] = (unsigned int)(q >> 4);
+            word |= (unsigned int)(q & 15) << (4 * k);
+        }
+        nib[(wave * 64 + lane) * 8 + rg] = word;
+        if (c == 0) steps[(wave * 4 + g) * 8 + rg] = rowstep[r];
+    }
+}
+
+struct FixRaw { int4 ha[8], hb[8]; uint4 nq[2]; float4 st[2]; };
+
+// q = 16 * hi + nib (biased by 2^35) -> the double q - 2^35, exactly: the bits of 2^52 + q are assembled with two integer
+// instructions (v_alignbit_b32 puts the top four bits of q under the exponent, v_lshl_or_b32 forms the low dword), then one
+// subtraction.  (Integer conversions would be three double-rate instructions more per element.)
+__device__ __forceinline__ double fix_decode(unsigned int hi, unsigned int nib) {
+    const unsigned int top = __builtin_amdgcn_alignbit(0x04330000u, hi, 28);   // (0x04330000 << 4) | (hi >> 28) = 0x43300000 | q[35:32]
+    unsigned int lo = nib;
+    asm("v_lshl_or_b32 %0, %1, 4, %0" : "+v"(lo) : "v"(hi));
+    return __hiloint2double((int)top, (int)lo) - (0x1p52 + 0x1p35);
+}
+
+__device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, int lane, FixRaw &w) {
+    const int g = lane >> 4, c = lane & 15;
+    const int *head = reinterpret_cast<const int *>(tile) + (wave * 32 + g) * TS + 4 * c;
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        w.ha[rg] = *reinterpret_cast<const int4 *>(head + rg * 4 * TS);
+        w.hb[rg] = *reinterpret_cast<const int4 *>(head + rg * 4 * TS + 64);
+    }
+    const uint4 *nq = reinterpret_cast<const uint4 *>(tile + kFixHeadBytes) + (wave * 64 + lane) * 2;
+    w.nq[0] = nq[0]; w.nq[1] = nq[1];
+    const float4 *st = reinterpret_cast<const float4 *>(tile + kFixHeadBytes + kFixNibBytes) + (wave * 4 + g) * 2;
+    w.st[0] = st[0]; w.st[1] = st[1];
+}
+
+// the product of split_tile_product for a fixed-point tile (always off the diagonal)
+__device__ __forceinline__ void fix_tile_product(const FixRaw &w, const double *sI, const double *sJ, double (*sT)[TS],
+                                                 double *__restrict__ part1, double *__restrict__ part2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    double rj[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+    double tc[8], v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+    const float stv[8] = {w.st[0].x, w.st[0].y, w.st[0].z, w.st[0].w, w.st[1].x, w.st[1].y, w.st[1].z, w.st[1].w};
+    const unsigned int nw[8] = {w.nq[0].x, w.nq[0].y, w.nq[0].z, w.nq[0].w, w.nq[1].x, w.nq[1].y, w.nq[1].z, w.nq[1].w};
+    // the row's step folded into its right-hand-side value; requested one row group ahead, so that the column products can
+    // be issued together with the row products (otherwise the compiler parks the eight decoded elements -- and spills)
+    double ri = (double)stv[0] * sI[wave * 32 + g];
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        const double step = (double)stv[rg];
+        const double ri_next = rg + 1 < 8 ? (double)stv[rg + 1] * sI[wave * 32 + 4 * (rg + 1) + g] : 0.0;
+        const int hh[8] = {w.ha[rg].x, w.ha[rg].y, w.ha[rg].z, w.ha[rg].w, w.hb[rg].x, w.hb[rg].y, w.hb[rg].z, w.hb[rg].w};
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const double m0 = fix_decode((unsigned int)hh[k], (nw[rg] >> (4 * k)) & 15u);             // exact 36-bit integers
+            const double m1 = fix_decode((unsigned int)hh[k + 1], (nw[rg] >> (4 * k + 4)) & 15u);
+            tc[k] = opaque(fma(m0, ri, tc[k]));          // (pinned: left to itself the compiler parks all 64 decoded elements of the
+            tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));  //  lane and issues the column products after the loop -- and spills)
+            a0 = fma(m0, rj[k], a0);
+            a1 = fma(m1, rj[k + 1], a1);
+        }
+        v[rg] = step * (a0 + a1);
+        ri = ri_next;
+    }
+    tile_reduce_store(v, tc, sT, true, part1, part2);
+}
+
 // raw registers of one lane's share of a split tile (8 row groups: two float4 heads, one uint4 of tails)
 struct SplitRaw { float4 ha[8], hb[8]; uint4 lq[8]; };
 
@@ -657,8 +858,8 @@ __device__ __forceinline__ void split_tile_product(const SplitRaw &w, const doub
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
             const double m0 = split_decode(hh[k], qq[k]), m1 = split_decode(hh[k + 1], qq[k + 1]);
-            tc[k] = fma(m0, ri, tc[k]);
-            tc[k + 1] = fma(m1, ri, tc[k + 1]);
+            tc[k] = fma(m0, ri, tc[k]);                  // (pinning these as in fix_tile_product frees 40 registers and a third
+            tc[k + 1] = fma(m1, ri, tc[k + 1]);          //  workgroup per CU, but measured 31.9 us against 30.6)
             a0 = fma(m0, rj[k], a0);
             a1 = fma(m1, rj[k + 1], a1);
         }
@@ -714,6 +915,74 @@ symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__res
     else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
     __syncthreads();
     split_tile_product(w, sI, sJ, sT, I != J, part1 + (int64_t)t * TS, part2 + (int64_t)t * TS);
+}
+
+// The mixed storage's kernel: fixed-point tiles hold 74 KB instead of 96, so THREE workgroups per CU are needed to keep as many
+// bytes in flight (two: 27.5 us at cfg3 = 5.7 TB/s).  The fixed-point path fits the 168 registers that allows; the few float-head
+// tiles (the diagonal ones) are processed in two halves of 64 rows to fit as well.
+__global__ void __launch_bounds__(256, 3)
+symv_tile_mixed_kernel(const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, const double *__restrict__ rhs, int64_t np,
+                       int ntiles, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    if (status != nullptr && status[0].converged) return;
+    __shared__ double sI[TS], sJ[TS], sT[4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char *tile = Mp + (size_t)t * kSplitTileBytes;
+    double *part1 = part1_all + (int64_t)t * TS, *part2 = part2_all + (int64_t)t * TS;
+    if (types[t] != 0) {                             // (uniform) 36-bit fixed point
+        FixRaw f;
+        fix_load(tile, wave, lane, f);
+        if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+        else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+        __syncthreads();
+        fix_tile_product(f, sI, sJ, sT, part1, part2);
+        return;
+    }
+    // float head + 16-bit tail, two halves of four row groups
+    const int c = lane & 15, g = lane >> 4;
+    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+    __syncthreads();
+    double rj[8], tc[8], v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+    const float *head = reinterpret_cast<const float *>(tile) + (wave * 32 + g) * TS + 4 * c;
+    const unsigned short *tail = reinterpret_cast<const unsigned short *>(tile + (size_t)TS * TS * 4) + (wave * 32 + g) * TS + 8 * c;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float4 ha[4], hb[4];
+        uint4 lq[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int rg = 4 * half + r4;
+            ha[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
+            hb[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
+            lq[r4] = *reinterpret_cast<const uint4 *>(tail + rg * 4 * TS);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int rg = 4 * half + r4;
+            const double ri = sI[wave * 32 + 4 * rg + g];
+            const float hh[8] = {ha[r4].x, ha[r4].y, ha[r4].z, ha[r4].w, hb[r4].x, hb[r4].y, hb[r4].z, hb[r4].w};
+            const unsigned int qq[8] = {lq[r4].x & 0xffffu, lq[r4].x >> 16, lq[r4].y & 0xffffu, lq[r4].y >> 16,
+                                        lq[r4].z & 0xffffu, lq[r4].z >> 16, lq[r4].w & 0xffffu, lq[r4].w >> 16};
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const double m0 = split_decode(hh[k], qq[k]), m1 = split_decode(hh[k + 1], qq[k + 1]);
+                tc[k] = opaque(fma(m0, ri, tc[k]));
+                tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
+                a0 = fma(m0, rj[k], a0);
+                a1 = fma(m1, rj[k + 1], a1);
+            }
+            v[rg] = a0 + a1;
+        }
+    }
+    tile_reduce_store(v, tc, sT, I != J, part1, part2);
 }
 
 // the same for a batch of problems that each own their matrix (windows): blockIdx.y = matrix, serving nrhs right-hand sides
@@ -1904,6 +2173,17 @@ int32_t launch_pack_tiles_split_batch(const double *M, int64_t np, int nbatch, u
     return LPVS_OK;
 }
 
+// mixed packing (single matrix): types = ntiles bytes after the tile slots; absmax = 8 bytes of device scratch
+int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s) {
+    const int nblk = (int)(np / TS);
+    LPVS_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, s, M, np * np, absmax);
+    const double step_scale = 0x1p-44 * std::sqrt(8192.0 / (double)np);
+    hipLaunchKernelGGL(pack_tiles_mixed_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, M, np, Mp, types, absmax, step_scale);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_pack_tiles_split(const double *M, int64_t np, unsigned char *Mp, hipStream_t s) {
     const int nblk = (int)(np / TS);
     hipLaunchKernelGGL(pack_tiles_split_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, M, np, Mp);
@@ -1923,9 +2203,10 @@ bool fused_ok(const AdmmParams &p) {
     return p.prox_kind == LPVS_PROX_GROUP_L2 && p.group_len <= TS && TS % p.group_len == 0 && p.n % p.group_len == 0;
 }
 
-static void launch_split(const unsigned char *Mp, const double *rhs, int64_t np, unsigned ntiles, double *part1, double *part2,
-                         const AdmmStatus *status, hipStream_t s) {
-    hipLaunchKernelGGL(symv_tile_split_kernel, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
+static void launch_split(const unsigned char *Mp, const unsigned char *types, const double *rhs, int64_t np, unsigned ntiles, double *part1,
+                         double *part2, const AdmmStatus *status, hipStream_t s) {
+    if (types != nullptr) hipLaunchKernelGGL(symv_tile_mixed_kernel, dim3(ntiles), dim3(256), 0, s, Mp, types, rhs, np, (int)ntiles, part1, part2, status);
+    else hipLaunchKernelGGL(symv_tile_split_kernel, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
 }
 
 // persistent grid of the wave-specialised multi-signal kernel: one workgroup per CU, evened out over the rounds so that
@@ -1977,7 +2258,7 @@ static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hip
         hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,
                            (int)ntiles, part1, part2, status);
     else if (p.mp_split)
-        launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, ntiles, part1, part2, status, s);
+        launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types, p.rhs, p.np, ntiles, part1, part2, status, s);
     else
         hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
 }

@@ -257,7 +257,10 @@ struct lpvs_problem {
     DevBuf G, b, M, x, z, u, rhs, bs, scratch, status, work, istat, part, Mp;
     bool M_valid = false; double M_shift = 0;
     bool Mp_valid = false;   // Mp is the packed copy of the CURRENT M (cleared whenever M is recomputed or G changes)
-    int Mp_mode = 0;         // storage of Mp: kMpF64 / kMpF32 / kMpSplit (see make_params)
+    int Mp_mode = 0;         // storage of Mp: kMpF64 / kMpF32 / kMpSplit / kMpMixed (see make_params)
+    double Mp_stream_bytes = 0;   // bytes of Mp one mat-vec launch reads (mixed storage: depends on the tile formats chosen)
+    int64_t Mp_fixed_tiles = 0;
+    bool Mp_demoted = false;      // mixed storage was asked for, but fewer than half of the tiles qualified: stored as split
     DevBuf xb; bool offset_form = false;   // xb = M * (signed b), computed at admm_init from the full-precision M (AdmmParams::xb)
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
@@ -326,15 +329,19 @@ int32_t copy_state_in(lpvs_problem *h, void *dev, const double *src) {
 }
 
 // storage of the tile-packed inverse streamed by the ADMM mat-vec of large problems
-enum { kMpNone = 0, kMpF64 = 1, kMpF32 = 2, kMpSplit = 3 };
-// LPVS_M_STORAGE = split (default) | f64: how a double-precision handle stores the tile-packed inverse its mat-vec streams.
-// split = float head + 16-bit tail (6 bytes, 40 significant bits, admm.hip); _f32 handles always stream floats.  Handles with
-// several right-hand sides decode the same 6-byte tiles on the way into the LDS image their matrix-core tile product reads.
+enum { kMpNone = 0, kMpF64 = 1, kMpF32 = 2, kMpSplit = 3, kMpMixed = 4 };
+// LPVS_M_STORAGE = mixed (default) | split | f64: how a double-precision handle stores the tile-packed inverse its mat-vec streams.
+// split = float head + 16-bit tail (6 bytes, 40 significant bits, admm.hip); mixed (single-signal handles) = the same, except that
+// tiles whose entries are all small against max|M| (the off-diagonal tiles of the LPV / Fourier inverses) are 36-bit fixed point
+// (4.53 bytes per element); _f32 handles always stream floats.  Handles with several right-hand sides decode 6-byte tiles on
+// the way into the LDS image their matrix-core tile product reads.
 int mp_mode_for(const lpvs_problem *h) {
     if (h->np < kSymmetricMinNp) return kMpNone;
     if (h->f32) return kMpF32;
     const char *e = getenv("LPVS_M_STORAGE");
-    return (e && std::string(e) == "f64") ? kMpF64 : kMpSplit;
+    if (e && std::string(e) == "f64") return kMpF64;
+    if (h->ns > 1 || (e && std::string(e) == "split")) return kMpSplit;
+    return kMpMixed;
 }
 
 AdmmParams make_params(const lpvs_problem *h) {
@@ -343,7 +350,8 @@ AdmmParams make_params(const lpvs_problem *h) {
                  h->rhs.as<double>(), h->mu, h->tol, h->prox_kind, h->prox_param, h->group_len, h->status.as<AdmmStatus>(),
                  h->scratch.as<double>(), h->part.as<double>(), sym ? h->Mp.as<double>() : nullptr, (int)h->ns};
     p.mp_f32 = sym && h->Mp_mode == kMpF32 ? 1 : 0;
-    p.mp_split = sym && h->Mp_mode == kMpSplit ? 1 : 0;
+    p.mp_split = sym && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed) ? 1 : 0;
+    p.mp_types = sym && h->Mp_mode == kMpMixed ? h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np) : nullptr;
     p.xb = sym && h->offset_form ? h->xb.as<double>() : nullptr;
     return p;
 }
@@ -984,13 +992,36 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     h->drop_graph();
     LPVS_TRY(factorize(h, 1.0 / mu));            // no-op when M is cached for this shift; clears Mp_valid otherwise
     const int mode = mp_mode_for(h);
-    if (h->np >= kSymmetricMinNp && (!h->Mp_valid || h->Mp_mode != mode)) {   // tile-packed lower triangle for the half-traffic mat-vec
-        const size_t elt = mode == kMpF32 ? 4 : (mode == kMpSplit ? 6 : 8);
-        if (!h->Mp.p || h->Mp.bytes < elt * symv_packed_doubles(h->np)) LPVS_TRY(h->Mp.alloc(elt * symv_packed_doubles(h->np)));
+    const bool demoted = mode == kMpMixed && h->Mp_mode == kMpSplit && h->Mp_demoted;   // mixed was tried for this M and found no small tiles
+    if (h->np >= kSymmetricMinNp && (!h->Mp_valid || (h->Mp_mode != mode && !demoted))) {   // tile-packed lower triangle for the half-traffic mat-vec
+        h->Mp_demoted = false;
+        const size_t elt = mode == kMpF32 ? 4 : (mode == kMpSplit || mode == kMpMixed ? 6 : 8);
+        const size_t ntiles = symv_packed_doubles(h->np) / (128 * 128);
+        const size_t need = elt * symv_packed_doubles(h->np) + (mode == kMpMixed ? ((ntiles + 255) / 256) * 256 + 256 : 0);   // + tile types + max|M|
+        if (!h->Mp.p || h->Mp.bytes < need) LPVS_TRY(h->Mp.alloc(need));
+        h->Mp_stream_bytes = (double)elt * (double)symv_packed_doubles(h->np);
+        h->Mp_fixed_tiles = 0;
         if (mode == kMpF32) LPVS_TRY(launch_pack_tiles_f32(h->M.as<double>(), h->np, h->Mp.as<float>(), s));
         else if (mode == kMpSplit) LPVS_TRY(launch_pack_tiles_split(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), s));
-        else LPVS_TRY(launch_pack_tiles(h->M.as<double>(), h->np, h->Mp.as<double>(), s));
-        h->Mp_valid = true; h->Mp_mode = mode;
+        else if (mode == kMpMixed) {
+            unsigned char *types = h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np);
+            LPVS_TRY(launch_pack_tiles_mixed(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), types,
+                                             reinterpret_cast<unsigned long long *>(types + ((ntiles + 255) / 256) * 256), s));
+            std::vector<unsigned char> ht(ntiles);
+            LPVS_HIP(hipMemcpyAsync(ht.data(), types, ntiles, hipMemcpyDeviceToHost, s));
+            LPVS_HIP(hipStreamSynchronize(s));
+            for (unsigned char t : ht) h->Mp_fixed_tiles += t != 0;
+            h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)kMixedFixedTileBytes + (double)(ntiles - (size_t)h->Mp_fixed_tiles) * (double)kMixedFloatTileBytes;
+            if (2 * (size_t)h->Mp_fixed_tiles < ntiles) {
+                // not a diagonally dominant inverse: the mixed kernel (three workgroups per CU, float-head tiles in two halves) would
+                // only lose against the plain 6-byte kernel -- store every tile in the float-head format
+                LPVS_TRY(launch_pack_tiles_split(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), s));
+                h->Mp_fixed_tiles = 0;
+                h->Mp_stream_bytes = 6.0 * (double)symv_packed_doubles(h->np);
+                h->Mp_valid = true; h->Mp_mode = kMpSplit; h->Mp_demoted = true;
+            }
+        } else LPVS_TRY(launch_pack_tiles(h->M.as<double>(), h->np, h->Mp.as<double>(), s));
+        if (!(mode == kMpMixed && h->Mp_mode == kMpSplit && h->Mp_valid)) { h->Mp_valid = true; h->Mp_mode = mode; }
     }
     LPVS_HIP(hipMemsetAsync(h->part.p, 0, h->part.bytes, s));   // zero the ticket / block norms
     h->mu = mu; h->tol = tol; h->sign = linear_sign;
@@ -1004,7 +1035,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     if (linear_sign < 0) for (auto &q : hb) q = -q;
     LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
     // reduced-precision copies of M (split, f32) are only ever applied to (z-u)/mu: x = xb + M~ (z-u)/mu, xb = M b in full precision
-    h->offset_form = h->np >= kSymmetricMinNp && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpF32) && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
+    h->offset_form = h->np >= kSymmetricMinNp && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
     if (h->offset_form) {
         if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
         LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->bs.as<double>(), h->xb.as<double>(), s, (int)h->ns));   // every signal's M b
@@ -1087,7 +1118,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     return LPVS_OK;
 }
 
-/* 0: full symmetric matrix (plain mat-vec, n < 2048), 1: tile-packed doubles, 2: tile-packed floats, 3: tile-packed split */
+/* 0: full symmetric matrix (plain mat-vec, n < 2048), 1: tile-packed doubles, 2: tile-packed floats, 3: tile-packed split, 4: mixed */
 int32_t lpvs_admm_matvec_kind(lpvs_problem *h, int32_t *kind) {
     if (!h || !kind) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited) { set_error("lpvs_admm_matvec_kind before lpvs_admm_init"); return LPVS_ESTATE; }
@@ -1109,8 +1140,7 @@ int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_laun
     LPVS_HIP(hipEventRecord(h->ev[1].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     *us_per_launch = h->ev[1].ms() * 1e3 / reps;
-    const double elt = !sym ? 8.0 : (h->Mp_mode == kMpF32 ? 4.0 : (h->Mp_mode == kMpSplit ? 6.0 : 8.0));
-    if (bytes_per_launch) *bytes_per_launch = elt * (double)(sym ? symv_packed_doubles(h->np) : (size_t)h->np * (size_t)h->np);
+    if (bytes_per_launch) *bytes_per_launch = sym ? h->Mp_stream_bytes : 8.0 * (double)h->np * (double)h->np;
     return LPVS_OK;
 }
 

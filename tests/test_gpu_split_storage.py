@@ -1,6 +1,8 @@
-"""6-byte ("split": float head + 16-bit tail, 40 significant bits) storage of the tile-packed inverse streamed by the ADMM
-mat-vec of large single-signal problems (the default of _f64 handles), against the 8-byte storage (LPVS_M_STORAGE=f64) and
-the CPU oracle.  GPU only.
+"""Reduced storage of the tile-packed inverse streamed by the ADMM mat-vec of large single-signal problems, against the 8-byte
+storage (LPVS_M_STORAGE=f64) and the CPU oracle.  GPU only.
+  split: float head + 16-bit tail, 40 significant bits, 6 bytes per element (LPVS_M_STORAGE=split)
+  mixed: the default -- split for the diagonal tiles, 36-bit fixed point with a per-row step (4.53 bytes) for tiles whose entries
+         are all small against max|M| (decided per tile when packing; admm.hip)
 
 The split form adds a relative error <= 2^-40 = 9.1e-13 per element of M = (G + I/mu)^-1.  Applied naively (x = M~ (b + v))
 that error is amplified by cond(G + I/mu): measured 5.3e-9 rel-L2 in z at the cfg3 size, above the 1e-9 parity bound.  The
@@ -52,12 +54,15 @@ def test_split_and_f64_storage_against_oracle(L, oracle, kind):
                    "l1": (L.NormL1(1.0), oracle.NormL1(1.0)),
                    "ball": (L.IndBallL0(20), oracle.IndBallL0(20))}[kind]
     rs = _solve(L, y, X, V, w, Nv, prox, 300, 0.0, "split")
+    rm = _solve(L, y, X, V, w, Nv, prox, 300, 0.0, None)         # the default: mixed
     rd = _solve(L, y, X, V, w, Nv, prox, 300, 0.0, "f64")
     npk = 2176 * (2176 + 128) // 2
     assert rs["info"]["kernel"] == "symv_tile_split_kernel" and rs["nbytes"] == 6 * npk
+    # few samples: hardly any tile of this inverse is small enough for fixed point, and the handle falls back to the 6-byte format
+    assert rm["info"]["kernel"] == "symv_tile_split_kernel" and rm["nbytes"] == 6 * npk
     assert rd["info"]["kernel"] == "symv_tile_kernel<double>" and rd["nbytes"] == 8 * npk
     ro = oracle.admm_gram(rs["G"], rs["b"], oprox, iters=300, tol=0.0, mu=0.05)
-    for r in (rs, rd):
+    for r in (rs, rm, rd):
         assert r["it"] == 300
         assert rel(r["z"], ro["z"]) <= 1e-9 and rel(r["x"], ro["x"]) <= 1e-9 and rel(r["u"], ro["u"]) <= 1e-9, (kind, rel(r["z"], ro["z"]))
         assert np.array_equal(r["z"] != 0, ro["z"] != 0)
@@ -69,11 +74,14 @@ def test_split_storage_single_matvec_accuracy_and_stopping_iteration(L, oracle):
     y, X, V, w = _lpv_problem(3000, Nf, Nv, 6)
     prox = L.SlicedSeparableSum.frequency_groups(3.0, Nf, 2 * Nv)
     a = _solve(L, y, X, V, w, Nv, prox, 1, 0.0, "split")
+    m = _solve(L, y, X, V, w, Nv, prox, 1, 0.0, None)
     b = _solve(L, y, X, V, w, Nv, prox, 1, 0.0, "f64")
     assert rel(a["x"], b["x"]) <= 5e-12, rel(a["x"], b["x"])      # one mat-vec: 2^-40 per element, no cancellation to speak of
+    assert rel(m["x"], b["x"]) <= 5e-12, rel(m["x"], b["x"])      # mixed: the fixed-point tiles add about a quarter to that
     ro = oracle.admm_gram(a["G"], a["b"], oracle.GroupL2(3.0, 2 * Nv), iters=5000, tol=1e-6, mu=0.05)
-    c = _solve(L, y, X, V, w, Nv, prox, 5000, 1e-6, "split")
-    assert c["conv"] and c["it"] == ro["iters"] and rel(c["z"], ro["z"]) <= 1e-9
+    for st in ("split", None):
+        c = _solve(L, y, X, V, w, Nv, prox, 5000, 1e-6, st)
+        assert c["conv"] and c["it"] == ro["iters"] and rel(c["z"], ro["z"]) <= 1e-9
 
 
 def test_split_storage_extreme_values_roundtrip(L):
@@ -87,13 +95,16 @@ def test_split_storage_extreme_values_roundtrip(L):
     G = np.diag(d) + B @ B.T
     bvec = rng.standard_normal(n)
     outs = {}
-    for storage in ("split", "f64"):
+    for storage in ("split", "mixed", "f64"):
         if storage:
             os.environ["LPVS_M_STORAGE"] = storage
         try:
             with L.Problem.gram(G, bvec) as p:
                 p.set_prox(L.NormL1(1e-3))
                 p.admm_init(None, μ=1.0, tol=0.0)
+                if storage == "mixed":                            # a diagonally dominant inverse: every off-diagonal tile is fixed point
+                    nfixed = round((6 * 2048 * (2048 + 128) // 2 - p.time_matvec(1)[1]) / (98304 - 74240))
+                    assert nfixed == 16 * 15 // 2, nfixed
                 p.admm_run(1)
                 outs[storage] = p.admm_get()[0]                  # x after the first iteration = M b
         finally:
@@ -102,6 +113,7 @@ def test_split_storage_extreme_values_roundtrip(L):
     xe = Minv @ bvec
     assert rel(outs["f64"], xe) <= 1e-11
     assert rel(outs["split"], xe) <= 1e-11 and rel(outs["split"], outs["f64"]) <= 3e-12
+    assert rel(outs["mixed"], xe) <= 1e-11 and rel(outs["mixed"], outs["f64"]) <= 3e-12
 
 
 def test_split_vs_f64_at_cfg3_fullsize(L):
@@ -110,7 +122,7 @@ def test_split_vs_f64_at_cfg3_fullsize(L):
     y, X, V, w = bench.synth_signal(1 << 20, 512, 0, torch.device("cuda"))
     prox = L.SlicedSeparableSum.frequency_groups(5.0, 512, 16)
     out = {}
-    for st in ("split", "f64"):
+    for st in ("mixed", "split", "f64"):
         os.environ["LPVS_M_STORAGE"] = st
         try:
             with L.Problem.lpv(y, X, V, w, 8) as p:
@@ -121,8 +133,9 @@ def test_split_vs_f64_at_cfg3_fullsize(L):
                 out[st] = (p.admm_get()[1], us, nb)
         finally:
             os.environ.pop("LPVS_M_STORAGE", None)
-    r = rel(out["split"][0], out["f64"][0])
-    print(f"cfg3 N=2^20 2000 iterations: rel-L2(z split vs f64) = {r:.3e}; mat-vec {out['split'][1]:.2f} us ({out['split'][2] / out['split'][1] * 1e-6:.0f} GB/s) "
-          f"vs {out['f64'][1]:.2f} us ({out['f64'][2] / out['f64'][1] * 1e-6:.0f} GB/s)")
-    assert np.array_equal(out["split"][0] != 0, out["f64"][0] != 0)
-    assert r <= 1e-9, r                                          # measured 1.2e-10 (offset form); 5.3e-9 without it
+    for st in ("mixed", "split"):
+        r = rel(out[st][0], out["f64"][0])
+        print(f"cfg3 N=2^20 2000 iterations: rel-L2(z {st} vs f64) = {r:.3e}; mat-vec {out[st][1]:.2f} us ({out[st][2] * 1e-6:.1f} MB, {out[st][2] / out[st][1] * 1e-6:.0f} GB/s) "
+              f"vs {out['f64'][1]:.2f} us ({out['f64'][2] / out['f64'][1] * 1e-6:.0f} GB/s)")
+        assert np.array_equal(out[st][0] != 0, out["f64"][0] != 0)
+        assert r <= 1e-9, r                                      # measured 1.2e-10 (split, offset form; 5.3e-9 without it)
