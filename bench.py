@@ -278,17 +278,18 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         return None
     tm["matvec_us_per_iteration"] = tm_mv.get("matvec_us_per_iteration")
     tm["matvec_windows"] = tm_mv.get("matvec_windows")
-    elt = 8 if os.environ.get("LPVS_M_STORAGE") == "f64" else 6      # bytes per stored element of the packed inverses (admm.hip)
-    np_, ntile_bytes = 512, elt * (512 * (512 + 128) // 2)
+    st = os.environ.get("LPVS_M_STORAGE", "mixed")                 # storage of the packed inverses (admm.hip)
     mv_us = tm.get("matvec_us_per_iteration")
     roof = None
     if mv_us:
         nmv = tm.get("matvec_windows") or (hi - lo)
-        achieved = nmv * ntile_bytes / (mv_us * 1e-6) * 1e-9
-        roof = {"bound": "hbm", "kernel": ("symv_tile_split_batch_kernel" if elt == 6 else "symv_tile_batch_kernel") +
-                          " (one tile-packed (Q + I/mu)^-1 per window in %d-byte elements, all windows of the shard per launch)" % elt,
+        mv_bytes = tm_mv.get("matvec_bytes_per_launch") or nmv * (8 if st == "f64" else 6) * (512 * (512 + 128) // 2)
+        achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
+        kern = {"f64": "symv_tile_batch_kernel (8-byte elements)", "split": "symv_tile_split_batch_kernel (6-byte elements)"}.get(
+            st, "symv_tile_mixed_batch_kernel (6-byte float-head tiles on the diagonal, 36-bit fixed-point tiles elsewhere)")
+        roof = {"bound": "hbm", "kernel": kern + ": one tile-packed (Q + I/mu)^-1 per window, all windows of the shard per launch",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": nmv * ntile_bytes, "launch_us": mv_us, "windows_per_launch": nmv, "launches_per_step": iters,
+                "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "windows_per_launch": nmv, "launches_per_step": iters,
                 "note": "HIP events around 200 back-to-back launches of the batch mat-vec on the library's stream (rank 0's shard)"}
     out = {
         "metric": "windows/sec, ls_windowpsd estimator=ls_sparse_spectral (NormL1), %d windows x N=2^%d, Nf=%d, %d ADMM iters per window"

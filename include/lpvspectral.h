@@ -263,9 +263,10 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
                                   int32_t linear_sign, int64_t win_lo, int64_t win_hi, int32_t device,
                                   double *x_re, double *x_im, double *S_out, int64_t *iters_out);
 
-/* phase times of the calling thread's last batched-window call (HIP events on the library's stream), out[0..7]:
+/* phase times of the calling thread's last batched-window call (HIP events on the library's stream), out[0..9]:
  * Gram + rhs ms, inverse ms, ADMM / dense-solve ms, windows, batch mat-vec microseconds per launch (only when the environment
- * has LPVS_WINDOW_MATVEC_TIMING: 200 extra launches after the last pass), windows of that pass, passes, 1 if structured Gram */
+ * has LPVS_WINDOW_MATVEC_TIMING: 200 extra launches after the last pass), windows of that pass, passes, 1 if structured Gram,
+ * bytes of packed inverses one of those timed launches reads, reserved */
 int32_t lpvs_windowpsd_last_timing(double *out, int32_t n_out);
 
 /* estimator of the batched-window engine */

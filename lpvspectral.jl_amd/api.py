@@ -711,11 +711,11 @@ def windowpsd_sparse_batched(y, t, freqs, n, noverlap=-1, W=None, proxg=None, λ
 
 def windowpsd_last_timing():
     """Phase times (HIP events) of this thread's last batched-window call."""
-    o = np.zeros(8)
-    check(lib().lpvs_windowpsd_last_timing(out_ptr(o), 8))
+    o = np.zeros(10)
+    check(lib().lpvs_windowpsd_last_timing(out_ptr(o), 10))
     d = dict(gram_rhs_ms=o[0], inverse_ms=o[1], solve_ms=o[2], windows=int(o[3]), passes=int(o[6]), structured_gram=bool(o[7]))
     if o[4] > 0:
-        d["matvec_us_per_iteration"] = float(o[4]); d["matvec_windows"] = int(o[5])
+        d["matvec_us_per_iteration"] = float(o[4]); d["matvec_windows"] = int(o[5]); d["matvec_bytes_per_launch"] = float(o[8])
     return d
 
 

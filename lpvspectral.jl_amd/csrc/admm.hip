@@ -11,6 +11,7 @@
 // can be enqueued without a host round trip and still stop at exactly the reference's iteration.
 #include "lpvs_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -682,6 +683,8 @@ __device__ __forceinline__ void tile_reduce_store(double (&v)[8], double (&tc)[8
 
 __global__ void __launch_bounds__(256)
 absmax_kernel(const double *__restrict__ M, int64_t count, unsigned long long *__restrict__ out) {
+    M += (int64_t)blockIdx.y * count;                // blockIdx.y = matrix of a batch
+    out += blockIdx.y;
     double m = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) m = fmax(m, fabs(M[i]));
 #pragma unroll
@@ -689,12 +692,16 @@ absmax_kernel(const double *__restrict__ M, int64_t count, unsigned long long *_
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));   // positive doubles order like integers
 }
 
-// mixed packing of ONE matrix: tile blockIdx.x -> float-head format or fixed point; types[blockIdx.x] says which
+// mixed packing: tile blockIdx.x of matrix blockIdx.y -> float-head format or fixed point; types[matrix][tile] says which
 __global__ void __launch_bounds__(256)
 pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char *__restrict__ Mp, unsigned char *__restrict__ types,
                         const unsigned long long *__restrict__ absmax_bits, double step_scale) {
     int I, J;
     tile_index(blockIdx.x, I, J);
+    M += (int64_t)blockIdx.y * np * np;              // blockIdx.y = matrix of a batch
+    Mp += (size_t)blockIdx.y * gridDim.x * kSplitTileBytes;
+    types += (size_t)blockIdx.y * gridDim.x;
+    absmax_bits += blockIdx.y;
     const double *src = M + (int64_t)I * TS * np + (int64_t)J * TS;
     unsigned char *slot = Mp + (size_t)blockIdx.x * kSplitTileBytes;
     __shared__ float rowstep[TS];
@@ -983,6 +990,87 @@ symv_tile_mixed_kernel(const unsigned char *__restrict__ Mp, const unsigned char
         }
     }
     tile_reduce_store(v, tc, sT, I != J, part1, part2);
+}
+
+// mixed storage for a batch of problems that each own their matrix (windows): blockIdx.y = matrix, serving nrhs right-hand sides
+// (one right-hand side per matrix only: a loop over right-hand sides around the tile held in registers does not fit the 168
+// registers of three workgroups per CU -- batches with several signals per window keep the uniform 6-byte kernel)
+__global__ void __launch_bounds__(256, 3)
+symv_tile_mixed_batch_kernel(const unsigned char *__restrict__ Mp_all, const unsigned char *__restrict__ types_all, size_t mp_stride,
+                             const double *__restrict__ rhs_all, int64_t np, int ntiles, double *__restrict__ part1_all,
+                             double *__restrict__ part2_all, const AdmmStatus *status) {
+    constexpr int nrhs = 1;
+    const int mat = blockIdx.y;
+    {
+        bool all = status != nullptr;
+        for (int r = 0; r < nrhs && all; ++r) all = status[mat * nrhs + r].converged != 0;
+        if (all) return;
+    }
+    __shared__ double sI[TS], sJ[TS], sT[4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char *tile = Mp_all + (size_t)mat * mp_stride + (size_t)t * kSplitTileBytes;
+    auto stage_rhs = [&](int sg, int rr) {            // right-hand side sg's blocks I and J -> LDS
+        const double *rhs = rhs_all + (int64_t)sg * np;
+        if (rr > 0) __syncthreads();   // previous right-hand side's readers are done with sI / sJ / sT
+        if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+        else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+        __syncthreads();
+    };
+    if (types_all[(size_t)mat * ntiles + t] != 0) {  // (uniform) 36-bit fixed point: the tile stays in registers for every right-hand side
+        FixRaw f;
+        fix_load(tile, wave, lane, f);
+        stage_rhs(mat, 0);
+        fix_tile_product(f, sI, sJ, sT, part1_all + ((int64_t)mat * ntiles + t) * TS, part2_all + ((int64_t)mat * ntiles + t) * TS);
+        return;
+    }
+    // float head + 16-bit tail, two halves of four row groups
+    const int c = lane & 15, g = lane >> 4;
+    const float *head = reinterpret_cast<const float *>(tile) + (wave * 32 + g) * TS + 4 * c;
+    const unsigned short *tail = reinterpret_cast<const unsigned short *>(tile + (size_t)TS * TS * 4) + (wave * 32 + g) * TS + 8 * c;
+    for (int rr = 0; rr < nrhs; ++rr) {
+        const int sg = mat * nrhs + rr;
+        if (status != nullptr && status[sg].converged) continue;   // uniform
+        stage_rhs(sg, rr);
+        double rj[8], tc[8], v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 ha[4], hb[4];
+            uint4 lq[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rg = 4 * half + r4;
+                ha[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
+                hb[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
+                lq[r4] = *reinterpret_cast<const uint4 *>(tail + rg * 4 * TS);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rg = 4 * half + r4;
+                const double ri = sI[wave * 32 + 4 * rg + g];
+                const float hh[8] = {ha[r4].x, ha[r4].y, ha[r4].z, ha[r4].w, hb[r4].x, hb[r4].y, hb[r4].z, hb[r4].w};
+                const unsigned int qq[8] = {lq[r4].x & 0xffffu, lq[r4].x >> 16, lq[r4].y & 0xffffu, lq[r4].y >> 16,
+                                            lq[r4].z & 0xffffu, lq[r4].z >> 16, lq[r4].w & 0xffffu, lq[r4].w >> 16};
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    const double m0 = split_decode(hh[k], qq[k]), m1 = split_decode(hh[k + 1], qq[k + 1]);
+                    tc[k] = opaque(fma(m0, ri, tc[k]));
+                    tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
+                    a0 = fma(m0, rj[k], a0);
+                    a1 = fma(m1, rj[k + 1], a1);
+                }
+                v[rg] = a0 + a1;
+            }
+        }
+        tile_reduce_store(v, tc, sT, I != J, part1_all + ((int64_t)sg * ntiles + t) * TS, part2_all + ((int64_t)sg * ntiles + t) * TS);
+    }
 }
 
 // the same for a batch of problems that each own their matrix (windows): blockIdx.y = matrix, serving nrhs right-hand sides
@@ -2013,6 +2101,11 @@ int32_t launch_pack_tiles_batch(const double *M, int64_t np, int nbatch, double 
 
 bool fused_ok(const AdmmParams &p);
 
+static void launch_mixed_batch(const AdmmBatch &p, unsigned ntiles, unsigned ns, double *part1, double *part2, const AdmmStatus *status, hipStream_t s) {
+    hipLaunchKernelGGL(symv_tile_mixed_batch_kernel, dim3(ntiles, ns), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
+                       (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, part1, part2, status);
+}
+
 int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s) {
     // packed-symmetric form (half the matrix bytes per iteration) when the batch has tile-packed matrices and the
     // prox can be fused; AdmmParams with ns = nbatch has the layout the fused update kernel expects
@@ -2027,7 +2120,9 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
         unsigned int *ticket = reinterpret_cast<unsigned int *>(blocknorm + (size_t)nblk * ns);
         const int nrhs = p.nrhs > 0 ? p.nrhs : 1;
         for (int64_t i = 0; i < iters; ++i) {
-            if (p.mp_split)
+            if (p.mp_split && p.mp_types && nrhs == 1)
+                launch_mixed_batch(p, ntiles, ns, part1, part2, p.status, s);
+            else if (p.mp_split)
                 hipLaunchKernelGGL(symv_tile_split_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp),
                                    (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, nrhs, part1, part2, p.status);
             else
@@ -2056,7 +2151,9 @@ int32_t launch_admm_batch_matvec_only(const AdmmBatch &p, int reps, hipStream_t 
     const int nrhs = p.nrhs > 0 ? p.nrhs : 1;
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     for (int i = 0; i < reps; ++i) {
-        if (p.mp_split)
+        if (p.mp_split && p.mp_types && nrhs == 1)
+            launch_mixed_batch(p, ntiles, ns, part1, part2, nullptr, s);
+        else if (p.mp_split)
             hipLaunchKernelGGL(symv_tile_split_batch_kernel, dim3(ntiles, ns / (unsigned)nrhs), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp),
                                (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, nrhs, part1, part2, (const AdmmStatus *)nullptr);
         else
@@ -2175,11 +2272,19 @@ int32_t launch_pack_tiles_split_batch(const double *M, int64_t np, int nbatch, u
 
 // mixed packing (single matrix): types = ntiles bytes after the tile slots; absmax = 8 bytes of device scratch
 int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s) {
+    return launch_pack_tiles_mixed_batch(M, np, 1, Mp, types, absmax, s);
+}
+
+// ... of nbatch matrices: types = [nbatch][ntiles] bytes, absmax = nbatch * 8 bytes of device scratch
+int32_t launch_pack_tiles_mixed_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, unsigned char *types, unsigned long long *absmax,
+                                      hipStream_t s) {
     const int nblk = (int)(np / TS);
-    LPVS_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, s, M, np * np, absmax);
+    LPVS_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned long long) * (size_t)nbatch, s));
+    const int64_t count = np * np;
+    const unsigned gx = (unsigned)std::min<int64_t>(1024, ceil_div(count, 256 * 8));
+    hipLaunchKernelGGL(absmax_kernel, dim3(gx, (unsigned)nbatch), dim3(256), 0, s, M, count, absmax);
     const double step_scale = 0x1p-44 * std::sqrt(8192.0 / (double)np);
-    hipLaunchKernelGGL(pack_tiles_mixed_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, M, np, Mp, types, absmax, step_scale);
+    hipLaunchKernelGGL(pack_tiles_mixed_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2), (unsigned)nbatch), dim3(256), 0, s, M, np, Mp, types, absmax, step_scale);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

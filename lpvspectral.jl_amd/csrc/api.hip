@@ -1301,7 +1301,7 @@ namespace {
 // phase times (ms) of the calling thread's last engine call: [0] Gram + rhs, [1] inverse (+ pack), [2] ADMM iterations or dense
 // solves, [3] windows, [4] batch mat-vec microseconds per launch (LPVS_WINDOW_MATVEC_TIMING=1 only, last pass), [5] windows of
 // that pass, [6] passes, [7] 1 if the structured Gram was used
-thread_local double g_win_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_win_timing[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] = bytes of packed inverses one timed mat-vec launch reads
 
 // sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations) is called in window order, signals innermost
 template <class Sink>
@@ -1501,6 +1501,17 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
             // where the tile-packed path runs at all (LPVS_M_STORAGE=f64: doubles)
             const bool split = split_storage && admm_batch_uses_tiles(ab);
             if (split) {
+                // mixed storage (36-bit fixed-point tiles where a window's inverse is small; the Fourier inverses are nearly diagonal):
+                // tile formats and the per-matrix max|M| live behind the 6-byte slots of the Mp buffer (sized for doubles)
+                static const bool mixed = [] { const char *e = getenv("LPVS_M_STORAGE"); return !(e && std::string(e) == "split"); }();
+                const size_t nt = symv_packed_doubles(np) / (128 * 128);
+                unsigned char *types = Mp.as<unsigned char>() + 6 * symv_packed_doubles(np) * (size_t)bw;
+                const size_t types_bytes = ((nt * (size_t)bw + 255) / 256) * 256;
+                if (mixed && ns == 1 && 6 * symv_packed_doubles(np) * (size_t)bw + types_bytes + 8 * (size_t)bw <= Mp.bytes) {
+                    LPVS_TRY(launch_pack_tiles_mixed_batch(M.as<double>(), np, nb_, Mp.as<unsigned char>(), types,
+                                                           reinterpret_cast<unsigned long long *>(types + types_bytes), s));
+                    ab.mp_types = types;
+                } else
                 LPVS_TRY(launch_pack_tiles_split_batch(M.as<double>(), np, nb_, Mp.as<unsigned char>(), s));
                 LPVS_TRY(launch_batch_matvec(M.as<double>(), np, nprob, (int)ns, bvec.as<double>(), xb.as<double>(), s));   // xb = M b, full precision
                 ab.xb = xb.as<double>(); ab.mp_split = 1;
@@ -1533,6 +1544,17 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
                 LPVS_HIP(hipEventRecord(ev[3].b, s));
                 LPVS_HIP(hipStreamSynchronize(s));
                 g_win_timing[4] = ev[3].ms() * 1e3 / 200; g_win_timing[5] = nb_;
+                const size_t nt = symv_packed_doubles(np) / (128 * 128);
+                double bytes = (double)(ab.mp_split ? 6 : 8) * (double)symv_packed_doubles(np) * (double)nb_;
+                if (ab.mp_types) {
+                    std::vector<unsigned char> ht(nt * (size_t)nb_);
+                    LPVS_HIP(hipMemcpyAsync(ht.data(), ab.mp_types, ht.size(), hipMemcpyDeviceToHost, s));
+                    LPVS_HIP(hipStreamSynchronize(s));
+                    size_t nfix = 0;
+                    for (unsigned char t : ht) nfix += t != 0;
+                    bytes = (double)nfix * (double)kMixedFixedTileBytes + (double)(ht.size() - nfix) * (double)kMixedFloatTileBytes;
+                }
+                g_win_timing[8] = bytes;
             }
             tr.mark("admm");
             sol = z.as<double>();
@@ -1576,15 +1598,15 @@ struct HostOut {
 
 namespace lpvs {
 int32_t windows_engine_run(const WinJob &job, const WinSink &sink) { return windows_engine(job, sink); }
-void windows_last_timing(double *out8) { for (int i = 0; i < 8; ++i) out8[i] = g_win_timing[i]; }
-void windows_set_timing(const double *in8) { for (int i = 0; i < 8; ++i) g_win_timing[i] = in8[i]; }
+void windows_last_timing(double *out10) { for (int i = 0; i < 10; ++i) out10[i] = g_win_timing[i]; }
+void windows_set_timing(const double *in10) { for (int i = 0; i < 10; ++i) g_win_timing[i] = in10[i]; }
 }  // namespace lpvs
 
 extern "C" {
 
 int32_t lpvs_windowpsd_last_timing(double *out, int32_t n_out) {
     if (!out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
-    for (int i = 0; i < n_out && i < 8; ++i) out[i] = g_win_timing[i];
+    for (int i = 0; i < n_out && i < 10; ++i) out[i] = g_win_timing[i];
     return LPVS_OK;
 }
 

@@ -194,6 +194,8 @@ int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s
 int32_t launch_pack_tiles_f32(const double *M, int64_t np, float *Mp, hipStream_t s);
 int32_t launch_pack_tiles_split(const double *M, int64_t np, unsigned char *Mp, hipStream_t s);   // 6 * symv_packed_doubles(np) bytes
 int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s);
+int32_t launch_pack_tiles_mixed_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, unsigned char *types, unsigned long long *absmax,
+                                      hipStream_t s);
 constexpr size_t kMixedFixedTileBytes = 128 * 128 * 4 + 128 * 128 / 2 + 128 * 4, kMixedFloatTileBytes = 128 * 128 * 6;
 // element conversions for the _f32 entry points (device buffers)
 int32_t launch_cvt_f32_f64(const float *src, double *dst, int64_t count, hipStream_t s);
@@ -216,6 +218,7 @@ struct AdmmBatch {
     int nrhs = 1;         // problems per matrix: problem q uses matrix q / nrhs (signals sharing a window's Gram)
     const double *xb = nullptr;   // offset form: x = xb + M~ (z-u)/mu, xb = M b per problem ([nbatch][np]); nullptr: classic
     int mp_split = 0;     // Mp holds 6-byte elements (float head + 16-bit tail)
+    const unsigned char *mp_types = nullptr;   // mixed storage: [matrix][tile] formats (1 = 36-bit fixed point), see admm.hip
 };
 bool admm_batch_uses_tiles(const AdmmBatch &p);   // will launch_admm_batch_iterations take the tile-packed path for this batch?
 int32_t launch_batch_matvec(const double *A, int64_t np, int nprob, int nrhs, const double *v, double *out, hipStream_t s);   // out_q = A[q / nrhs] v_q
@@ -254,7 +257,7 @@ struct WinJob {
 // sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations): window order, signals innermost
 typedef std::function<void(int64_t, int64_t, const double *, const double *, int64_t)> WinSink;
 int32_t windows_engine_run(const WinJob &job, const WinSink &sink);
-void windows_last_timing(double *out8);           // the calling thread's last engine call
-void windows_set_timing(const double *in8);
+void windows_last_timing(double *out10);          // the calling thread's last engine call
+void windows_set_timing(const double *in10);
 
 }  // namespace lpvs

@@ -83,7 +83,7 @@ struct Shard {
     hipStream_t stream = nullptr;
     int32_t rc = LPVS_OK;
     std::string err;
-    double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double timing[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 }  // namespace
@@ -178,8 +178,8 @@ int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const doubl
     struct Cleanup { std::vector<Shard> &s; ~Cleanup() { for (auto &S : s) if (S.stream) { (void)hipSetDevice(S.device); (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); } } } cleanup{sh};
     for (auto &S : sh) if (S.rc != LPVS_OK) { set_error("device %d (windows [%lld,%lld)): %s", S.device, (long long)S.lo, (long long)S.hi, S.err.c_str()); return S.rc; }
     {   // timing of the call = the slowest shard's phases
-        double tmax[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (auto &S : sh) for (int i = 0; i < 8; ++i) if (S.timing[i] > tmax[i]) tmax[i] = S.timing[i];
+        double tmax[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (auto &S : sh) for (int i = 0; i < 10; ++i) if (S.timing[i] > tmax[i]) tmax[i] = S.timing[i];
         tmax[3] = (double)k;
         windows_set_timing(tmax);
     }
