@@ -634,8 +634,10 @@ pack_tiles_split_kernel(const double *__restrict__ M, int64_t np, unsigned char 
 // Measured on cfg3's inverse (tools/quant_study.py): |dM v| / |x| = 3.9e-13 with these tiles against 3.2e-13 with 40-bit
 // elements everywhere (32-bit fixed point: 3.8e-12).  Eligibility is decided per tile when packing: every row's step must be
 // <= 2^-44 * max|M| * sqrt(8192 / np) (the fixed-point errors of a row add up over ~np entries); diagonal tiles and tiles
-// that fail keep the 6-byte float-head format, so a matrix without this structure loses nothing.  tile type: 0 = float head
-// + 16-bit tail, 1 = fixed point.  Decoding: v_bfe_u32, v_alignbit_b32, v_lshl_or_b32, one v_add_f64 (exact integer in a double);
+// that fail keep the 6-byte float-head format, so a matrix without this structure loses nothing.  A DIAGONAL tile whose entries
+// off the main diagonal pass the same test is stored as fixed point too, with its 128 diagonal entries apart in doubles (1024 B
+// after the steps; their fixed-point value is 0) -- the nearly diagonal inverses of the Fourier windows.  tile type: 0 = float
+// head + 16-bit tail, 1 = fixed point, 2 = fixed point + double diagonal.  Decoding: v_bfe_u32, v_alignbit_b32, v_lshl_or_b32, one v_add_f64 (exact integer in a double);
 // the row step multiplies the row sum once and the row's right-hand-side value once (for the transposed product).
 // Layouts follow the lane ownership of the split kernel (lane (g, c) of wave w: rows 32w + 4rg + g, columns 4c+k, 64+4c+k):
 //   nibbles: dword (w*64 + lane)*8 + rg holds the row group's 8 nibbles, nibble k at bits 4k (k < 4: column 4c+k, else 64+4c+k-4)
@@ -646,7 +648,8 @@ constexpr size_t kFixHeadBytes = (size_t)TS * TS * 4, kFixNibBytes = (size_t)TS 
 // tc[k] = its partial column sums of its 8 columns; row sums by a halving butterfly over the 16 column lanes, column sums over the
 // wave's four row lanes and then over the four waves through LDS.  All 256 threads call it.
 __device__ __forceinline__ void tile_reduce_store(double (&v)[8], double (&tc)[8], double (*sT)[TS], bool offdiag,
-                                                  double *__restrict__ part1, double *__restrict__ part2) {
+                                                  double *__restrict__ part1, double *__restrict__ part2,
+                                                  const double *__restrict__ diag = nullptr, const double *sI = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -661,7 +664,8 @@ __device__ __forceinline__ void tile_reduce_store(double (&v)[8], double (&tc)[8
     v[0] += __shfl_xor(v[0], 1, 64);
     if ((c & 1) == 0) {
         const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
-        part1[wave * 32 + 4 * rg + g] = v[0];
+        const int row = wave * 32 + 4 * rg + g;
+        part1[row] = diag != nullptr ? fma(diag[row], sI[row], v[0]) : v[0];   // (a diagonal tile whose diagonal is kept apart in doubles)
     }
     if (offdiag) {
 #pragma unroll
@@ -707,12 +711,14 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
     __shared__ float rowstep[TS];
     __shared__ int bad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) bad = (I == J);
+    if (threadIdx.x == 0) bad = 0;
     __syncthreads();
-    if (I != J) {
+    {
         const double limit = __longlong_as_double((long long)*absmax_bits) * step_scale;     // largest admissible step
         for (int r = wave; r < TS; r += 4) {
-            double m = fmax(fabs(src[(int64_t)r * np + lane]), fabs(src[(int64_t)r * np + 64 + lane]));
+            const double e0 = (I == J && lane == r) ? 0.0 : fabs(src[(int64_t)r * np + lane]);          // (a diagonal tile: without its diagonal)
+            const double e1 = (I == J && 64 + lane == r) ? 0.0 : fabs(src[(int64_t)r * np + 64 + lane]);
+            double m = fmax(e0, e1);
 #pragma unroll
             for (int w = 32; w >= 1; w >>= 1) m = fmax(m, __shfl_xor(m, w, 64));
             if (lane == 0) {
@@ -726,7 +732,7 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
     }
     __syncthreads();
     const bool fixed = !bad;
-    if (threadIdx.x == 0) types[blockIdx.x] = fixed ? 1 : 0;
+    if (threadIdx.x == 0) types[blockIdx.x] = fixed ? (I == J ? 2 : 1) : 0;
     if (!fixed) {
         float *head = reinterpret_cast<float *>(slot);
         unsigned short *tail = reinterpret_cast<unsigned short *>(slot + (size_t)TS * TS * 4);
@@ -755,7 +761,7 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int col = k < 4 ? 4 * c + k : 64 + 4 * c + (k - 4);
-            double qd = rint(src[(int64_t)r * np + col] * inv);
+            double qd = (I == J && col == r) ? 0.0 : rint(src[(int64_t)r * np + col] * inv);
             qd = fmin(fmax(qd, -0x1p35 + 1.0), 0x1p35 - 1.0);
             const unsigned long long q = (unsigned long long)((long long)qd + (1ll << 35));   // biased: 0 < q < 2^36
             hi[r * TS + col] = (unsigned int)(q >> 4);
@@ -764,6 +770,8 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
         nib[(wave * 64 + lane) * 8 + rg] = word;
         if (c == 0) steps[(wave * 4 + g) * 8 + rg] = rowstep[r];
     }
+    if (I == J && threadIdx.x < TS)
+        reinterpret_cast<double *>(slot + kFixHeadBytes + kFixNibBytes + TS * 4)[threadIdx.x] = src[(int64_t)threadIdx.x * np + threadIdx.x];
 }
 
 struct FixRaw { int4 ha[8], hb[8]; uint4 nq[2]; float4 st[2]; };
@@ -794,7 +802,7 @@ __device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, in
 
 // the product of split_tile_product for a fixed-point tile (always off the diagonal)
 __device__ __forceinline__ void fix_tile_product(const FixRaw &w, const double *sI, const double *sJ, double (*sT)[TS],
-                                                 double *__restrict__ part1, double *__restrict__ part2) {
+                                                 double *__restrict__ part1, double *__restrict__ part2, const double *__restrict__ diag = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     double rj[8];
@@ -826,7 +834,7 @@ __device__ __forceinline__ void fix_tile_product(const FixRaw &w, const double *
         v[rg] = step * (a0 + a1);
         ri = ri_next;
     }
-    tile_reduce_store(v, tc, sT, true, part1, part2);
+    tile_reduce_store(v, tc, sT, diag == nullptr, part1, part2, diag, sI);
 }
 
 // raw registers of one lane's share of a split tile (8 row groups: two float4 heads, one uint4 of tails)
@@ -938,13 +946,13 @@ symv_tile_mixed_kernel(const unsigned char *__restrict__ Mp, const unsigned char
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned char *tile = Mp + (size_t)t * kSplitTileBytes;
     double *part1 = part1_all + (int64_t)t * TS, *part2 = part2_all + (int64_t)t * TS;
-    if (types[t] != 0) {                             // (uniform) 36-bit fixed point
+    if (types[t] != 0) {                             // (uniform) 36-bit fixed point; type 2: a diagonal tile, its diagonal apart in doubles
         FixRaw f;
         fix_load(tile, wave, lane, f);
         if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
         else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
         __syncthreads();
-        fix_tile_product(f, sI, sJ, sT, part1, part2);
+        fix_tile_product(f, sI, sJ, sT, part1, part2, types[t] == 2 ? reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4) : nullptr);
         return;
     }
     // float head + 16-bit tail, two halves of four row groups
@@ -1019,11 +1027,13 @@ symv_tile_mixed_batch_kernel(const unsigned char *__restrict__ Mp_all, const uns
         else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
         __syncthreads();
     };
-    if (types_all[(size_t)mat * ntiles + t] != 0) {  // (uniform) 36-bit fixed point: the tile stays in registers for every right-hand side
+    const unsigned char ttype = types_all[(size_t)mat * ntiles + t];
+    if (ttype != 0) {                                // (uniform) 36-bit fixed point; type 2: a diagonal tile, its diagonal apart in doubles
         FixRaw f;
         fix_load(tile, wave, lane, f);
         stage_rhs(mat, 0);
-        fix_tile_product(f, sI, sJ, sT, part1_all + ((int64_t)mat * ntiles + t) * TS, part2_all + ((int64_t)mat * ntiles + t) * TS);
+        fix_tile_product(f, sI, sJ, sT, part1_all + ((int64_t)mat * ntiles + t) * TS, part2_all + ((int64_t)mat * ntiles + t) * TS,
+                         ttype == 2 ? reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4) : nullptr);
         return;
     }
     // float head + 16-bit tail, two halves of four row groups

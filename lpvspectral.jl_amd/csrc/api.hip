@@ -1010,8 +1010,10 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
             std::vector<unsigned char> ht(ntiles);
             LPVS_HIP(hipMemcpyAsync(ht.data(), types, ntiles, hipMemcpyDeviceToHost, s));
             LPVS_HIP(hipStreamSynchronize(s));
-            for (unsigned char t : ht) h->Mp_fixed_tiles += t != 0;
-            h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)kMixedFixedTileBytes + (double)(ntiles - (size_t)h->Mp_fixed_tiles) * (double)kMixedFloatTileBytes;
+            size_t ndiag = 0;
+            for (unsigned char t : ht) { h->Mp_fixed_tiles += t != 0; ndiag += t == 2; }
+            h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)kMixedFixedTileBytes + (double)ndiag * 1024.0 +
+                                 (double)(ntiles - (size_t)h->Mp_fixed_tiles) * (double)kMixedFloatTileBytes;
             if (2 * (size_t)h->Mp_fixed_tiles < ntiles) {
                 // not a diagonally dominant inverse: the mixed kernel (three workgroups per CU, float-head tiles in two halves) would
                 // only lose against the plain 6-byte kernel -- store every tile in the float-head format
@@ -1503,7 +1505,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
             if (split) {
                 // mixed storage (36-bit fixed-point tiles where a window's inverse is small; the Fourier inverses are nearly diagonal):
                 // tile formats and the per-matrix max|M| live behind the 6-byte slots of the Mp buffer (sized for doubles)
-                static const bool mixed = [] { const char *e = getenv("LPVS_M_STORAGE"); return !(e && std::string(e) == "split"); }();
+                const bool mixed = [] { const char *e = getenv("LPVS_M_STORAGE"); return !(e && std::string(e) == "split"); }();
                 const size_t nt = symv_packed_doubles(np) / (128 * 128);
                 unsigned char *types = Mp.as<unsigned char>() + 6 * symv_packed_doubles(np) * (size_t)bw;
                 const size_t types_bytes = ((nt * (size_t)bw + 255) / 256) * 256;
@@ -1550,9 +1552,9 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
                     std::vector<unsigned char> ht(nt * (size_t)nb_);
                     LPVS_HIP(hipMemcpyAsync(ht.data(), ab.mp_types, ht.size(), hipMemcpyDeviceToHost, s));
                     LPVS_HIP(hipStreamSynchronize(s));
-                    size_t nfix = 0;
-                    for (unsigned char t : ht) nfix += t != 0;
-                    bytes = (double)nfix * (double)kMixedFixedTileBytes + (double)(ht.size() - nfix) * (double)kMixedFloatTileBytes;
+                    size_t nfix = 0, ndiag = 0;
+                    for (unsigned char t : ht) { nfix += t != 0; ndiag += t == 2; }
+                    bytes = (double)nfix * (double)kMixedFixedTileBytes + (double)ndiag * 1024.0 + (double)(ht.size() - nfix) * (double)kMixedFloatTileBytes;
                 }
                 g_win_timing[8] = bytes;
             }

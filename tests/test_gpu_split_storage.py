@@ -103,8 +103,8 @@ def test_split_storage_extreme_values_roundtrip(L):
                 p.set_prox(L.NormL1(1e-3))
                 p.admm_init(None, μ=1.0, tol=0.0)
                 if storage == "mixed":                            # a diagonally dominant inverse: every off-diagonal tile is fixed point
-                    nfixed = round((6 * 2048 * (2048 + 128) // 2 - p.time_matvec(1)[1]) / (98304 - 74240))
-                    assert nfixed == 16 * 15 // 2, nfixed
+                    saved = 6 * 2048 * (2048 + 128) // 2 - p.time_matvec(1)[1]       # (diagonal tiles may be too: 98304 -> 75264 B)
+                    assert 120 * (98304 - 74240) <= saved <= 120 * (98304 - 74240) + 16 * (98304 - 75264), saved
                 p.admm_run(1)
                 outs[storage] = p.admm_get()[0]                  # x after the first iteration = M b
         finally:

@@ -81,9 +81,13 @@ def test_csd_cohere_sparse_estimator_vs_oracle(L, oracle, noverlap, zero):
     assert rel(S, Sseq) <= 1e-9                                 # engine: 6-byte copy of the inverses; handles of this size: doubles
 
 
-def test_engine_shared_gram_equals_separate_runs_and_shards(L):
+def test_engine_shared_gram_equals_separate_runs_and_shards(L, monkeypatch):
     """ns = 3 signals through one engine call == three single-signal calls, bit for bit (same kernels, same order); disjoint
-    window ranges reproduce the whole; accumulators are the in-order sums of the per-window products."""
+    window ranges reproduce the whole; accumulators are the in-order sums of the per-window products.  (Bit for bit needs the
+    same storage of the packed inverses on both sides: single-signal batches default to the mixed storage, batches with several
+    signals per window to uniform 6-byte elements -- LPVS_M_STORAGE=split makes both uniform; test_mixed_vs_split_windows below
+    holds the default against it.)"""
+    monkeypatch.setenv("LPVS_M_STORAGE", "split")
     rng = np.random.default_rng(12)
     Lh, n, noverlap = 6000, 750, 250
     t = np.cumsum(0.5 + rng.random(Lh))
@@ -167,3 +171,22 @@ def test_multi_device_driver_shards_reproduce_single_device(L, monkeypatch):
     S1, _ = L.ls_windowcsd(Y[0], Y[1], t, f, nw=7, noverlap=0, window_func=L.hanning, λ=1e-4)
     S2, _ = L.ls_windowcsd(Y[0], Y[1], t, f, nw=7, noverlap=0, window_func=L.hanning, λ=1e-4, ngpus=0)   # all visible devices
     assert np.array_equal(S1, S2)
+
+
+def test_mixed_vs_split_windows(L, monkeypatch):
+    """The default (mixed) storage of single-signal window batches against uniform 6-byte elements and doubles: same stopping
+    iterations, coefficients within the parity bound."""
+    rng = np.random.default_rng(12)
+    Lh, n, noverlap = 6000, 750, 250
+    t = np.cumsum(0.5 + rng.random(Lh))
+    f = np.arange(0, 48) / 120.0
+    y = np.sin(2 * np.pi * f[5] * t) + 0.2 * rng.standard_normal(Lh)
+    W = L.hanning(n)
+    eng = dict(estimator=1, lam=0.0, prox=(1, 0.4, 0), μ=0.05, tol=1e-8, iters=2000, sign=-1)
+    out = {}
+    for st in ("mixed", "split", "f64"):
+        monkeypatch.setenv("LPVS_M_STORAGE", st)
+        out[st] = L.windows_estimate([y], t, f, n, noverlap, W, eng)
+    for st in ("mixed", "split"):
+        assert np.array_equal(out[st][1], out["f64"][1])
+        assert rel(out[st][0], out["f64"][0]) <= 1e-9, (st, rel(out[st][0], out["f64"][0]))
