@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--nwin", type=int, default=CFG4["nwin"], help="cfg4 diagnostic only; the configured count is 1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-path", action="store_true", help="skip the extra (untimed) dense-MFMA Gram measurement")
+    ap.add_argument("--no-alt-storage", action="store_true",
+                    help="skip the extra (untimed) mat-vec / whole-step measurements with the other storages of the inverse (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI, the judged path) or gloo (functional rehearsal)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="f32: float32 inputs through the _f32 entry points (double assembly, single-precision copy of M streamed by "
@@ -375,7 +377,7 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
     # the same mat-vec with the inverse stored in doubles (LPVS_M_STORAGE=f64) and in uniform 6-byte elements (=split), for the
     # record: not on the timed path
     alt, alt6 = None, None
-    if args.dtype == "f64" and mv_info["kernel"] in ("symv_tile_split_kernel", "symv_tile_mixed_kernel"):
+    if args.dtype == "f64" and not args.no_alt_storage and mv_info["kernel"] in ("symv_tile_split_kernel", "symv_tile_mixed_kernel"):
         for st in ("f64", "split"):
             if st == "split" and mv_info["kernel"] == "symv_tile_split_kernel":
                 continue
