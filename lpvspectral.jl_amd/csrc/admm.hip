@@ -1845,9 +1845,6 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
                           int ntiles, double *__restrict__ blocknorm_all, int parity, int commit_prev) {
     const int sg = blockIdx.y;
     AdmmStatus *status = p.status + sg;
-    // `converged` is written by workgroup 0 of a launch only when that launch's commit finds convergence, and then
-    // every workgroup of the launch (whether it reads the flag before or after that write) returns without writing.
-    if (status->converged) return;
     __shared__ double sh[3 * TS], sq[TS], gs[TS], slot;
     const double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
     double *bn_prev = blocknorm_all + ((int64_t)sg * 2 + (parity ^ 1)) * nblk, *bn_cur = blocknorm_all + ((int64_t)sg * 2 + parity) * nblk;
@@ -1855,19 +1852,47 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     const int64_t li_ = (int64_t)I * TS + i, gi = (int64_t)sg * p.np + li_;
     const bool row = threadIdx.x < TS, ok = row && li_ < p.n;
     const bool offset_form = p.xb != nullptr;                       // x = xb + M (z-u)/mu
-    const double ui = ok ? p.u[gi] : 0.0, bi = ok ? (offset_form ? p.xb[gi] : p.b[gi]) : 0.0;   // in flight together with the partials
-    // the first 16 tile partials of this thread's quarter of the row block are requested BEFORE the pending norm is summed:
-    // the norm's loads, reduction and barrier then overlap the partials' memory latency instead of preceding it
+    // EVERY load of the prologue is issued before anything is waited for -- the convergence flag, u, xb (or b), the first 16 tile
+    // partials of this thread's quarter of the row block and the previous iteration's block norms -- and all of them
+    // unconditionally (clamped addresses, values selected afterwards): a load under a branch makes the compiler drain the memory
+    // pipe right there, and the kernel is nothing but memory latency (measured: three dependent round trips, 5.7 us per launch).
+    const int conv_flag = __builtin_nontemporal_load(&status->converged);
+    const double u_raw = p.u[gi], b_raw = (offset_form ? p.xb : p.b)[gi];
     const int gq = threadIdx.x >> 7;
     const int per = (nblk + 3) / 4, e0 = gq * per, e1 = e0 + per < nblk ? e0 + per : nblk;
+    // (32-bit element offsets from part1: both partial arrays live in one buffer, part2 behind part1; the 64-bit form of this
+    // address arithmetic was 300 instructions ahead of the first load)
+    const unsigned p2off = (unsigned)(part2 - part1);
+    const unsigned rowoff = (unsigned)(I * (I + 1) / 2) * TS + i;
     auto at = [&](int e) -> const double * {
-        return e <= I ? part1 + ((int64_t)I * (I + 1) / 2 + e) * TS + i : part2 + ((int64_t)e * (e + 1) / 2 + I) * TS + i;
+        return part1 + (e <= I ? rowoff + (unsigned)e * TS : p2off + ((unsigned)(e * (e + 1) / 2 + I)) * TS + i);
     };
     double pre[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) pre[q] = e0 + q < e1 ? *at(e0 + q) : 0.0;
+    for (int q = 0; q < 16; ++q) pre[q] = *at(e0 + q < nblk ? e0 + q : nblk - 1);
+    const int lane64 = threadIdx.x & 63;
+    const double bn_raw = bn_prev[lane64 < nblk ? lane64 : nblk - 1];
+    // (a use of every loaded value BEFORE the early exit: otherwise the compiler tests the flag first and sinks the loads below
+    // the branch -- two dependent scalar round trips ahead of everything else)
+    asm volatile("" :: "v"(u_raw), "v"(b_raw), "v"(bn_raw), "v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]), "v"(pre[4]), "v"(pre[5]),
+                 "v"(pre[6]), "v"(pre[7]), "v"(pre[8]), "v"(pre[9]), "v"(pre[10]), "v"(pre[11]), "v"(pre[12]), "v"(pre[13]), "v"(pre[14]),
+                 "v"(pre[15]), "s"(conv_flag));
+    // `converged` is written by workgroup 0 of a launch only when that launch's commit finds convergence, and then
+    // every workgroup of the launch (whether it reads the flag before or after that write) returns without writing.
+    if (conv_flag) return;
+    const double ui = ok ? u_raw : 0.0, bi = ok ? b_raw : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pre[q] = e0 + q < e1 ? pre[q] : 0.0;
     if (commit_prev) {                                               // uniform (host-known): commit the previous iteration
-        const double nxz = pending_norm(bn_prev, nblk, &slot);
+        if (threadIdx.x < 64) {   // lane q sums blocks q, q+64, ...; then the wave's fixed shuffle pattern (as pending_norm)
+            double part = 0;
+            part += lane64 < nblk ? bn_raw : 0.0;
+            for (int q = lane64 + 64; q < nblk; q += 64) part += bn_prev[q];
+            const double w = wave_sum(part);
+            if (threadIdx.x == 0) slot = w;
+        }
+        __syncthreads();
+        const double nxz = sqrt(slot);                               // norm(tmp)   src/lasso.jl:157
         const bool conv = nxz < p.tol;                               //             src/lasso.jl:164
         if (I == 0 && threadIdx.x == 0) {
             status->iters += 1;
