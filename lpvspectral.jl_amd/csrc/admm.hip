@@ -2381,7 +2381,7 @@ static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hip
         const char *e = getenv("LPVS_MULTI_MATVEC");
         return !e ? 2 : (std::string(e) == "valu" ? 0 : (std::string(e) == "dma" ? 1 : 2));
     }();
-    if (p.ns > 1 && !p.mp_f32 && (p.mp_split || multi == 2)) {
+    if (p.ns > 1 && !p.mp_f32 && (p.mp_split || (multi == 2 && p.np <= 49152))) {   // (31-bit byte offsets into the partials: np <= 49152)
         if (p.mp_split) launch_mfma_stream<true>(p, ntiles, part1, part2, status, s);
         else launch_mfma_stream<false>(p, ntiles, part1, part2, status, s);
     } else if (p.ns > 8 && !p.mp_f32 && multi == 1) {

@@ -340,6 +340,7 @@ int mp_mode_for(const lpvs_problem *h) {
     if (h->f32) return kMpF32;
     const char *e = getenv("LPVS_M_STORAGE");
     if (e && std::string(e) == "f64") return kMpF64;
+    if (h->ns > 1 && h->np > 49152) return kMpF64;   // the streaming multi-signal kernel addresses its partials with 31-bit byte offsets
     if (h->ns > 1 || (e && std::string(e) == "split")) return kMpSplit;
     return kMpMixed;
 }
