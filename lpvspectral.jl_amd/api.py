@@ -395,7 +395,7 @@ class Problem:
         return {0: dict(kernel="symv_kernel", storage="full symmetric f64", bytes_formula="8 B x np^2"),
                 1: dict(kernel="symv_tile_kernel<double>", storage="tile-packed lower triangle, f64 (8 B)",
                         bytes_formula="8 B x np(np+128)/2 (np = %d)" % np_),
-                2: dict(kernel="symv_tile_kernel<float>", storage="tile-packed lower triangle, f32 (4 B)",
+                2: dict(kernel="symv_tile_f32_kernel" if self.ns == 1 else "symv_tile_kernel<float>", storage="tile-packed lower triangle, f32 (4 B)",
                         bytes_formula="4 B x np(np+128)/2 (np = %d)" % np_),
                 4: dict(kernel="symv_tile_mixed_kernel", storage="tile-packed lower triangle, mixed: float head + 16-bit tail (6 B, 40 significant bits) "
                                                                  "for the diagonal tiles, 36-bit fixed point with per-row steps (4.53 B) for tiles of small entries",

@@ -932,6 +932,52 @@ symv_tile_split_kernel(const unsigned char *__restrict__ Mp, const double *__res
     split_tile_product(w, sI, sJ, sT, I != J, part1 + (int64_t)t * TS, part2 + (int64_t)t * TS);
 }
 
+// Single-precision copy of M (the _f32 handles), one right-hand side: the lane ownership and reductions of the split kernel on
+// plain float tiles (64 KB: three workgroups per CU).  The generic symv_tile_kernel<float> ran at 4.5 TB/s inside the iteration
+// (30 us per launch at n = 8192).
+__global__ void __launch_bounds__(256, 3)
+symv_tile_f32_kernel(const float *__restrict__ Mp, const double *__restrict__ rhs, int64_t np, int ntiles,
+                     double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+    if (status != nullptr && status[0].converged) return;
+    __shared__ double sI[TS], sJ[TS], sT[4][TS];
+    const int t = blockIdx.x;
+    int I, J;
+    tile_index(t, I, J);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const float *head = Mp + (size_t)t * TS * TS + (wave * 32 + g) * TS + 4 * c;
+    float4 ha[8], hb[8];
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        ha[rg] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
+        hb[rg] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
+    }
+    if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
+    else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
+    __syncthreads();
+    double rj[8], tc[8], v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        const double ri = sI[wave * 32 + 4 * rg + g];
+        const float hh[8] = {ha[rg].x, ha[rg].y, ha[rg].z, ha[rg].w, hb[rg].x, hb[rg].y, hb[rg].z, hb[rg].w};
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const double m0 = (double)hh[k], m1 = (double)hh[k + 1];
+            tc[k] = opaque(fma(m0, ri, tc[k]));
+            tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
+            a0 = fma(m0, rj[k], a0);
+            a1 = fma(m1, rj[k + 1], a1);
+        }
+        v[rg] = a0 + a1;
+    }
+    tile_reduce_store(v, tc, sT, I != J, part1_all + (int64_t)t * TS, part2_all + (int64_t)t * TS);
+}
+
 // The mixed storage's kernel: fixed-point tiles hold 74 KB instead of 96, so THREE workgroups per CU are needed to keep as many
 // bytes in flight (two: 27.5 us at cfg3 = 5.7 TB/s).  The fixed-point path fits the 168 registers that allows; the few float-head
 // tiles (the diagonal ones) are processed in two halves of 64 rows to fit as well.
@@ -2394,6 +2440,9 @@ static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hip
         hipLaunchKernelGGL(symv_tile_mfma_kernel<8>, dim3(ntiles), dim3(256), symv_mfma_lds<8>(), s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
     } else if (p.ns > 1 && !p.mp_f32)
         hipLaunchKernelGGL((symv_tile_multi_kernel<double, 8>), dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
+    else if (p.mp_f32 && p.ns == 1)
+        hipLaunchKernelGGL(symv_tile_f32_kernel, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, (int)ntiles, part1,
+                           part2, status);
     else if (p.mp_f32)
         hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,
                            (int)ntiles, part1, part2, status);
