@@ -231,6 +231,23 @@ int32_t lpvs_windows_estimate_f32(const float *Y, int64_t ns, const float *t, in
                                   int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
                                   int32_t linear_sign, int64_t win_lo, int64_t win_hi, int32_t device, float *x_re, float *x_im,
                                   int64_t *iters_out);
+/* lpvs_windows_estimate_multi_f64 / lpvs_windowcsd_f64 / lpvs_problem_create_lpv_rows_f64 / lpvs_problem_solve_ridge_f64 /
+ * lpvs_admm_set_state_f64 for Float32 callers */
+int32_t lpvs_windows_estimate_multi_f32(const float *Y, int64_t ns, const float *t, int64_t L, int64_t n, int64_t noverlap,
+                                        const float *W, const float *freqs, int64_t Nf, int32_t estimator, double lam,
+                                        int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
+                                        int64_t iters, int32_t linear_sign, const int32_t *devices, int32_t ngpus, float *x_re,
+                                        float *x_im, int64_t *iters_out);
+int32_t lpvs_windowcsd_f32(const float *y, const float *u, const float *t, int64_t L, int64_t n, int64_t noverlap,
+                           const float *W, const float *freqs, int64_t Nf, int32_t estimator, double lam, int32_t prox_kind,
+                           double prox_param, int64_t group_len, double mu, double tol, int64_t iters, int32_t linear_sign,
+                           int64_t win_lo, int64_t win_hi, int32_t device, float *Syu_re, float *Syu_im, float *Syy,
+                           float *Suu, float *x_re, float *x_im, int64_t *iters_out);
+int32_t lpvs_problem_create_lpv_rows_f32(const float *Y, int64_t ns, const float *X, const float *V, int64_t N_local,
+                                         const float *w, int64_t Nf, int64_t Nv, int32_t normalize, int32_t coulomb,
+                                         const double *ranges4, int32_t device, lpvs_problem **out);
+int32_t lpvs_problem_solve_ridge_f32(lpvs_problem *h, double ridge, float *x_out);
+int32_t lpvs_admm_set_state_f32(lpvs_problem *h, const float *x, const float *z, const float *u, int64_t iters_done);
 int32_t lpvs_admm_init_f32(lpvs_problem *h, const float *x0, double mu, double tol,
                            int32_t linear_sign);
 int32_t lpvs_admm_get_f32(lpvs_problem *h, float *x_out, float *z_out, float *u_out);

@@ -86,6 +86,13 @@ SIGNATURES = {
     "lpvs_problem_create_lpv_multi_f32": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.POINTER(_P)]),
     "lpvs_windows_estimate_f32": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
                                           _I64, _I64, _I32, _P, _P, _P]),
+    "lpvs_windows_estimate_multi_f32": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
+                                                _P, _I32, _P, _P, _P]),
+    "lpvs_windowcsd_f32": (_I32, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
+                                   _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "lpvs_problem_create_lpv_rows_f32": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I32, C.POINTER(_P)]),
+    "lpvs_problem_solve_ridge_f32": (_I32, [_P, _F64, _P]),
+    "lpvs_admm_set_state_f32": (_I32, [_P, _P, _P, _P, _I64]),
     "lpvs_admm_init_f32": (_I32, [_P, _P, _F64, _F64, _I32]),
     "lpvs_admm_get_f32": (_I32, [_P, _P, _P, _P]),
     "lpvs_problem_get_params_f32": (_I32, [_P, _I32, _P, _P]),

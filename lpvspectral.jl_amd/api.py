@@ -250,18 +250,21 @@ class Problem:
         """Partial problem over a ROW SHARD ``(y, X, V)`` of one signal: ``ranges`` =
         ``[min V, max V, max|V|, max|X|]`` over ALL rows.  Its Gram / rhs are partial sums; exchange them with
         :meth:`device_gram` + an all-reduce, then :meth:`gram_modified`."""
-        ky, py, N = as_f64(y)
-        kx, px, Nx = as_f64(X)
-        kv, pv, Nvv = as_f64(V)
-        kw, pw, Nf = as_f64(w)
+        f32 = is_f32(y) and not _lib.is_device_array(y)       # Float32 record: the _f32 entry point
+        conv = as_f32 if f32 else as_f64
+        ky, py, N = conv(np.asarray(y, dtype=np.float32) if f32 else y)
+        kx, px, Nx = conv(np.asarray(X, dtype=np.float32) if f32 else X)
+        kv, pv, Nvv = conv(np.asarray(V, dtype=np.float32) if f32 else V)
+        kw, pw, Nf = conv(np.asarray(w, dtype=np.float32) if f32 else w)
         assert N == Nx == Nvv, "y, X and V has to be the same length"
         r4 = np.ascontiguousarray(np.asarray(ranges, dtype=np.float64).ravel())
         assert r4.size == 4
         h = C.c_void_p()
-        check(lib().lpvs_problem_create_lpv_rows_f64(py, 1, px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)),
-                                                     out_ptr(r4), int(device), C.byref(h)))
+        fn = lib().lpvs_problem_create_lpv_rows_f32 if f32 else lib().lpvs_problem_create_lpv_rows_f64
+        check(fn(py, 1, px, pv, N, pw, Nf, int(Nv), int(bool(normalize)), int(bool(coulomb)), out_ptr(r4), int(device), C.byref(h)))
         p = cls(h, "lpv")
         p.Nf, p.nb = Nf, (2 * Nv if coulomb else Nv)
+        p.f32 = f32
         return p
 
     @classmethod
@@ -342,8 +345,9 @@ class Problem:
         return M
 
     def solve_ridge(self, ridge):
-        x = np.zeros(self.n)
-        check(lib().lpvs_problem_solve_ridge_f64(self._h, float(ridge), out_ptr(x)))
+        x = np.zeros(self.n, dtype=np.float32 if self.f32 else np.float64)
+        fn = lib().lpvs_problem_solve_ridge_f32 if self.f32 else lib().lpvs_problem_solve_ridge_f64
+        check(fn(self._h, float(ridge), out_ptr(x)))
         return x
 
     def set_prox(self, proxg):
@@ -366,9 +370,10 @@ class Problem:
 
     def admm_set_state(self, x, z, u, iters=0):
         """Resume: install iterates saved by :meth:`admm_get` (after :meth:`admm_init` with the same parameters)."""
-        arrs = [np.asfortranarray(np.asarray(a, dtype=np.float64)) for a in (x, z, u)]
+        arrs = [np.asfortranarray(np.asarray(a, dtype=np.float32 if self.f32 else np.float64)) for a in (x, z, u)]
         assert all(a.size == self.n * self.ns for a in arrs), "x, z, u have the wrong length"
-        check(lib().lpvs_admm_set_state_f64(self._h, out_ptr(arrs[0]), out_ptr(arrs[1]), out_ptr(arrs[2]), int(iters)))
+        fn = lib().lpvs_admm_set_state_f32 if self.f32 else lib().lpvs_admm_set_state_f64
+        check(fn(self._h, out_ptr(arrs[0]), out_ptr(arrs[1]), out_ptr(arrs[2]), int(iters)))
 
     def admm_get(self):
         shape = self.n if self.ns == 1 else (self.n, self.ns)
@@ -798,12 +803,14 @@ def windows_estimate_multi(Y, t, freqs, n, noverlap, W, eng, ngpus=0, devices=No
     """``lpvs_windows_estimate_multi_f64``: ALL windows, split into contiguous ranges over ``ngpus`` devices driven by
     this one process (a host thread per device), the coefficients gathered by one RCCL all-gather.  Same return value as
     :func:`windows_estimate` over the full window range."""
-    Ys = [np.ascontiguousarray(_host(y)) for y in Y]
+    f32 = all(is_f32(y) and not _lib.is_device_array(y) for y in Y)      # Float32 records: lpvs_windows_estimate_multi_f32
+    dt = np.float32 if f32 else np.float64
+    Ys = [np.ascontiguousarray(np.asarray(_host(y), dtype=dt)) for y in Y]
     ns, Ly = len(Ys), len(Ys[0])
     assert all(len(e) == Ly for e in Ys), "signals must have the same length"
     keep = np.ascontiguousarray(np.stack(Ys))
-    th = np.ascontiguousarray(_host(t)); fh = np.ascontiguousarray(_host(freqs))
-    Wh = None if W is None else np.ascontiguousarray(_host(W))
+    th = np.ascontiguousarray(np.asarray(_host(t), dtype=dt)); fh = np.ascontiguousarray(np.asarray(_host(freqs), dtype=dt))
+    Wh = None if W is None else np.ascontiguousarray(np.asarray(_host(W), dtype=dt))
     assert Ly == len(th), "y and t has to be the same length"
     k = C.c_int64(0)
     check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
@@ -811,10 +818,10 @@ def windows_estimate_multi(Y, t, freqs, n, noverlap, W, eng, ngpus=0, devices=No
     dv = None if devices is None else np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
     if dv is not None:
         ngpus = len(dv)
-    xre, xim = np.zeros((ns, max(k, 1), Nf)), np.zeros((ns, max(k, 1), Nf))
+    xre, xim = np.zeros((ns, max(k, 1), Nf), dtype=dt), np.zeros((ns, max(k, 1), Nf), dtype=dt)
     its = np.zeros((ns, max(k, 1)), dtype=np.int64)
     kind, param, glen = eng["prox"]
-    check(lib().lpvs_windows_estimate_multi_f64(out_ptr(keep), ns, out_ptr(th), Ly, int(n), int(noverlap), None if Wh is None else out_ptr(Wh),
+    check((lib().lpvs_windows_estimate_multi_f32 if f32 else lib().lpvs_windows_estimate_multi_f64)(out_ptr(keep), ns, out_ptr(th), Ly, int(n), int(noverlap), None if Wh is None else out_ptr(Wh),
                                                 out_ptr(fh), Nf, int(eng["estimator"]), float(eng["lam"]), int(kind), float(param), int(glen),
                                                 float(eng["μ"]), float(eng["tol"]), int(eng["iters"]), int(eng["sign"]),
                                                 None if dv is None else out_ptr(dv), int(ngpus), out_ptr(xre), out_ptr(xim), out_ptr(its)))
@@ -824,21 +831,24 @@ def windows_estimate_multi(Y, t, freqs, n, noverlap, W, eng, ngpus=0, devices=No
 def windowcsd_batched(y, u, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None, device=0):
     """``lpvs_windowcsd_f64``: the accumulators ``(Syu, Syy, Suu)`` over the windows ``[win_lo, win_hi)`` in window order
     (one Gram / factorisation per window, two right-hand sides), plus the per-window ``xy, xu``."""
-    ky, py, Ly = as_f64(y)
-    ku, pu, Lu = as_f64(u)
-    kt, pt, Lt = as_f64(t)
-    kf, pf, Nf = as_f64(freqs)
-    kw, pw, nW = as_f64(W)
+    f32 = is_f32(y) and is_f32(u) and not _lib.is_device_array(y) and not _lib.is_device_array(u)   # Float32 records: lpvs_windowcsd_f32
+    dt = np.float32 if f32 else np.float64
+    conv = (lambda a: as_f32(None if a is None else np.asarray(_host(a), dtype=np.float32))) if f32 else as_f64
+    ky, py, Ly = conv(y)
+    ku, pu, Lu = conv(u)
+    kt, pt, Lt = conv(t)
+    kf, pf, Nf = conv(freqs)
+    kw, pw, nW = conv(W)
     assert Ly == Lu == Lt, "y, u and t has to be the same length"
     assert W is None or nW == n, "W must have one weight per window sample"
     k = C.c_int64(0)
     check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
     win_hi = int(k.value) if win_hi is None else int(win_hi)
     nwin = win_hi - int(win_lo)
-    sre, sim, syy, suu = (np.zeros(Nf) for _ in range(4))
-    xre, xim = np.zeros((2, max(nwin, 1), Nf)), np.zeros((2, max(nwin, 1), Nf))
+    sre, sim, syy, suu = (np.zeros(Nf, dtype=dt) for _ in range(4))
+    xre, xim = np.zeros((2, max(nwin, 1), Nf), dtype=dt), np.zeros((2, max(nwin, 1), Nf), dtype=dt)
     kind, param, glen = eng["prox"]
-    check(lib().lpvs_windowcsd_f64(py, pu, pt, Ly, int(n), int(noverlap), pw, pf, Nf, int(eng["estimator"]), float(eng["lam"]), int(kind),
+    check((lib().lpvs_windowcsd_f32 if f32 else lib().lpvs_windowcsd_f64)(py, pu, pt, Ly, int(n), int(noverlap), pw, pf, Nf, int(eng["estimator"]), float(eng["lam"]), int(kind),
                                    float(param), int(glen), float(eng["μ"]), float(eng["tol"]), int(eng["iters"]), int(eng["sign"]),
                                    int(win_lo), win_hi, int(device), out_ptr(sre), out_ptr(sim), out_ptr(syy), out_ptr(suu), out_ptr(xre),
                                    out_ptr(xim), None))

@@ -1600,7 +1600,11 @@ struct HostOut {
 }  // namespace
 
 namespace lpvs {
-int32_t windows_engine_run(const WinJob &job, const WinSink &sink) { return windows_engine(job, sink); }
+int32_t windows_engine_run(const WinJob &job, const WinSink &sink) {
+    // (worker threads of multi.hip: the float-grid admission is a thread-local switch)
+    struct Admit { bool prev; explicit Admit(bool on) : prev(g_f32_admission) { if (on) g_f32_admission = true; } ~Admit() { g_f32_admission = prev; } } admit(job.f32_grid);
+    return windows_engine(job, sink);
+}
 void windows_last_timing(double *out10) { for (int i = 0; i < 10; ++i) out10[i] = g_win_timing[i]; }
 void windows_set_timing(const double *in10) { for (int i = 0; i < 10; ++i) g_win_timing[i] = in10[i]; }
 }  // namespace lpvs
@@ -1829,6 +1833,66 @@ int32_t lpvs_windows_estimate_f32(const float *Y, int64_t ns, const float *t, in
                                        iters, linear_sign, win_lo, win_hi, device, o.as<double>(), o.as<double>() + cnt, iters_out));
     LPVS_TRY(narrow_out(x_re, o.as<double>(), cnt, nullptr));
     return narrow_out(x_im, o.as<double>() + cnt, cnt, nullptr);
+}
+
+// ls_windowcsd / ls_cohere accumulators for Float32 callers
+int32_t lpvs_windowcsd_f32(const float *y, const float *u, const float *t, int64_t L, int64_t n, int64_t noverlap, const float *W,
+                           const float *freqs, int64_t Nf, int32_t estimator, double lam, int32_t prox_kind, double prox_param,
+                           int64_t group_len, double mu, double tol, int64_t iters, int32_t linear_sign, int64_t win_lo, int64_t win_hi,
+                           int32_t device, float *Syu_re, float *Syu_im, float *Syy, float *Suu, float *x_re, float *x_im, int64_t *iters_out) {
+    if (!y || !u || !t || !freqs || L <= 0 || Nf <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    LPVS_HIP(hipSetDevice(device));
+    WideArg dy, du, dt, dW, df;
+    LPVS_TRY(dy.set(y, L, nullptr)); LPVS_TRY(du.set(u, L, nullptr)); LPVS_TRY(dt.set(t, L, nullptr)); LPVS_TRY(dW.set(W, n, nullptr));
+    LPVS_TRY(df.set(freqs, Nf, nullptr));
+    const int64_t nwin = win_hi > win_lo ? win_hi - win_lo : 0, cnt = 2 * nwin * Nf;
+    DevBuf o; LPVS_TRY(o.alloc(sizeof(double) * (size_t)((cnt > 0 ? cnt : 1) * 2 + 4 * Nf)));
+    double *xr = o.as<double>(), *xi = xr + cnt, *acc = xi + cnt;          // acc: Syu_re, Syu_im, Syy, Suu
+    struct Admit { Admit() { g_f32_admission = true; } ~Admit() { g_f32_admission = false; } } admit;
+    LPVS_TRY(lpvs_windowcsd_f64(dy.p, du.p, dt.p, L, n, noverlap, dW.p, df.p, Nf, estimator, lam, prox_kind, prox_param, group_len, mu, tol, iters,
+                                linear_sign, win_lo, win_hi, device, acc, acc + Nf, acc + 2 * Nf, acc + 3 * Nf, x_re ? xr : nullptr,
+                                x_im ? xi : nullptr, iters_out));
+    LPVS_TRY(narrow_out(Syu_re, acc, Nf, nullptr)); LPVS_TRY(narrow_out(Syu_im, acc + Nf, Nf, nullptr));
+    LPVS_TRY(narrow_out(Syy, acc + 2 * Nf, Nf, nullptr)); LPVS_TRY(narrow_out(Suu, acc + 3 * Nf, Nf, nullptr));
+    LPVS_TRY(narrow_out(x_re, xr, cnt, nullptr));
+    return narrow_out(x_im, xi, cnt, nullptr);
+}
+
+// one signal, sample rows sharded over ranks (see lpvs_problem_create_lpv_rows_f64), Float32 records
+int32_t lpvs_problem_create_lpv_rows_f32(const float *Y, int64_t ns, const float *X, const float *V, int64_t N_local, const float *w, int64_t Nf,
+                                         int64_t Nv, int32_t normalize, int32_t coulomb, const double *ranges4, int32_t device,
+                                         lpvs_problem **out) {
+    if (!Y || !X || !V || !w || N_local <= 0 || Nf <= 0 || ns <= 0) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    LPVS_TRY(need_device());
+    LPVS_HIP(hipSetDevice(device));
+    WideArg dY, dX, dV, dw;
+    LPVS_TRY(dY.set(Y, N_local * ns, nullptr)); LPVS_TRY(dX.set(X, N_local, nullptr)); LPVS_TRY(dV.set(V, N_local, nullptr));
+    LPVS_TRY(dw.set(w, Nf, nullptr));
+    struct Admit { Admit() { g_f32_admission = true; } ~Admit() { g_f32_admission = false; } } admit;
+    LPVS_TRY(lpvs_problem_create_lpv_rows_f64(dY.p, ns, dX.p, dV.p, N_local, dw.p, Nf, Nv, normalize, coulomb, ranges4, device, out));
+    (*out)->f32 = true;
+    return LPVS_OK;
+}
+
+// dense estimators on a Float32 handle: the ridge solution in floats
+int32_t lpvs_problem_solve_ridge_f32(lpvs_problem *h, double ridge, float *x_out) {
+    if (!h || !x_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    const int64_t cnt = h->n;                        // (single right-hand side, as the f64 entry point)
+    DevBuf t; LPVS_TRY(t.alloc(sizeof(double) * (size_t)cnt));
+    LPVS_TRY(lpvs_problem_solve_ridge_f64(h, ridge, t.as<double>()));
+    return narrow_out(x_out, t.as<double>(), cnt, h->stream);
+}
+
+// re-entry from iterates saved as floats
+int32_t lpvs_admm_set_state_f32(lpvs_problem *h, const float *x, const float *z, const float *u, int64_t iters_done) {
+    if (!h || !x || !z || !u) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    LPVS_HIP(hipSetDevice(h->device));
+    const int64_t cnt = h->n * h->ns;
+    WideArg dx, dz, du;
+    LPVS_TRY(dx.set(x, cnt, h->stream)); LPVS_TRY(dz.set(z, cnt, h->stream)); LPVS_TRY(du.set(u, cnt, h->stream));
+    return lpvs_admm_set_state_f64(h, dx.p, dz.p, du.p, iters_done);
 }
 
 int32_t lpvs_admm_init_f32(lpvs_problem *h, const float *x0, double mu, double tol, int32_t linear_sign) {

@@ -253,6 +253,7 @@ struct WinJob {
     int prox_kind; double prox_param; int64_t group_len; double mu, tol; int64_t iters; int linear_sign;
     int64_t win_lo, win_hi; int device;
     double t_absmax = -1.0;                       // max|t| over the WHOLE record when (t, L) is only a span of it (< 0: compute)
+    bool f32_grid = false;                        // the frequency grid was widened from floats: snap it to the progression it was rounded from
 };
 // sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations): window order, signals innermost
 typedef std::function<void(int64_t, int64_t, const double *, const double *, int64_t)> WinSink;

@@ -93,11 +93,11 @@ using namespace lpvs;
 
 extern "C" {
 
-int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap,
-                                        const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam,
-                                        int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
-                                        int32_t linear_sign, const int32_t *devices, int32_t ngpus, double *x_re, double *x_im,
-                                        int64_t *iters_out) {
+static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap,
+                                      const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam,
+                                      int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
+                                      int32_t linear_sign, const int32_t *devices, int32_t ngpus, double *x_re, double *x_im,
+                                      int64_t *iters_out, bool f32_grid) {
     if (!Y || !t || !freqs || ns < 1 || Nf < 1) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
@@ -153,6 +153,7 @@ int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const doubl
         WinJob job{ys.data(), ns, th, L, n, noverlap, Wh, fh, Nf, estimator, lam, prox_kind, prox_param, group_len, mu, tol, iters, linear_sign,
                    S.lo, S.hi, S.device};
         job.t_absmax = tam;
+        job.f32_grid = f32_grid;
         double *img = S.host.data();
         S.rc = windows_engine_run(job, [&](int64_t w, int64_t sg, const double *re, const double *im, int64_t its) {
             double *e = img + ((size_t)w * (size_t)ns + (size_t)sg) * (size_t)(2 * Nf + 1);
@@ -221,6 +222,53 @@ int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const doubl
     }
     if (dre) LPVS_HIP(hipMemcpy(x_re, sre.data(), sizeof(double) * sre.size(), hipMemcpyHostToDevice));
     if (dim_) LPVS_HIP(hipMemcpy(x_im, sim.data(), sizeof(double) * sim.size(), hipMemcpyHostToDevice));
+    return LPVS_OK;
+}
+
+int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap,
+                                        const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam,
+                                        int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
+                                        int32_t linear_sign, const int32_t *devices, int32_t ngpus, double *x_re, double *x_im,
+                                        int64_t *iters_out) {
+    return windows_estimate_multi(Y, ns, t, L, n, noverlap, W, freqs, Nf, estimator, lam, prox_kind, prox_param, group_len, mu, tol, iters,
+                                  linear_sign, devices, ngpus, x_re, x_im, iters_out, false);
+}
+
+// Float32 records (host or device): widened on the host, float grids snapped to their progression, coefficients returned as floats
+int32_t lpvs_windows_estimate_multi_f32(const float *Y, int64_t ns, const float *t, int64_t L, int64_t n, int64_t noverlap,
+                                        const float *W, const float *freqs, int64_t Nf, int32_t estimator, double lam,
+                                        int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
+                                        int32_t linear_sign, const int32_t *devices, int32_t ngpus, float *x_re, float *x_im,
+                                        int64_t *iters_out) {
+    if (!Y || !t || !freqs || ns < 1 || Nf < 1 || L < 1) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    auto widen = [&](const float *p, int64_t cnt, std::vector<double> &out) -> bool {
+        if (!p) return true;
+        std::vector<float> tmp;
+        const float *src = p;
+        if (is_device_ptr(p)) {
+            tmp.resize((size_t)cnt);
+            if (hipMemcpy(tmp.data(), p, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+            src = tmp.data();
+        }
+        out.resize((size_t)cnt);
+        for (int64_t i = 0; i < cnt; ++i) out[(size_t)i] = (double)src[i];
+        return true;
+    };
+    std::vector<double> hY, ht, hW, hf;
+    if (!widen(Y, L * ns, hY) || !widen(t, L, ht) || !widen(W, n, hW) || !widen(freqs, Nf, hf)) { set_error("staging of device arguments failed"); return LPVS_EDEVICE; }
+    int64_t k = 0;
+    LPVS_TRY(lpvs_window_count(L, n, noverlap, &k));
+    const size_t cnt = (size_t)(ns * k * Nf);
+    std::vector<double> re(cnt > 0 ? cnt : 1), im(cnt > 0 ? cnt : 1);
+    LPVS_TRY(windows_estimate_multi(hY.data(), ns, ht.data(), L, n, noverlap, W ? hW.data() : nullptr, hf.data(), Nf, estimator, lam, prox_kind,
+                                    prox_param, group_len, mu, tol, iters, linear_sign, devices, ngpus, re.data(), im.data(), iters_out, true));
+    auto narrow = [&](float *dst, const std::vector<double> &v) -> bool {
+        if (!dst || cnt == 0) return true;
+        std::vector<float> f(cnt);
+        for (size_t i = 0; i < cnt; ++i) f[i] = (float)v[i];
+        return hipMemcpy(dst, f.data(), sizeof(float) * cnt, hipMemcpyDefault) == hipSuccess;
+    };
+    if (!narrow(x_re, re) || !narrow(x_im, im)) { (void)hipGetLastError(); set_error("copy of the coefficients failed"); return LPVS_EDEVICE; }
     return LPVS_OK;
 }
 

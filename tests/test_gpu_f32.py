@@ -141,3 +141,52 @@ def test_f32_multi_signal_and_window_engine_entry_points(L, oracle):
     Sso, _ = oracle.ls_windowpsd(y.astype(np.float64), t64, f64, nw=8, noverlap=0,
                                  estimator=lambda yy, tt, ff, W, **k: oracle.ls_sparse_spectral(yy, tt, ff, W, **k), lam=0.5, mu=0.05, tol=1e-9, iters=2000)
     assert rel(Ss, Sso) <= 1e-4 and int(np.argmax(Ss)) == 8
+
+
+def test_f32_remaining_entry_points(L):
+    """lpvs_problem_create_lpv_rows_f32, lpvs_problem_solve_ridge_f32, lpvs_admm_set_state_f32, lpvs_windows_estimate_multi_f32,
+    lpvs_windowcsd_f32: float in / out around the same double arithmetic as their _f64 twins on the widened inputs."""
+    rng = np.random.default_rng(52)
+    N, Nf, Nv = 1500, 12, 4
+    X = np.sort(rng.random(N) * 10).astype(np.float32); V = np.linspace(0, 1, N).astype(np.float32)
+    w = (2 * np.pi * (np.arange(Nf) + 1.0) * 2).astype(np.float32)
+    y = (np.cos(w[3].astype(np.float64) * X) * (1 + V) + 0.05 * rng.standard_normal(N)).astype(np.float32)
+    X64, V64, w64, y64 = (a.astype(np.float64) for a in (X, V, w, y))
+    prox = L.SlicedSeparableSum.frequency_groups(2.0, Nf, 2 * Nv)
+    # row-sharded constructor with the whole record as its one shard == the plain constructor
+    with L.Problem.lpv_rows(y, X, V, w, Nv, L.lpv_ranges(X64, V64)) as pr, L.Problem.lpv(y, X, V, w, Nv) as pl, \
+            L.Problem.lpv(y64, X64, V64, w64, Nv) as pd:
+        assert pr.f32 and pl.f32 and not pd.f32
+        for p in (pr, pl, pd):
+            p.set_prox(prox)
+            p.admm_init(None, μ=0.05, tol=0.0)
+            p.admm_run(60)
+        xr, zr, ur = pr.admm_get(); xl, zl, ul = pl.admm_get(); xd, zd, ud = pd.admm_get()
+        assert xr.dtype == np.float32 and np.array_equal(zr, zl)
+        assert rel(zr, zd) <= 2e-5 and np.array_equal(zr != 0, zd != 0)
+        # re-entry from float iterates: 60 + 40 iterations == 100 iterations up to the float rounding of the saved state
+        pl.admm_init(None, μ=0.05, tol=0.0)
+        pl.admm_set_state(xl, zl, ul, iters=60)
+        it, _, _ = pl.admm_run(40)
+        pd.admm_run(40)
+        assert it == 100
+        assert rel(pl.admm_get()[1], pd.admm_get()[1]) <= 5e-5
+        # dense estimator on the float handle
+        a32, a64 = pl.solve_ridge(1e-3), pd.solve_ridge(1e-3)
+        assert a32.dtype == np.float32 and rel(a32, a64) <= 2e-5
+    # windows on several devices driven by one process (here: one device), float records
+    Lh = 4000
+    t = np.cumsum(0.5 + rng.random(Lh)).astype(np.float32)
+    f = (np.arange(1, 33) / 80.0).astype(np.float32)
+    t64, f64 = t.astype(np.float64), f.astype(np.float64)
+    ys = (np.sin(2 * np.pi * f64[8] * t64) + 0.1 * rng.standard_normal(Lh)).astype(np.float32)
+    us = (0.7 * np.sin(2 * np.pi * f64[8] * t64 + 0.5) + 0.1 * rng.standard_normal(Lh)).astype(np.float32)
+    eng = dict(estimator=1, lam=0.0, prox=(1, 0.5, 0), μ=0.05, tol=1e-9, iters=500, sign=-1)
+    W = L.hanning(500).astype(np.float32)
+    xm, itm = L.windows_estimate_multi([ys, us], t, f, 500, 0, W, eng, ngpus=1)
+    xs, its = L.windows_estimate([ys, us], t, f, 500, 0, W, eng)
+    xd, itd = L.windows_estimate([ys.astype(np.float64), us.astype(np.float64)], t64, f64, 500, 0, W.astype(np.float64), eng)
+    assert xm.dtype == np.complex64 and np.array_equal(xm, xs) and np.array_equal(itm, its)
+    assert rel(xm, xd) <= 2e-5
+    Syu, Syy, Suu, xy, xu = L.windowcsd_batched(ys, us, t, f, 500, 0, W, eng)
+    assert Syy.dtype == np.float32 and np.array_equal(xy, xs[0]) and np.array_equal(xu, xs[1])
