@@ -444,7 +444,8 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         "config": {"workload": "cfg3: ls_sparse_spectral_lpv group-lasso N=2^%d Nf=%d Nv=%d n=%d lambda=%g mu=%g iters=%d tol=0, one signal per GPU"
                                % (args.log2n, NF, NV, 2 * NF * NV, LAMBDA, MU, iters),
                    "signals_per_step_per_gpu": 1.0 / world if rowsh else 1, "gram_form": form,
-                   "gram": ("structured (VALU f64, nudft.hip); MFMA path not taken" if form == "ap" else "dense f64 MFMA (%s)" % form),
+                   "gram": ("structured, slot sums by a non-uniform FFT (nufft.hip); MFMA path not taken" if form == "ap-nufft" else
+                            "structured (VALU f64, nudft.hip); MFMA path not taken" if form == "ap" else "dense f64 MFMA (%s)" % form),
                    "matvec_storage": mv_info["storage"], "whole_step_with_8_byte_storage": alt_step, "concurrent_solves_per_gpu": args.streams,
                    "sharding": "sample rows of one signal over the ranks, one all-reduce of the Gram (SURVEY 8(e)(2))" if rowsh else "independent signals",
                    "final_gather": "none" if (world == 1 or rowsh) else ("rccl" if args.backend == "nccl" else args.backend) + " all_gather"},

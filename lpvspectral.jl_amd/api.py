@@ -434,7 +434,7 @@ class Problem:
         check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 9))
         return dict(basis_ms=t[0], gram_ms=t[1], reduce_rhs_ms=t[2], factor_ms=t[3], admm_ms=t[4],
                     gram_issued_flops=t[5], gram_flops=t[6], admm_iters=t[7],
-                    gram_form=("given", "kr", "krs", "panel", "ap")[int(t[8])])
+                    gram_form=("given", "kr", "krs", "panel", "ap", "ap-nufft")[int(t[8])])
 
 
 # --------------------------------------------------------------------------- ADMM driver

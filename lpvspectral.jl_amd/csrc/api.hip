@@ -546,6 +546,7 @@ struct ApSlots {
     bool ok = false;
     double emax = 0;
     int64_t nf8 = 0, s8 = 0, nsl = 0;
+    bool merged = false;   // one progression j*D serves differences and sums (see above)
     int64_t s0 = 0;        // slot of the sum frequency 2a (split layout: nf8; merged: j0)
     double delta = 0;      // merged layout: 2a - j0*D
     std::vector<double> eps, om_hi, om_lo, omr_hi, omr_lo;
@@ -588,7 +589,7 @@ static ApSlots make_ap_slots(const std::vector<double> &hw, double xam) {
         const long long j0 = llroundl(j0r);
         const long double delta = 2.0L * a0 - (long double)j0 * D;
         if (j0 >= 0 && j0 < Nf && std::fabs((double)delta) * xam <= 1e-7) {
-            merged = true;
+            merged = true; sl.merged = true;
             sl.s0 = j0; sl.delta = (double)delta;
             sl.nsl = round_up(j0 + 2 * Nf - 1, 8);
             sl.s8 = sl.nsl;
@@ -682,20 +683,50 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         LPVS_TRY(tab.alloc(sizeof(double) * (size_t)nsl * (size_t)P * 4));
         LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)nf8 * (size_t)nb * 4));
         LPVS_HIP(hipEventRecord(h->ev[1].a, s));
-        LPVS_TRY(launch_nudft(dX.p, nullptr, N, KK.as<double>(), P, (int)P, sd.hi.as<double>(), sd.lo.as<double>(), (int)nsl, step, part.as<double>(), tab.as<double>(), s));
+        // merged slot layout: the slot sums are Fourier coefficients at the multiples of ONE step -> non-uniform FFT (nufft.hip);
+        // LPVS_NUDFT=direct keeps the direct evaluation of nudft.hip
+        const bool nufft_on = [] { const char *e = getenv("LPVS_NUDFT"); return !(e && std::string(e) == "direct"); }();
+        const bool nufft = nufft_on && sl.merged && nufft_applicable(N, nsl, P);
+        DevBuf nwork;
+        const int nfg = nufft_grid_size(nsl);
+        double xam_ = 0;
+        if (nufft) {
+            LPVS_TRY(nwork.alloc(nufft_work_bytes(N, nsl, P)));
+            if (ranges) xam_ = ranges[3];
+            else { double xl_, xh_; LPVS_TRY(device_minmax(dX.p, N, &xl_, &xh_, &xam_, s)); }
+            LPVS_TRY(launch_nufft_tab(dX.p, nullptr, N, xam_, KK.as<double>(), P, (int)P, step.hi[1], step.lo[1], 0, (int)nsl, nfg, false, nwork.p,
+                                      tab.as<double>(), s));
+            h->gram_form = 5;
+        } else {
+            h->gram_form = 4;
+            LPVS_TRY(launch_nudft(dX.p, nullptr, N, KK.as<double>(), P, (int)P, sd.hi.as<double>(), sd.lo.as<double>(), (int)nsl, step, part.as<double>(), tab.as<double>(), s));
+        }
         LPVS_TRY(launch_ap_assemble(tab.as<double>(), sd.eps.as<double>(), Nf, sl.s0, sl.delta, nb, h->n, h->G.as<double>(), h->np, s));
         LPVS_HIP(hipEventRecord(h->ev[1].b, s));
         LPVS_HIP(hipEventRecord(h->ev[2].a, s));
+        // right-hand sides: the slots a + f*D are the modes s0/2 + f of the same step when s0 is even -> same grid, same coordinates
+        const bool nufft_rhs = nufft && sl.s0 % 2 == 0 && (int)(sl.s0 / 2 + nf8) <= (int)nsl;
+        DevBuf epsr;                                  // mode (s0/2 + f) D is a + f D - delta/2: the residual joins the first-order term
+        if (nufft_rhs) {
+            std::vector<double> er(sl.eps.size());
+            for (size_t f = 0; f < er.size(); ++f) er[f] = sl.eps[f] + 0.5 * sl.delta;
+            LPVS_TRY(epsr.alloc(sizeof(double) * er.size()));
+            LPVS_TRY(copy_to_device(epsr.p, er.data(), sizeof(double) * er.size(), s));
+            LPVS_HIP(hipStreamSynchronize(s));       // (er is a local)
+        }
         for (int64_t q = 0; q < ns; ++q) {   // b_q = Phi' y_q: Nf slots a + f*D, weights y K_j, first-order eps correction
-            LPVS_TRY(launch_nudft(dX.p, dy.p + q * N, N, K.as<double>(), ldk, (int)nb, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)nf8, step, part.as<double>(), tabb.as<double>(), s));
-            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), sd.eps.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
+            if (nufft_rhs)
+                LPVS_TRY(launch_nufft_tab(dX.p, dy.p + q * N, N, xam_, K.as<double>(), ldk, (int)nb, step.hi[1], step.lo[1], (int)(sl.s0 / 2), (int)nf8, nfg,
+                                          true, nwork.p, tabb.as<double>(), s));
+            else
+                LPVS_TRY(launch_nudft(dX.p, dy.p + q * N, N, K.as<double>(), ldk, (int)nb, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)nf8, step, part.as<double>(), tabb.as<double>(), s));
+            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), nufft_rhs ? epsr.as<double>() : sd.eps.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
         }
         LPVS_HIP(hipEventRecord(h->ev[2].b, s));
         LPVS_HIP(hipStreamSynchronize(s));
         h->t_basis = h->ev[0].ms(); h->t_gram = h->ev[1].ms(); h->t_reduce = h->ev[2].ms();
         h->gram_launches = 8.0 * (double)N * (double)nsl * (double)P;   // flops the structured form issues (4 fma per sample, slot, pair)
         h->gram_flops = (double)N * (double)h->n * (double)(h->n + 1);
-        h->gram_form = 4;
         guard.h = nullptr;
         *out = h;
         return LPVS_OK;

@@ -130,6 +130,12 @@ int32_t launch_nudft(const double *x, const double *y, int64_t N, const double *
 int32_t launch_nudft_windows(const double *x, const double *y, const double *Wt, const double *om_hi, const double *om_lo, int nslots,
                              const ApStep &step, const int64_t *seg_dev, int nwin, int segs_per_window, double *partial, double *tab,
                              hipStream_t s);
+// the same slot sums by a type-1 non-uniform FFT when the slot frequencies are j * D (nufft.hip); work: nufft_work_bytes
+int nufft_grid_size(int64_t nslots);
+bool nufft_applicable(int64_t N, int64_t nslots, int64_t nq);
+size_t nufft_work_bytes(int64_t N, int64_t nslots, int64_t nq);
+int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam, const double *Wt, int64_t ldw, int nq, double D_hi, double D_lo,
+                         int mode0, int nslots, int nf, bool reuse_coords, void *work, double *tab, hipStream_t s);
 // s0 = slot of the sum frequency 2a (sum of (f, f') = slot s0 + f + f'), delta = residual of 2a against that slot
 int32_t launch_ap_assemble_fourier(const double *tab, const double *eps, int64_t Nf, int64_t s0, double delta, int zf, int64_t n, double *G,
                                    int64_t ldg, int nbatch, int64_t tab_stride, int64_t g_stride, hipStream_t s);

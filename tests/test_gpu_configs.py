@@ -109,7 +109,7 @@ def test_cfg3_fullsize_structured_vs_dense_end_to_end(L):
                 out[form] = dict(z=z, x=x, it=it, nxz=nxz, params=p.params(0), form=p.timing()["gram_form"])
         finally:
             del os.environ["LPVS_GRAM_FORM"]
-    assert out["ap"]["form"] == "ap" and out["krs"]["form"] == "krs"
+    assert out["ap"]["form"] in ("ap", "ap-nufft") and out["krs"]["form"] == "krs"   # (slot sums direct or by non-uniform FFT)
     assert out["ap"]["it"] == out["krs"]["it"] == 2000
     za, zk = out["ap"]["z"], out["krs"]["z"]
     ga = np.abs(za).reshape(512, 16).sum(1) > 0
@@ -187,7 +187,7 @@ def test_cfg5_fullshape_eight_channels_invariants(L):
                      + 0.7 * torch.sin(w[(53 * q + 700) % Nf] * X) * V
                      + 0.1 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g) for q in range(ns)], dim=1)
     with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
-        assert p.n == 32768 and p.timing()["gram_form"] == "ap"
+        assert p.n == 32768 and p.timing()["gram_form"] in ("ap", "ap-nufft")
         p.set_prox(L.IndBallL0(r))
         p.admm_init(None, μ=mu, tol=0.0)
         it, _, conv = p.admm_run(30)

@@ -20,7 +20,7 @@ def test_lpv_structured_gram_small_and_ragged_sizes(L, oracle, N, Nf, Nv):
     y = rng.standard_normal(N)
     with L.Problem.lpv(y, X, V, w, Nv) as p:
         G, b = p.get_gram()
-        assert p.timing()["gram_form"] == "ap"
+        assert p.timing()["gram_form"] in ("ap", "ap-nufft")
     Phi = oracle.lpv_regressor(X, V, w, Nv)
     Go, bo = oracle.gram(Phi, y)
     assert np.abs(G - Go).max() <= _tol(w, X) * np.abs(Go).max()
@@ -35,7 +35,7 @@ def test_fourier_structured_gram_tiny_grids(L, oracle, f):
     y = rng.standard_normal(N)
     with L.Problem.fourier(y, t, f) as p:
         G, b = p.get_gram()
-        assert p.timing()["gram_form"] == "ap"
+        assert p.timing()["gram_form"] in ("ap", "ap-nufft")
     A, zf = oracle.get_fourier_regressor(t, f)
     Go, bo = oracle.gram(A, y)
     tol = _tol(2 * np.pi * f, t)
@@ -167,6 +167,6 @@ def test_structured_gram_at_the_admission_boundary(L, monkeypatch):
             Gd, bd = p.get_gram()
         monkeypatch.delenv("LPVS_GRAM_FORM")
         res[tag] = (form, np.abs(G - Gd).max() / np.abs(Gd).max(), np.abs(b - bd).max() / np.abs(bd).max())
-    assert res["below"][0] == "ap" and res["above"][0] in ("krs", "kr")
+    assert res["below"][0] in ("ap", "ap-nufft") and res["above"][0] in ("krs", "kr")
     assert res["below"][1] <= 1e-12 and res["below"][2] <= 1e-11, res
     assert res["above"][1] == 0.0

@@ -1,0 +1,72 @@
+"""Slot sums of the structured Gram by non-uniform FFT (csrc/nufft.hip, the default when the slot frequencies are multiples of one
+step and N >= 4096) against their direct evaluation (csrc/nudft.hip, LPVS_NUDFT=direct) and against the oracle.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _gram(L, y, X, V, w, Nv, mode, monkeypatch):
+    if mode:
+        monkeypatch.setenv("LPVS_NUDFT", mode)
+    else:
+        monkeypatch.delenv("LPVS_NUDFT", raising=False)
+    with L.Problem.lpv(y, X, V, w, Nv) as p:
+        G, b = p.get_gram()
+        form = p.timing()["gram_form"]
+    return G, b, form
+
+
+@pytest.mark.parametrize("N,Nf,Nv,a_over_D,shuffle", [(4096, 24, 3, 1.0, False),     # w = D (1..Nf): s0 = 2, right-hand sides by NUFFT too
+                                                      (20000, 130, 4, 0.0, True),      # default_freqs-like grid from zero, unsorted samples
+                                                      (70001, 300, 2, 1.5, False),     # s0 = 3 (odd): right-hand sides stay direct; ragged chunk
+                                                      (33000, 64, 8, 2.0, True)])
+def test_nufft_gram_equals_direct_evaluation(L, N, Nf, Nv, a_over_D, shuffle, monkeypatch):
+    rng = np.random.default_rng(N)
+    X = rng.random(N) * 400.0 - 100.0                    # negative abscissae too
+    if not shuffle:
+        X = np.sort(X)
+    V = rng.random(N) * 2 - 0.5
+    D = 0.731
+    w = D * (a_over_D + np.arange(Nf))
+    y = rng.standard_normal(N)
+    Gd, bd, fd = _gram(L, y, X, V, w, Nv, "direct", monkeypatch)
+    Gn, bn, fn = _gram(L, y, X, V, w, Nv, None, monkeypatch)
+    assert fd == "ap" and fn == "ap-nufft"
+    assert np.abs(Gn - Gd).max() <= 1e-12 * np.abs(Gd).max(), np.abs(Gn - Gd).max() / np.abs(Gd).max()
+    assert np.abs(bn - bd).max() <= 1e-12 * np.abs(bd).max(), np.abs(bn - bd).max() / np.abs(bd).max()
+    assert np.array_equal(Gn, Gn.T)
+    # fixed-point accumulation: no dependence on the order the hardware serves the scatter in
+    G2, b2, _ = _gram(L, y, X, V, w, Nv, None, monkeypatch)
+    assert np.array_equal(Gn, G2) and np.array_equal(bn, b2)
+
+
+def test_nufft_gram_against_the_oracle_and_multi_signal_rhs(L, oracle, monkeypatch):
+    rng = np.random.default_rng(3)
+    N, Nf, Nv, ns = 6000, 20, 3, 3
+    X = np.sort(rng.random(N) * 60.0); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) / 8
+    Y = rng.standard_normal((N, ns))
+    monkeypatch.delenv("LPVS_NUDFT", raising=False)
+    with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
+        G, _ = p.get_gram()
+        b = p.get_rhs()
+        assert p.timing()["gram_form"] == "ap-nufft"
+    Phi = oracle.lpv_regressor(X, V, w, Nv)
+    tol = 1e-12 + 4.5e-16 * np.abs(w).max() * np.abs(X).max()
+    for q in range(ns):
+        Go, bo = oracle.gram(Phi, Y[:, q])
+        assert np.abs(G - Go).max() <= tol * np.abs(Go).max()
+        assert np.abs(b[:, q] - bo).max() <= 10 * tol * max(np.abs(bo).max(), 1.0)
+
+
+def test_small_problems_and_split_slot_layouts_keep_the_direct_sums(L, monkeypatch):
+    monkeypatch.delenv("LPVS_NUDFT", raising=False)
+    rng = np.random.default_rng(4)
+    for N, w in ((1000, 0.5 * (1 + np.arange(12.0))),                 # too few samples for the grid to pay
+                 (8000, 0.37 + 0.5 * np.arange(12.0))):                # 2a is not a multiple of D: two slot families
+        X = np.sort(rng.random(N) * 30.0); V = rng.random(N)
+        with L.Problem.lpv(rng.standard_normal(N), X, V, w, 3) as p:
+            assert p.timing()["gram_form"] == "ap"
