@@ -34,7 +34,8 @@ namespace {
 
 constexpr int NU_W = 16;                             // kernel width (grid points)
 constexpr double NU_BETA = 2.30 * NU_W;
-constexpr int NU_GPW = 4;                            // grids per spreading workgroup (4 x nf x 8 B of LDS: nf <= 4096)
+// grids per spreading workgroup: GPW x nf x 8 B of LDS -- 4 for nf <= 4096, 2 for nf = 8192 (the cfg5 slot count)
+static int nu_gpw(int nf) { return nf <= 4096 ? 4 : 2; }
 constexpr double NU_MAGIC = 6755399441055744.0;      // 1.5 * 2^52
 constexpr int NU_CHUNK = 32768;                      // samples per spreading workgroup
 
@@ -79,26 +80,34 @@ nufft_colmax_kernel(const double *__restrict__ Wt, const double *__restrict__ y,
     for (int q = threadIdx.x; q < nq && q < 256; q += 256) if (m[q]) atomicMax(out + q, m[q]);
 }
 
-// grid gamma = 2 q + twin (twin: weights x_n c_q[n]);  invq[gamma] = 1 / quantum.  Workgroup (group of NU_GPW grids, chunk of samples).
+// grid gamma = 2 q + twin (twin: weights x_n c_q[n]);  invq[gamma] = 1 / quantum.  Workgroup (group of GPW grids = GPW/2 weight
+// columns, chunk of samples).
+template <int GPW>
 __global__ void __launch_bounds__(256)
 nufft_spread_kernel(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ Wt, int64_t ldw, int nq, int64_t N, int nf,
                     const int *__restrict__ cell0, const double *__restrict__ taps, const double *__restrict__ invq,
                     long long *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) long long G[];          // [NU_GPW][nf]
+    extern __shared__ __attribute__((aligned(16))) long long G[];          // [GPW][nf]
     const int gg = blockIdx.x, ch = blockIdx.y;
-    for (int e = threadIdx.x; e < NU_GPW * nf; e += 256) G[e] = 0;
+    for (int e = threadIdx.x; e < GPW * nf; e += 256) G[e] = 0;
     __syncthreads();
-    const int q0 = gg * (NU_GPW / 2);                // the group's two weight columns (plain + twin each)
-    const double iq[NU_GPW] = {q0 < nq ? invq[2 * q0] : 0.0, q0 < nq ? invq[2 * q0 + 1] : 0.0,
-                               q0 + 1 < nq ? invq[2 * q0 + 2] : 0.0, q0 + 1 < nq ? invq[2 * q0 + 3] : 0.0};
+    constexpr int NC = GPW / 2;                      // weight columns of the group (plain + twin grid each)
+    const int q0 = gg * NC;
+    double iq[GPW];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { iq[2 * c] = q0 + c < nq ? invq[2 * (q0 + c)] : 0.0; iq[2 * c + 1] = q0 + c < nq ? invq[2 * (q0 + c) + 1] : 0.0; }
     const int64_t n0 = (int64_t)ch * NU_CHUNK, n1 = n0 + NU_CHUNK < N ? n0 + NU_CHUNK : N;
     const long long magic_bits = __double_as_longlong(NU_MAGIC);
     for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
         const int c0 = cell0[n];
-        const double xv = x[n];
-        const double yv = y ? y[n] : 1.0;
-        const double w0 = q0 < nq ? Wt[n * ldw + q0] * yv : 0.0, w1 = q0 + 1 < nq ? Wt[n * ldw + q0 + 1] * yv : 0.0;
-        const double cw[NU_GPW] = {w0 * iq[0], (xv * w0) * iq[1], w1 * iq[2], (xv * w1) * iq[3]};   // weights in quanta
+        const double xv = x[n], yv = y ? y[n] : 1.0;
+        double cw[GPW];                              // weights in quanta
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double wv = q0 + c < nq ? Wt[n * ldw + q0 + c] * yv : 0.0;
+            cw[2 * c] = wv * iq[2 * c];
+            cw[2 * c + 1] = (xv * wv) * iq[2 * c + 1];
+        }
         const double2 *tp = reinterpret_cast<const double2 *>(taps + n * NU_W);
 #pragma unroll
         for (int k2 = 0; k2 < NU_W / 2; ++k2) {
@@ -108,7 +117,7 @@ nufft_spread_kernel(const double *__restrict__ x, const double *__restrict__ y, 
                 const double tv = h ? t.y : t.x;
                 const int cell = (c0 + 2 * k2 + h) & (nf - 1);
 #pragma unroll
-                for (int gi = 0; gi < NU_GPW; ++gi) {
+                for (int gi = 0; gi < GPW; ++gi) {
                     const long long a = __double_as_longlong(fma(cw[gi], tv, NU_MAGIC)) - magic_bits;   // round(cw * tap), exactly
                     atomicAdd(reinterpret_cast<unsigned long long *>(&G[gi * nf + cell]), (unsigned long long)a);
                 }
@@ -116,36 +125,42 @@ nufft_spread_kernel(const double *__restrict__ x, const double *__restrict__ y, 
         }
     }
     __syncthreads();
-    long long *out = partial + ((int64_t)ch * gridDim.x + gg) * NU_GPW * nf;
-    for (int e = threadIdx.x; e < NU_GPW * nf; e += 256) out[e] = G[e];
+    long long *out = partial + ((int64_t)ch * gridDim.x + gg) * GPW * nf;
+    for (int e = threadIdx.x; e < GPW * nf; e += 256) out[e] = G[e];
 }
 
 // integer sum of the chunk partials -> grid[gamma][g] as doubles (gamma = 2 q + twin)
 __global__ void __launch_bounds__(256)
-nufft_reduce_kernel(const long long *__restrict__ partial, int ngroups, int nchunks, int nf, double *__restrict__ grid) {
+nufft_reduce_kernel(const long long *__restrict__ partial, int ngroups, int nchunks, int nf, int gpw, double *__restrict__ grid) {
     const int gamma = blockIdx.y, q = gamma >> 1, twin = gamma & 1;
-    const int gg = q / (NU_GPW / 2), gi = (q % (NU_GPW / 2)) * 2 + twin;
+    const int gg = q / (gpw / 2), gi = (q % (gpw / 2)) * 2 + twin;
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= nf) return;
     long long s = 0;
-    for (int ch = 0; ch < nchunks; ++ch) s += partial[(((int64_t)ch * ngroups + gg) * NU_GPW + gi) * nf + g];
+    for (int ch = 0; ch < nchunks; ++ch) s += partial[(((int64_t)ch * ngroups + gg) * gpw + gi) * nf + g];
     grid[(int64_t)gamma * nf + g] = (double)s;
 }
 
 // grid gamma: pruned DFT for the modes of this workgroup's block, deconvolution, scaling
 //   tab[(j * nq + q) * 4 + 2 twin + {0, 1}] = {Re, Im} sum_g grid[g] e^{+2 pi i j g / nf} * quantum / phihat[j]
+// HALF: the twiddle table holds g < nf / 2 only (e^{2 pi i (g + nf/2) / nf} = -e^{2 pi i g / nf}, the sign goes onto the grid value):
+// 16 nf instead of 24 nf bytes of LDS, which is what lets nf = 8192 fit.
+template <bool HALF>
 __global__ void __launch_bounds__(256)
 nufft_modes_kernel(const double *__restrict__ grid, int nf, int nq, int mode0, int nslots,
                    const double *__restrict__ scale /* [2 nq][nslots] = quantum / phihat(mode0 + slot) */, double *__restrict__ tab) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Gd = lds;                                // [nf]
-    double2 *tw = reinterpret_cast<double2 *>(lds + nf);   // [nf]  e^{2 pi i g / nf}
+    double2 *tw = reinterpret_cast<double2 *>(lds + nf);   // [nf] or [nf / 2]  e^{2 pi i g / nf}
     const int gamma = blockIdx.x, q = gamma >> 1, twin = gamma & 1;
+    const int ntw = HALF ? nf >> 1 : nf;
     for (int g = threadIdx.x; g < nf; g += 256) {
         Gd[g] = grid[(int64_t)gamma * nf + g];
-        double sn, cs;
-        sincospi(2.0 * (double)g / (double)nf, &sn, &cs);
-        tw[g] = make_double2(cs, sn);
+        if (g < ntw) {
+            double sn, cs;
+            sincospi(2.0 * (double)g / (double)nf, &sn, &cs);
+            tw[g] = make_double2(cs, sn);
+        }
     }
     __syncthreads();
     const int j = blockIdx.y * 256 + threadIdx.x;    // output slot j = mode mode0 + j
@@ -153,12 +168,16 @@ nufft_modes_kernel(const double *__restrict__ grid, int nf, int nq, int mode0, i
     double ac0 = 0, as0 = 0, ac1 = 0, as1 = 0;       // two interleaved chains (even / odd g), added at the end: fixed order
     int idx = 0;
     const int mask = nf - 1, mj = (mode0 + j) & mask;
+    const int hmask = mask >> 1, hbit = nf >> 1;
     for (int g = 0; g < nf; g += 2) {
-        const double2 t0 = tw[idx];
+        const double2 t0 = tw[HALF ? idx & hmask : idx];
+        const bool n0 = HALF && (idx & hbit);
         idx = (idx + mj) & mask;
-        const double2 t1 = tw[idx];
+        const double2 t1 = tw[HALF ? idx & hmask : idx];
+        const bool n1 = HALF && (idx & hbit);
         idx = (idx + mj) & mask;
-        const double v0 = Gd[g], v1 = Gd[g + 1];
+        double v0 = Gd[g], v1 = Gd[g + 1];
+        if (HALF) { v0 = n0 ? -v0 : v0; v1 = n1 ? -v1 : v1; }
         ac0 = fma(v0, t0.x, ac0); as0 = fma(v0, t0.y, as0);
         ac1 = fma(v1, t1.x, ac1); as1 = fma(v1, t1.y, as1);
     }
@@ -178,15 +197,15 @@ int nufft_grid_size(int64_t nslots) {
 }
 bool nufft_applicable(int64_t N, int64_t nslots, int64_t nq) {
     const int nf = nufft_grid_size(nslots);
-    return nf <= 4096 && N >= 4096 && nq >= 1;       // (NU_GPW grids of nf 64-bit cells have to fit the LDS)
+    return nf <= 8192 && N >= 4096 && nq >= 1 && nq <= 256;   // (at least two grids of nf 64-bit cells have to fit the LDS)
 }
 size_t nufft_work_bytes(int64_t N, int64_t nslots, int64_t nq) {
-    const int nf = nufft_grid_size(nslots);
-    const int64_t ngroups = (nq + NU_GPW / 2 - 1) / (NU_GPW / 2), nchunks = (N + NU_CHUNK - 1) / NU_CHUNK;
+    const int nf = nufft_grid_size(nslots), gpw = nu_gpw(nf);
+    const int64_t ngroups = (nq + gpw / 2 - 1) / (gpw / 2), nchunks = (N + NU_CHUNK - 1) / NU_CHUNK;
     size_t b = 0;
     b += sizeof(double) * (size_t)N * NU_W;                                   // taps
     b += ((sizeof(int) * (size_t)N + 255) / 256) * 256;                       // cell0
-    b += sizeof(long long) * (size_t)nchunks * (size_t)ngroups * NU_GPW * (size_t)nf;   // chunk partial grids
+    b += sizeof(long long) * (size_t)nchunks * (size_t)ngroups * (size_t)gpw * (size_t)nf;   // chunk partial grids
     b += sizeof(double) * (size_t)(2 * nq) * (size_t)(nslots + 1);            // scale table + 1 / quantum
     b += sizeof(double) * (size_t)(2 * nq) * (size_t)nf;                      // reduced grids
     b += sizeof(unsigned long long) * (size_t)nq + 256;                       // column maxima
@@ -198,11 +217,12 @@ size_t nufft_work_bytes(int64_t N, int64_t nslots, int64_t nq) {
 // `work` are those of an earlier call with the same x, N, D and nf.
 int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam, const double *Wt, int64_t ldw, int nq, double D_hi, double D_lo,
                          int mode0, int nslots, int nf, bool reuse_coords, void *work, double *tab, hipStream_t s) {
-    const int ngroups = (nq + NU_GPW / 2 - 1) / (NU_GPW / 2), nchunks = (int)((N + NU_CHUNK - 1) / NU_CHUNK);
+    const int gpw = nu_gpw(nf);
+    const int ngroups = (nq + gpw / 2 - 1) / (gpw / 2), nchunks = (int)((N + NU_CHUNK - 1) / NU_CHUNK);
     unsigned char *wp = static_cast<unsigned char *>(work);
     double *taps = reinterpret_cast<double *>(wp); wp += sizeof(double) * (size_t)N * NU_W;
     int *cell0 = reinterpret_cast<int *>(wp); wp += ((sizeof(int) * (size_t)N + 255) / 256) * 256;
-    long long *partial = reinterpret_cast<long long *>(wp); wp += sizeof(long long) * (size_t)nchunks * (size_t)ngroups * NU_GPW * (size_t)nf;
+    long long *partial = reinterpret_cast<long long *>(wp); wp += sizeof(long long) * (size_t)nchunks * (size_t)ngroups * (size_t)gpw * (size_t)nf;
     double *scale = reinterpret_cast<double *>(wp); wp += sizeof(double) * (size_t)(2 * nq) * (size_t)nslots;
     double *invq = reinterpret_cast<double *>(wp); wp += sizeof(double) * (size_t)(2 * nq);
     double *grid = reinterpret_cast<double *>(wp); wp += sizeof(double) * (size_t)(2 * nq) * (size_t)nf;
@@ -272,15 +292,28 @@ int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam
     }
     LPVS_TRY(copy_to_device(scale, hscale.data(), sizeof(double) * hscale.size(), s));
     LPVS_TRY(copy_to_device(invq, hinvq.data(), sizeof(double) * hinvq.size(), s));
-    const size_t lds_spread = sizeof(long long) * NU_GPW * (size_t)nf;
-    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_spread_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spread));
-    hipLaunchKernelGGL(nufft_spread_kernel, dim3((unsigned)ngroups, (unsigned)nchunks), dim3(256), lds_spread, s, x, y, Wt, ldw, nq, N, nf, cell0, taps,
-                       invq, partial);
-    hipLaunchKernelGGL(nufft_reduce_kernel, dim3((unsigned)ceil_div(nf, 256), (unsigned)(2 * nq)), dim3(256), 0, s, partial, ngroups, nchunks, nf, grid);
-    const size_t lds_modes = sizeof(double) * 3 * (size_t)nf;
-    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_modes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_modes));
-    hipLaunchKernelGGL(nufft_modes_kernel, dim3((unsigned)(2 * nq), (unsigned)ceil_div(nslots, 256)), dim3(256), lds_modes, s, grid, nf, nq, mode0, nslots,
-                       scale, tab);
+    const size_t lds_spread = sizeof(long long) * (size_t)gpw * (size_t)nf;
+    if (gpw == 4) {
+        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_spread_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spread));
+        hipLaunchKernelGGL(nufft_spread_kernel<4>, dim3((unsigned)ngroups, (unsigned)nchunks), dim3(256), lds_spread, s, x, y, Wt, ldw, nq, N, nf, cell0,
+                           taps, invq, partial);
+    } else {
+        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_spread_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spread));
+        hipLaunchKernelGGL(nufft_spread_kernel<2>, dim3((unsigned)ngroups, (unsigned)nchunks), dim3(256), lds_spread, s, x, y, Wt, ldw, nq, N, nf, cell0,
+                           taps, invq, partial);
+    }
+    hipLaunchKernelGGL(nufft_reduce_kernel, dim3((unsigned)ceil_div(nf, 256), (unsigned)(2 * nq)), dim3(256), 0, s, partial, ngroups, nchunks, nf, gpw, grid);
+    if (nf <= 4096) {
+        const size_t lds_modes = sizeof(double) * 3 * (size_t)nf;
+        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_modes_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_modes));
+        hipLaunchKernelGGL(nufft_modes_kernel<false>, dim3((unsigned)(2 * nq), (unsigned)ceil_div(nslots, 256)), dim3(256), lds_modes, s, grid, nf, nq, mode0,
+                           nslots, scale, tab);
+    } else {
+        const size_t lds_modes = sizeof(double) * 2 * (size_t)nf;
+        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_modes_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_modes));
+        hipLaunchKernelGGL(nufft_modes_kernel<true>, dim3((unsigned)(2 * nq), (unsigned)ceil_div(nslots, 256)), dim3(256), lds_modes, s, grid, nf, nq, mode0,
+                           nslots, scale, tab);
+    }
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
