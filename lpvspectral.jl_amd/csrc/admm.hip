@@ -786,18 +786,29 @@ __device__ __forceinline__ double fix_decode(unsigned int hi, unsigned int nib) 
     return __hiloint2double((int)top, (int)lo) - (0x1p52 + 0x1p35);
 }
 
+// one 16-byte load; NT: non-temporal (streams larger than the 256 MiB Infinity Cache read ~14 % faster that way -- tools/stream_read.hip:
+// 600 MB at 7.0 instead of 6.1 TB/s -- while a stream that fits it, the single-problem inverse of cfg3, gains nothing)
+template <bool NT, typename V>
+__device__ __forceinline__ V load16(const void *p) {
+    typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(V) == 16, "16-byte vectors only");
+    const u32x4n r = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4n *>(p)) : *reinterpret_cast<const u32x4n *>(p);
+    return __builtin_bit_cast(V, r);
+}
+
+template <bool NT = false>
 __device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, int lane, FixRaw &w) {
     const int g = lane >> 4, c = lane & 15;
     const int *head = reinterpret_cast<const int *>(tile) + (wave * 32 + g) * TS + 4 * c;
 #pragma unroll
     for (int rg = 0; rg < 8; ++rg) {
-        w.ha[rg] = *reinterpret_cast<const int4 *>(head + rg * 4 * TS);
-        w.hb[rg] = *reinterpret_cast<const int4 *>(head + rg * 4 * TS + 64);
+        w.ha[rg] = load16<NT, int4>(head + rg * 4 * TS);
+        w.hb[rg] = load16<NT, int4>(head + rg * 4 * TS + 64);
     }
     const uint4 *nq = reinterpret_cast<const uint4 *>(tile + kFixHeadBytes) + (wave * 64 + lane) * 2;
-    w.nq[0] = nq[0]; w.nq[1] = nq[1];
+    w.nq[0] = load16<NT, uint4>(nq); w.nq[1] = load16<NT, uint4>(nq + 1);
     const float4 *st = reinterpret_cast<const float4 *>(tile + kFixHeadBytes + kFixNibBytes) + (wave * 4 + g) * 2;
-    w.st[0] = st[0]; w.st[1] = st[1];
+    w.st[0] = load16<NT, float4>(st); w.st[1] = load16<NT, float4>(st + 1);
 }
 
 // the product of split_tile_product for a fixed-point tile (always off the diagonal)
@@ -1049,6 +1060,7 @@ symv_tile_mixed_kernel(const unsigned char *__restrict__ Mp, const unsigned char
 // mixed storage for a batch of problems that each own their matrix (windows): blockIdx.y = matrix, serving nrhs right-hand sides
 // (one right-hand side per matrix only: a loop over right-hand sides around the tile held in registers does not fit the 168
 // registers of three workgroups per CU -- batches with several signals per window keep the uniform 6-byte kernel)
+template <bool NT>
 __global__ void __launch_bounds__(256, 3)
 symv_tile_mixed_batch_kernel(const unsigned char *__restrict__ Mp_all, const unsigned char *__restrict__ types_all, size_t mp_stride,
                              const double *__restrict__ rhs_all, int64_t np, int ntiles, double *__restrict__ part1_all,
@@ -1076,7 +1088,7 @@ symv_tile_mixed_batch_kernel(const unsigned char *__restrict__ Mp_all, const uns
     const unsigned char ttype = types_all[(size_t)mat * ntiles + t];
     if (ttype != 0) {                                // (uniform) 36-bit fixed point; type 2: a diagonal tile, its diagonal apart in doubles
         FixRaw f;
-        fix_load(tile, wave, lane, f);
+        fix_load<NT>(tile, wave, lane, f);
         stage_rhs(mat, 0);
         fix_tile_product(f, sI, sJ, sT, part1_all + ((int64_t)mat * ntiles + t) * TS, part2_all + ((int64_t)mat * ntiles + t) * TS,
                          ttype == 2 ? reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4) : nullptr);
@@ -1102,9 +1114,9 @@ symv_tile_mixed_batch_kernel(const unsigned char *__restrict__ Mp_all, const uns
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int rg = 4 * half + r4;
-                ha[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
-                hb[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
-                lq[r4] = *reinterpret_cast<const uint4 *>(tail + rg * 4 * TS);
+                ha[r4] = load16<NT, float4>(head + rg * 4 * TS);
+                hb[r4] = load16<NT, float4>(head + rg * 4 * TS + 64);
+                lq[r4] = load16<NT, uint4>(tail + rg * 4 * TS);
             }
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -2183,8 +2195,15 @@ int32_t launch_pack_tiles_batch(const double *M, int64_t np, int nbatch, double 
 bool fused_ok(const AdmmParams &p);
 
 static void launch_mixed_batch(const AdmmBatch &p, unsigned ntiles, unsigned ns, double *part1, double *part2, const AdmmStatus *status, hipStream_t s) {
-    hipLaunchKernelGGL(symv_tile_mixed_batch_kernel, dim3(ntiles, ns), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
-                       (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, part1, part2, status);
+    // non-temporal loads once the inverses of the batch no longer fit the Infinity Cache (LPVS_NT_LOADS=0 / 1 forces either)
+    const char *e = getenv("LPVS_NT_LOADS");
+    const bool nt = e ? e[0] == '1' : (size_t)ntiles * kSplitTileBytes * ns > ((size_t)240 << 20);
+    if (nt)
+        hipLaunchKernelGGL(symv_tile_mixed_batch_kernel<true>, dim3(ntiles, ns), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
+                           (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, part1, part2, status);
+    else
+        hipLaunchKernelGGL(symv_tile_mixed_batch_kernel<false>, dim3(ntiles, ns), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
+                           (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, part1, part2, status);
 }
 
 int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s) {

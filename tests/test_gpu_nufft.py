@@ -23,7 +23,7 @@ def _gram(L, y, X, V, w, Nv, mode, monkeypatch):
                                                       (20000, 130, 4, 0.0, True),      # default_freqs-like grid from zero, unsorted samples
                                                       (70001, 300, 2, 1.5, False),     # s0 = 3 (odd): right-hand sides stay direct; ragged chunk
                                                       (33000, 64, 8, 2.0, True),
-                                                      (9000, 1100, 2, 1.0, False)])    # fine grid of 8192 cells: two grids per workgroup, half twiddle table
+                                                      (9000, 1000, 2, 1.0, False)])    # fine grid of 8192 cells: two grids per workgroup, half twiddle table
 def test_nufft_gram_equals_direct_evaluation(L, N, Nf, Nv, a_over_D, shuffle, monkeypatch):
     rng = np.random.default_rng(N)
     X = rng.random(N) * 400.0 - 100.0                    # negative abscissae too
