@@ -304,7 +304,8 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                    "windows_per_gpu": [L.sharding.shard_range(nwin, world, r)[1] - L.sharding.shard_range(nwin, world, r)[0] for r in range(world)],
                    "sharding": "contiguous window ranges per rank, no data-path collective",
                    "final_gather": "none" if world == 1 else ("rccl" if args.backend == "nccl" else args.backend) + " all_gather of per-window coefficients, PSD summed in window order",
-                   "gram": "structured (VALU f64, nudft.hip); MFMA path not taken"},
+                   "gram": {"ap-nufft": "structured, slot sums by a non-uniform FFT per window (nufft.hip); MFMA path not taken",
+                            "ap": "structured (VALU f64, nudft.hip); MFMA path not taken"}.get(tm.get("gram_form"), "dense f64 MFMA (panel form)")},
         "admm_iters_per_sec": nwin * iters * steps / elapsed,
         "phase_ms_rank0": {k: v for k, v in tm.items() if k.endswith("_ms")},
         "psd_argmax": int(np.argmax(S)), "iters_min_max": [int(its.min()), int(its.max())],

@@ -1432,6 +1432,29 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     ApSlotsDev sd;
     DrainOnExit drain(s);
     const int64_t nprob_max = bw * ns;
+    // slot sums by non-uniform FFT (nufft.hip) when one progression serves all slots; LPVS_NUDFT=direct keeps the direct sums
+    const bool wnufft = ap && sl.merged && nufft_windows_applicable(n, sl.nsl) &&
+                        [] { const char *e = getenv("LPVS_NUDFT"); return !(e && std::string(e) == "direct"); }();
+    const bool wnufft_rhs = wnufft && sl.s0 % 2 == 0 && sl.s0 / 2 + sl.nf8 <= sl.nsl;   // a + f D = mode s0/2 + f (residual delta/2 -> eps)
+    const int nfg = wnufft ? nufft_grid_size(sl.nsl) : 0;
+    const int64_t wcols = wnufft_rhs ? 1 + ns : 1;
+    DevBuf wgrids, wscale_g, wscale_r, wepsr;
+    if (wnufft) {
+        LPVS_TRY(wgrids.alloc(sizeof(double) * (size_t)bw * (size_t)wcols * 2 * (size_t)nfg));
+        const std::vector<double> sg = nufft_window_scale(nfg, 0, (int)sl.nsl);
+        LPVS_TRY(wscale_g.alloc(sizeof(double) * sg.size()));
+        LPVS_TRY(copy_to_device(wscale_g.p, sg.data(), sizeof(double) * sg.size(), s));
+        if (wnufft_rhs) {
+            const std::vector<double> sr = nufft_window_scale(nfg, (int)(sl.s0 / 2), (int)sl.nf8);
+            std::vector<double> er(sl.eps.size());
+            for (size_t f = 0; f < er.size(); ++f) er[f] = sl.eps[f] + 0.5 * sl.delta;
+            LPVS_TRY(wscale_r.alloc(sizeof(double) * sr.size()));
+            LPVS_TRY(wepsr.alloc(sizeof(double) * er.size()));
+            LPVS_TRY(copy_to_device(wscale_r.p, sr.data(), sizeof(double) * sr.size(), s));
+            LPVS_TRY(copy_to_device(wepsr.p, er.data(), sizeof(double) * er.size(), s));
+        }
+        LPVS_HIP(hipStreamSynchronize(s));           // (the host vectors are locals)
+    }
     if (ap) {
         LPVS_TRY(sd.upload(sl, s));
         LPVS_TRY(seg.alloc(sizeof(int64_t) * 3 * (size_t)bw * (size_t)spw));
@@ -1466,7 +1489,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     std::vector<AdmmStatus> hst((size_t)nprob_max);
     std::vector<int> hist_((size_t)bw);
     const bool want_mv = sparse && getenv("LPVS_WINDOW_MATVEC_TIMING") != nullptr;
-    g_win_timing[3] = (double)nwin; g_win_timing[7] = ap ? 1 : 0;
+    g_win_timing[3] = (double)nwin; g_win_timing[7] = ap ? (wnufft ? 2 : 1) : 0;   // Gram form: 0 dense, 1 structured (direct sums), 2 structured (NUFFT)
 
     for (int64_t w0 = 0; w0 < nwin; w0 += bw) {
         const int nb_ = (int)((nwin - w0 < bw) ? nwin - w0 : bw);
@@ -1486,15 +1509,32 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
             LPVS_TRY(copy_to_device(seg.p, hseg.data(), sizeof(int64_t) * 3 * (size_t)nb_ * (size_t)spw, s));
             LPVS_HIP(hipMemsetAsync(G, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
             LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
-            LPVS_TRY(launch_nudft_windows(dt.p, nullptr, Wdev, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, seg.as<int64_t>(), nb_, spw,
-                                          npart.as<double>(), tab.as<double>(), s));
+            const int64_t gstride = wcols * 2 * (int64_t)nfg;      // doubles per window in wgrids: [column][plain, x-weighted][nfg]
+            if (wnufft) {   // column 0 = the window weights alone (Gram); with it, in the same pass over the samples, signal 0
+                LPVS_TRY(launch_nufft_window_spread(dt.p, Wdev, nullptr, wnufft_rhs ? dys[0].p : nullptr, wnufft_rhs, offs.as<int64_t>(), nb_, n, sl.step.hi[1],
+                                                    sl.step.lo[1], nfg, wgrids.as<double>(), wgrids.as<double>() + 2 * (int64_t)nfg, gstride, s));
+                LPVS_TRY(launch_nufft_window_modes(wgrids.as<double>(), gstride, nb_, nfg, 0, (int)sl.nsl, wscale_g.as<double>(), tab.as<double>(), sl.nsl * 4, s));
+            } else {
+                LPVS_TRY(launch_nudft_windows(dt.p, nullptr, Wdev, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, seg.as<int64_t>(), nb_, spw,
+                                              npart.as<double>(), tab.as<double>(), s));
+            }
             LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.s0, sl.delta, (int)zf, nreg, G, np, nb_, sl.nsl * 4,
                                                 np * np, s));                                       // Q = A'WA   src/lasso.jl:119
             tr.mark("gram (structured)");
             for (int64_t q = 0; q < ns; ++q) {   // q_s = A'W y_s for every signal sharing the window   :120
-                LPVS_TRY(launch_nudft_windows(dt.p, dys[(size_t)q].p, Wdev, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, seg.as<int64_t>(),
-                                              nb_, spw, npart.as<double>(), tabb.as<double>(), s));
-                LPVS_TRY(launch_ap_rhs_fourier(tabb.as<double>(), sd.eps.as<double>(), Nf, (int)zf, bvec.as<double>() + q * np, nb_, sl.nf8 * 4, ns * np, s));
+                if (wnufft_rhs) {
+                    if (q >= 1 && q % 2 == 1)        // signals 1, 2 | 3, 4 | ... two to a pass
+                        LPVS_TRY(launch_nufft_window_spread(dt.p, Wdev, dys[(size_t)q].p, q + 1 < ns ? dys[(size_t)q + 1].p : nullptr, q + 1 < ns, offs.as<int64_t>(), nb_,
+                                                            n, sl.step.hi[1], sl.step.lo[1], nfg, wgrids.as<double>() + (1 + q) * 2 * (int64_t)nfg,
+                                                            wgrids.as<double>() + (2 + q) * 2 * (int64_t)nfg, gstride, s));
+                    LPVS_TRY(launch_nufft_window_modes(wgrids.as<double>() + (1 + q) * 2 * (int64_t)nfg, gstride, nb_, nfg, (int)(sl.s0 / 2), (int)sl.nf8,
+                                                       wscale_r.as<double>(), tabb.as<double>(), sl.nf8 * 4, s));
+                } else {
+                    LPVS_TRY(launch_nudft_windows(dt.p, dys[(size_t)q].p, Wdev, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, seg.as<int64_t>(),
+                                                  nb_, spw, npart.as<double>(), tabb.as<double>(), s));
+                }
+                LPVS_TRY(launch_ap_rhs_fourier(tabb.as<double>(), wnufft_rhs ? wepsr.as<double>() : sd.eps.as<double>(), Nf, (int)zf, bvec.as<double>() + q * np, nb_,
+                                               sl.nf8 * 4, ns * np, s));
             }
         } else {
             LPVS_TRY(launch_window_panels(dt.p, offs.as<int64_t>(), nb_, n, nrows, df.p, Nf, (int)zf, P.as<double>(), ld, s));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <functional>
 #include <string>
+#include <vector>
 
 #include "../../include/lpvspectral.h"
 
@@ -136,6 +137,12 @@ bool nufft_applicable(int64_t N, int64_t nslots, int64_t nq);
 size_t nufft_work_bytes(int64_t N, int64_t nslots, int64_t nq);
 int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam, const double *Wt, int64_t ldw, int nq, double D_hi, double D_lo,
                          int mode0, int nslots, int nf, bool reuse_coords, void *work, double *tab, hipStream_t s);
+bool nufft_windows_applicable(int64_t n, int64_t nslots);
+std::vector<double> nufft_window_scale(int nf, int mode0, int nslots);
+int32_t launch_nufft_window_spread(const double *x, const double *W, const double *yA, const double *yB, bool hasB, const int64_t *offs_dev, int nwin,
+                                   int64_t n, double D_hi, double D_lo, int nf, double *gridA, double *gridB, int64_t grid_bstride, hipStream_t s);
+int32_t launch_nufft_window_modes(const double *grids, int64_t grid_bstride, int nwin, int nf, int mode0, int nslots, const double *scale_dev, double *tab,
+                                  int64_t tab_bstride, hipStream_t s);
 // s0 = slot of the sum frequency 2a (sum of (f, f') = slot s0 + f + f'), delta = residual of 2a against that slot
 int32_t launch_ap_assemble_fourier(const double *tab, const double *eps, int64_t Nf, int64_t s0, double delta, int zf, int64_t n, double *G,
                                    int64_t ldg, int nbatch, int64_t tab_stride, int64_t g_stride, hipStream_t s);

@@ -6,8 +6,9 @@
 // and the standard three steps get them in O(N w + nf nslots) per weight vector:
 //   1. spread:  every sample is convolved onto a fine periodic grid of nf >= 3.9 nslots points (nf a power of two) with the
 //      "exponential of semicircle" kernel  phi(z) = exp(beta (sqrt(1 - z^2) - 1)),  w = 16 grid points wide, beta = 2.30 w
-//      (Barnett, Magland, af Klinteberg, SIAM J. Sci. Comput. 41 (2019)): aliasing error 3e-15 of sum|c| at this oversampling
-//      (tools/nufft_accuracy.py restates the experiment);
+//      (Barnett, Magland, af Klinteberg, SIAM J. Sci. Comput. 41 (2019)): 2e-14 of sum|c| in a coefficient at this oversampling,
+//      aliasing and the double rounding of steps 2 and 3 together (w = 14: 3e-14, w = 12: 2e-12; tools/nufft_accuracy.py restates
+//      the experiment in numpy against long-double direct sums);
 //   2. the nslots wanted modes of the grid by a pruned direct DFT (nf * nslots complex MACs per grid: 0.3 GFLOP per grid at cfg3,
 //      not worth an FFT);
 //   3. division by the kernel's Fourier transform phihat(j) (Gauss-Legendre quadrature on the host, long double).
@@ -148,7 +149,10 @@ nufft_reduce_kernel(const long long *__restrict__ partial, int ngroups, int nchu
 template <bool HALF>
 __global__ void __launch_bounds__(256)
 nufft_modes_kernel(const double *__restrict__ grid, int nf, int nq, int mode0, int nslots,
-                   const double *__restrict__ scale /* [2 nq][nslots] = quantum / phihat(mode0 + slot) */, double *__restrict__ tab) {
+                   const double *__restrict__ scale /* [2 nq][nslots] = quantum / phihat(mode0 + slot) */, double *__restrict__ tab,
+                   int64_t scale_stride /* nslots; 0: one row for every grid */, int64_t grid_bstride, int64_t tab_bstride /* blockIdx.z = batch entry */) {
+    grid += (int64_t)blockIdx.z * grid_bstride;
+    tab += (int64_t)blockIdx.z * tab_bstride;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Gd = lds;                                // [nf]
     double2 *tw = reinterpret_cast<double2 *>(lds + nf);   // [nf] or [nf / 2]  e^{2 pi i g / nf}
@@ -181,13 +185,130 @@ nufft_modes_kernel(const double *__restrict__ grid, int nf, int nq, int mode0, i
         ac0 = fma(v0, t0.x, ac0); as0 = fma(v0, t0.y, as0);
         ac1 = fma(v1, t1.x, ac1); as1 = fma(v1, t1.y, as1);
     }
-    const double sc = scale[(int64_t)gamma * nslots + j];
+    const double sc = scale[(int64_t)gamma * scale_stride + j];
     double *o = tab + ((int64_t)j * nq + q) * 4 + 2 * twin;
     o[0] = (ac0 + ac1) * sc;
     o[1] = (as0 + as1) * sc;
 }
 
+
+// ---- windows of one long signal (the batched-window engine): ONE weight vector per window and signal, so a workgroup owns a
+// window outright: its maxima (-> quanta), the spreading of up to two weight columns (A: the window function alone -- the Gram --
+// or a signal; B: a signal) with their x-weighted twins into four LDS grids, kernel values computed on the fly (nothing is shared
+// between weight vectors that would pay for a table), and the scaled grids to global.  A window's result depends on its own
+// samples only: window shards reproduce the whole run bit for bit.
+__global__ void __launch_bounds__(256)
+nufft_window_kernel(const double *__restrict__ x, const double *__restrict__ W, const double *__restrict__ yA, const double *__restrict__ yB, int hasB,
+                    const int64_t *__restrict__ offs, int64_t n, double D_hi, double D_lo, int nf, double *__restrict__ gridA,
+                    double *__restrict__ gridB, int64_t grid_bstride) {
+    extern __shared__ __attribute__((aligned(16))) long long G[];          // [4][nf]: A, x A, B, x B
+    __shared__ unsigned long long smax[4];
+    const int win = blockIdx.x;
+    const int64_t r0 = offs[win];
+    const int ng = hasB ? 4 : 2;
+    for (int e = threadIdx.x; e < ng * nf; e += 256) G[e] = 0;
+    if (threadIdx.x < 4) smax[threadIdx.x] = 0;
+    __syncthreads();
+    // maxima of |c| and |x c| (integer max on the bit patterns of non-negative doubles: order-independent)
+    {
+        double m[4] = {0, 0, 0, 0};
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const double xv = fabs(x[r0 + i]), wv = W ? W[i] : 1.0;
+            const double cA = fabs(yA ? wv * yA[r0 + i] : wv), cB = hasB ? fabs(wv * yB[r0 + i]) : 0.0;
+            m[0] = fmax(m[0], cA); m[1] = fmax(m[1], xv * cA); m[2] = fmax(m[2], cB); m[3] = fmax(m[3], xv * cB);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (m[g] > 0.0) atomicMax(&smax[g], (unsigned long long)__double_as_longlong(m[g]));
+    }
+    __syncthreads();
+    double quantum[4], iq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const double bound = __longlong_as_double((long long)smax[g]) * (double)n;   // >= the sum of |weights| falling into any cell
+        int e = 0;
+        (void)frexp(bound > 0.0 ? bound : 1.0, &e);                                  // bound < 2^e
+        quantum[g] = ldexp(1.0, e - 62);                                             // power of two: the scalings are exact
+        iq[g] = bound > 0.0 ? 1.0 / quantum[g] : 0.0;
+    }
+    constexpr double I2PI_HI = 0.15915494309189535, I2PI_LO = -9.8393384885635288e-18;   // 1 / (2 pi) in double-double
+    const long long magic_bits = __double_as_longlong(NU_MAGIC);
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double xv = x[r0 + i], wv = W ? W[i] : 1.0;
+        const double cA = yA ? wv * yA[r0 + i] : wv, cB = hasB ? wv * yB[r0 + i] : 0.0;
+        const double cw[4] = {cA * iq[0], (xv * cA) * iq[1], cB * iq[2], (xv * cB) * iq[3]};
+        const double th = D_hi * xv, tl = fma(D_hi, xv, -th) + D_lo * xv;                     // D x (double-double), as nufft_coord_kernel
+        const double uh = th * I2PI_HI, ul = fma(th, I2PI_HI, -uh) + (th * I2PI_LO + tl * I2PI_HI);
+        double r = (uh - rint(uh)) + ul;
+        r -= floor(r);
+        double p = r * (double)nf;
+        if (p >= (double)nf) p -= (double)nf;
+        const int g0 = (int)ceil(p - 0.5 * NU_W);
+#pragma unroll 4
+        for (int k = 0; k < NU_W; ++k) {
+            const double z = ((double)(g0 + k) - p) * (2.0 / NU_W);
+            const double sq = 1.0 - z * z;
+            const double tv = sq > 0.0 ? exp(NU_BETA * (sqrt(sq) - 1.0)) : exp(-NU_BETA);
+            const int cell = (g0 + k + nf) & (nf - 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g >= 2 && !hasB) break;          // (uniform)
+                const long long a = __double_as_longlong(fma(cw[g], tv, NU_MAGIC)) - magic_bits;   // round(cw * tap), exactly
+                atomicAdd(reinterpret_cast<unsigned long long *>(&G[g * nf + cell]), (unsigned long long)a);
+            }
+        }
+    }
+    __syncthreads();
+    double *oA = gridA + (int64_t)win * grid_bstride, *oB = hasB ? gridB + (int64_t)win * grid_bstride : nullptr;
+    for (int e = threadIdx.x; e < 2 * nf; e += 256) {
+        const int twin = e >= nf;
+        oA[e] = (double)G[e] * quantum[twin];
+        if (hasB) oB[e] = (double)G[2 * nf + e] * quantum[2 + twin];
+    }
+}
+
 }  // namespace
+
+// phihat(j) = int_{-w/2}^{w/2} phi(2 t / w) cos(2 pi j t / nf) dt  (grid units), j < nmodes: 96-point Gauss-Legendre in long double;
+// depends on the grid size only -- computed once per process and (nf, nmodes)
+static std::vector<long double> nufft_phihat(int nf, int nmodes) {
+    static const std::vector<std::pair<long double, long double>> gl = [] {
+        const int n = 96;                                                      // nodes / weights on [-1, 1] by Newton on P_n
+        std::vector<std::pair<long double, long double>> r((size_t)n);
+        const long double pi = 3.141592653589793238462643383279502884L;
+        for (int i = 0; i < n; ++i) {
+            long double z = cosl(pi * (i + 0.75L) / (n + 0.5L)), pp = 0;
+            for (int it = 0; it < 100; ++it) {
+                long double p1 = 1, p2 = 0;
+                for (int k = 1; k <= n; ++k) { const long double p3 = p2; p2 = p1; p1 = ((2 * k - 1) * z * p2 - (k - 1) * p3) / k; }
+                pp = n * (z * p1 - p2) / (z * z - 1);
+                const long double dz = p1 / pp;
+                z -= dz;
+                if (fabsl(dz) < 1e-19L) break;
+            }
+            r[(size_t)i] = {z, 2 / ((1 - z * z) * pp * pp)};
+        }
+        return r;
+    }();
+    static std::mutex phat_mu;
+    static std::map<std::pair<int, int>, std::vector<long double>> phat_cache;
+    std::lock_guard<std::mutex> lk(phat_mu);
+    auto it = phat_cache.find({nf, nmodes});
+    if (it == phat_cache.end()) {
+        std::vector<long double> v((size_t)nmodes);
+        const long double pi = 3.141592653589793238462643383279502884L, half = 0.5L * NU_W;
+        for (int j = 0; j < nmodes; ++j) {
+            long double acc = 0;
+            for (const auto &nw : gl) {
+                const long double z = nw.first, t = z * half;
+                acc += nw.second * half * expl((long double)NU_BETA * (sqrtl(1 - z * z) - 1)) * cosl(2 * pi * (long double)j * t / (long double)nf);
+            }
+            v[(size_t)j] = acc;
+        }
+        it = phat_cache.emplace(std::make_pair(nf, nmodes), std::move(v)).first;
+    }
+    return it->second;
+}
 
 // fine grid for nslots modes: the smallest power of two >= 3.9 nslots (oversampling ~2 of the two-sided mode range)
 int nufft_grid_size(int64_t nslots) {
@@ -237,48 +358,8 @@ int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam
     std::vector<unsigned long long> hm((size_t)nq);
     LPVS_HIP(hipMemcpyAsync(hm.data(), colmax, sizeof(unsigned long long) * (size_t)nq, hipMemcpyDeviceToHost, s));
     LPVS_HIP(hipStreamSynchronize(s));
-    // phihat(j) = int_{-w/2}^{w/2} phi(2 t / w) cos(2 pi j t / nf) dt  (grid units), 64-point Gauss-Legendre on [0, w/2] x 2 ... in long double
-    static const std::vector<std::pair<long double, long double>> gl = [] {
-        const int n = 96;                                                      // nodes / weights on [-1, 1] by Newton on P_n
-        std::vector<std::pair<long double, long double>> r((size_t)n);
-        const long double pi = 3.141592653589793238462643383279502884L;
-        for (int i = 0; i < n; ++i) {
-            long double z = cosl(pi * (i + 0.75L) / (n + 0.5L)), pp = 0;
-            for (int it = 0; it < 100; ++it) {
-                long double p1 = 1, p2 = 0;
-                for (int k = 1; k <= n; ++k) { const long double p3 = p2; p2 = p1; p1 = ((2 * k - 1) * z * p2 - (k - 1) * p3) / k; }
-                pp = n * (z * p1 - p2) / (z * z - 1);
-                const long double dz = p1 / pp;
-                z -= dz;
-                if (fabsl(dz) < 1e-19L) break;
-            }
-            r[(size_t)i] = {z, 2 / ((1 - z * z) * pp * pp)};
-        }
-        return r;
-    }();
     std::vector<double> hscale((size_t)(2 * nq) * (size_t)nslots), hinvq((size_t)(2 * nq));
-    // (the kernel's transform depends on the grid size only: computed once per process and grid size)
-    static std::mutex phat_mu;
-    static std::map<std::pair<int, int>, std::vector<long double>> phat_cache;
-    std::vector<long double> phat;
-    {
-        std::lock_guard<std::mutex> lk(phat_mu);
-        auto it = phat_cache.find({nf, mode0 + nslots});
-        if (it == phat_cache.end()) {
-            std::vector<long double> v((size_t)(mode0 + nslots));
-            const long double pi = 3.141592653589793238462643383279502884L, half = 0.5L * NU_W;
-            for (int j = 0; j < mode0 + nslots; ++j) {
-                long double acc = 0;
-                for (const auto &nw : gl) {
-                    const long double z = nw.first, t = z * half;
-                    acc += nw.second * half * expl((long double)NU_BETA * (sqrtl(1 - z * z) - 1)) * cosl(2 * pi * (long double)j * t / (long double)nf);
-                }
-                v[(size_t)j] = acc;
-            }
-            it = phat_cache.emplace(std::make_pair(nf, mode0 + nslots), std::move(v)).first;
-        }
-        phat = it->second;
-    }
+    const std::vector<long double> phat = nufft_phihat(nf, mode0 + nslots);
     for (int q = 0; q < nq; ++q) {
         const double cmax = __builtin_bit_cast(double, hm[(size_t)q]);
         for (int twin = 0; twin < 2; ++twin) {
@@ -307,13 +388,47 @@ int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam
         const size_t lds_modes = sizeof(double) * 3 * (size_t)nf;
         LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_modes_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_modes));
         hipLaunchKernelGGL(nufft_modes_kernel<false>, dim3((unsigned)(2 * nq), (unsigned)ceil_div(nslots, 256)), dim3(256), lds_modes, s, grid, nf, nq, mode0,
-                           nslots, scale, tab);
+                           nslots, scale, tab, (int64_t)nslots, (int64_t)0, (int64_t)0);
     } else {
         const size_t lds_modes = sizeof(double) * 2 * (size_t)nf;
         LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_modes_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_modes));
         hipLaunchKernelGGL(nufft_modes_kernel<true>, dim3((unsigned)(2 * nq), (unsigned)ceil_div(nslots, 256)), dim3(256), lds_modes, s, grid, nf, nq, mode0,
-                           nslots, scale, tab);
+                           nslots, scale, tab, (int64_t)nslots, (int64_t)0, (int64_t)0);
     }
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+
+// ---- batched windows
+bool nufft_windows_applicable(int64_t n, int64_t nslots) {
+    return n >= 2048 && nslots >= 64 && nufft_grid_size(nslots) <= 4096;   // (four grids of nf 64-bit cells in LDS)
+}
+// 1 / phihat(mode0 + j), j < nslots: the per-mode scale shared by every window (their quanta are folded into the grids)
+std::vector<double> nufft_window_scale(int nf, int mode0, int nslots) {
+    const std::vector<long double> phat = nufft_phihat(nf, mode0 + nslots);
+    std::vector<double> r((size_t)nslots);
+    for (int j = 0; j < nslots; ++j) r[(size_t)j] = (double)(1.0L / phat[(size_t)(mode0 + j)]);
+    return r;
+}
+// Spread window q = samples offs[q] .. offs[q] + n of (x, yA, yB) with the window weights W[0..n) (nullptr = 1) onto fine grids:
+// gridA / gridB + q * grid_bstride hold [2][nf] doubles (plain, x-weighted).  yA == nullptr: unit signal (the Gram's weights).
+int32_t launch_nufft_window_spread(const double *x, const double *W, const double *yA, const double *yB, bool hasB, const int64_t *offs_dev, int nwin,
+                                   int64_t n, double D_hi, double D_lo, int nf, double *gridA, double *gridB, int64_t grid_bstride, hipStream_t s) {
+    const size_t lds = sizeof(long long) * 4 * (size_t)nf;
+    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(nufft_window_kernel, dim3((unsigned)nwin), dim3(256), lds, s, x, W, yA, yB, hasB ? 1 : 0, offs_dev, n, D_hi, D_lo, nf, gridA, gridB,
+                       grid_bstride);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+// tab + q * tab_bstride: [nslots][4] = {Re, Im, x-weighted Re, x-weighted Im} of modes mode0 .. of window q's grids
+int32_t launch_nufft_window_modes(const double *grids, int64_t grid_bstride, int nwin, int nf, int mode0, int nslots, const double *scale_dev, double *tab,
+                                  int64_t tab_bstride, hipStream_t s) {
+    const size_t lds_modes = sizeof(double) * 3 * (size_t)nf;
+    LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_modes_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_modes));
+    hipLaunchKernelGGL(nufft_modes_kernel<false>, dim3(2, (unsigned)ceil_div(nslots, 256), (unsigned)nwin), dim3(256), lds_modes, s, grids, nf, 1, mode0, nslots,
+                       scale_dev, tab, (int64_t)0, grid_bstride, tab_bstride);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
