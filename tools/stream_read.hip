@@ -39,11 +39,125 @@ __global__ void __launch_bounds__(256) read_chunks_plain(const u32x4 *__restrict
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
 }
 
+
+// the mat-vec's shape: ONE workgroup per 74 240-byte tile (grid = nchunks), every thread issues its 18 16-byte loads (+2 small) up front.
+// PATTERN 0: as the packed tiles are laid out now -- a wave instruction covers 4 rows x 256 B at 512-B stride;
+// PATTERN 1: lane order -- a wave instruction covers 1 KiB contiguous.
+template <int PATTERN>
+__global__ void __launch_bounds__(256, 3) read_tiles(const u32x4 *__restrict__ src, int64_t chunk16, unsigned *sink) {
+    const u32x4 *p = src + (int64_t)blockIdx.x * chunk16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    u32x4 v[18];
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        if (PATTERN == 0) {
+            const int base = ((wave * 32 + g + 4 * rg) * 128 + 4 * c) / 4;      // in 16-byte units: row (wave*32 + 4 rg + g), column 4c
+            v[2 * rg] = p[base];
+            v[2 * rg + 1] = p[base + 16];
+        } else {
+            const int base = ((wave * 8 + rg) * 2) * 64 + lane;
+            v[2 * rg] = p[base];
+            v[2 * rg + 1] = p[base + 64];
+        }
+    }
+    v[16] = p[4096 + (wave * 64 + lane) * 2];
+    v[17] = p[4096 + (wave * 64 + lane) * 2 + 1];
+    u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 18; ++u) acc ^= v[u];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
+// ... and with the mat-vec's arithmetic on the loaded words (MATH 1: the 36-bit decode of admm.hip -- alignbit, bfe, lshl_or, add_f64 --
+// and two FMAs per element, then the row / column reductions; MATH 2: one instruction less per element: the assembled double is used as
+// it is, biased, and the bias is taken off the row / column sums), to see what the arithmetic costs on top of the stream.
+__device__ __forceinline__ double opaque_d(double v) { asm volatile("" : "+v"(v)); return v; }
+template <int MATH>
+__global__ void __launch_bounds__(256, 3) math_tiles(const u32x4 *__restrict__ src, int64_t chunk16, const double *__restrict__ rhs, double *__restrict__ out) {
+    __shared__ double sI[128], sJ[128], sT[4][128];
+    const u32x4 *p = src + (int64_t)blockIdx.x * chunk16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    u32x4 ha[8], hb[8];
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        const int base = ((wave * 32 + g + 4 * rg) * 128 + 4 * c) / 4;
+        ha[rg] = p[base];
+        hb[rg] = p[base + 16];
+    }
+    const u32x4 n0 = p[4096 + (wave * 64 + lane) * 2], n1 = p[4096 + (wave * 64 + lane) * 2 + 1];
+    if (threadIdx.x < 128) sI[threadIdx.x] = rhs[(blockIdx.x % 61) * 128 + threadIdx.x]; else sJ[threadIdx.x - 128] = rhs[(blockIdx.x % 59) * 128 + threadIdx.x - 128];
+    __syncthreads();
+    double rj[8], tc[8], v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+    const unsigned nw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+    double sumr = 0;
+    if (MATH == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sumr += rj[k];
+    }
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        const double ri = sI[wave * 32 + 4 * rg + g];
+        const unsigned hh[8] = {ha[rg].x, ha[rg].y, ha[rg].z, ha[rg].w, hb[rg].x, hb[rg].y, hb[rg].z, hb[rg].w};
+        double a0 = 0, a1 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double m;
+            if (MATH == 1) {
+                const unsigned top = __builtin_amdgcn_alignbit(0x04330000u, hh[k], 28);
+                unsigned lo = (nw[rg] >> (4 * k)) & 15u;
+                asm("v_lshl_or_b32 %0, %1, 4, %0" : "+v"(lo) : "v"(hh[k]));
+                m = __hiloint2double((int)top, (int)lo) - (0x1p52 + 0x1p35);
+            } else {
+                // 2^36 + q: exponent 0x423, mantissa = q << 16:  hi dword = 0x42300000 | (q >> 16) = alignbit(0x423, hh, 12),  lo dword = (hh << 20) | (nib << 16)
+                const unsigned top = __builtin_amdgcn_alignbit(0x423u, hh[k], 12);
+                unsigned lo = ((nw[rg] >> (4 * k)) & 15u) << 16;       // (a layout with the nibble pre-shifted would make this one v_and)
+                asm("v_lshl_or_b32 %0, %1, 20, %0" : "+v"(lo) : "v"(hh[k]));
+                m = __hiloint2double((int)top, (int)lo);
+            }
+            tc[k] = opaque_d(fma(m, ri, tc[k]));
+            if (k & 1) a1 = fma(m, rj[k], a1); else a0 = fma(m, rj[k], a0);
+        }
+        v[rg] = (a0 + a1) - (MATH == 2 ? (0x1p36 + 0x1p35) * sumr : 0.0);
+    }
+#pragma unroll
+    for (int m = 8, cnt = 4; m >= 2; m >>= 1, cnt >>= 1) {
+        const bool up = (c & m) != 0;
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const double lo_ = opaque_d(v[k]), hi_ = opaque_d(v[k + cnt]);
+            v[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1, 64);
+    double *o1 = out + (int64_t)blockIdx.x * 256, *o2 = o1 + 128;
+    if ((c & 1) == 0) {
+        const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
+        o1[wave * 32 + 4 * rg + g] = v[0];
+    }
+#pragma unroll
+    for (int m = 32, cnt = 4; m >= 16; m >>= 1, cnt >>= 1) {
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const double lo_ = opaque_d(tc[k]), hi_ = opaque_d(tc[k + cnt]);
+            tc[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+        }
+    }
+    const int col = ((lane & 32) ? 64 : 0) + 4 * c + ((lane & 16) ? 2 : 0);
+    sT[wave][col] = tc[0]; sT[wave][col + 1] = tc[1];
+    __syncthreads();
+    if (threadIdx.x < 128) o2[threadIdx.x] = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+}
+
 int main() {
     const int64_t chunk = 74240;                       // one fixed-point tile
     unsigned *sink; hipMalloc(&sink, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (double mb : {38.0, 100.0, 156.5, 200.0, 268.5, 600.0}) {
+    for (double mb : {38.0, 156.5, 268.5, 764.0}) {
         const int64_t nchunks = (int64_t)(mb * 1e6 / chunk);
         const int64_t bytes = nchunks * chunk;
         u32x4 *buf; hipMalloc(&buf, bytes); hipMemset(buf, 1, bytes);
@@ -63,6 +177,42 @@ int main() {
                 printf("%7.1f MB  %s  grid %5d: %7.2f us per pass  %6.2f TB/s\n", bytes / 1e6, variant ? "nt   " : "plain", grid, ms * 1e3 / reps,
                        bytes / (ms * 1e-3 / reps) / 1e12);
             }
+        for (int pattern = 0; pattern < 2; ++pattern) {
+            const int reps = 100;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass) hipEventRecord(e0, 0);
+                for (int r = 0; r < (pass ? reps : 5); ++r) {
+                    if (pattern == 0) hipLaunchKernelGGL(read_tiles<0>, dim3((unsigned)nchunks), dim3(256), 0, 0, buf, chunk / 16, sink);
+                    else hipLaunchKernelGGL(read_tiles<1>, dim3((unsigned)nchunks), dim3(256), 0, 0, buf, chunk / 16, sink);
+                }
+                if (pass) hipEventRecord(e1, 0);
+            }
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%7.1f MB  tile-shaped, one workgroup per tile, %s: %7.2f us per pass  %6.2f TB/s\n", bytes / 1e6,
+                   pattern ? "lane-order layout (1 KiB per wave instruction)" : "row layout (4 x 256 B per wave instruction) ", ms * 1e3 / reps,
+                   bytes / (ms * 1e-3 / reps) / 1e12);
+        }
+        {
+            double *rhs, *out; hipMalloc(&rhs, 8192 * 8); hipMemset(rhs, 0, 8192 * 8); hipMalloc(&out, nchunks * 256 * 8);
+            for (int math = 1; math <= 2; ++math) {
+                const int reps = 100;
+                for (int pass = 0; pass < 2; ++pass) {
+                    if (pass) hipEventRecord(e0, 0);
+                    for (int r = 0; r < (pass ? reps : 5); ++r) {
+                        if (math == 1) hipLaunchKernelGGL(math_tiles<1>, dim3((unsigned)nchunks), dim3(256), 0, 0, buf, chunk / 16, rhs, out);
+                        else hipLaunchKernelGGL(math_tiles<2>, dim3((unsigned)nchunks), dim3(256), 0, 0, buf, chunk / 16, rhs, out);
+                    }
+                    if (pass) hipEventRecord(e1, 0);
+                }
+                hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("%7.1f MB  tile-shaped + the mat-vec's arithmetic (%s): %7.2f us per pass  %6.2f TB/s\n", bytes / 1e6,
+                       math == 1 ? "decode as admm.hip: 4 + 2 instructions per element" : "biased decode: 3 + 2 instructions per element      ", ms * 1e3 / reps,
+                       bytes / (ms * 1e-3 / reps) / 1e12);
+            }
+            hipFree(rhs); hipFree(out);
+        }
         hipFree(buf);
     }
     return 0;
