@@ -649,10 +649,11 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     const std::string form = form_env ? form_env : "auto";
     bool use_ap = false;
     ApSlots sl;
+    double xam = 0;                                  // max|X| (over all rows of the signal)
     if (form == "auto" || form == "ap") {
         std::vector<double> hw;
         LPVS_TRY(fetch_host(hw, w, Nf));
-        double xlo, xhi, xam;
+        double xlo, xhi;
         if (ranges) xam = ranges[3];
         else LPVS_TRY(device_minmax(dX.p, N, &xlo, &xhi, &xam, s));
         sl = make_ap_slots(hw, xam);
@@ -663,7 +664,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         const int64_t nf8 = sl.nf8, nsl = sl.nsl, P = nb * (nb + 1) / 2;
         const ApStep &step = sl.step;
         double lo, hi, am, gamma; std::vector<double> vc;
-        DevBuf K, KK, dvc, part, tab, tabb;
+        DevBuf K, KK, dvc, part, tab, tabb, nwork, epsr;   // (all temporaries before the drain guard: released only after the stream is idle)
         ApSlotsDev sd;
         DrainOnExit drain(s);
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
@@ -686,16 +687,17 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         // merged slot layout: the slot sums are Fourier coefficients at the multiples of ONE step -> non-uniform FFT (nufft.hip);
         // LPVS_NUDFT=direct keeps the direct evaluation of nudft.hip
         const bool nufft_on = [] { const char *e = getenv("LPVS_NUDFT"); return !(e && std::string(e) == "direct"); }();
-        const bool nufft = nufft_on && sl.merged && nufft_applicable(N, nsl, P);
-        DevBuf nwork;
+        bool nufft = nufft_on && sl.merged && nufft_applicable(N, nsl, P);
         const int nfg = nufft_grid_size(nsl);
-        double xam_ = 0;
+        const double xam_ = xam;
         if (nufft) {
             LPVS_TRY(nwork.alloc(nufft_work_bytes(N, nsl, P)));
-            if (ranges) xam_ = ranges[3];
-            else { double xl_, xh_; LPVS_TRY(device_minmax(dX.p, N, &xl_, &xh_, &xam_, s)); }
-            LPVS_TRY(launch_nufft_tab(dX.p, nullptr, N, xam_, KK.as<double>(), P, (int)P, step.hi[1], step.lo[1], 0, (int)nsl, nfg, false, nwork.p,
-                                      tab.as<double>(), s));
+            const int32_t rc = launch_nufft_tab(dX.p, nullptr, N, xam_, KK.as<double>(), P, (int)P, step.hi[1], step.lo[1], 0, (int)nsl, nfg, false, nwork.p,
+                                                tab.as<double>(), s);
+            if (rc == kNufftNonFinite) nufft = false;    // NaN / Inf in the inputs: the direct sums propagate them as the reference does
+            else if (rc != LPVS_OK) return rc;
+        }
+        if (nufft) {
             h->gram_form = 5;
         } else {
             h->gram_form = 4;
@@ -706,7 +708,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         LPVS_HIP(hipEventRecord(h->ev[2].a, s));
         // right-hand sides: the slots a + f*D are the modes s0/2 + f of the same step when s0 is even -> same grid, same coordinates
         const bool nufft_rhs = nufft && sl.s0 % 2 == 0 && (int)(sl.s0 / 2 + nf8) <= (int)nsl;
-        DevBuf epsr;                                  // mode (s0/2 + f) D is a + f D - delta/2: the residual joins the first-order term
+        // mode (s0/2 + f) D is a + f D - delta/2: the residual joins the first-order term (epsr)
         if (nufft_rhs) {
             std::vector<double> er(sl.eps.size());
             for (size_t f = 0; f < er.size(); ++f) er[f] = sl.eps[f] + 0.5 * sl.delta;
@@ -715,12 +717,16 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
             LPVS_HIP(hipStreamSynchronize(s));       // (er is a local)
         }
         for (int64_t q = 0; q < ns; ++q) {   // b_q = Phi' y_q: Nf slots a + f*D, weights y K_j, first-order eps correction
-            if (nufft_rhs)
-                LPVS_TRY(launch_nufft_tab(dX.p, dy.p + q * N, N, xam_, K.as<double>(), ldk, (int)nb, step.hi[1], step.lo[1], (int)(sl.s0 / 2), (int)nf8, nfg,
-                                          true, nwork.p, tabb.as<double>(), s));
-            else
+            bool by_nufft = nufft_rhs;
+            if (by_nufft) {
+                const int32_t rc = launch_nufft_tab(dX.p, dy.p + q * N, N, xam_, K.as<double>(), ldk, (int)nb, step.hi[1], step.lo[1], (int)(sl.s0 / 2), (int)nf8, nfg,
+                                                    true, nwork.p, tabb.as<double>(), s);
+                if (rc == kNufftNonFinite) by_nufft = false;   // a NaN / Inf in this signal
+                else if (rc != LPVS_OK) return rc;
+            }
+            if (!by_nufft)
                 LPVS_TRY(launch_nudft(dX.p, dy.p + q * N, N, K.as<double>(), ldk, (int)nb, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)nf8, step, part.as<double>(), tabb.as<double>(), s));
-            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), nufft_rhs ? epsr.as<double>() : sd.eps.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
+            LPVS_TRY(launch_ap_rhs(tabb.as<double>(), by_nufft ? epsr.as<double>() : sd.eps.as<double>(), Nf, nb, h->b.as<double>() + q * h->np, s));
         }
         LPVS_HIP(hipEventRecord(h->ev[2].b, s));
         LPVS_HIP(hipStreamSynchronize(s));

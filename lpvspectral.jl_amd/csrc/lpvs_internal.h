@@ -137,6 +137,7 @@ bool nufft_applicable(int64_t N, int64_t nslots, int64_t nq);
 size_t nufft_work_bytes(int64_t N, int64_t nslots, int64_t nq);
 int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam, const double *Wt, int64_t ldw, int nq, double D_hi, double D_lo,
                          int mode0, int nslots, int nf, bool reuse_coords, void *work, double *tab, hipStream_t s);
+constexpr int32_t kNufftNonFinite = -1000;       // launch_nufft_tab: a weight vector holds NaN / Inf -- take the direct sums (not an error)
 bool nufft_windows_applicable(int64_t n, int64_t nslots);
 std::vector<double> nufft_window_scale(int nf, int mode0, int nslots);
 int32_t launch_nufft_window_spread(const double *x, const double *W, const double *yA, const double *yB, bool hasB, const int64_t *offs_dev, int nwin,

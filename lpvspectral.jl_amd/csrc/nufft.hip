@@ -74,7 +74,8 @@ nufft_colmax_kernel(const double *__restrict__ Wt, const double *__restrict__ y,
         const int q = (int)(e % ldw);
         if (q < nq) {
             const double v = fabs(y ? Wt[e] * y[e / ldw] : Wt[e]);
-            if (v > 0.0) atomicMax(&m[q & 255], (unsigned long long)__double_as_longlong(v));
+            // (a NaN weight counts as +Inf: the caller then takes the direct sums, which propagate it as the reference does)
+            if (v > 0.0 || v != v) atomicMax(&m[q & 255], v != v ? 0x7ff0000000000000ull : (unsigned long long)__double_as_longlong(v));
         }
     }
     __syncthreads();
@@ -216,6 +217,8 @@ nufft_window_kernel(const double *__restrict__ x, const double *__restrict__ W, 
             const double xv = fabs(x[r0 + i]), wv = W ? W[i] : 1.0;
             const double cA = fabs(yA ? wv * yA[r0 + i] : wv), cB = hasB ? fabs(wv * yB[r0 + i]) : 0.0;
             m[0] = fmax(m[0], cA); m[1] = fmax(m[1], xv * cA); m[2] = fmax(m[2], cB); m[3] = fmax(m[3], xv * cB);
+            if (!(xv * cA < 1.0 / 0.0)) m[0] = m[1] = 1.0 / 0.0;      // NaN or Inf in x, W or the signal: the window's sums are NaN, as the
+            if (!(xv * cB < 1.0 / 0.0)) m[2] = m[3] = 1.0 / 0.0;      // direct sums (and the reference) would have them
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -226,10 +229,11 @@ nufft_window_kernel(const double *__restrict__ x, const double *__restrict__ W, 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const double bound = __longlong_as_double((long long)smax[g]) * (double)n;   // >= the sum of |weights| falling into any cell
+        const bool finite = bound < 1.0 / 0.0;
         int e = 0;
-        (void)frexp(bound > 0.0 ? bound : 1.0, &e);                                  // bound < 2^e
-        quantum[g] = ldexp(1.0, e - 62);                                             // power of two: the scalings are exact
-        iq[g] = bound > 0.0 ? 1.0 / quantum[g] : 0.0;
+        (void)frexp(bound > 0.0 && finite ? bound : 1.0, &e);                        // bound < 2^e
+        quantum[g] = finite ? ldexp(1.0, e - 62) : __longlong_as_double(0x7ff8000000000000ll);   // power of two: the scalings are exact
+        iq[g] = bound > 0.0 && finite ? 1.0 / ldexp(1.0, e - 62) : 0.0;
     }
     constexpr double I2PI_HI = 0.15915494309189535, I2PI_LO = -9.8393384885635288e-18;   // 1 / (2 pi) in double-double
     const long long magic_bits = __double_as_longlong(NU_MAGIC);
@@ -358,6 +362,8 @@ int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam
     std::vector<unsigned long long> hm((size_t)nq);
     LPVS_HIP(hipMemcpyAsync(hm.data(), colmax, sizeof(unsigned long long) * (size_t)nq, hipMemcpyDeviceToHost, s));
     LPVS_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < nq; ++q)                     // non-finite weights (or abscissae): no fixed-point grid can hold them
+        if (!std::isfinite(__builtin_bit_cast(double, hm[(size_t)q])) || !std::isfinite(xam)) return kNufftNonFinite;
     std::vector<double> hscale((size_t)(2 * nq) * (size_t)nslots), hinvq((size_t)(2 * nq));
     const std::vector<long double> phat = nufft_phihat(nf, mode0 + nslots);
     for (int q = 0; q < nq; ++q) {

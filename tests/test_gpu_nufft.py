@@ -99,3 +99,34 @@ def test_window_engine_nufft_equals_direct_sums(L, ns, window, monkeypatch):
     assert np.abs(xn - xd).max() <= 1e-10 * np.abs(xd).max(), np.abs(xn - xd).max() / np.abs(xd).max()
     part = api.windows_estimate(Ys, t, f, n, 0, W, eng, win_lo=2, win_hi=5)[0]
     assert np.array_equal(part, xn[:, 2:5])
+
+
+def test_non_finite_inputs_propagate_as_with_direct_sums(L, monkeypatch):
+    """A NaN in the signal poisons b (and nothing else); a NaN in a window's samples poisons that window's coefficients only -- with
+    the NUFFT exactly as with the direct sums (a fixed-point grid cannot hold a NaN: the library detects it and says so in floating point)."""
+    from lpvspectral_jl_amd import _lib, api
+    rng = np.random.default_rng(9)
+    N, Nf, Nv = 6000, 20, 3
+    X = np.sort(rng.random(N) * 60.0); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) / 8
+    y = rng.standard_normal(N); y[1234] = np.nan
+    monkeypatch.delenv("LPVS_NUDFT", raising=False)
+    with L.Problem.lpv(y, X, V, w, Nv) as p:
+        G, b = p.get_gram()
+        assert p.timing()["gram_form"] == "ap-nufft"
+    assert np.isfinite(G).all() and np.isnan(b).all()
+    n, nwin, Nfw = 4096, 4, 96
+    t = np.arange(n * nwin) * 0.5
+    f = np.arange(Nfw) / (2.0 * Nfw)
+    yw = np.sin(2 * np.pi * f[9] * t) + 0.1 * rng.standard_normal(n * nwin)
+    yw[n + 17] = np.inf                                                  # window 1
+    eng = dict(estimator=_lib.EST_SPARSE, lam=0.0, prox=(_lib.PROX_L1, 0.3, 0), μ=0.01, tol=0.0, iters=20, sign=_lib.LINEAR_LEAST_SQUARES)
+    res = {}
+    for mode in ("direct", None):
+        if mode:
+            monkeypatch.setenv("LPVS_NUDFT", mode)
+        else:
+            monkeypatch.delenv("LPVS_NUDFT", raising=False)
+        res[mode] = api.windows_estimate([yw], t, f, n, 0, None, eng)[0][0]
+    for x in res.values():
+        assert not np.isfinite(x[1]).any() and np.isfinite(x[[0, 2, 3]]).all()
