@@ -88,9 +88,13 @@ template <int GPW>
 __global__ void __launch_bounds__(256)
 nufft_spread_kernel(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ Wt, int64_t ldw, int nq, int64_t N, int nf,
                     const int *__restrict__ cell0, const double *__restrict__ taps, const double *__restrict__ invq,
-                    long long *__restrict__ partial) {
+                    long long *__restrict__ partial, int ngroups, int nchunks) {
     extern __shared__ __attribute__((aligned(16))) long long G[];          // [GPW][nf]
-    const int gg = blockIdx.x, ch = blockIdx.y;
+    // consecutive workgroup ids go round the eight XCDs: all column groups of a chunk are dealt to ONE XCD, so the chunk's kernel
+    // values (4 MB) are fetched into one L2 instead of eight (PMC before: 2.2 GB fetched per launch at cfg3, 16x the table)
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int gg = jj % ngroups, ch = xcd + 8 * (jj / ngroups);
+    if (ch >= nchunks) return;
     for (int e = threadIdx.x; e < GPW * nf; e += 256) G[e] = 0;
     __syncthreads();
     constexpr int NC = GPW / 2;                      // weight columns of the group (plain + twin grid each)
@@ -127,7 +131,7 @@ nufft_spread_kernel(const double *__restrict__ x, const double *__restrict__ y, 
         }
     }
     __syncthreads();
-    long long *out = partial + ((int64_t)ch * gridDim.x + gg) * GPW * nf;
+    long long *out = partial + ((int64_t)ch * ngroups + gg) * GPW * nf;
     for (int e = threadIdx.x; e < GPW * nf; e += 256) out[e] = G[e];
 }
 
@@ -382,12 +386,12 @@ int32_t launch_nufft_tab(const double *x, const double *y, int64_t N, double xam
     const size_t lds_spread = sizeof(long long) * (size_t)gpw * (size_t)nf;
     if (gpw == 4) {
         LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_spread_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spread));
-        hipLaunchKernelGGL(nufft_spread_kernel<4>, dim3((unsigned)ngroups, (unsigned)nchunks), dim3(256), lds_spread, s, x, y, Wt, ldw, nq, N, nf, cell0,
-                           taps, invq, partial);
+        hipLaunchKernelGGL(nufft_spread_kernel<4>, dim3((unsigned)(8 * ngroups * ceil_div(nchunks, 8))), dim3(256), lds_spread, s, x, y, Wt, ldw, nq, N, nf, cell0,
+                           taps, invq, partial, ngroups, nchunks);
     } else {
         LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nufft_spread_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spread));
-        hipLaunchKernelGGL(nufft_spread_kernel<2>, dim3((unsigned)ngroups, (unsigned)nchunks), dim3(256), lds_spread, s, x, y, Wt, ldw, nq, N, nf, cell0,
-                           taps, invq, partial);
+        hipLaunchKernelGGL(nufft_spread_kernel<2>, dim3((unsigned)(8 * ngroups * ceil_div(nchunks, 8))), dim3(256), lds_spread, s, x, y, Wt, ldw, nq, N, nf, cell0,
+                           taps, invq, partial, ngroups, nchunks);
     }
     hipLaunchKernelGGL(nufft_reduce_kernel, dim3((unsigned)ceil_div(nf, 256), (unsigned)(2 * nq)), dim3(256), 0, s, partial, ngroups, nchunks, nf, gpw, grid);
     if (nf <= 4096) {
