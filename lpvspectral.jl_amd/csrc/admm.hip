@@ -2558,8 +2558,434 @@ int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, h
     return LPVS_OK;
 }
 
+// =====================================================================================================================
+// ONE launch per ADMM iteration (single-signal handles with the mixed storage, offset form, fusable prox).
+//
+// The two-launch iteration spends 6.9 of 31.7 us per iteration at cfg3 on the end of the mat-vec launch and on the update kernel
+// (two memory round trips: it gathers 64 tile partials per row).  Here the tile workgroups do not store partials: they ADD them into
+// the next x with 64-bit FIXED-POINT global atomics -- integer addition is associative, so the sum does not depend on the order the
+// memory side serves the adds in (the device nufft.hip uses for its grids) -- and the NEXT launch's tile workgroups rebuild their two
+// right-hand-side blocks from x in their prologue (prox and dual update of 256 elements: a few instructions, redundantly per tile,
+// while the tile's own bytes are in flight).  The workgroup of a diagonal tile also writes the block's x, z, u, its ||x-z||^2 and the
+// maxima the next quantum needs, and zeroes the block of the accumulator after next.  Launch boundaries are the only synchronisation.
+//
+//   launch with index g (the right-hand side rhs_g it multiplies):   update u_{g-1} in the prologue (x_{g-1} = xb + q_{g-1} * acc,
+//   z, u, rhs_g), then acc' += round(M~ rhs_g / q_g).   The first launch of a chunk takes rhs from memory (no update); the chunk's last
+//   update is a launch of the same kernel without the tile part (one workgroup per row block), which also leaves rhs in memory.
+//
+// The quantum needs a bound on |M~ rhs_g| BEFORE the launch: every prox of the fused set shrinks, |2z - v| <= |v|, so
+// |rhs_g| <= |x_{g-1} + u_{g-2}| / mu <= (max|xb| + R max|rhs_{g-1}| + max|u_{g-2}|) / mu =: V_g with R the largest absolute row sum of
+// M~ -- all three maxima are left behind by the update two launches back -- and |M~ rhs_g| <= R V_g.  q_g = 2^(e-62) with R V_g < 2^e:
+// no overflow for any input, and at cfg3 q is still ~2^-55 of |x| (the bound is loose by 2^6..2^7; an int64 has ten bits more than a
+// double's mantissa).  Everything is deterministic: the quantum is computed identically by every workgroup from values written by an
+// earlier launch, and no workgroup reads what another workgroup of the same launch writes (u is double-buffered, the accumulators
+// rotate through three buffers, per-parity slots hold block norms, maxima and quanta).
+// =====================================================================================================================
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+struct FiBufs {   // views into AdmmParams::fi (8-byte units): see fi_doubles()
+    long long *acc0; int64_t np;
+    double *ualt, *bn, *qbuf, *consts;
+    double2 *rec;                                    // per parity and row block: {max|rhs|, max|u|} left by the block's last update
+    __host__ __device__ __forceinline__ long long *acc(int slot) const { return acc0 + (int64_t)slot * np; }   // (no array: a dynamically indexed one lives in scratch)
+};
+__host__ __device__ __forceinline__ FiBufs fi_views(double *fi, int64_t np, int nblk) {
+    FiBufs f;
+    f.acc0 = reinterpret_cast<long long *>(fi); f.np = np;
+    f.ualt = fi + 3 * np;
+    f.bn = fi + 4 * np; f.rec = reinterpret_cast<double2 *>(f.bn + 2 * nblk + ((2 * nblk) & 1));   // (16-byte aligned)
+    f.qbuf = reinterpret_cast<double *>(f.rec + 2 * nblk); f.consts = f.qbuf + 2;
+    return f;
+}
+size_t fi_doubles(int64_t np) { return (size_t)(4 * np + 6 * (np / TS) + 6); }
+bool fi_applicable(const AdmmParams &p) {
+    static const bool on = [] { const char *e = getenv("LPVS_ITERATION"); return !(e && std::string(e) == "two"); }();
+    return on && p.fi != nullptr && p.ns == 1 && p.mp_types != nullptr && p.xb != nullptr && p.part != nullptr && p.Mp != nullptr && fused_ok(p) &&
+           p.np <= 49152;                            // (six clamped loads per lane cover the block norms / maxima of 384 row blocks)
+}
+
+// R = max_i sum_j |M_ij| (one wave per row) -> consts[0] as the bit pattern of a non-negative double (integer max: order-independent)
+__global__ void __launch_bounds__(256)
+fi_rowsum_kernel(const double *__restrict__ M, int64_t np, unsigned long long *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= np) return;
+    const double2 *m2 = reinterpret_cast<const double2 *>(M + r * np);
+    double acc = 0;
+    for (int64_t j = lane; j < np / 2; j += 64) { const double2 m = m2[j]; acc += fabs(m.x) + fabs(m.y); }
+    acc = wave_sum(acc);
+    if (lane == 0) atomicMax(out, (unsigned long long)__double_as_longlong(acc));
+}
+// max|xb| -> consts[1]; the records an update two / one launches before iteration `base` would have left, from rhs and u in memory:
+//   rec[(base-1)&1] = {max|rhs|, max|u|};  rec[(base-2)&1] = {0, mu max|rhs|}  (so that V_base = (max|xb| + mu max|rhs|) / mu >= max|rhs|).
+// One workgroup.
+__global__ void __launch_bounds__(256)
+fi_state_kernel(AdmmParams p, int nblk, long long base, int with_consts) {
+    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    __shared__ double sh[3][4];
+    double mx = 0, mr = 0, mu_ = 0;
+    for (int64_t e = threadIdx.x; e < p.np; e += 256) {
+        mx = fmax(mx, fabs(p.xb[e])); mr = fmax(mr, fabs(p.rhs[e])); mu_ = fmax(mu_, fabs(p.u[e]));
+    }
+    mx = wave_max(mx); mr = wave_max(mr); mu_ = wave_max(mu_);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = mx; sh[1][threadIdx.x >> 6] = mr; sh[2][threadIdx.x >> 6] = mu_; }
+    __syncthreads();
+    mx = fmax(fmax(sh[0][0], sh[0][1]), fmax(sh[0][2], sh[0][3]));
+    mr = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
+    mu_ = fmax(fmax(sh[2][0], sh[2][1]), fmax(sh[2][2], sh[2][3]));
+    const int p1 = (int)((base + 1) & 1), p2 = (int)(base & 1);      // parities of base - 1 and base - 2
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        f.rec[p1 * nblk + b] = make_double2(mr, mu_);
+        f.rec[p2 * nblk + b] = make_double2(0.0, p.mu * mr);
+        f.bn[b] = 0.0; f.bn[nblk + b] = 0.0;
+    }
+    if (threadIdx.x == 0) {
+        if (with_consts) f.consts[1] = mx;
+        f.qbuf[0] = 0.0; f.qbuf[1] = 0.0;
+    }
+}
+
+enum { FI_FIRST = 0, FI_MID = 1, FI_LAST = 2 };
+
+// g: FIRST / MID -- index of the right-hand side this launch multiplies (the update it performs is u_{g-1});  LAST -- g - 1 is the
+// update it performs (it multiplies nothing).  aslot: accumulator this launch adds into (FIRST / MID) resp. would have (LAST).
+template <int MODE, int NK>
+__global__ void __launch_bounds__(256, 3)
+admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
+                       int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev) {
+    __shared__ double sI[TS], sJ[TS], sT[4][TS], sq[2 * TS], gs[2 * TS], red[3][4];
+    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Launch order: the diagonal tiles first.  Their workgroups own the row blocks' state (the longest prologue) and at cfg3 they are
+    // the float-head tiles (96 KB, loaded in two halves after the prologue): dealt out in tile order the last workgroup of the launch
+    // would be the slowest one.
+    int I, J;
+    if (MODE == FI_LAST || (int)blockIdx.x < nblk) { I = J = blockIdx.x; }
+    else {
+        const int k = (int)blockIdx.x - nblk;                           // k-th tile below the diagonal: k = I (I - 1) / 2 + J, J < I
+        I = (int)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);
+        while (I * (I - 1) / 2 > k) --I;
+        while ((I + 1) * I / 2 <= k) ++I;
+        J = k - I * (I - 1) / 2;
+    }
+    const int t = I * (I + 1) / 2 + J;
+    const unsigned char *tile = Mp + (size_t)t * kSplitTileBytes;
+    const unsigned char ttype = MODE == FI_LAST ? 0 : types[t];
+    AdmmStatus *status = p.status;
+    // ---- every load before the first wait, all of them unconditional (a load under a branch or in a loop of unknown length makes the
+    // compiler wait for EVERYTHING at the next use): the state of this thread's element FIRST (loads return in order: the update then
+    // runs while the tile is still streaming in), block norms and maxima as six clamped loads per lane (np <= 49152), then the tile
+    // through a buffer descriptor of size 0 for a float-head tile (its loads are dropped; that format is read in two halves below).
+    const int conv_flag = __builtin_nontemporal_load(&status->converged);
+    const int blk = threadIdx.x < TS ? I : J, i = threadIdx.x & (TS - 1);
+    const int64_t e = (int64_t)blk * TS + i;
+    const bool ok = e < p.n;
+    const int pg = (int)(g & 1), pg1 = pg ^ 1;                         // parities of g (= g - 2) and of g - 1
+    double rhs_mem = 0, xbv = 0, uv = 0, qprev = 0;
+    long long accp = 0;
+    if (MODE == FI_FIRST) rhs_mem = p.rhs[e];
+    else {
+        accp = f.acc((aslot + 2) % 3)[e];                              // sums of the previous launch
+        xbv = p.xb[e];
+        uv = (uslot ? f.ualt : p.u)[e];
+        qprev = f.qbuf[pg1];
+    }
+    double bnv[NK];
+    double2 recv[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {                                     // NK = 1 (up to 64 row blocks: np <= 8192) or 6
+        const int b = lane + 64 * k < nblk ? lane + 64 * k : nblk - 1;
+        bnv[k] = MODE != FI_FIRST ? f.bn[pg * nblk + b] : 0.0;         // ||x-z||^2 blocks of update u_{g-2}
+        recv[k] = MODE != FI_LAST ? f.rec[pg * nblk + b] : make_double2(0.0, 0.0);
+    }
+    const double Rrow = p.fi_R, xbmax = p.fi_xbmax;                    // (host copies: kernel arguments, not loads)
+    __builtin_amdgcn_sched_barrier(0);               // (the scheduler must not sink state loads below the tile's: they are wanted first)
+    FixRaw fr;
+    if (MODE != FI_LAST) {
+        typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
+        // (issued for every tile BELOW the diagonal without waiting for its format byte -- a float-head tile there, none at cfg3,
+        // costs 74 KB of wasted reads; a diagonal tile in the fixed format is loaded further down)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tile), 0, I != J ? (int)kMixedFixedTileBytes : 0, 0x00020000);
+        const int gq_ = lane >> 4, c_ = lane & 15;
+        const int off_head = ((wave * 32 + gq_) * TS + 4 * c_) * 4;
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            fr.ha[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4), 0));
+            fr.hb[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4) + 256, 0));
+        }
+        const int off_nq = (int)kFixHeadBytes + (wave * 64 + lane) * 32, off_st = (int)(kFixHeadBytes + kFixNibBytes) + (wave * 4 + gq_) * 32;
+        fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 0, 0));
+        fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 16, 0));
+        fr.st[0] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 0, 0));
+        fr.st[1] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 16, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double mR = 0, mU = 0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { mR = fmax(mR, recv[k].x); mU = fmax(mU, recv[k].y); }
+    if (conv_flag) return;
+    if (MODE != FI_FIRST && commit_prev) {                             // (uniform, host-known) commit update u_{g-2}
+        double part = 0.0;                                             // lane q sums blocks q, q + 64, ...; then the wave's fixed shuffle pattern
+#pragma unroll
+        for (int k = 0; k < NK; ++k) part += lane + 64 * k < nblk ? bnv[k] : 0.0;
+        const double nxz = sqrt(wave_sum(part));                       // every wave, identically     norm(tmp)   src/lasso.jl:157
+        const bool conv = nxz < p.tol;                                 //                             src/lasso.jl:164
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            status->iters += 1;
+            status->nxz = nxz;
+            if (conv) status->converged = 1;
+        }
+        if (conv) return;                                              // every workgroup takes the same decision
+    }
+    // ---- update u_{g-1} for this thread's element (threads < 128: block I, the others: block J)
+    double rhs_v;
+    if (MODE == FI_FIRST) rhs_v = rhs_mem;
+    else {
+        const double xi = ok ? xbv + (double)accp * qprev : 0.0;       // x = xb + M~ (z-u)/mu: the exact integer sum, scaled once
+        const double ui = ok ? uv : 0.0;
+        const double v = xi + ui;
+        double zi = 0.0;
+        if (p.prox_kind == LPVS_PROX_L1) {
+            const double gl = p.mu * p.prox_param;
+            zi = v + (v <= -gl ? gl : (v >= gl ? -gl : -v));
+        } else if (p.prox_kind == LPVS_PROX_L0) {
+            zi = fabs(v) > sqrt(2.0 * p.mu * p.prox_param) ? v : 0.0;
+        } else {  // group: block soft-threshold, norms through LDS (as admm_fused_update2_kernel)
+            const int gl = (int)p.group_len;
+            sq[threadIdx.x] = v * v;
+            __syncthreads();
+            if (i < TS / gl) {
+                double s2 = 0;
+                for (int q = 0; q < gl; ++q) s2 += sq[(threadIdx.x & TS) + i * gl + q];   // sequential, as norm() on the slice
+                double scale = 1.0 - p.prox_param * p.mu / sqrt(s2);                      // s2 == 0 -> -inf -> 0
+                if (!(scale > 0)) scale = 0.0;
+                gs[(threadIdx.x & TS) + i] = scale;
+            }
+            __syncthreads();
+            zi = gs[(threadIdx.x & TS) + i / gl] * v;
+        }
+        if (!ok) zi = 0.0;
+        const double d = xi - zi, un = ui + d;                         // src/lasso.jl:154-155
+        rhs_v = ok ? (zi - un) / p.mu : 0.0;
+        if (I == J) {                                                  // the block's owner (uniform): state, norm, maxima, next accumulator
+            const bool own = threadIdx.x < TS;
+            if (own) {
+                p.x[e] = xi; p.z[e] = zi;
+                (MODE == FI_LAST ? p.u : (uslot ? p.u : f.ualt))[e] = un;
+                if (MODE == FI_LAST) p.rhs[e] = rhs_v;
+            }
+            const double d2 = own && ok ? d * d : 0.0;
+            const double w0 = wave_sum(d2), w1 = wave_max(own ? fabs(rhs_v) : 0.0), w2 = wave_max(own ? fabs(un) : 0.0);
+            if (lane == 0) { red[0][wave] = w0; red[1][wave] = w1; red[2][wave] = w2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                f.bn[pg1 * nblk + I] = red[0][0] + red[0][1];
+                f.rec[pg1 * nblk + I] = make_double2(fmax(red[1][0], red[1][1]), fmax(red[2][0], red[2][1]));
+            }
+        }
+    }
+    if (MODE == FI_LAST) return;
+    if (I == J && threadIdx.x < TS) f.acc((aslot + 1) % 3)[e] = 0;      // the accumulator of the next launch
+    if (threadIdx.x < TS) sI[i] = rhs_v; else sJ[i] = rhs_v;
+    // ---- this launch's quantum (identical in every workgroup)
+    mR = wave_max(mR); mU = wave_max(mU);
+    double B = Rrow * ((xbmax + Rrow * mR + mU) / p.mu) * 1.000001;
+    if (!(B > 0x1p-900)) B = 0x1p-900;
+    int eb = 0;
+    (void)frexp(B, &eb);                                               // B < 2^eb
+    const double quantum = ldexp(1.0, eb - 62), invq = ldexp(1.0, 62 - eb);
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.qbuf[pg] = quantum;
+    __syncthreads();
+    // ---- tile product
+    const int c = lane & 15, gq = lane >> 4;
+    double rj[8], tc[8], v[8];
+    const double *diag = nullptr;
+    if (ttype != 0) {
+        if (I == J) fix_load(tile, wave, lane, fr);                    // (uniform) a diagonal tile in the fixed format: its bytes only now
+        // (fix_tile_product without its tail)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+        const float stv[8] = {fr.st[0].x, fr.st[0].y, fr.st[0].z, fr.st[0].w, fr.st[1].x, fr.st[1].y, fr.st[1].z, fr.st[1].w};
+        const unsigned int nw[8] = {fr.nq[0].x, fr.nq[0].y, fr.nq[0].z, fr.nq[0].w, fr.nq[1].x, fr.nq[1].y, fr.nq[1].z, fr.nq[1].w};
+        double ri = (double)stv[0] * sI[wave * 32 + gq];
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            const double step = (double)stv[rg];
+            const double ri_next = rg + 1 < 8 ? (double)stv[rg + 1] * sI[wave * 32 + 4 * (rg + 1) + gq] : 0.0;
+            const int hh[8] = {fr.ha[rg].x, fr.ha[rg].y, fr.ha[rg].z, fr.ha[rg].w, fr.hb[rg].x, fr.hb[rg].y, fr.hb[rg].z, fr.hb[rg].w};
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const double m0 = fix_decode((unsigned int)hh[k], (nw[rg] >> (4 * k)) & 15u);
+                const double m1 = fix_decode((unsigned int)hh[k + 1], (nw[rg] >> (4 * k + 4)) & 15u);
+                tc[k] = opaque(fma(m0, ri, tc[k]));
+                tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
+                a0 = fma(m0, rj[k], a0);
+                a1 = fma(m1, rj[k + 1], a1);
+            }
+            v[rg] = step * (a0 + a1);
+            ri = ri_next;
+        }
+        if (ttype == 2) diag = reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4);
+    } else {
+        // float head + 16-bit tail, two halves of four row groups (as symv_tile_mixed_kernel)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+        const float *head = reinterpret_cast<const float *>(tile) + (wave * 32 + gq) * TS + 4 * c;
+        const unsigned short *tail = reinterpret_cast<const unsigned short *>(tile + (size_t)TS * TS * 4) + (wave * 32 + gq) * TS + 8 * c;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 ha[4], hb[4];
+            uint4 lq[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rg = 4 * half + r4;
+                ha[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
+                hb[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
+                lq[r4] = *reinterpret_cast<const uint4 *>(tail + rg * 4 * TS);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rg = 4 * half + r4;
+                const double ri = sI[wave * 32 + 4 * rg + gq];
+                const float hh[8] = {ha[r4].x, ha[r4].y, ha[r4].z, ha[r4].w, hb[r4].x, hb[r4].y, hb[r4].z, hb[r4].w};
+                const unsigned int qq[8] = {lq[r4].x & 0xffffu, lq[r4].x >> 16, lq[r4].y & 0xffffu, lq[r4].y >> 16,
+                                            lq[r4].z & 0xffffu, lq[r4].z >> 16, lq[r4].w & 0xffffu, lq[r4].w >> 16};
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    const double m0 = split_decode(hh[k], qq[k]), m1 = split_decode(hh[k + 1], qq[k + 1]);
+                    tc[k] = opaque(fma(m0, ri, tc[k]));
+                    tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
+                    a0 = fma(m0, rj[k], a0);
+                    a1 = fma(m1, rj[k + 1], a1);
+                }
+                v[rg] = a0 + a1;
+            }
+        }
+    }
+    // ---- row sums (halving butterfly over the 16 column lanes), column sums (four row lanes, then the four waves), added into x
+#pragma unroll
+    for (int m = 8, cnt = 4; m >= 2; m >>= 1, cnt >>= 1) {
+        const bool up = (c & m) != 0;
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) {
+            const double lo_ = opaque(v[k]), hi_ = opaque(v[k + cnt]);
+            v[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1, 64);
+    unsigned long long *acc_cur = reinterpret_cast<unsigned long long *>(f.acc(aslot));
+    if ((c & 1) == 0) {
+        const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
+        const int row = wave * 32 + 4 * rg + gq;
+        const double r1 = diag != nullptr ? fma(diag[row], sI[row], v[0]) : v[0];
+        atomicAdd(acc_cur + (int64_t)I * TS + row, (unsigned long long)__double2ll_rn(r1 * invq));
+    }
+    if (I != J) {
+#pragma unroll
+        for (int m = 32, cnt = 4; m >= 16; m >>= 1, cnt >>= 1) {
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int k = 0; k < cnt; ++k) {
+                const double lo_ = opaque(tc[k]), hi_ = opaque(tc[k + cnt]);
+                tc[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+            }
+        }
+        const int col = ((lane & 32) ? 64 : 0) + 4 * c + ((lane & 16) ? 2 : 0);
+        sT[wave][col] = tc[0]; sT[wave][col + 1] = tc[1];
+        __syncthreads();
+        if (threadIdx.x < TS) {
+            const double r2 = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+            atomicAdd(acc_cur + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
+        }
+    }
+}
+
+// constants and records of the one-launch iteration (after lpvs_admm_init / set_state; base = iterations done so far)
+int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s) {
+    const int nblk = (int)(p.np / TS);
+    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    if (with_consts) {
+        LPVS_HIP(hipMemsetAsync(f.consts, 0, sizeof(double) * 2, s));
+        hipLaunchKernelGGL(fi_rowsum_kernel, dim3((unsigned)ceil_div(p.np, 4)), dim3(256), 0, s, p.M, p.np, reinterpret_cast<unsigned long long *>(f.consts));
+    }
+    hipLaunchKernelGGL(fi_state_kernel, dim3(1), dim3(256), 0, s, p, nblk, base, with_consts ? 1 : 0);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+// after a chunk: if an update of THIS chunk converged before the chunk's last one, its u may sit in the alternate buffer
+__global__ void __launch_bounds__(256)
+fi_fixup_kernel(AdmmParams p, int nblk, long long base, long long iters) {
+    const AdmmStatus *status = p.status;
+    if (!status->converged) return;
+    const long long ic = status->iters - base - 1;                     // chunk-local index of the converged update
+    if (ic < 0 || ic > iters - 2 || ((ic + 1) & 1) == 0) return;       // (u_ic was written to slot (ic + 1) & 1; the last update writes p.u itself)
+    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < p.np) p.u[e] = f.ualt[e];
+}
+
+int32_t fi_read_consts(const AdmmParams &p, double out[2], hipStream_t s) {
+    const FiBufs f = fi_views(p.fi, p.np, (int)(p.np / TS));
+    LPVS_HIP(hipMemcpyAsync(out, f.consts, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+    LPVS_HIP(hipStreamSynchronize(s));
+    return LPVS_OK;
+}
+
+// a chunk of `iters` iterations: first launch (mat-vec of the right-hand side in memory), iters - 1 fused launches, the last update
+static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, hipStream_t s) {
+    const int nblk = (int)(p.np / TS);
+    const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
+    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    const unsigned char *Mp = reinterpret_cast<const unsigned char *>(p.Mp);
+    LPVS_HIP(hipMemsetAsync(f.acc(0), 0, sizeof(long long) * (size_t)p.np, s));
+    const long long base = p.fi_base;
+    const bool small = nblk <= 64;                    // one load per lane covers the block norms / maxima
+    auto launch = [&](int mode, unsigned grid, long long g, int aslot, int uslot, int commit_prev) {
+        void (*k)(AdmmParams, const unsigned char *, const unsigned char *, int, int, long long, int, int, int) =
+            mode == FI_FIRST ? (small ? admm_iter_mixed_kernel<FI_FIRST, 1> : admm_iter_mixed_kernel<FI_FIRST, 6>)
+            : mode == FI_MID ? (small ? admm_iter_mixed_kernel<FI_MID, 1> : admm_iter_mixed_kernel<FI_MID, 6>)
+                             : (small ? admm_iter_mixed_kernel<FI_LAST, 1> : admm_iter_mixed_kernel<FI_LAST, 6>);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot, commit_prev);
+    };
+    launch(FI_FIRST, ntiles, base, 0, 0, 0);
+    for (int64_t j = 1; j < iters; ++j)   // launch j: update u_{j-1} (reads u from slot (j-1) & 1, writes the other), mat-vec of rhs_j
+        launch(FI_MID, ntiles, base + j, (int)(j % 3), (int)((j - 1) & 1), j >= 2 ? 1 : 0);
+    // the chunk's last update u_{iters-1}: sums of launch iters - 1, u from slot (iters - 1) & 1, everything back in the handle's vectors
+    launch(FI_LAST, (unsigned)nblk, base + iters, (int)(iters % 3), (int)((iters - 1) & 1), iters >= 2 ? 1 : 0);
+    hipLaunchKernelGGL(fi_fixup_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p, nblk, base, (long long)iters);
+    // commit the chunk's last update (deferred convergence test, as in the two-launch iteration)
+    hipLaunchKernelGGL(admm_commit_kernel, dim3(1), dim3(64), 0, s, p, nblk, f.bn, (int)((base + iters - 1) & 1));
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
     const bool sym = p.part != nullptr && p.Mp != nullptr;
+    if (sym && fi_applicable(p)) {   // the one-launch iteration's kernel without its update (it adds into an accumulator that every chunk clears)
+        const int nblk = (int)(p.np / TS);
+        const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
+        for (int i = 0; i < reps; ++i) {
+            if (nblk <= 64)
+                hipLaunchKernelGGL((admm_iter_mixed_kernel<FI_FIRST, 1>), dim3(ntiles), dim3(256), 0, s, p, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
+                                   (int)ntiles, nblk, p.fi_base, 0, 0, 0);
+            else
+                hipLaunchKernelGGL((admm_iter_mixed_kernel<FI_FIRST, 6>), dim3(ntiles), dim3(256), 0, s, p, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
+                                   (int)ntiles, nblk, p.fi_base, 0, 0, 0);
+        }
+        LPVS_HIP(hipGetLastError());
+        return LPVS_OK;
+    }
     for (int i = 0; i < reps; ++i) {
         if (sym) {
             launch_sym_matvec(p, nullptr, s);
@@ -2573,6 +2999,7 @@ int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
 
 int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s) {
     const bool sym = p.part != nullptr && p.Mp != nullptr;
+    if (sym && iters > 0 && fi_applicable(p)) return launch_fi_chunk(p, iters, s);
     for (int64_t i = 0; i < iters; ++i) {
         if (sym) {
             launch_iteration_sym(p, s, (int)i);

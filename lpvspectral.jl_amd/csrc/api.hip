@@ -262,6 +262,7 @@ struct lpvs_problem {
     int64_t Mp_fixed_tiles = 0;
     bool Mp_demoted = false;      // mixed storage was asked for, but fewer than half of the tiles qualified: stored as split
     DevBuf xb; bool offset_form = false;   // xb = M * (signed b), computed at admm_init from the full-precision M (AdmmParams::xb)
+    DevBuf fi; long long fi_sync = -1; double fi_R = 0, fi_xbmax = 0;      // one-launch iteration (AdmmParams::fi): its records are those of iteration fi_sync
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
     // timing (ms) -- see lpvs_problem_get_timing
@@ -354,6 +355,8 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.mp_split = sym && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed) ? 1 : 0;
     p.mp_types = sym && h->Mp_mode == kMpMixed ? h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np) : nullptr;
     p.xb = sym && h->offset_form ? h->xb.as<double>() : nullptr;
+    p.fi = sym && h->offset_form && h->ns == 1 && h->Mp_mode == kMpMixed && h->fi.p ? h->fi.as<double>() : nullptr;
+    p.fi_R = h->fi_R; p.fi_xbmax = h->fi_xbmax;
     return p;
 }
 
@@ -1080,8 +1083,16 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
         LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->bs.as<double>(), h->xb.as<double>(), s, (int)h->ns));   // every signal's M b
     }
+    if (h->offset_form && h->ns == 1 && h->Mp_mode == kMpMixed && !h->fi.p) LPVS_TRY(h->fi.alloc(sizeof(double) * fi_doubles(h->np)));
     const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_init(p, s));
+    h->fi_sync = -1;
+    if (p.fi) {   // constants (largest row sum of M, max|xb|) and the records of iteration 0
+        LPVS_TRY(launch_fi_setup(p, 0, true, s));
+        double hc[2] = {0, 0};
+        LPVS_TRY(fi_read_consts(p, hc, s));              // (synchronises)
+        h->fi_R = hc[0]; h->fi_xbmax = hc[1]; h->fi_sync = 0;
+    }
     LPVS_HIP(hipStreamSynchronize(s));
     h->inited = true;
     return LPVS_OK;
@@ -1098,6 +1109,7 @@ int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *
     LPVS_TRY(copy_state_in(h, h->u.p, u));
     const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_restate(p, iters_done, s));
+    h->fi_sync = -1;                                  // (the next run rebuilds the one-launch iteration's records from the new state)
     LPVS_HIP(hipStreamSynchronize(s));
     return LPVS_OK;
 }
@@ -1107,14 +1119,16 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     if (!h->inited) { set_error("lpvs_admm_run before lpvs_admm_init"); return LPVS_ESTATE; }
     LPVS_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    const AdmmParams p = make_params(h);
+    AdmmParams p = make_params(h);
     const size_t ns = (size_t)h->ns;
     std::vector<AdmmStatus> st0(ns), st(ns);
     LPVS_HIP(hipMemcpyAsync(st0.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
     LPVS_HIP(hipStreamSynchronize(s));
     bool all0 = true;
     for (auto &q : st0) all0 = all0 && q.converged;
+    p.fi_base = st0[0].iters;
     if (max_iters > 0 && !all0) {
+        if (fi_applicable(p) && h->fi_sync != p.fi_base) LPVS_TRY(launch_fi_setup(p, p.fi_base, false, s));   // state set from outside, or the last chunk took the other path
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
         int64_t todo = max_iters;
         constexpr int64_t kGraphIters = 50;
@@ -1152,6 +1166,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
         all = all && st[q].converged;
     }
     if (max_iters > 0 && !all0) { h->t_admm += h->ev[0].ms(); h->admm_iters_timed += (double)(it_max - it0_max); }
+    if (max_iters > 0 && !all0) h->fi_sync = fi_applicable(p) ? (long long)st[0].iters : -1;   // (the other path leaves no records behind)
     if (iters_done) *iters_done = it_max;     // ns > 1: the slowest signal; per-signal values via lpvs_admm_status
     if (nxz) *nxz = nxz_max;
     if (converged) *converged = all ? 1 : 0;

@@ -201,7 +201,16 @@ struct AdmmParams {
     // the full-precision inverse; the per-iteration product then never multiplies the large constant vector b by the
     // reduced-precision copy of M (its rounding would otherwise be amplified by cond(G + I/mu)).  nullptr: x = M (b + (z-u)/mu).
     const double *xb = nullptr;
+    // one-launch iteration (admm.hip): fixed-point accumulators, alternate u, per-parity block norms / maxima / quanta; nullptr = the
+    // two-launch iteration.  fi_base = iterations committed before the chunk about to be launched.
+    double *fi = nullptr;
+    long long fi_base = 0;
+    double fi_R = 0, fi_xbmax = 0;   // largest absolute row sum of M (x 1) and max|xb|: host copies of fi's constants
 };
+size_t fi_doubles(int64_t np);
+bool fi_applicable(const AdmmParams &p);
+int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s);
+int32_t fi_read_consts(const AdmmParams &p, double out[2], hipStream_t s);
 size_t symv_part_doubles(int64_t np, int64_t ns = 1);
 size_t symv_packed_doubles(int64_t np);
 int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s);
