@@ -393,6 +393,14 @@ class Problem:
         k = C.c_int32(0)
         check(lib().lpvs_admm_matvec_kind(self._h, C.byref(k)))
         np_ = -(-self.n // 128) * 128
+        one_launch = bool(int(k.value) & 16)
+        k = C.c_int32(int(k.value) & 15)
+        if one_launch:                                                     # mixed storage, single signal, fusable prox
+            return dict(kernel="admm_iter_mixed_kernel", one_launch_iteration=True,
+                        storage="tile-packed lower triangle, mixed: float head + 16-bit tail (6 B, 40 significant bits) for the diagonal tiles, "
+                                "36-bit fixed point with per-row steps (4.53 B) for tiles of small entries; tile partials added into x by 64-bit "
+                                "fixed-point atomics, prox / dual update in the next launch's prologue",
+                        bytes_formula="98304 B per 6-byte tile, 74240 B per fixed-point tile (np = %d; 8-byte form %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2))
         if self.ns > 1 and int(k.value) in (1, 3):
             elt = 8 if int(k.value) == 1 else 6
             return dict(kernel="symv_tile_mfma_ws_kernel", storage="tile-packed lower triangle, %s" % ("f64 (8 B)" if elt == 8 else "float head + 16-bit tail (6 B, 40 significant bits)"),

@@ -2603,7 +2603,8 @@ __host__ __device__ __forceinline__ FiBufs fi_views(double *fi, int64_t np, int 
 }
 size_t fi_doubles(int64_t np) { return (size_t)(4 * np + 6 * (np / TS) + 6); }
 bool fi_applicable(const AdmmParams &p) {
-    static const bool on = [] { const char *e = getenv("LPVS_ITERATION"); return !(e && std::string(e) == "two"); }();
+    const char *env = getenv("LPVS_ITERATION");      // (read per call: tests and tools switch it between handles)
+    const bool on = !(env && std::string(env) == "two");
     return on && p.fi != nullptr && p.ns == 1 && p.mp_types != nullptr && p.xb != nullptr && p.part != nullptr && p.Mp != nullptr && fused_ok(p) &&
            p.np <= 49152;                            // (six clamped loads per lane cover the block norms / maxima of 384 row blocks)
 }

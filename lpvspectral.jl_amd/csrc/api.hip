@@ -1173,11 +1173,13 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     return LPVS_OK;
 }
 
-/* 0: full symmetric matrix (plain mat-vec, n < 2048), 1: tile-packed doubles, 2: tile-packed floats, 3: tile-packed split, 4: mixed */
+/* 0: full symmetric matrix (plain mat-vec, n < 2048), 1: tile-packed doubles, 2: tile-packed floats, 3: tile-packed split, 4: mixed;
+   + 16: the iteration runs as ONE launch (fixed-point accumulation of the tile partials, update in the next launch's prologue) */
 int32_t lpvs_admm_matvec_kind(lpvs_problem *h, int32_t *kind) {
     if (!h || !kind) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited) { set_error("lpvs_admm_matvec_kind before lpvs_admm_init"); return LPVS_ESTATE; }
     *kind = h->np >= kSymmetricMinNp ? h->Mp_mode : kMpNone;
+    if (fi_applicable(make_params(h))) *kind |= 16;   // one launch per iteration (with the prox currently set)
     return LPVS_OK;
 }
 

@@ -1,0 +1,92 @@
+"""The one-launch ADMM iteration (csrc/admm.hip: fixed-point accumulation of the tile partials, update in the next launch's
+prologue; the default for single-signal handles with the mixed storage) against the two-launch iteration (LPVS_ITERATION=two):
+same iterates to rounding, same stopping iteration, invariant under chunking, re-entry from a saved state, all fusable prox
+operators.  GPU only."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _signal(N, Nf, rng):
+    X = np.sort(rng.random(N) * (10.0 * N / 500)); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) * 25.0 / Nf
+    y = 2 * V ** 2 * np.cos(w[Nf // 10] * X) + 2 / (5 * V + 1) * np.cos(w[Nf // 3] * X - 0.3) + 0.1 * rng.standard_normal(N)
+    return y, X, V, w
+
+
+def _proxes(L, Nf, Nv):
+    return {"group": L.SlicedSeparableSum.frequency_groups(2.0, Nf, 2 * Nv), "l1": L.NormL1(0.5), "l0": L.NormL0(0.02)}
+
+
+@pytest.fixture(scope="module")
+def problem(L):
+    rng = np.random.default_rng(21)
+    N, Nf, Nv = 1 << 18, 128, 8                          # n = 2048: 16 row blocks, 136 tiles; enough samples for the mixed storage to hold
+    return (N, Nf, Nv) + _signal(N, Nf, rng)
+
+
+def _run(L, problem, prox, chunks, monkeypatch, mode, tol=0.0, state=None):
+    N, Nf, Nv, y, X, V, w = problem
+    if mode == "two":
+        monkeypatch.setenv("LPVS_ITERATION", "two")
+    else:
+        monkeypatch.delenv("LPVS_ITERATION", raising=False)
+    with L.Problem.lpv(y, X, V, w, Nv) as p:
+        p.set_prox(prox)
+        p.admm_init(None, μ=0.05, tol=tol)
+        if state is not None:
+            p.admm_set_state(*state)
+        info = p.matvec_info()
+        assert info["kernel"] == ("symv_tile_mixed_kernel" if mode == "two" else "admm_iter_mixed_kernel"), info
+        for c in chunks:
+            it, nxz, conv = p.admm_run(c)
+            if conv:
+                break
+        return (it, nxz, conv) + p.admm_get()
+
+
+@pytest.mark.parametrize("kind", ["group", "l1", "l0"])
+def test_one_launch_iteration_equals_two_launch_iteration(L, problem, kind, monkeypatch):
+    prox = _proxes(L, problem[1], problem[2])[kind]
+    a = _run(L, problem, prox, [300], monkeypatch, "two")
+    b = _run(L, problem, prox, [300], monkeypatch, "one")
+    assert a[0] == b[0] == 300
+    for va, vb in zip(a[3:], b[3:]):                     # x, z, u
+        assert np.abs(va - vb).max() <= 1e-12 * max(np.abs(va).max(), 1.0), np.abs(va - vb).max()
+    assert np.array_equal(a[4] != 0, b[4] != 0)          # same support
+    assert abs(a[1] - b[1]) <= 1e-10 * a[1]
+
+
+def test_one_launch_iteration_does_not_depend_on_chunking(L, problem, monkeypatch):
+    prox = _proxes(L, problem[1], problem[2])["group"]
+    ref = _run(L, problem, prox, [240], monkeypatch, "one")
+    for chunks in ([80, 80, 80], [1, 1, 2, 3, 233], [239, 1], [7] * 34 + [2]):
+        r = _run(L, problem, prox, chunks, monkeypatch, "one")
+        assert r[0] == ref[0] == 240 and r[1] == ref[1]
+        for a, b in zip(r[3:], ref[3:]):
+            assert np.array_equal(a, b)
+
+
+def test_one_launch_iteration_stops_where_the_two_launch_one_does(L, problem, monkeypatch):
+    """tol > 0: same stopping iteration (the convergence test is deferred by one launch in both schemes), the iterates of the converged
+    iteration -- whatever the parity of the iteration (the alternate u buffer) and wherever in a chunk it falls."""
+    prox = _proxes(L, problem[1], problem[2])["l1"]
+    for tol in (3e-3, 2.5e-3, 1e-3):
+        a = _run(L, problem, prox, [4000], monkeypatch, "two", tol=tol)
+        assert a[2]
+        for chunks in ([4000], [a[0] - 1, 50], [a[0], 50], [a[0] + 1, 50], [13] * 400):
+            b = _run(L, problem, prox, chunks, monkeypatch, "one", tol=tol)
+            assert b[2] and b[0] == a[0], (tol, chunks, a[0], b[0])
+            for va, vb in zip(a[3:], b[3:]):
+                assert np.abs(va - vb).max() <= 1e-12 * max(np.abs(va).max(), 1.0)
+
+
+def test_one_launch_iteration_resumes_from_a_saved_state(L, problem, monkeypatch):
+    prox = _proxes(L, problem[1], problem[2])["group"]
+    full = _run(L, problem, prox, [200], monkeypatch, "one")
+    half = _run(L, problem, prox, [120], monkeypatch, "one")
+    rest = _run(L, problem, prox, [80], monkeypatch, "one", state=(half[3], half[4], half[5], 120))
+    assert rest[0] == 200
+    for a, b in zip(rest[3:], full[3:]):
+        assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1.0)
