@@ -418,7 +418,8 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         # launch without an update and one update-only launch per 2000); mv_only_us = the same kernel without its update, back to back
         mv_us = phase["admm_ms"] * 1e3 / iters
     mv_share = iters * mv_us * 1e-3 / (elapsed / steps * 1e3)
-    traffic, traffic_src = pmc_traffic(mv_info["kernel"]) if args.log2n == LOG2N else (None, None)
+    # (the one-launch kernel's instance that carries the update: <1, ...>; <0, ...> is a chunk's first launch, <2, ...> its last update)
+    traffic, traffic_src = pmc_traffic(mv_info["kernel"] + ("<1" if mv_info.get("one_launch_iteration") else "")) if args.log2n == LOG2N else (None, None)
     achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
     # ---- the dense f64-MFMA Gram the library uses when w is NOT an arithmetic progression: measured once outside
     # the timed region (same inputs, LPVS_GRAM_FORM=krs) so both rooflines are on the record.

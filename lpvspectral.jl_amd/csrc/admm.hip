@@ -2658,7 +2658,7 @@ template <int MODE, int NK>
 __global__ void __launch_bounds__(256, 3)
 admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
                        int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev) {
-    __shared__ double sI[TS], sJ[TS], sT[4][TS], sq[2 * TS], gs[2 * TS], red[3][4];
+    __shared__ double sI[TS], sJ[TS], sT[4][TS], sq[2 * TS], red[3][4];
     const FiBufs f = fi_views(p.fi, p.np, nblk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Launch order: the diagonal tiles first.  Their workgroups own the row blocks' state (the longest prologue) and at cfg3 they are
@@ -2756,18 +2756,17 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
         } else if (p.prox_kind == LPVS_PROX_L0) {
             zi = fabs(v) > sqrt(2.0 * p.mu * p.prox_param) ? v : 0.0;
         } else {  // group: block soft-threshold, norms through LDS (as admm_fused_update2_kernel)
+            // every lane sums its own group (LDS broadcast reads, the same sequential order as norm() on the slice): one barrier
+            // instead of two, no lanes idling behind eight of them
             const int gl = (int)p.group_len;
             sq[threadIdx.x] = v * v;
             __syncthreads();
-            if (i < TS / gl) {
-                double s2 = 0;
-                for (int q = 0; q < gl; ++q) s2 += sq[(threadIdx.x & TS) + i * gl + q];   // sequential, as norm() on the slice
-                double scale = 1.0 - p.prox_param * p.mu / sqrt(s2);                      // s2 == 0 -> -inf -> 0
-                if (!(scale > 0)) scale = 0.0;
-                gs[(threadIdx.x & TS) + i] = scale;
-            }
-            __syncthreads();
-            zi = gs[(threadIdx.x & TS) + i / gl] * v;
+            const double *grp = sq + (threadIdx.x & TS) + (i / gl) * gl;
+            double s2 = 0;
+            for (int q = 0; q < gl; ++q) s2 += grp[q];
+            double scale = 1.0 - p.prox_param * p.mu / sqrt(s2);                          // s2 == 0 -> -inf -> 0
+            if (!(scale > 0)) scale = 0.0;
+            zi = scale * v;
         }
         if (!ok) zi = 0.0;
         const double d = xi - zi, un = ui + d;                         // src/lasso.jl:154-155
