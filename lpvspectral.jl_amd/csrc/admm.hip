@@ -799,16 +799,18 @@ __device__ __forceinline__ V load16(const void *p) {
 template <bool NT = false>
 __device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, int lane, FixRaw &w) {
     const int g = lane >> 4, c = lane & 15;
+    // nibbles and steps FIRST: loads return in order, and the first row group's products need them -- requested last, they kept
+    // every product waiting for the tile's last byte (all of a tile's arithmetic then sat at the end of its load)
+    const uint4 *nq = reinterpret_cast<const uint4 *>(tile + kFixHeadBytes) + (wave * 64 + lane) * 2;
+    w.nq[0] = load16<NT, uint4>(nq); w.nq[1] = load16<NT, uint4>(nq + 1);
+    const float4 *st = reinterpret_cast<const float4 *>(tile + kFixHeadBytes + kFixNibBytes) + (wave * 4 + g) * 2;
+    w.st[0] = load16<NT, float4>(st); w.st[1] = load16<NT, float4>(st + 1);
     const int *head = reinterpret_cast<const int *>(tile) + (wave * 32 + g) * TS + 4 * c;
 #pragma unroll
     for (int rg = 0; rg < 8; ++rg) {
         w.ha[rg] = load16<NT, int4>(head + rg * 4 * TS);
         w.hb[rg] = load16<NT, int4>(head + rg * 4 * TS + 64);
     }
-    const uint4 *nq = reinterpret_cast<const uint4 *>(tile + kFixHeadBytes) + (wave * 64 + lane) * 2;
-    w.nq[0] = load16<NT, uint4>(nq); w.nq[1] = load16<NT, uint4>(nq + 1);
-    const float4 *st = reinterpret_cast<const float4 *>(tile + kFixHeadBytes + kFixNibBytes) + (wave * 4 + g) * 2;
-    w.st[0] = load16<NT, float4>(st); w.st[1] = load16<NT, float4>(st + 1);
 }
 
 // the product of split_tile_product for a fixed-point tile (always off the diagonal)
@@ -844,6 +846,7 @@ __device__ __forceinline__ void fix_tile_product(const FixRaw &w, const double *
         }
         v[rg] = step * (a0 + a1);
         ri = ri_next;
+        __builtin_amdgcn_sched_barrier(0);               // (row group by row group, as the bytes arrive)
     }
     tile_reduce_store(v, tc, sT, diag == nullptr, part1, part2, diag, sI);
 }
@@ -2650,6 +2653,39 @@ fi_state_kernel(AdmmParams p, int nblk, long long base, int with_consts) {
     }
 }
 
+// v[rg] = the lane's partial row sums of its 8 row groups, tc[k] = its partial column sums of its 8 columns (fix_tile_product without
+// its tail): row group by row group, as the bytes arrive
+__device__ __forceinline__ void fi_fixed_product(const FixRaw &fr, const double *sI, const double *sJ, int wave, int lane, double (&v)[8], double (&tc)[8]) {
+    const int c = lane & 15, gq = lane >> 4;
+    double rj[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+    const float stv[8] = {fr.st[0].x, fr.st[0].y, fr.st[0].z, fr.st[0].w, fr.st[1].x, fr.st[1].y, fr.st[1].z, fr.st[1].w};
+    const unsigned int nw[8] = {fr.nq[0].x, fr.nq[0].y, fr.nq[0].z, fr.nq[0].w, fr.nq[1].x, fr.nq[1].y, fr.nq[1].z, fr.nq[1].w};
+    double ri = (double)stv[0] * sI[wave * 32 + gq];
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        const double step = (double)stv[rg];
+        const double ri_next = rg + 1 < 8 ? (double)stv[rg + 1] * sI[wave * 32 + 4 * (rg + 1) + gq] : 0.0;
+        const int hh[8] = {fr.ha[rg].x, fr.ha[rg].y, fr.ha[rg].z, fr.ha[rg].w, fr.hb[rg].x, fr.hb[rg].y, fr.hb[rg].z, fr.hb[rg].w};
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const double m0 = fix_decode((unsigned int)hh[k], (nw[rg] >> (4 * k)) & 15u);
+            const double m1 = fix_decode((unsigned int)hh[k + 1], (nw[rg] >> (4 * k + 4)) & 15u);
+            tc[k] = opaque(fma(m0, ri, tc[k]));
+            tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
+            a0 = fma(m0, rj[k], a0);
+            a1 = fma(m1, rj[k + 1], a1);
+        }
+        v[rg] = step * (a0 + a1);
+        ri = ri_next;
+        __builtin_amdgcn_sched_barrier(0);           // (no hoisting of later groups' decodes: they would wait for later bytes)
+    }
+}
+
 enum { FI_FIRST = 0, FI_MID = 1, FI_LAST = 2 };
 
 // g: FIRST / MID -- index of the right-hand side this launch multiplies (the update it performs is u_{g-1});  LAST -- g - 1 is the
@@ -2713,16 +2749,16 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tile), 0, I != J ? (int)kMixedFixedTileBytes : 0, 0x00020000);
         const int gq_ = lane >> 4, c_ = lane & 15;
         const int off_head = ((wave * 32 + gq_) * TS + 4 * c_) * 4;
+        const int off_nq = (int)kFixHeadBytes + (wave * 64 + lane) * 32, off_st = (int)(kFixHeadBytes + kFixNibBytes) + (wave * 4 + gq_) * 32;
+        fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 0, 0));    // (nibbles and steps first: fix_load)
+        fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 16, 0));
+        fr.st[0] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 0, 0));
+        fr.st[1] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 16, 0));
 #pragma unroll
         for (int rg = 0; rg < 8; ++rg) {
             fr.ha[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4), 0));
             fr.hb[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4) + 256, 0));
         }
-        const int off_nq = (int)kFixHeadBytes + (wave * 64 + lane) * 32, off_st = (int)(kFixHeadBytes + kFixNibBytes) + (wave * 4 + gq_) * 32;
-        fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 0, 0));
-        fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 16, 0));
-        fr.st[0] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 0, 0));
-        fr.st[1] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 16, 0));
     }
     __builtin_amdgcn_sched_barrier(0);
     double mR = 0, mU = 0;
@@ -2805,33 +2841,13 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     double rj[8], tc[8], v[8];
     const double *diag = nullptr;
     if (ttype != 0) {
-        if (I == J) fix_load(tile, wave, lane, fr);                    // (uniform) a diagonal tile in the fixed format: its bytes only now
-        // (fix_tile_product without its tail)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tc[k] = 0.0;
-        const float stv[8] = {fr.st[0].x, fr.st[0].y, fr.st[0].z, fr.st[0].w, fr.st[1].x, fr.st[1].y, fr.st[1].z, fr.st[1].w};
-        const unsigned int nw[8] = {fr.nq[0].x, fr.nq[0].y, fr.nq[0].z, fr.nq[0].w, fr.nq[1].x, fr.nq[1].y, fr.nq[1].z, fr.nq[1].w};
-        double ri = (double)stv[0] * sI[wave * 32 + gq];
-#pragma unroll
-        for (int rg = 0; rg < 8; ++rg) {
-            const double step = (double)stv[rg];
-            const double ri_next = rg + 1 < 8 ? (double)stv[rg + 1] * sI[wave * 32 + 4 * (rg + 1) + gq] : 0.0;
-            const int hh[8] = {fr.ha[rg].x, fr.ha[rg].y, fr.ha[rg].z, fr.ha[rg].w, fr.hb[rg].x, fr.hb[rg].y, fr.hb[rg].z, fr.hb[rg].w};
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                const double m0 = fix_decode((unsigned int)hh[k], (nw[rg] >> (4 * k)) & 15u);
-                const double m1 = fix_decode((unsigned int)hh[k + 1], (nw[rg] >> (4 * k + 4)) & 15u);
-                tc[k] = opaque(fma(m0, ri, tc[k]));
-                tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
-                a0 = fma(m0, rj[k], a0);
-                a1 = fma(m1, rj[k + 1], a1);
-            }
-            v[rg] = step * (a0 + a1);
-            ri = ri_next;
-        }
+        // (two call sites, two register sets: a tile loaded under a branch into the registers of the prefetched one would make the
+        // compiler wait for everything before the first product)
+        if (I == J) {                                // (uniform) a diagonal tile in the fixed format: its bytes only now
+            FixRaw fd;
+            fix_load(tile, wave, lane, fd);
+            fi_fixed_product(fd, sI, sJ, wave, lane, v, tc);
+        } else fi_fixed_product(fr, sI, sJ, wave, lane, v, tc);
         if (ttype == 2) diag = reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4);
     } else {
         // float head + 16-bit tail, two halves of four row groups (as symv_tile_mixed_kernel)
