@@ -168,6 +168,113 @@ __global__ void __launch_bounds__(256, 3) math_tiles(const u32x4 *__restrict__ s
     }
 }
 
+// ... and a PERSISTENT variant of the last one: G resident workgroups walk their tiles for `passes` iterations inside one launch; after
+// a pass every workgroup requests the first tile of its next pass (the matrix does not change), then a grid-wide barrier on a counter
+// (agent-scope atomics, bounded spin) lets the accumulators settle.  Does keeping the tile stream running across the iteration
+// boundary beat back-to-back launches (whose ramp and end are exposed)?
+struct TileRegs { u32x4 ha[8], hb[8], n0, n1; };
+__device__ __forceinline__ void tile_issue(TileRegs &r, const u32x4 *p, int wave, int lane, int g, int c) {
+    r.n0 = p[4096 + (wave * 64 + lane) * 2]; r.n1 = p[4096 + (wave * 64 + lane) * 2 + 1];
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+        const int base = ((wave * 32 + g + 4 * rg) * 128 + 4 * c) / 4;
+        r.ha[rg] = p[base]; r.hb[rg] = p[base + 16];
+    }
+}
+__global__ void __launch_bounds__(256, 3) persist_tiles(const u32x4 *__restrict__ src, int64_t chunk16, int nchunks, const double *__restrict__ rhs,
+                                                        unsigned long long *acc /* [2][8192] */, unsigned *counter, int passes, unsigned *fail) {
+    __shared__ double sI[128], sJ[128], sT[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const int G = gridDim.x;
+    TileRegs tr;
+    tile_issue(tr, src + (int64_t)blockIdx.x * chunk16, wave, lane, g, c);
+    for (int pass = 0; pass < passes; ++pass) {
+        unsigned long long *acc_cur = acc + (pass & 1) * 8192;
+        const long long *acc_prev = reinterpret_cast<const long long *>(acc + ((pass + 1) & 1) * 8192);
+        for (int t = blockIdx.x; t < nchunks; t += G) {
+            {   // right-hand side rebuilt from the previous pass's sums (agent-scope loads: other XCDs' atomics)
+                const int blk = threadIdx.x < 128 ? (t % 61) : (t % 59), e = blk * 128 + (threadIdx.x & 127);
+                const long long a = __hip_atomic_load(acc_prev + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double xv = (double)a * 0x1p-40 + rhs[e], uv = rhs[8192 + e];
+                const double vv = xv + uv, zv = vv > 0.1 ? vv - 0.1 : (vv < -0.1 ? vv + 0.1 : 0.0);
+                const double r = (2.0 * zv - vv) * 20.0;
+                __syncthreads();
+                if (threadIdx.x < 128) sI[threadIdx.x] = r; else sJ[threadIdx.x - 128] = r;
+                __syncthreads();
+            }
+            double rj[8], tc[8], v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+            const unsigned nw[8] = {tr.n0.x, tr.n0.y, tr.n0.z, tr.n0.w, tr.n1.x, tr.n1.y, tr.n1.z, tr.n1.w};
+#pragma unroll
+            for (int rg = 0; rg < 8; ++rg) {
+                const double ri = sI[wave * 32 + 4 * rg + g];
+                const unsigned hh[8] = {tr.ha[rg].x, tr.ha[rg].y, tr.ha[rg].z, tr.ha[rg].w, tr.hb[rg].x, tr.hb[rg].y, tr.hb[rg].z, tr.hb[rg].w};
+                double a0 = 0, a1 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned top = __builtin_amdgcn_alignbit(0x04330000u, hh[k], 28);
+                    unsigned lo = (nw[rg] >> (4 * k)) & 15u;
+                    asm("v_lshl_or_b32 %0, %1, 4, %0" : "+v"(lo) : "v"(hh[k]));
+                    const double m = __hiloint2double((int)top, (int)lo) - (0x1p52 + 0x1p35);
+                    tc[k] = opaque_d(fma(m, ri, tc[k]));
+                    if (k & 1) a1 = fma(m, rj[k], a1); else a0 = fma(m, rj[k], a0);
+                }
+                v[rg] = a0 + a1;
+            }
+            // the next tile of this pass, or the first tile of the next pass: requested before the reductions
+            const int tn = t + G < nchunks ? t + G : blockIdx.x;
+            tile_issue(tr, src + (int64_t)tn * chunk16, wave, lane, g, c);
+#pragma unroll
+            for (int m = 8, cnt = 4; m >= 2; m >>= 1, cnt >>= 1) {
+                const bool up = (c & m) != 0;
+#pragma unroll
+                for (int k = 0; k < cnt; ++k) {
+                    const double lo_ = opaque_d(v[k]), hi_ = opaque_d(v[k + cnt]);
+                    v[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+                }
+            }
+            v[0] += __shfl_xor(v[0], 1, 64);
+            if ((c & 1) == 0) {
+                const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
+                atomicAdd(acc_cur + (t % 61) * 128 + wave * 32 + 4 * rg + g, (unsigned long long)(long long)rint(v[0] * 0x1p40));
+            }
+#pragma unroll
+            for (int m = 32, cnt = 4; m >= 16; m >>= 1, cnt >>= 1) {
+                const bool up = (lane & m) != 0;
+#pragma unroll
+                for (int k = 0; k < cnt; ++k) {
+                    const double lo_ = opaque_d(tc[k]), hi_ = opaque_d(tc[k + cnt]);
+                    tc[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+                }
+            }
+            const int col = ((lane & 32) ? 64 : 0) + 4 * c + ((lane & 16) ? 2 : 0);
+            sT[wave][col] = tc[0]; sT[wave][col + 1] = tc[1];
+            __syncthreads();
+            if (threadIdx.x < 128) {
+                const double r2 = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+                atomicAdd(acc_cur + (t % 59) * 128 + threadIdx.x, (unsigned long long)(long long)rint(r2 * 0x1p40));
+            }
+        }
+        // grid barrier: my adds are performed (release), one arrival per workgroup, bounded spin
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)G * (unsigned)(pass + 1);
+            int spins = 0;
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++spins > 2000000 || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+}
+
 int main() {
     const int64_t chunk = 74240;                       // one fixed-point tile
     unsigned *sink; hipMalloc(&sink, 4);
@@ -228,6 +335,24 @@ int main() {
                 printf("%7.1f MB  tile-shaped + the mat-vec's arithmetic (%s): %7.2f us per pass  %6.2f TB/s\n", bytes / 1e6,
                        math == 1 ? "decode as admm.hip: 4 + 2 instructions per element" : math == 2 ? "biased decode: 3 + 2 instructions per element      " : "as the first, partial sums by 64-bit fixed-point global atomics, rhs rebuilt in the prologue", ms * 1e3 / reps,
                        bytes / (ms * 1e-3 / reps) / 1e12);
+            }
+            if (mb > 150 && mb < 160) {   // the persistent variant at the cfg3 size only
+                unsigned *ctr; hipMalloc(&ctr, 8);
+                for (int G : {520, 640, 693, 768}) {
+                    const int passes = 200;
+                    hipMemset(ctr, 0, 8); hipMemset(acc, 0, 2 * 8192 * 8);
+                    hipLaunchKernelGGL(persist_tiles, dim3(G), dim3(256), 0, 0, buf, chunk / 16, (int)nchunks, rhs3, acc, ctr, 3, ctr + 1);   // warm
+                    hipMemset(ctr, 0, 8);
+                    hipEventRecord(e0, 0);
+                    hipLaunchKernelGGL(persist_tiles, dim3(G), dim3(256), 0, 0, buf, chunk / 16, (int)nchunks, rhs3, acc, ctr, passes, ctr + 1);
+                    hipEventRecord(e1, 0);
+                    hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    unsigned h[2]; hipMemcpy(h, ctr, 8, hipMemcpyDeviceToHost);
+                    printf("%7.1f MB  persistent, %d workgroups, %d passes in one launch, grid barrier per pass: %7.2f us per pass  %6.2f TB/s  (barrier failed: %u)\n",
+                           bytes / 1e6, G, passes, ms * 1e3 / passes, bytes / (ms * 1e-3 / passes) / 1e12, h[1]);
+                }
+                hipFree(ctr);
             }
             hipFree(rhs); hipFree(out);
         }
