@@ -282,17 +282,28 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
     tm["matvec_windows"] = tm_mv.get("matvec_windows")
     st = os.environ.get("LPVS_M_STORAGE", "mixed")                 # storage of the packed inverses (admm.hip)
     mv_us = tm.get("matvec_us_per_iteration")
+    one_launch = bool(tm_mv.get("one_launch_iteration"))
+    mv_only_us = mv_us
+    if one_launch and mv_us:
+        # the iteration IS one launch of the batch kernel: its duration inside the timed region = HIP events around the ADMM loops of
+        # the last timed step / launches (every 256 iterations one extra launch without an update and one update-only launch)
+        mv_us = tm["solve_ms"] * 1e3 / iters
     roof = None
     if mv_us:
         nmv = tm.get("matvec_windows") or (hi - lo)
         mv_bytes = tm_mv.get("matvec_bytes_per_launch") or nmv * (8 if st == "f64" else 6) * (512 * (512 + 128) // 2)
         achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
         kern = {"f64": "symv_tile_batch_kernel (8-byte elements)", "split": "symv_tile_split_batch_kernel (6-byte elements)"}.get(
-            st, "symv_tile_mixed_batch_kernel (6-byte float-head tiles on the diagonal, 36-bit fixed-point tiles elsewhere)")
+            st, ("admm_iter_mixed_kernel<batch> (the whole ADMM iteration of every window in one launch; 36-bit fixed-point tiles, tile partials "
+                 "added into x by 64-bit fixed-point atomics)") if one_launch else
+                "symv_tile_mixed_batch_kernel (6-byte float-head tiles on the diagonal, 36-bit fixed-point tiles elsewhere)")
         roof = {"bound": "hbm", "kernel": kern + ": one tile-packed (Q + I/mu)^-1 per window, all windows of the shard per launch",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "windows_per_launch": nmv, "launches_per_step": iters,
-                "note": "HIP events around 200 back-to-back launches of the batch mat-vec on the library's stream (rank 0's shard)"}
+                "matvec_only_launch_us": mv_only_us,
+                "note": ("launch_us = HIP events around the ADMM loop of the last timed step / iterations (one launch per iteration); "
+                         "matvec_only_launch_us = 200 back-to-back launches of the same kernel without its update (rank 0's shard)") if one_launch else
+                        "HIP events around 200 back-to-back launches of the batch mat-vec on the library's stream (rank 0's shard)"}
     out = {
         "metric": "windows/sec, ls_windowpsd estimator=ls_sparse_spectral (NormL1), %d windows x N=2^%d, Nf=%d, %d ADMM iters per window"
                   % (nwin, CFG4["log2n"], Nf, iters),

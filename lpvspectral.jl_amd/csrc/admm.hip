@@ -2209,12 +2209,32 @@ static void launch_mixed_batch(const AdmmBatch &p, unsigned ntiles, unsigned ns,
                            (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, part1, part2, status);
 }
 
+enum { FI_FIRST = 0, FI_MID = 1, FI_LAST = 2 };   // modes of admm_iter_mixed_kernel (further down)
+static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, size_t mp_stride, bool prefetch_all, hipStream_t s);
+typedef void (*FiKernel)(AdmmParams, const unsigned char *, const unsigned char *, int, int, long long, int, int, int, size_t, int);
+static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa);
+static AdmmParams batch_as_params(const AdmmBatch &p) {   // AdmmParams with ns = nbatch has the layout the fused kernels expect
+    AdmmParams q{p.M, p.np, p.n, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len, p.status,
+                 nullptr, p.part, p.Mp, p.nbatch};
+    q.xb = p.xb; q.mp_split = p.mp_split; q.mp_types = p.mp_types; q.fi = p.fi; q.fi_base = p.fi_base; q.fi_prefetch_all = p.fi_prefetch_all;
+    return q;
+}
+bool fi_batch_applicable(const AdmmBatch &p) {
+    const char *env = getenv("LPVS_ITERATION");
+    const AdmmParams q = batch_as_params(p);
+    return !(env && std::string(env) == "two") && p.fi != nullptr && p.nrhs <= 1 && p.mp_split && p.mp_types != nullptr && p.xb != nullptr && p.part != nullptr &&
+           p.Mp != nullptr && fused_ok(q) && p.np <= 8192 && (int64_t)p.nbatch * p.np * 8 < ((int64_t)1 << 40);
+}
+int32_t launch_fi_batch_setup(const AdmmBatch &p, hipStream_t s) { return launch_fi_setup(batch_as_params(p), 0, true, s); }
+
 int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStream_t s) {
     // packed-symmetric form (half the matrix bytes per iteration) when the batch has tile-packed matrices and the
     // prox can be fused; AdmmParams with ns = nbatch has the layout the fused update kernel expects
-    AdmmParams q{p.M, p.np, p.n, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len, p.status,
-                 nullptr, p.part, p.Mp, p.nbatch};
-    q.xb = p.xb;
+    AdmmParams q = batch_as_params(p);
+    if (iters > 0 && fi_batch_applicable(p)) {        // one launch per iteration for the whole batch
+        const int nblk_ = (int)(p.np / TS);
+        return launch_fi_chunk(q, iters, true, (size_t)(nblk_ * (nblk_ + 1) / 2) * kSplitTileBytes, p.fi_prefetch_all != 0, s);
+    }
     if (p.Mp != nullptr && p.part != nullptr && fused_ok(q)) {
         const int nblk = (int)(p.np / TS);
         const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), ns = (unsigned)p.nbatch;
@@ -2253,6 +2273,16 @@ int32_t launch_admm_batch_matvec_only(const AdmmBatch &p, int reps, hipStream_t 
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), ns = (unsigned)p.nbatch;
     const int nrhs = p.nrhs > 0 ? p.nrhs : 1;
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
+    if (fi_batch_applicable(p)) {   // the one-launch iteration's kernel without its update (it adds into an accumulator that every chunk clears)
+        const AdmmParams q = batch_as_params(p);
+        const char *nte = getenv("LPVS_NT_LOADS");
+        const bool nt = nte ? nte[0] == '1' : (size_t)ntiles * kSplitTileBytes * (size_t)ns > ((size_t)240 << 20);
+        for (int i = 0; i < reps; ++i)
+            hipLaunchKernelGGL(fi_kernel(FI_FIRST, true, true, nt, p.fi_prefetch_all != 0), dim3(ntiles, ns), dim3(256), 0, s, q, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
+                               (int)ntiles, nblk, p.fi_base, 0, 0, 0, (size_t)ntiles * kSplitTileBytes, p.fi_prefetch_all);
+        LPVS_HIP(hipGetLastError());
+        return LPVS_OK;
+    }
     for (int i = 0; i < reps; ++i) {
         if (p.mp_split && p.mp_types && nrhs == 1)
             launch_mixed_batch(p, ntiles, ns, part1, part2, nullptr, s);
@@ -2596,15 +2626,15 @@ struct FiBufs {   // views into AdmmParams::fi (8-byte units): see fi_doubles()
     double2 *rec;                                    // per parity and row block: {max|rhs|, max|u|} left by the block's last update
     __host__ __device__ __forceinline__ long long *acc(int slot) const { return acc0 + (int64_t)slot * np; }   // (no array: a dynamically indexed one lives in scratch)
 };
-__host__ __device__ __forceinline__ FiBufs fi_views(double *fi, int64_t np, int nblk) {
+__host__ __device__ __forceinline__ FiBufs fi_views(double *fi, int64_t np /* all problems' rows */, int nblk /* all problems' row blocks */, int nprob = 1) {
     FiBufs f;
     f.acc0 = reinterpret_cast<long long *>(fi); f.np = np;
     f.ualt = fi + 3 * np;
-    f.bn = fi + 4 * np; f.rec = reinterpret_cast<double2 *>(f.bn + 2 * nblk + ((2 * nblk) & 1));   // (16-byte aligned)
-    f.qbuf = reinterpret_cast<double *>(f.rec + 2 * nblk); f.consts = f.qbuf + 2;
+    f.bn = fi + 4 * np; f.rec = reinterpret_cast<double2 *>(f.bn + 2 * nblk);   // (16-byte aligned: np is a multiple of 128)
+    f.qbuf = reinterpret_cast<double *>(f.rec + 2 * nblk); f.consts = f.qbuf + 2 * nprob;
     return f;
 }
-size_t fi_doubles(int64_t np) { return (size_t)(4 * np + 6 * (np / TS) + 6); }
+size_t fi_doubles(int64_t np, int64_t nprob) { return (size_t)((4 * np + 6 * (np / TS) + 4) * nprob + 2); }
 bool fi_applicable(const AdmmParams &p) {
     const char *env = getenv("LPVS_ITERATION");      // (read per call: tests and tools switch it between handles)
     const bool on = !(env && std::string(env) == "two");
@@ -2612,28 +2642,32 @@ bool fi_applicable(const AdmmParams &p) {
            p.np <= 49152;                            // (six clamped loads per lane cover the block norms / maxima of 384 row blocks)
 }
 
-// R = max_i sum_j |M_ij| (one wave per row) -> consts[0] as the bit pattern of a non-negative double (integer max: order-independent)
+// R = max_i sum_j |M_ij| (one wave per row) -> consts[2 sg] as the bit pattern of a non-negative double (integer max: order-independent);
+// blockIdx.y = problem of a batch (matrices np x np apart)
 __global__ void __launch_bounds__(256)
-fi_rowsum_kernel(const double *__restrict__ M, int64_t np, unsigned long long *__restrict__ out) {
+fi_rowsum_kernel(const double *__restrict__ M, int64_t np, int64_t n, unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * 4 + wave;
-    if (r >= np) return;
-    const double2 *m2 = reinterpret_cast<const double2 *>(M + r * np);
+    if (r >= n) return;                              // (valid rows only: a pad row holds a 1 on its diagonal and multiplies a zero -- counting
+                                                     //  it would loosen the bound, and with it the quantum, by 1 / mu)
+    const double2 *m2 = reinterpret_cast<const double2 *>(M + ((int64_t)blockIdx.y * np + r) * np);
     double acc = 0;
     for (int64_t j = lane; j < np / 2; j += 64) { const double2 m = m2[j]; acc += fabs(m.x) + fabs(m.y); }
     acc = wave_sum(acc);
-    if (lane == 0) atomicMax(out, (unsigned long long)__double_as_longlong(acc));
+    if (lane == 0) atomicMax(out + 2 * blockIdx.y, (unsigned long long)__double_as_longlong(acc));
 }
-// max|xb| -> consts[1]; the records an update two / one launches before iteration `base` would have left, from rhs and u in memory:
+// max|xb| -> consts[2 sg + 1]; the records an update two / one launches before iteration `base` would have left, from rhs and u in memory:
 //   rec[(base-1)&1] = {max|rhs|, max|u|};  rec[(base-2)&1] = {0, mu max|rhs|}  (so that V_base = (max|xb| + mu max|rhs|) / mu >= max|rhs|).
-// One workgroup.
+// One workgroup per problem (blockIdx.x).
 __global__ void __launch_bounds__(256)
 fi_state_kernel(AdmmParams p, int nblk, long long base, int with_consts) {
-    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    const int sg = blockIdx.x, nprob = gridDim.x;
+    const FiBufs f = fi_views(p.fi, (int64_t)nprob * p.np, nprob * nblk, nprob);
+    const int64_t voff = (int64_t)sg * p.np;
     __shared__ double sh[3][4];
     double mx = 0, mr = 0, mu_ = 0;
     for (int64_t e = threadIdx.x; e < p.np; e += 256) {
-        mx = fmax(mx, fabs(p.xb[e])); mr = fmax(mr, fabs(p.rhs[e])); mu_ = fmax(mu_, fabs(p.u[e]));
+        mx = fmax(mx, fabs(p.xb[voff + e])); mr = fmax(mr, fabs(p.rhs[voff + e])); mu_ = fmax(mu_, fabs(p.u[voff + e]));
     }
     mx = wave_max(mx); mr = wave_max(mr); mu_ = wave_max(mu_);
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = mx; sh[1][threadIdx.x >> 6] = mr; sh[2][threadIdx.x >> 6] = mu_; }
@@ -2642,14 +2676,15 @@ fi_state_kernel(AdmmParams p, int nblk, long long base, int with_consts) {
     mr = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
     mu_ = fmax(fmax(sh[2][0], sh[2][1]), fmax(sh[2][2], sh[2][3]));
     const int p1 = (int)((base + 1) & 1), p2 = (int)(base & 1);      // parities of base - 1 and base - 2
+    const int nbt = nprob * nblk, boff = sg * nblk;
     for (int b = threadIdx.x; b < nblk; b += 256) {
-        f.rec[p1 * nblk + b] = make_double2(mr, mu_);
-        f.rec[p2 * nblk + b] = make_double2(0.0, p.mu * mr);
-        f.bn[b] = 0.0; f.bn[nblk + b] = 0.0;
+        f.rec[p1 * nbt + boff + b] = make_double2(mr, mu_);
+        f.rec[p2 * nbt + boff + b] = make_double2(0.0, p.mu * mr);
+        f.bn[boff + b] = 0.0; f.bn[nbt + boff + b] = 0.0;
     }
     if (threadIdx.x == 0) {
-        if (with_consts) f.consts[1] = mx;
-        f.qbuf[0] = 0.0; f.qbuf[1] = 0.0;
+        if (with_consts) f.consts[2 * sg + 1] = mx;
+        f.qbuf[sg] = 0.0; f.qbuf[nprob + sg] = 0.0;
     }
 }
 
@@ -2686,16 +2721,24 @@ __device__ __forceinline__ void fi_fixed_product(const FixRaw &fr, const double 
     }
 }
 
-enum { FI_FIRST = 0, FI_MID = 1, FI_LAST = 2 };
 
 // g: FIRST / MID -- index of the right-hand side this launch multiplies (the update it performs is u_{g-1});  LAST -- g - 1 is the
 // update it performs (it multiplies nothing).  aslot: accumulator this launch adds into (FIRST / MID) resp. would have (LAST).
-template <int MODE, int NK>
+// BATCH: blockIdx.y = problem of a batch that each own their matrix (the windows of ls_windowpsd; p.ns = problems, vectors [ns][np],
+// mp_stride = bytes between their packed matrices); NT: non-temporal tile loads (batches beyond the Infinity Cache).
+// prefetch_all: every tile of the batch is in the fixed format, so the diagonal tiles (and their double diagonals) are requested up
+// front like the others (cfg4: four of a window's ten tiles); otherwise diagonal tiles are loaded after the prologue (cfg3: float-head).
+template <int MODE, int NK, bool BATCH, bool NT, bool PA>
 __global__ void __launch_bounds__(256, 3)
 admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
-                       int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev) {
+                       int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev, size_t mp_stride, int /* PA as a run-time value: unused */) {
+    constexpr bool prefetch_all = PA;               // (a template parameter: the two cases need different register sets, together they spill)
     __shared__ double sI[TS], sJ[TS], sT[4][TS], sq[2 * TS], red[3][4];
-    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    const int sg = BATCH ? (int)blockIdx.y : 0, nprob = BATCH ? (int)gridDim.y : 1;
+    const int64_t voff = (int64_t)sg * p.np;                           // this problem's vectors
+    const int boff = sg * nblk, nbt = nprob * nblk;                    // ... and its slots among the per-block records
+    const FiBufs f = fi_views(p.fi, (int64_t)nprob * p.np, nbt, nprob);
+    Mp += (size_t)sg * mp_stride; types += (size_t)sg * (size_t)ntiles;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Launch order: the diagonal tiles first.  Their workgroups own the row blocks' state (the longest prologue) and at cfg3 they are
     // the float-head tiles (96 KB, loaded in two halves after the prologue): dealt out in tile order the last workgroup of the launch
@@ -2712,7 +2755,7 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     const int t = I * (I + 1) / 2 + J;
     const unsigned char *tile = Mp + (size_t)t * kSplitTileBytes;
     const unsigned char ttype = MODE == FI_LAST ? 0 : types[t];
-    AdmmStatus *status = p.status;
+    AdmmStatus *status = p.status + sg;
     // ---- every load before the first wait, all of them unconditional (a load under a branch or in a loop of unknown length makes the
     // compiler wait for EVERYTHING at the next use): the state of this thread's element FIRST (loads return in order: the update then
     // runs while the tile is still streaming in), block norms and maxima as six clamped loads per lane (np <= 49152), then the tile
@@ -2724,40 +2767,51 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     const int pg = (int)(g & 1), pg1 = pg ^ 1;                         // parities of g (= g - 2) and of g - 1
     double rhs_mem = 0, xbv = 0, uv = 0, qprev = 0;
     long long accp = 0;
-    if (MODE == FI_FIRST) rhs_mem = p.rhs[e];
+    if (MODE == FI_FIRST) rhs_mem = p.rhs[voff + e];
     else {
-        accp = f.acc((aslot + 2) % 3)[e];                              // sums of the previous launch
-        xbv = p.xb[e];
-        uv = (uslot ? f.ualt : p.u)[e];
-        qprev = f.qbuf[pg1];
+        accp = f.acc((aslot + 2) % 3)[voff + e];                       // sums of the previous launch
+        xbv = p.xb[voff + e];
+        uv = (uslot ? f.ualt : p.u)[voff + e];
+        qprev = f.qbuf[pg1 * nprob + sg];
     }
     double bnv[NK];
     double2 recv[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {                                     // NK = 1 (up to 64 row blocks: np <= 8192) or 6
         const int b = lane + 64 * k < nblk ? lane + 64 * k : nblk - 1;
-        bnv[k] = MODE != FI_FIRST ? f.bn[pg * nblk + b] : 0.0;         // ||x-z||^2 blocks of update u_{g-2}
-        recv[k] = MODE != FI_LAST ? f.rec[pg * nblk + b] : make_double2(0.0, 0.0);
+        bnv[k] = MODE != FI_FIRST ? f.bn[pg * nbt + boff + b] : 0.0;   // ||x-z||^2 blocks of update u_{g-2}
+        recv[k] = MODE != FI_LAST ? f.rec[pg * nbt + boff + b] : make_double2(0.0, 0.0);
     }
-    const double Rrow = p.fi_R, xbmax = p.fi_xbmax;                    // (host copies: kernel arguments, not loads)
+    // (single problems: host copies, kernel arguments instead of loads)
+    const double Rrow = BATCH ? f.consts[2 * sg] : p.fi_R, xbmax = BATCH ? f.consts[2 * sg + 1] : p.fi_xbmax;
     __builtin_amdgcn_sched_barrier(0);               // (the scheduler must not sink state loads below the tile's: they are wanted first)
     FixRaw fr;
+    double diag_pre = 0.0;
     if (MODE != FI_LAST) {
         typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
         // (issued for every tile BELOW the diagonal without waiting for its format byte -- a float-head tile there, none at cfg3,
-        // costs 74 KB of wasted reads; a diagonal tile in the fixed format is loaded further down)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tile), 0, I != J ? (int)kMixedFixedTileBytes : 0, 0x00020000);
+        // costs 74 KB of wasted reads; a diagonal tile is requested here only when the whole batch is in the fixed format, with the
+        // 1 KiB of its double diagonal behind the steps -- otherwise it is loaded further down)
+        constexpr int aux = NT ? 2 : 0;
+        const int tbytes = I != J ? (int)kMixedFixedTileBytes : (prefetch_all ? (int)kMixedFixedTileBytes + TS * 8 : 0);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tile), 0, tbytes, 0x00020000);
         const int gq_ = lane >> 4, c_ = lane & 15;
         const int off_head = ((wave * 32 + gq_) * TS + 4 * c_) * 4;
         const int off_nq = (int)kFixHeadBytes + (wave * 64 + lane) * 32, off_st = (int)(kFixHeadBytes + kFixNibBytes) + (wave * 4 + gq_) * 32;
-        fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 0, 0));    // (nibbles and steps first: fix_load)
-        fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 16, 0));
-        fr.st[0] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 0, 0));
-        fr.st[1] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 16, 0));
+        fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 0, aux));    // (nibbles and steps first: fix_load)
+        fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 16, aux));
+        fr.st[0] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 0, aux));
+        fr.st[1] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 16, aux));
 #pragma unroll
         for (int rg = 0; rg < 8; ++rg) {
-            fr.ha[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4), 0));
-            fr.hb[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4) + 256, 0));
+            fr.ha[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4), aux));
+            fr.hb[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4) + 256, aux));
+        }
+        if (PA) {   // the lane's row after the row butterfly: its entry of a diagonal tile's double diagonal (dropped for every other tile)
+            const int rgo = ((c_ & 8) ? 4 : 0) + ((c_ & 4) ? 2 : 0) + ((c_ & 2) ? 1 : 0);
+            typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
+            const u32x2b dw = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(kFixHeadBytes + kFixNibBytes) + TS * 4 + (wave * 32 + 4 * rgo + gq_) * 8, 0, 0);
+            diag_pre = __builtin_bit_cast(double, dw);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -2810,22 +2864,22 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
         if (I == J) {                                                  // the block's owner (uniform): state, norm, maxima, next accumulator
             const bool own = threadIdx.x < TS;
             if (own) {
-                p.x[e] = xi; p.z[e] = zi;
-                (MODE == FI_LAST ? p.u : (uslot ? p.u : f.ualt))[e] = un;
-                if (MODE == FI_LAST) p.rhs[e] = rhs_v;
+                p.x[voff + e] = xi; p.z[voff + e] = zi;
+                (MODE == FI_LAST ? p.u : (uslot ? p.u : f.ualt))[voff + e] = un;
+                if (MODE == FI_LAST) p.rhs[voff + e] = rhs_v;
             }
             const double d2 = own && ok ? d * d : 0.0;
             const double w0 = wave_sum(d2), w1 = wave_max(own ? fabs(rhs_v) : 0.0), w2 = wave_max(own ? fabs(un) : 0.0);
             if (lane == 0) { red[0][wave] = w0; red[1][wave] = w1; red[2][wave] = w2; }
             __syncthreads();
             if (threadIdx.x == 0) {
-                f.bn[pg1 * nblk + I] = red[0][0] + red[0][1];
-                f.rec[pg1 * nblk + I] = make_double2(fmax(red[1][0], red[1][1]), fmax(red[2][0], red[2][1]));
+                f.bn[pg1 * nbt + boff + I] = red[0][0] + red[0][1];
+                f.rec[pg1 * nbt + boff + I] = make_double2(fmax(red[1][0], red[1][1]), fmax(red[2][0], red[2][1]));
             }
         }
     }
     if (MODE == FI_LAST) return;
-    if (I == J && threadIdx.x < TS) f.acc((aslot + 1) % 3)[e] = 0;      // the accumulator of the next launch
+    if (I == J && threadIdx.x < TS) f.acc((aslot + 1) % 3)[voff + e] = 0;   // the accumulator of the next launch
     if (threadIdx.x < TS) sI[i] = rhs_v; else sJ[i] = rhs_v;
     // ---- this launch's quantum (identical in every workgroup)
     mR = wave_max(mR); mU = wave_max(mU);
@@ -2834,21 +2888,21 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     int eb = 0;
     (void)frexp(B, &eb);                                               // B < 2^eb
     const double quantum = ldexp(1.0, eb - 62), invq = ldexp(1.0, 62 - eb);
-    if (blockIdx.x == 0 && threadIdx.x == 0) f.qbuf[pg] = quantum;
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.qbuf[pg * nprob + sg] = quantum;
     __syncthreads();
     // ---- tile product
     const int c = lane & 15, gq = lane >> 4;
     double rj[8], tc[8], v[8];
     const double *diag = nullptr;
-    if (ttype != 0) {
+    if (PA || ttype != 0) {
         // (two call sites, two register sets: a tile loaded under a branch into the registers of the prefetched one would make the
         // compiler wait for everything before the first product)
-        if (I == J) {                                // (uniform) a diagonal tile in the fixed format: its bytes only now
+        if (!PA && I == J) {                         // (uniform) a diagonal tile in the fixed format that was not requested up front: only now
             FixRaw fd;
             fix_load(tile, wave, lane, fd);
             fi_fixed_product(fd, sI, sJ, wave, lane, v, tc);
         } else fi_fixed_product(fr, sI, sJ, wave, lane, v, tc);
-        if (ttype == 2) diag = reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4);
+        if (ttype == 2 && !prefetch_all) diag = reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4);
     } else {
         // float head + 16-bit tail, two halves of four row groups (as symv_tile_mixed_kernel)
 #pragma unroll
@@ -2864,9 +2918,9 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int rg = 4 * half + r4;
-                ha[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS);
-                hb[r4] = *reinterpret_cast<const float4 *>(head + rg * 4 * TS + 64);
-                lq[r4] = *reinterpret_cast<const uint4 *>(tail + rg * 4 * TS);
+                ha[r4] = load16<NT, float4>(head + rg * 4 * TS);
+                hb[r4] = load16<NT, float4>(head + rg * 4 * TS + 64);
+                lq[r4] = load16<NT, uint4>(tail + rg * 4 * TS);
             }
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -2903,8 +2957,8 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     if ((c & 1) == 0) {
         const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
         const int row = wave * 32 + 4 * rg + gq;
-        const double r1 = diag != nullptr ? fma(diag[row], sI[row], v[0]) : v[0];
-        atomicAdd(acc_cur + (int64_t)I * TS + row, (unsigned long long)__double2ll_rn(r1 * invq));
+        const double r1 = diag != nullptr ? fma(diag[row], sI[row], v[0]) : (PA && I == J ? fma(diag_pre, sI[row], v[0]) : v[0]);   // (PA: every diagonal tile keeps its diagonal apart)
+        atomicAdd(acc_cur + voff + (int64_t)I * TS + row, (unsigned long long)__double2ll_rn(r1 * invq));
     }
     if (I != J) {
 #pragma unroll
@@ -2921,34 +2975,51 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
         __syncthreads();
         if (threadIdx.x < TS) {
             const double r2 = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
-            atomicAdd(acc_cur + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
+            atomicAdd(acc_cur + voff + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
         }
     }
 }
 
-// constants and records of the one-launch iteration (after lpvs_admm_init / set_state; base = iterations done so far)
+// constants and records of the one-launch iteration (after lpvs_admm_init / set_state; base = iterations done so far); p.ns problems
 int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s) {
-    const int nblk = (int)(p.np / TS);
-    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    const int nblk = (int)(p.np / TS), nprob = p.ns;
+    const FiBufs f = fi_views(p.fi, (int64_t)nprob * p.np, nprob * nblk, nprob);
     if (with_consts) {
-        LPVS_HIP(hipMemsetAsync(f.consts, 0, sizeof(double) * 2, s));
-        hipLaunchKernelGGL(fi_rowsum_kernel, dim3((unsigned)ceil_div(p.np, 4)), dim3(256), 0, s, p.M, p.np, reinterpret_cast<unsigned long long *>(f.consts));
+        LPVS_HIP(hipMemsetAsync(f.consts, 0, sizeof(double) * 2 * (size_t)nprob, s));
+        hipLaunchKernelGGL(fi_rowsum_kernel, dim3((unsigned)ceil_div(p.np, 4), (unsigned)nprob), dim3(256), 0, s, p.M, p.np, p.n, reinterpret_cast<unsigned long long *>(f.consts));
     }
-    hipLaunchKernelGGL(fi_state_kernel, dim3(1), dim3(256), 0, s, p, nblk, base, with_consts ? 1 : 0);
+    hipLaunchKernelGGL(fi_state_kernel, dim3((unsigned)nprob), dim3(256), 0, s, p, nblk, base, with_consts ? 1 : 0);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
 
 // after a chunk: if an update of THIS chunk converged before the chunk's last one, its u may sit in the alternate buffer
+// (blockIdx.y = problem)
 __global__ void __launch_bounds__(256)
 fi_fixup_kernel(AdmmParams p, int nblk, long long base, long long iters) {
-    const AdmmStatus *status = p.status;
+    const int sg = blockIdx.y, nprob = gridDim.y;
+    const AdmmStatus *status = p.status + sg;
     if (!status->converged) return;
     const long long ic = status->iters - base - 1;                     // chunk-local index of the converged update
     if (ic < 0 || ic > iters - 2 || ((ic + 1) & 1) == 0) return;       // (u_ic was written to slot (ic + 1) & 1; the last update writes p.u itself)
-    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    const FiBufs f = fi_views(p.fi, (int64_t)nprob * p.np, nprob * nblk, nprob);
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < p.np) p.u[e] = f.ualt[e];
+    if (e < p.np) p.u[(int64_t)sg * p.np + e] = f.ualt[(int64_t)sg * p.np + e];
+}
+// commits the chunk's last update (one workgroup of 64 lanes per problem; block norms of parity `par`)
+__global__ void __launch_bounds__(64)
+fi_commit_kernel(AdmmParams p, int nblk, int par) {
+    const int sg = blockIdx.x, nprob = gridDim.x;
+    AdmmStatus *status = p.status + sg;
+    if (status->converged) return;
+    const FiBufs f = fi_views(p.fi, (int64_t)nprob * p.np, nprob * nblk, nprob);
+    __shared__ double slot;
+    const double nxz = pending_norm(f.bn + (int64_t)par * nprob * nblk + (int64_t)sg * nblk, nblk, &slot);
+    if (threadIdx.x == 0) {
+        status->iters += 1;
+        status->nxz = nxz;
+        if (nxz < p.tol) status->converged = 1;
+    }
 }
 
 int32_t fi_read_consts(const AdmmParams &p, double out[2], hipStream_t s) {
@@ -2958,30 +3029,43 @@ int32_t fi_read_consts(const AdmmParams &p, double out[2], hipStream_t s) {
     return LPVS_OK;
 }
 
-// a chunk of `iters` iterations: first launch (mat-vec of the right-hand side in memory), iters - 1 fused launches, the last update
-static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, hipStream_t s) {
-    const int nblk = (int)(p.np / TS);
+// a chunk of `iters` iterations: first launch (mat-vec of the right-hand side in memory), iters - 1 fused launches, the last update.
+// Single problem (p.ns == 1, batch == false) or a batch of p.ns problems that each own their matrix (mp_stride bytes apart).
+template <int NK, bool BATCH, bool NT, bool PA>
+static FiKernel fi_kernel_mode(int mode) {
+    return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, NK, BATCH, NT, PA> : mode == FI_MID ? admm_iter_mixed_kernel<FI_MID, NK, BATCH, NT, PA>
+                                                                                                  : admm_iter_mixed_kernel<FI_LAST, NK, BATCH, NT, PA>;
+}
+static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa) {
+    if (batch) {
+        if (nt) return pa ? fi_kernel_mode<1, true, true, true>(mode) : fi_kernel_mode<1, true, true, false>(mode);
+        return pa ? fi_kernel_mode<1, true, false, true>(mode) : fi_kernel_mode<1, true, false, false>(mode);
+    }
+    if (small) return pa ? fi_kernel_mode<1, false, false, true>(mode) : fi_kernel_mode<1, false, false, false>(mode);
+    return pa ? fi_kernel_mode<6, false, false, true>(mode) : fi_kernel_mode<6, false, false, false>(mode);
+}
+static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, size_t mp_stride, bool prefetch_all, hipStream_t s) {
+    const int nblk = (int)(p.np / TS), nprob = batch ? p.ns : 1;
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
-    const FiBufs f = fi_views(p.fi, p.np, nblk);
+    const FiBufs f = fi_views(p.fi, (int64_t)nprob * p.np, nprob * nblk, nprob);
     const unsigned char *Mp = reinterpret_cast<const unsigned char *>(p.Mp);
-    LPVS_HIP(hipMemsetAsync(f.acc(0), 0, sizeof(long long) * (size_t)p.np, s));
+    LPVS_HIP(hipMemsetAsync(f.acc(0), 0, sizeof(long long) * (size_t)p.np * (size_t)nprob, s));
     const long long base = p.fi_base;
     const bool small = nblk <= 64;                    // one load per lane covers the block norms / maxima
+    const char *nte = getenv("LPVS_NT_LOADS");
+    const bool nt = batch && (nte ? nte[0] == '1' : (size_t)ntiles * kSplitTileBytes * (size_t)nprob > ((size_t)240 << 20));
     auto launch = [&](int mode, unsigned grid, long long g, int aslot, int uslot, int commit_prev) {
-        void (*k)(AdmmParams, const unsigned char *, const unsigned char *, int, int, long long, int, int, int) =
-            mode == FI_FIRST ? (small ? admm_iter_mixed_kernel<FI_FIRST, 1> : admm_iter_mixed_kernel<FI_FIRST, 6>)
-            : mode == FI_MID ? (small ? admm_iter_mixed_kernel<FI_MID, 1> : admm_iter_mixed_kernel<FI_MID, 6>)
-                             : (small ? admm_iter_mixed_kernel<FI_LAST, 1> : admm_iter_mixed_kernel<FI_LAST, 6>);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot, commit_prev);
+        hipLaunchKernelGGL(fi_kernel(mode, small, batch, nt, prefetch_all), dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
+                           commit_prev, mp_stride, prefetch_all ? 1 : 0);
     };
     launch(FI_FIRST, ntiles, base, 0, 0, 0);
     for (int64_t j = 1; j < iters; ++j)   // launch j: update u_{j-1} (reads u from slot (j-1) & 1, writes the other), mat-vec of rhs_j
         launch(FI_MID, ntiles, base + j, (int)(j % 3), (int)((j - 1) & 1), j >= 2 ? 1 : 0);
     // the chunk's last update u_{iters-1}: sums of launch iters - 1, u from slot (iters - 1) & 1, everything back in the handle's vectors
     launch(FI_LAST, (unsigned)nblk, base + iters, (int)(iters % 3), (int)((iters - 1) & 1), iters >= 2 ? 1 : 0);
-    hipLaunchKernelGGL(fi_fixup_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p, nblk, base, (long long)iters);
+    hipLaunchKernelGGL(fi_fixup_kernel, dim3((unsigned)ceil_div(p.np, 256), (unsigned)nprob), dim3(256), 0, s, p, nblk, base, (long long)iters);
     // commit the chunk's last update (deferred convergence test, as in the two-launch iteration)
-    hipLaunchKernelGGL(admm_commit_kernel, dim3(1), dim3(64), 0, s, p, nblk, f.bn, (int)((base + iters - 1) & 1));
+    hipLaunchKernelGGL(fi_commit_kernel, dim3((unsigned)nprob), dim3(64), 0, s, p, nblk, (int)((base + iters - 1) & 1));
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -2991,14 +3075,9 @@ int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
     if (sym && fi_applicable(p)) {   // the one-launch iteration's kernel without its update (it adds into an accumulator that every chunk clears)
         const int nblk = (int)(p.np / TS);
         const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
-        for (int i = 0; i < reps; ++i) {
-            if (nblk <= 64)
-                hipLaunchKernelGGL((admm_iter_mixed_kernel<FI_FIRST, 1>), dim3(ntiles), dim3(256), 0, s, p, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
-                                   (int)ntiles, nblk, p.fi_base, 0, 0, 0);
-            else
-                hipLaunchKernelGGL((admm_iter_mixed_kernel<FI_FIRST, 6>), dim3(ntiles), dim3(256), 0, s, p, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
-                                   (int)ntiles, nblk, p.fi_base, 0, 0, 0);
-        }
+        for (int i = 0; i < reps; ++i)
+            hipLaunchKernelGGL(fi_kernel(FI_FIRST, nblk <= 64, false, false, p.fi_prefetch_all != 0), dim3(ntiles), dim3(256), 0, s, p, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
+                               (int)ntiles, nblk, p.fi_base, 0, 0, 0, (size_t)0, p.fi_prefetch_all);
         LPVS_HIP(hipGetLastError());
         return LPVS_OK;
     }
@@ -3015,7 +3094,7 @@ int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
 
 int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s) {
     const bool sym = p.part != nullptr && p.Mp != nullptr;
-    if (sym && iters > 0 && fi_applicable(p)) return launch_fi_chunk(p, iters, s);
+    if (sym && iters > 0 && fi_applicable(p)) return launch_fi_chunk(p, iters, false, 0, p.fi_prefetch_all != 0, s);
     for (int64_t i = 0; i < iters; ++i) {
         if (sym) {
             launch_iteration_sym(p, s, (int)i);

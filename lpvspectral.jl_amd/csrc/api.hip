@@ -357,6 +357,7 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.xb = sym && h->offset_form ? h->xb.as<double>() : nullptr;
     p.fi = sym && h->offset_form && h->ns == 1 && h->Mp_mode == kMpMixed && h->fi.p ? h->fi.as<double>() : nullptr;
     p.fi_R = h->fi_R; p.fi_xbmax = h->fi_xbmax;
+    p.fi_prefetch_all = sym && h->Mp_mode == kMpMixed && h->Mp_fixed_tiles == (int64_t)(symv_packed_doubles(h->np) / (128 * 128)) ? 1 : 0;
     return p;
 }
 
@@ -1451,7 +1452,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         Wdev = Wp.as<double>();
     }
     PhaseTrace tr(s);
-    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, xb, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb;
+    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, xb, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb, fibuf;
     ApSlotsDev sd;
     DrainOnExit drain(s);
     const int64_t nprob_max = bw * ns;
@@ -1617,10 +1618,26 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
             }
             LPVS_HIP(hipEventRecord(ev[1].b, s));
             LPVS_HIP(hipMemsetAsync(part.p, 0, part.bytes, s));   // tickets / block norms
+            // one launch per iteration (admm.hip): accumulators / records of the whole pass, whether every tile is fixed point
+            if (ab.mp_types != nullptr && ab.xb != nullptr && ns == 1) {
+                if (!fibuf.p) LPVS_TRY(fibuf.alloc(sizeof(double) * fi_doubles(np, bw)));
+                ab.fi = fibuf.as<double>();
+                if (fi_batch_applicable(ab)) {
+                    const size_t nt = symv_packed_doubles(np) / (128 * 128);
+                    std::vector<unsigned char> ht(nt * (size_t)nb_);
+                    LPVS_HIP(hipMemcpyAsync(ht.data(), ab.mp_types, ht.size(), hipMemcpyDeviceToHost, s));
+                    LPVS_HIP(hipStreamSynchronize(s));
+                    bool allfix = true;
+                    for (unsigned char t : ht) allfix = allfix && t != 0;
+                    ab.fi_prefetch_all = allfix ? 1 : 0;
+                } else ab.fi = nullptr;
+            }
             LPVS_HIP(hipEventRecord(ev[2].a, s));
             LPVS_TRY(launch_admm_batch_init(ab, s));
+            if (ab.fi) LPVS_TRY(launch_fi_batch_setup(ab, s));
             for (int64_t done = 0; done < a.iters;) {   // chunks: stop early once every problem of the batch has converged
                 const int64_t chunk = a.iters - done < 256 ? a.iters - done : 256;
+                ab.fi_base = done;
                 LPVS_TRY(launch_admm_batch_iterations(ab, chunk, s));
                 done += chunk;
                 LPVS_HIP(hipMemcpyAsync(hst.data(), status.p, sizeof(AdmmStatus) * (size_t)nprob, hipMemcpyDeviceToHost, s));
@@ -1634,6 +1651,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
                 LPVS_HIP(hipStreamSynchronize(s));
             }
             LPVS_HIP(hipEventRecord(ev[2].b, s));
+            g_win_timing[9] = ab.fi != nullptr ? 1 : 0;   // the pass ran one launch per iteration
             if (want_mv && w0 + nb_ >= nwin) {
                 LPVS_TRY(launch_admm_batch_matvec_only(ab, 3, s));
                 LPVS_HIP(hipEventRecord(ev[3].a, s));

@@ -205,9 +205,10 @@ struct AdmmParams {
     // two-launch iteration.  fi_base = iterations committed before the chunk about to be launched.
     double *fi = nullptr;
     long long fi_base = 0;
-    double fi_R = 0, fi_xbmax = 0;   // largest absolute row sum of M (x 1) and max|xb|: host copies of fi's constants
+    double fi_R = 0, fi_xbmax = 0;   // largest absolute row sum of M (x 1) and max|xb|: host copies of fi's constants (single problems)
+    int fi_prefetch_all = 0;         // every tile is in the fixed format: diagonal tiles are requested up front too
 };
-size_t fi_doubles(int64_t np);
+size_t fi_doubles(int64_t np, int64_t nprob = 1);
 bool fi_applicable(const AdmmParams &p);
 int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s);
 int32_t fi_read_consts(const AdmmParams &p, double out[2], hipStream_t s);
@@ -242,7 +243,14 @@ struct AdmmBatch {
     const double *xb = nullptr;   // offset form: x = xb + M~ (z-u)/mu, xb = M b per problem ([nbatch][np]); nullptr: classic
     int mp_split = 0;     // Mp holds 6-byte elements (float head + 16-bit tail)
     const unsigned char *mp_types = nullptr;   // mixed storage: [matrix][tile] formats (1 = 36-bit fixed point), see admm.hip
+    // one-launch iteration for the whole batch (admm.hip; nrhs == 1, mixed storage, offset form, fusable prox): fi_doubles(np, nbatch)
+    // doubles of accumulators / records, iterations committed before the chunk about to be launched, "every tile is fixed point"
+    double *fi = nullptr;
+    long long fi_base = 0;
+    int fi_prefetch_all = 0;
 };
+bool fi_batch_applicable(const AdmmBatch &p);
+int32_t launch_fi_batch_setup(const AdmmBatch &p, hipStream_t s);   // constants and the records of iteration 0 (after launch_admm_batch_init)
 bool admm_batch_uses_tiles(const AdmmBatch &p);   // will launch_admm_batch_iterations take the tile-packed path for this batch?
 int32_t launch_batch_matvec(const double *A, int64_t np, int nprob, int nrhs, const double *v, double *out, hipStream_t s);   // out_q = A[q / nrhs] v_q
 int32_t launch_pack_tiles_split_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, hipStream_t s);
