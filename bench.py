@@ -302,7 +302,7 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                 "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "windows_per_launch": nmv, "launches_per_step": iters,
                 "matvec_only_launch_us": mv_only_us,
                 "note": ("launch_us = HIP events around the ADMM loop of the last timed step / iterations (one launch per iteration); "
-                         "matvec_only_launch_us = 200 back-to-back launches of the same kernel without its update (rank 0's shard)") if one_launch else
+                         "matvec_only_launch_us = 200 back-to-back launches of the two-launch scheme's stand-alone batch mat-vec (rank 0's shard)") if one_launch else
                         "HIP events around 200 back-to-back launches of the batch mat-vec on the library's stream (rank 0's shard)"}
     out = {
         "metric": "windows/sec, ls_windowpsd estimator=ls_sparse_spectral (NormL1), %d windows x N=2^%d, Nf=%d, %d ADMM iters per window"
@@ -479,8 +479,8 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                      "note": ("algorithmic bytes = %s (+ 0.2 MB of state vectors); M is read once per iteration; ONE launch per iteration: the kernel "
                               "rebuilds its right-hand-side blocks (prox + dual update) in the prologue and adds its partial sums into x with 64-bit "
                               "fixed-point atomics; launch_us = HIP events around the ADMM loops of the timed steps / launches (the two-launch scheme, "
-                              "LPVS_ITERATION=two: mat-vec 24.7-25.7 us + update 5.3 us = 31.6 us per iteration); matvec_only_launch_us = the same "
-                              "kernel without its update, 300 back-to-back launches" % mv_info["bytes_formula"])
+                              "LPVS_ITERATION=two: mat-vec 24.7-25.7 us + update 5.3 us = 31.6 us per iteration); matvec_only_launch_us = that "
+                              "scheme's stand-alone mat-vec kernel (the same product, no update), 300 back-to-back launches" % mv_info["bytes_formula"])
                              if mv_info.get("one_launch_iteration") else
                              "algorithmic bytes = %s; M is read once per iteration; duration = HIP events around 300 back-to-back launches on "
                              "the library's stream" % mv_info["bytes_formula"]},

@@ -2273,16 +2273,6 @@ int32_t launch_admm_batch_matvec_only(const AdmmBatch &p, int reps, hipStream_t 
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), ns = (unsigned)p.nbatch;
     const int nrhs = p.nrhs > 0 ? p.nrhs : 1;
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
-    if (fi_batch_applicable(p)) {   // the one-launch iteration's kernel without its update (it adds into an accumulator that every chunk clears)
-        const AdmmParams q = batch_as_params(p);
-        const char *nte = getenv("LPVS_NT_LOADS");
-        const bool nt = nte ? nte[0] == '1' : (size_t)ntiles * kSplitTileBytes * (size_t)ns > ((size_t)240 << 20);
-        for (int i = 0; i < reps; ++i)
-            hipLaunchKernelGGL(fi_kernel(FI_FIRST, true, true, nt, p.fi_prefetch_all != 0), dim3(ntiles, ns), dim3(256), 0, s, q, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
-                               (int)ntiles, nblk, p.fi_base, 0, 0, 0, (size_t)ntiles * kSplitTileBytes, p.fi_prefetch_all);
-        LPVS_HIP(hipGetLastError());
-        return LPVS_OK;
-    }
     for (int i = 0; i < reps; ++i) {
         if (p.mp_split && p.mp_types && nrhs == 1)
             launch_mixed_batch(p, ntiles, ns, part1, part2, nullptr, s);
@@ -3072,15 +3062,7 @@ static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, s
 
 int32_t launch_admm_matvec_only(const AdmmParams &p, int reps, hipStream_t s) {
     const bool sym = p.part != nullptr && p.Mp != nullptr;
-    if (sym && fi_applicable(p)) {   // the one-launch iteration's kernel without its update (it adds into an accumulator that every chunk clears)
-        const int nblk = (int)(p.np / TS);
-        const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
-        for (int i = 0; i < reps; ++i)
-            hipLaunchKernelGGL(fi_kernel(FI_FIRST, nblk <= 64, false, false, p.fi_prefetch_all != 0), dim3(ntiles), dim3(256), 0, s, p, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
-                               (int)ntiles, nblk, p.fi_base, 0, 0, 0, (size_t)0, p.fi_prefetch_all);
-        LPVS_HIP(hipGetLastError());
-        return LPVS_OK;
-    }
+    // (handles that iterate in one launch are timed on the stand-alone mat-vec of the two-launch scheme: the same product, no update)
     for (int i = 0; i < reps; ++i) {
         if (sym) {
             launch_sym_matvec(p, nullptr, s);
