@@ -395,6 +395,11 @@ class Problem:
         np_ = -(-self.n // 128) * 128
         one_launch = bool(int(k.value) & 16)
         k = C.c_int32(int(k.value) & 15)
+        if one_launch and int(k.value) == 2:                               # _f32 handles: single-precision copy of the inverse
+            return dict(kernel="admm_iter_mixed_kernel", one_launch_iteration=True,
+                        storage="tile-packed lower triangle, f32 (4 B); tile partials added into x by 64-bit fixed-point atomics, prox / dual "
+                                "update in the next launch's prologue",
+                        bytes_formula="4 B x np(np+128)/2 (np = %d)" % np_)
         if one_launch:                                                     # mixed storage, single signal, fusable prox
             return dict(kernel="admm_iter_mixed_kernel", one_launch_iteration=True,
                         storage="tile-packed lower triangle, mixed: float head + 16-bit tail (6 B, 40 significant bits) for the diagonal tiles, "

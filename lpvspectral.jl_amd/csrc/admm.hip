@@ -2212,7 +2212,7 @@ static void launch_mixed_batch(const AdmmBatch &p, unsigned ntiles, unsigned ns,
 enum { FI_FIRST = 0, FI_MID = 1, FI_LAST = 2 };   // modes of admm_iter_mixed_kernel (further down)
 static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, size_t mp_stride, bool prefetch_all, hipStream_t s);
 typedef void (*FiKernel)(AdmmParams, const unsigned char *, const unsigned char *, int, int, long long, int, int, int, size_t, int);
-static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa);
+static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa, bool f32);
 static AdmmParams batch_as_params(const AdmmBatch &p) {   // AdmmParams with ns = nbatch has the layout the fused kernels expect
     AdmmParams q{p.M, p.np, p.n, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len, p.status,
                  nullptr, p.part, p.Mp, p.nbatch};
@@ -2628,7 +2628,7 @@ size_t fi_doubles(int64_t np, int64_t nprob) { return (size_t)((4 * np + 6 * (np
 bool fi_applicable(const AdmmParams &p) {
     const char *env = getenv("LPVS_ITERATION");      // (read per call: tests and tools switch it between handles)
     const bool on = !(env && std::string(env) == "two");
-    return on && p.fi != nullptr && p.ns == 1 && p.mp_types != nullptr && p.xb != nullptr && p.part != nullptr && p.Mp != nullptr && fused_ok(p) &&
+    return on && p.fi != nullptr && p.ns == 1 && (p.mp_types != nullptr || p.mp_f32) && p.xb != nullptr && p.part != nullptr && p.Mp != nullptr && fused_ok(p) &&
            p.np <= 49152;                            // (six clamped loads per lane cover the block norms / maxima of 384 row blocks)
 }
 
@@ -2718,7 +2718,8 @@ __device__ __forceinline__ void fi_fixed_product(const FixRaw &fr, const double 
 // mp_stride = bytes between their packed matrices); NT: non-temporal tile loads (batches beyond the Infinity Cache).
 // prefetch_all: every tile of the batch is in the fixed format, so the diagonal tiles (and their double diagonals) are requested up
 // front like the others (cfg4: four of a window's ten tiles); otherwise diagonal tiles are loaded after the prologue (cfg3: float-head).
-template <int MODE, int NK, bool BATCH, bool NT, bool PA>
+// F32: the packed inverse is the plain single-precision copy of the _f32 handles (64 KB tiles, every tile requested up front; PA ignored).
+template <int MODE, int NK, bool BATCH, bool NT, bool PA, bool F32>
 __global__ void __launch_bounds__(256, 3)
 admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
                        int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev, size_t mp_stride, int /* PA as a run-time value: unused */) {
@@ -2743,8 +2744,8 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
         J = k - I * (I - 1) / 2;
     }
     const int t = I * (I + 1) / 2 + J;
-    const unsigned char *tile = Mp + (size_t)t * kSplitTileBytes;
-    const unsigned char ttype = MODE == FI_LAST ? 0 : types[t];
+    const unsigned char *tile = Mp + (size_t)t * (F32 ? (size_t)TS * TS * 4 : kSplitTileBytes);
+    const unsigned char ttype = (MODE == FI_LAST || F32) ? 0 : types[t];
     AdmmStatus *status = p.status + sg;
     // ---- every load before the first wait, all of them unconditional (a load under a branch or in a loop of unknown length makes the
     // compiler wait for EVERYTHING at the next use): the state of this thread's element FIRST (loads return in order: the update then
@@ -2776,8 +2777,19 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     const double Rrow = BATCH ? f.consts[2 * sg] : p.fi_R, xbmax = BATCH ? f.consts[2 * sg + 1] : p.fi_xbmax;
     __builtin_amdgcn_sched_barrier(0);               // (the scheduler must not sink state loads below the tile's: they are wanted first)
     FixRaw fr;
+    float4 fha[8], fhb[8];                           // F32: the lane's 8 row groups x 8 columns
     double diag_pre = 0.0;
-    if (MODE != FI_LAST) {
+    if (MODE != FI_LAST && F32) {
+        typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tile), 0, TS * TS * 4, 0x00020000);
+        const int off_head = ((wave * 32 + (lane >> 4)) * TS + 4 * (lane & 15)) * 4;
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            fha[rg] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4), 0));
+            fhb[rg] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4) + 256, 0));
+        }
+    }
+    if (MODE != FI_LAST && !F32) {
         typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
         // (issued for every tile BELOW the diagonal without waiting for its format byte -- a float-head tile there, none at cfg3,
         // costs 74 KB of wasted reads; a diagonal tile is requested here only when the whole batch is in the fixed format, with the
@@ -2884,7 +2896,29 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     const int c = lane & 15, gq = lane >> 4;
     double rj[8], tc[8], v[8];
     const double *diag = nullptr;
-    if (PA || ttype != 0) {
+    if (F32) {
+        // single-precision tile (symv_tile_f32_kernel's product), row group by row group as the bytes arrive
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tc[k] = 0.0;
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            const double ri = sI[wave * 32 + 4 * rg + gq];
+            const float hh[8] = {fha[rg].x, fha[rg].y, fha[rg].z, fha[rg].w, fhb[rg].x, fhb[rg].y, fhb[rg].z, fhb[rg].w};
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const double m0 = (double)hh[k], m1 = (double)hh[k + 1];
+                tc[k] = opaque(fma(m0, ri, tc[k]));
+                tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
+                a0 = fma(m0, rj[k], a0);
+                a1 = fma(m1, rj[k + 1], a1);
+            }
+            v[rg] = a0 + a1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (PA || ttype != 0) {
         // (two call sites, two register sets: a tile loaded under a branch into the registers of the prefetched one would make the
         // compiler wait for everything before the first product)
         if (!PA && I == J) {                         // (uniform) a diagonal tile in the fixed format that was not requested up front: only now
@@ -3021,12 +3055,13 @@ int32_t fi_read_consts(const AdmmParams &p, double out[2], hipStream_t s) {
 
 // a chunk of `iters` iterations: first launch (mat-vec of the right-hand side in memory), iters - 1 fused launches, the last update.
 // Single problem (p.ns == 1, batch == false) or a batch of p.ns problems that each own their matrix (mp_stride bytes apart).
-template <int NK, bool BATCH, bool NT, bool PA>
+template <int NK, bool BATCH, bool NT, bool PA, bool F32 = false>
 static FiKernel fi_kernel_mode(int mode) {
-    return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, NK, BATCH, NT, PA> : mode == FI_MID ? admm_iter_mixed_kernel<FI_MID, NK, BATCH, NT, PA>
-                                                                                                  : admm_iter_mixed_kernel<FI_LAST, NK, BATCH, NT, PA>;
+    return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, NK, BATCH, NT, PA, F32> : mode == FI_MID ? admm_iter_mixed_kernel<FI_MID, NK, BATCH, NT, PA, F32>
+                                                                                                       : admm_iter_mixed_kernel<FI_LAST, NK, BATCH, NT, PA, F32>;
 }
-static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa) {
+static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa, bool f32 = false) {
+    if (f32) return small ? fi_kernel_mode<1, false, false, true, true>(mode) : fi_kernel_mode<6, false, false, true, true>(mode);
     if (batch) {
         if (nt) return pa ? fi_kernel_mode<1, true, true, true>(mode) : fi_kernel_mode<1, true, true, false>(mode);
         return pa ? fi_kernel_mode<1, true, false, true>(mode) : fi_kernel_mode<1, true, false, false>(mode);
@@ -3045,7 +3080,7 @@ static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, s
     const char *nte = getenv("LPVS_NT_LOADS");
     const bool nt = batch && (nte ? nte[0] == '1' : (size_t)ntiles * kSplitTileBytes * (size_t)nprob > ((size_t)240 << 20));
     auto launch = [&](int mode, unsigned grid, long long g, int aslot, int uslot, int commit_prev) {
-        hipLaunchKernelGGL(fi_kernel(mode, small, batch, nt, prefetch_all), dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
+        hipLaunchKernelGGL(fi_kernel(mode, small, batch, nt, prefetch_all, p.mp_f32 != 0), dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
                            commit_prev, mp_stride, prefetch_all ? 1 : 0);
     };
     launch(FI_FIRST, ntiles, base, 0, 0, 0);

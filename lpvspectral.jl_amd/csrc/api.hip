@@ -355,7 +355,7 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.mp_split = sym && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed) ? 1 : 0;
     p.mp_types = sym && h->Mp_mode == kMpMixed ? h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np) : nullptr;
     p.xb = sym && h->offset_form ? h->xb.as<double>() : nullptr;
-    p.fi = sym && h->offset_form && h->ns == 1 && h->Mp_mode == kMpMixed && h->fi.p ? h->fi.as<double>() : nullptr;
+    p.fi = sym && h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && h->fi.p ? h->fi.as<double>() : nullptr;
     p.fi_R = h->fi_R; p.fi_xbmax = h->fi_xbmax;
     p.fi_prefetch_all = sym && h->Mp_mode == kMpMixed && h->Mp_fixed_tiles == (int64_t)(symv_packed_doubles(h->np) / (128 * 128)) ? 1 : 0;
     return p;
@@ -1084,7 +1084,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
         LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->bs.as<double>(), h->xb.as<double>(), s, (int)h->ns));   // every signal's M b
     }
-    if (h->offset_form && h->ns == 1 && h->Mp_mode == kMpMixed && !h->fi.p) LPVS_TRY(h->fi.alloc(sizeof(double) * fi_doubles(h->np)));
+    if (h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && !h->fi.p) LPVS_TRY(h->fi.alloc(sizeof(double) * fi_doubles(h->np)));
     const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_init(p, s));
     h->fi_sync = -1;

@@ -128,3 +128,27 @@ def test_padded_and_stiff_problems_keep_the_quantum_tight(L, monkeypatch):
         out[mode] = api.windows_estimate([yw], t, f, n, 0, None, eng)[0]
         assert api.windowpsd_last_timing()["one_launch_iteration"] == (mode == "one")
     assert np.abs(out["one"] - out["two"]).max() <= 1e-12 * np.abs(out["two"]).max(), np.abs(out["one"] - out["two"]).max() / np.abs(out["two"]).max()
+
+
+def test_float32_handles_iterate_in_one_launch_too(L, problem, monkeypatch):
+    """_f32 handles (single-precision copy of the inverse, double arithmetic): one-launch against two-launch iteration."""
+    N, Nf, Nv, y, X, V, w = problem
+    f32 = [a.astype(np.float32) for a in (y, X, V, w)]
+    res = {}
+    for mode in ("two", "one"):
+        if mode == "two":
+            monkeypatch.setenv("LPVS_ITERATION", "two")
+        else:
+            monkeypatch.delenv("LPVS_ITERATION", raising=False)
+        with L.Problem.lpv(*f32, Nv) as p:
+            assert p.f32
+            p.set_prox(L.SlicedSeparableSum.frequency_groups(2.0, Nf, 2 * Nv))
+            p.admm_init(None, μ=0.05, tol=0.0)
+            info = p.matvec_info()
+            assert info["kernel"] == ("symv_tile_f32_kernel" if mode == "two" else "admm_iter_mixed_kernel"), info
+            it, nxz, conv = p.admm_run(300)
+            res[mode] = (it, nxz) + p.admm_get()
+    assert res["one"][0] == res["two"][0] == 300
+    assert abs(res["one"][1] - res["two"][1]) <= 1e-9 * res["two"][1]
+    for a, b in zip(res["one"][2:], res["two"][2:]):                 # (read back as float32)
+        assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= 2e-7 * max(np.abs(b).max(), 1.0)
