@@ -152,3 +152,26 @@ def test_float32_handles_iterate_in_one_launch_too(L, problem, monkeypatch):
     assert abs(res["one"][1] - res["two"][1]) <= 1e-9 * res["two"][1]
     for a, b in zip(res["one"][2:], res["two"][2:]):                 # (read back as float32)
         assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= 2e-7 * max(np.abs(b).max(), 1.0)
+
+
+def test_more_than_64_row_blocks(L, monkeypatch):
+    """np = 12288 (96 row blocks): block norms and maxima take several loads per lane (the NK = 6 instances of the kernel)."""
+    rng = np.random.default_rng(8)
+    N, Nf, Nv = 1 << 20, 768, 8
+    y, X, V, w = _signal(N, Nf, rng)
+    res = {}
+    for mode in ("two", "one"):
+        if mode == "two":
+            monkeypatch.setenv("LPVS_ITERATION", "two")
+        else:
+            monkeypatch.delenv("LPVS_ITERATION", raising=False)
+        with L.Problem.lpv(y, X, V, w, Nv) as p:
+            p.set_prox(L.SlicedSeparableSum.frequency_groups(2.0, Nf, 2 * Nv))
+            p.admm_init(None, μ=0.05, tol=0.0)
+            assert p.matvec_info()["kernel"] == ("symv_tile_mixed_kernel" if mode == "two" else "admm_iter_mixed_kernel")
+            for c in (60, 1, 59):
+                it, nxz, conv = p.admm_run(c)
+            res[mode] = (it, nxz) + p.admm_get()
+    assert res["one"][0] == res["two"][0] == 120
+    for a, b in zip(res["one"][2:], res["two"][2:]):
+        assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1.0), np.abs(a - b).max()
