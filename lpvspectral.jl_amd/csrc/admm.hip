@@ -2610,6 +2610,25 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// max over the wave of a NON-NEGATIVE double, the same value in every lane: row scans and row broadcasts through DPP (a dozen
+// cycles per step) instead of six ds_bpermute round trips -- this sits between the arrival of the state and the first product of every
+// tile workgroup.  Zero is the identity: lanes without a source read 0 (bound_ctrl), disabled rows keep 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take0(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+    v = fmax(v, dpp_take0<0x111, 0xf>(v));           // row_shr:1   lane i: max over [i-1, i] of its row of 16
+    v = fmax(v, dpp_take0<0x112, 0xf>(v));           // row_shr:2            [i-3, i]
+    v = fmax(v, dpp_take0<0x114, 0xf>(v));           // row_shr:4            [i-7, i]
+    v = fmax(v, dpp_take0<0x118, 0xf>(v));           // row_shr:8            [i-15, i]: lane 15 of a row holds the row's maximum
+    v = fmax(v, dpp_take0<0x142, 0xa>(v));           // row_bcast:15 into rows 1 and 3
+    v = fmax(v, dpp_take0<0x143, 0xc>(v));           // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 struct FiBufs {   // views into AdmmParams::fi (8-byte units): see fi_doubles()
     long long *acc0; int64_t np;
     double *ualt, *bn, *qbuf, *consts;
@@ -2821,7 +2840,8 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
 #pragma unroll
     for (int k = 0; k < NK; ++k) { mR = fmax(mR, recv[k].x); mU = fmax(mU, recv[k].y); }
     if (conv_flag) return;
-    if (MODE != FI_FIRST && commit_prev) {                             // (uniform, host-known) commit update u_{g-2}
+    // (tol <= 0 can never stop: only the workgroup that keeps the status needs the norm then -- a dependent shuffle chain less in every other prologue)
+    if (MODE != FI_FIRST && commit_prev && (p.tol > 0.0 || blockIdx.x == 0)) {   // (uniform, host-known) commit update u_{g-2}
         double part = 0.0;                                             // lane q sums blocks q, q + 64, ...; then the wave's fixed shuffle pattern
 #pragma unroll
         for (int k = 0; k < NK; ++k) part += lane + 64 * k < nblk ? bnv[k] : 0.0;
@@ -2884,7 +2904,7 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     if (I == J && threadIdx.x < TS) f.acc((aslot + 1) % 3)[voff + e] = 0;   // the accumulator of the next launch
     if (threadIdx.x < TS) sI[i] = rhs_v; else sJ[i] = rhs_v;
     // ---- this launch's quantum (identical in every workgroup)
-    mR = wave_max(mR); mU = wave_max(mU);
+    mR = wave_max_nonneg(mR); mU = wave_max_nonneg(mU);
     double B = Rrow * ((xbmax + Rrow * mR + mU) / p.mu) * 1.000001;
     if (!(B > 0x1p-900)) B = 0x1p-900;
     int eb = 0;
