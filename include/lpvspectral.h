@@ -8,8 +8,9 @@
  *   - every function returns an int32 status (LPVS_OK or a negative LPVS_E* code);
  *     lpvs_last_error() gives the thread-local message of the last failure.
  *   - sizes are int64_t (Julia Int); matrices are COLUMN-MAJOR (Julia layout).
- *   - every array argument may be a HOST pointer or a DEVICE (HIP) pointer of the
- *     current device; the library detects which (hipPointerGetAttributes).  The
+ *   - every floating-point array argument may be a HOST pointer or a DEVICE (HIP) pointer of the
+ *     current device; the library detects which (hipPointerGetAttributes).  Integer outputs
+ *     (int64_t* counts, offsets, iteration counts) and scalar outputs are HOST pointers.  The
  *     caller owns all argument memory; it is never retained or freed here, and is
  *     only read/written for the duration of the call.  Device arguments are read on the
  *     library's own streams: work the caller has queued on other streams to produce them
@@ -18,7 +19,15 @@
  *     when the call returns.
  *   - a handle owns one HIP stream on one device; handles are not thread-safe,
  *     different handles may be used concurrently.
- *   - arithmetic type: fp64 (suffix _f64), the eltype of every reference test.
+ *   - arithmetic type: fp64 (suffix _f64), the eltype of every reference test: assembly, Gram,
+ *     factorisation, prox operators and every accumulation are double.  STORAGE CAVEAT: for
+ *     n >= 2048 the ADMM mat-vec of an _f64 handle streams, by default, a reduced-width COPY of
+ *     (G + I/mu)^-1 with >= 36 significant bits per element (LPVS_STORAGE_MIXED below), applied in
+ *     offset form x = M b + M~ (z-u)/mu with M b from the full doubles.  Measured cost: 1.1e-10
+ *     rel-L2 in z after 2000 iterations at N = 2^20, n = 8192 -- below the reference's own CG
+ *     tolerance sqrt(eps) = 1.5e-8 (src/lasso.jl:151, ProximalOperators iterative=true).
+ *     lpvs_problem_set_option(h, LPVS_OPT_M_STORAGE, LPVS_STORAGE_F64) streams the doubles
+ *     themselves (1.55x the bytes per iteration).
  *
  * File:line citations are into the reference (baggepinnen/LPVSpectral.jl v0.3.4).
  */
@@ -62,6 +71,38 @@ int32_t lpvs_device_count(void);          /* number of visible HIP devices (0 if
 const char *lpvs_last_error(void);        /* thread-local, valid until the next failing call */
 /* work buffers are cached per device between calls (cap: LPVS_POOL_GIB, default 128); this returns them to the driver */
 int32_t lpvs_release_cached_memory(void);
+
+/* ---- options: how a handle stores the inverse its ADMM mat-vec streams, how it iterates, which Gram form its constructor
+ * takes.  Value 0 (LPVS_OPT_DEFAULT) = the library's choice, which an environment variable of the same name may override for
+ * experiments (LPVS_M_STORAGE, LPVS_ITERATION, LPVS_GRAM_FORM, LPVS_NT_LOADS, LPVS_NUDFT); an explicit option wins over the
+ * environment.  Results do not depend on ITERATION / NT_LOADS / SLOT_SUMS beyond rounding (tests/test_gpu_one_launch.py,
+ * tests/test_gpu_nufft.py); M_STORAGE trades bytes per iteration against 1e-10 in the iterates (see the header comment).
+ *   lpvs_set_default_option:  thread-local default for handles created and batched-window calls made AFTERWARDS by the calling
+ *                             thread (the batched-window entry points have no handle to carry options);
+ *   lpvs_problem_set_option:  one handle.  M_STORAGE / ITERATION / NT_LOADS take effect at the next lpvs_admm_init / lpvs_admm_run;
+ *                             GRAM_FORM and SLOT_SUMS are constructor-time choices (LPVS_ESTATE on a handle: set the default). */
+#define LPVS_OPT_DEFAULT 0
+#define LPVS_OPT_M_STORAGE 1  /* LPVS_STORAGE_*  : packed inverse of n >= 2048 handles / window batches */
+#define LPVS_OPT_ITERATION 2  /* LPVS_ITERATION_*: one launch per ADMM iteration (where applicable) or mat-vec + update launches */
+#define LPVS_OPT_GRAM_FORM 3  /* LPVS_GRAM_*     : structured Gram for arithmetic-progression grids, or the dense MFMA forms */
+#define LPVS_OPT_NT_LOADS 4   /* LPVS_NT_*       : non-temporal tile loads in window batches (default: beyond 240 MiB of inverses) */
+#define LPVS_OPT_SLOT_SUMS 5  /* LPVS_SLOTS_*    : slot sums of the structured Gram by non-uniform FFT or by direct evaluation */
+#define LPVS_STORAGE_MIXED 1  /* float head + 16-bit tail (40 bits) for tiles with large entries, 36-bit fixed point elsewhere */
+#define LPVS_STORAGE_SPLIT 2  /* float head + 16-bit tail everywhere (6 bytes, 40 significant bits) */
+#define LPVS_STORAGE_F64 3    /* doubles (8 bytes): the reference-width copy */
+#define LPVS_ITERATION_ONE 1
+#define LPVS_ITERATION_TWO 2
+#define LPVS_GRAM_AP 1        /* structured (error unless the grid is an arithmetic progression up to rounding) */
+#define LPVS_GRAM_KRS 2       /* dense, symmetric-pair contraction */
+#define LPVS_GRAM_KR 3        /* dense, Khatri-Rao contraction */
+#define LPVS_NT_OFF 1
+#define LPVS_NT_ON 2
+#define LPVS_SLOTS_NUFFT 1
+#define LPVS_SLOTS_DIRECT 2
+int32_t lpvs_set_default_option(int32_t option, int32_t value);
+int32_t lpvs_get_default_option(int32_t option, int32_t *value);   /* the calling thread's explicit default (0 if none) */
+int32_t lpvs_problem_set_option(lpvs_problem *h, int32_t option, int32_t value);
+int32_t lpvs_problem_get_option(lpvs_problem *h, int32_t option, int32_t *value);   /* the value in effect for this handle */
 
 /* ---- a1  check_freq                                                  src/lsfft.jl:20-24
  * *zerofreq = 0 (no zero frequency) or 1 (zero frequency is first); LPVS_EARGUMENT if a
@@ -297,7 +338,8 @@ int32_t lpvs_windowpsd_last_timing(double *out, int32_t n_out);
  *   estimator   LPVS_EST_SPARSE (prox_*, mu, tol, iters, linear_sign as in lpvs_windowpsd_sparse_f64; lam unused) or
  *               LPVS_EST_DENSE (lam = ridge; the ADMM arguments are ignored)
  *   x_re, x_im  ns x (win_hi - win_lo) x Nf, signal-major then window-major: fourier2complex of every solution
- *   iters_out   ns x (win_hi - win_lo) iteration counts (0 for the dense estimator); may be NULL */
+ *   iters_out   ns x (win_hi - win_lo) iteration counts (0 for the dense estimator); may be NULL.  HOST memory only
+ *               (as every int64_t* output of this header: iteration counts are bookkeeping the host loop consumes) */
 int32_t lpvs_windows_estimate_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap,
                                   const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam,
                                   int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,

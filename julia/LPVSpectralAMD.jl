@@ -104,6 +104,39 @@ function get_fourier_regressor(t::AbstractArray{Float32}, f::AbstractArray{Float
     A, zf
 end
 
+# ---- options (include/lpvspectral.h LPVS_OPT_*) ---------------------------------------------------
+# Extensions (the reference has none of them): how a handle stores the inverse its ADMM mat-vec streams and how it iterates.
+#   storage   = :mixed (default: >= 36 significant bits per element, 1e-10 in the iterates) | :split (40 bits) | :f64 (doubles)
+#   iteration = :one (default where applicable: one launch per ADMM iteration) | :two
+#   gram_form = :ap | :krs | :kr,  nt_loads = :on | :off,  slot_sums = :nufft | :direct        (`nothing` = the library's choice)
+# Estimators take them as keywords (`ls_sparse_spectral_lpv(...; storage=:f64)`); results do not depend on them beyond rounding.
+const OPT_ID = (storage=Int32(1), iteration=Int32(2), gram_form=Int32(3), nt_loads=Int32(4), slot_sums=Int32(5))
+const OPT_VALUES = (storage=(mixed=1, split=2, f64=3), iteration=(one=1, two=2), gram_form=(ap=1, krs=2, kr=3),
+                    nt_loads=(off=1, on=2), slot_sums=(nufft=1, direct=2))
+optvalue(name::Symbol, v) = v === nothing ? Int32(0) : Int32(getfield(getfield(OPT_VALUES, name), Symbol(v)))
+function set_default_option(name::Symbol, v=nothing)       # thread-local: handles created / window batches run afterwards
+    oid, vid = getfield(OPT_ID, name), optvalue(name, v)
+    check(@ccall LIB.lpvs_set_default_option(oid::Int32, vid::Int32)::Int32)
+end
+function get_default_option(name::Symbol)
+    oid = getfield(OPT_ID, name); r = Ref{Int32}(0)
+    check(@ccall LIB.lpvs_get_default_option(oid::Int32, r::Ref{Int32})::Int32)
+    r[] == 0 ? nothing : keys(getfield(OPT_VALUES, name))[r[]]
+end
+const OPTION_KEYS = keys(OPT_ID)
+# run f() with the given option keywords as thread defaults, restore the previous defaults afterwards; returns the
+# remaining keywords (the reference's own: iters, tol, μ, ...)
+function with_options(f, kwargs)
+    mine = [(k, v) for (k, v) in pairs(kwargs) if k in OPTION_KEYS && v !== nothing]
+    prev = [(k, get_default_option(k)) for (k, _) in mine]
+    for (k, v) in mine; set_default_option(k, v); end
+    try
+        return f((; (k => v for (k, v) in pairs(kwargs) if !(k in OPTION_KEYS))...))
+    finally
+        for (k, v) in prev; set_default_option(k, v); end
+    end
+end
+
 # ---- handle wrapper ----------------------------------------------------------------------------
 mutable struct Problem
     h::Ptr{Cvoid}; n::Int; m::Int; ns::Int                 # m = complex parameters per signal, ns = right-hand sides
@@ -112,6 +145,16 @@ mutable struct Problem
         p = new(h, Int(n[]), m, ns)
         finalizer(q -> (@ccall LIB.lpvs_problem_destroy(q.h::Ptr{Cvoid})::Int32), p)
     end
+end
+
+function set_option!(p::Problem, name::Symbol, v=nothing)  # one handle; takes effect at the next admm init / run
+    oid, vid = getfield(OPT_ID, name), optvalue(name, v)
+    check(@ccall LIB.lpvs_problem_set_option(p.h::Ptr{Cvoid}, oid::Int32, vid::Int32)::Int32)
+end
+function get_option(p::Problem, name::Symbol)              # the value in effect (explicit, thread default or environment)
+    oid = getfield(OPT_ID, name); r = Ref{Int32}(0)
+    check(@ccall LIB.lpvs_problem_get_option(p.h::Ptr{Cvoid}, oid::Int32, r::Ref{Int32})::Int32)
+    r[] == 0 ? nothing : keys(getfield(OPT_VALUES, name))[r[]]
 end
 
 function fourier_problem(y, t, f, W; device=0)
@@ -287,38 +330,44 @@ _x0(q, zf) = zf === nothing ? [real.(q); imag.(q)] : [real.(q); imag.(q[2:end])]
 
 function ls_sparse_spectral(y::AbstractArray{T}, t, f=default_freqs(t); init=false, λ=T(1),
                             proxg=PO.NormL1(λ), device=0, kwargs...) where T          # src/lasso.jl:85-102
-    p = fourier_problem(y, t, f, nothing; device=device)
-    pp = proxparams(proxg, p.n)
-    pp === nothing && throw(ArgumentError("proxg of type $(typeof(proxg)) has no device kernel; use LPVSpectral.ls_sparse_spectral"))
-    x0 = init ? _x0(pack(p, solve_ridge(p, λ^2)), check_freq(f)) : nothing           # fourier_solve(A,y,zerofreq,λ), :92
-    admm!(p, x0, pp, +1; kwargs...)
-    params(p), f
+    with_options(kwargs) do kw                           # storage= / iteration= ... (extensions) apply to the handle created here
+        p = fourier_problem(y, t, f, nothing; device=device)
+        pp = proxparams(proxg, p.n)
+        pp === nothing && throw(ArgumentError("proxg of type $(typeof(proxg)) has no device kernel; use LPVSpectral.ls_sparse_spectral"))
+        x0 = init ? _x0(pack(p, solve_ridge(p, λ^2)), check_freq(f)) : nothing       # fourier_solve(A,y,zerofreq,λ), :92
+        admm!(p, x0, pp, +1; kw...)
+        params(p), f
+    end
 end
 function ls_sparse_spectral(y::AbstractArray{T}, t, f, W; init=false, λ=T(1), proxg=PO.NormL1(T(λ)), device=0,
                             kwargs...) where T                                       # src/lasso.jl:105-126
-    p = fourier_problem(y, t, f, W; device=device)
-    pp = proxparams(proxg, p.n)
-    pp === nothing && throw(ArgumentError("proxg of type $(typeof(proxg)) has no device kernel; use LPVSpectral.ls_sparse_spectral"))
-    x0 = init ? _x0(ls_spectral(y, t, f; λ=λ, device=device)[1], check_freq(f)) : nothing   # :112 -- the UNWEIGHTED solve
-    admm!(p, x0, pp, -1; kwargs...)                       # Quadratic(Q, q=+A'Wy) as written (:119-121)
-    params(p), f
+    with_options(kwargs) do kw
+        p = fourier_problem(y, t, f, W; device=device)
+        pp = proxparams(proxg, p.n)
+        pp === nothing && throw(ArgumentError("proxg of type $(typeof(proxg)) has no device kernel; use LPVSpectral.ls_sparse_spectral"))
+        x0 = init ? _x0(ls_spectral(y, t, f; λ=λ, device=device)[1], check_freq(f)) : nothing   # :112 -- the UNWEIGHTED solve
+        admm!(p, x0, pp, -1; kw...)                       # Quadratic(Q, q=+A'Wy) as written (:119-121)
+        params(p), f
+    end
 end
 
 function ls_sparse_spectral_lpv(y::AbstractVector{S}, X::AbstractVector{S}, V::AbstractVector{S}, w, Nv::Integer;
                                 λ=1, coulomb=false, normalize=true, device=0, kwargs...) where S   # src/lasso.jl:27-70
     coulomb && throw(ArgumentError("coulomb=true is ill-defined in the sparse LPV path (half of x is never written by prox!); use ls_spectral_lpv"))
     w = w[:]
-    p = lpv_problem(y, X, V, w, Nv, normalize, false; device=device)
-    local prm
-    try
-        admm!(p, nothing, (Int32(4), Float64(λ), Int64(2Nv)), +1; kwargs...)        # SlicedSeparableSum(NormL2(λ)...), :53-55
-        prm = params(p, 0)
-    catch e
-        e isa InterruptException || rethrow(e)
-        @info "Aborting"                                  # :61
-        prm = params(p, 1)                                # z = copy(x)
+    with_options(kwargs) do kw
+        p = lpv_problem(y, X, V, w, Nv, normalize, false; device=device)
+        local prm
+        try
+            admm!(p, nothing, (Int32(4), Float64(λ), Int64(2Nv)), +1; kw...)        # SlicedSeparableSum(NormL2(λ)...), :53-55
+            prm = params(p, 0)
+        catch e
+            e isa InterruptException || rethrow(e)
+            @info "Aborting"                              # :61
+            prm = params(p, 1)                            # z = copy(x)
+        end
+        SpectralExt(y, X, V, w, Nv, λ, coulomb, normalize, prm, nothing)
     end
-    SpectralExt(y, X, V, w, Nv, λ, coulomb, normalize, prm, nothing)
 end
 
 function ls_spectral_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer;
@@ -400,6 +449,7 @@ mapwindows(f::Function, args...) = mapwindows(f, Windows2(args...))
 function engine_args(estimator, nreg; kwargs...)
     kw = Dict{Symbol,Any}(kwargs)
     delete!(kw, :device)
+    for k in OPTION_KEYS; delete!(kw, k); end                # (applied as thread defaults by the drivers)
     if estimator === ls_spectral
         (get(kw, :verbose, false) || !issubset(keys(kw), (:λ, :verbose))) && return nothing
         return (est=EST_DENSE, lam=Float64(get(kw, :λ, 1e-10)), prox=(Int32(1), 0.0, Int64(0)), μ=0.05, tol=0.0, iters=0, sign=Int32(1))
@@ -442,7 +492,7 @@ function ls_windowpsd(y, t, freqs=nothing; nw=8, noverlap=-1, window_func=rect, 
     S = zeros(eltype(y), length(freqs))
     eng = nw > 0 ? engine_args(estimator, 2length(freqs); kwargs...) : nothing
     if eng !== nothing
-        x, _ = windows_estimate([y], t, freqs, n, windows.noverlap, windows.W, eng; ngpus=ngpus)
+        x, _ = with_options(kwargs) do _; windows_estimate([y], t, freqs, n, windows.noverlap, windows.W, eng; ngpus=ngpus); end
         for i in 1:nw
             S .+= abs2.(view(x, :, i, 1))                                            # :122, window order
         end
@@ -464,7 +514,7 @@ function ls_windowcsd(y, u, t, freqs=nothing; nw=10, noverlap=-1, window_func=re
     nw = length(windowsy)
     eng = nw > 0 ? engine_args(estimator, 2length(freqs); kwargs...) : nothing
     if eng !== nothing                                    # one Gram and one factorisation per window serve both signals
-        x, _ = windows_estimate([y, u], t, freqs, n, windowsy.noverlap, windowsy.W, eng; ngpus=ngpus)
+        x, _ = with_options(kwargs) do _; windows_estimate([y, u], t, freqs, n, windowsy.noverlap, windowsy.W, eng; ngpus=ngpus); end
         for i in 1:nw
             S += view(x, :, i, 1) .* conj.(view(x, :, i, 2))                         # :152
         end
@@ -486,7 +536,7 @@ function ls_cohere(y, u, t, freqs=nothing; nw=10, noverlap=-1, estimator=ls_spec
     windows = Windows3(y, t, u, n, noverlap, hanning)                                # :182
     eng = length(windows) > 0 ? engine_args(estimator, 2length(freqs); kwargs...) : nothing
     if eng !== nothing
-        x, _ = windows_estimate([y, u], t, freqs, n, windows.noverlap, windows.W, eng; ngpus=ngpus)
+        x, _ = with_options(kwargs) do _; windows_estimate([y, u], t, freqs, n, windows.noverlap, windows.W, eng; ngpus=ngpus); end
         for i in 1:length(windows)
             xy, xu = view(x, :, i, 1), view(x, :, i, 2)
             Syu .+= xy .* conj.(xu); Syy .+= abs2.(xy); Suu .+= abs2.(xu)           # :187-189

@@ -21,6 +21,28 @@ LPVS_EDEVICE, LPVS_EUNSUPPORTED, LPVS_ENUMERIC, LPVS_ESTATE = -5, -6, -7, -8
 PROX_L1, PROX_L0, PROX_BALL_L0, PROX_GROUP_L2 = 1, 2, 3, 4
 LINEAR_LEAST_SQUARES, LINEAR_QUADRATIC_AS_WRITTEN = 1, -1
 EST_SPARSE, EST_DENSE = 1, 2
+# options (include/lpvspectral.h LPVS_OPT_*): name -> (option id, {value name -> value}); None / "default" = 0
+OPTIONS = {
+    "storage": (1, {"mixed": 1, "split": 2, "f64": 3}),
+    "iteration": (2, {"one": 1, "two": 2}),
+    "gram_form": (3, {"ap": 1, "krs": 2, "kr": 3}),
+    "nt_loads": (4, {"off": 1, "on": 2}),
+    "slot_sums": (5, {"nufft": 1, "direct": 2}),
+}
+
+
+def option_ids(name, value):
+    """(option id, value id) of an option given by name (``storage="f64"``); ``None`` / ``"default"`` -> 0."""
+    if name not in OPTIONS:
+        raise KeyError(f"unknown option {name!r} (known: {sorted(OPTIONS)})")
+    oid, vals = OPTIONS[name]
+    if value is None or value == "default":
+        return oid, 0
+    if isinstance(value, bool):
+        value = "on" if value else "off"
+    if value not in vals:
+        raise ValueError(f"option {name}: unknown value {value!r} (known: {sorted(vals)})")
+    return oid, vals[value]
 
 
 class DeviceError(RuntimeError):
@@ -43,6 +65,10 @@ SIGNATURES = {
     "lpvs_device_count": (_I32, []),
     "lpvs_last_error": (C.c_char_p, []),
     "lpvs_release_cached_memory": (_I32, []),
+    "lpvs_set_default_option": (_I32, [_I32, _I32]),
+    "lpvs_get_default_option": (_I32, [_I32, C.POINTER(_I32)]),
+    "lpvs_problem_set_option": (_I32, [_P, _I32, _I32]),
+    "lpvs_problem_get_option": (_I32, [_P, _I32, C.POINTER(_I32)]),
     "lpvs_check_freq_f64": (_I32, [_P, _I64, _PI64]),
     "lpvs_fourier_regressor_f64": (_I32, [_P, _I64, _P, _I64, _P, _PI64]),
     "lpvs_basis_activation_f64": (_I32, [_P, _I64, _I64, _I32, _I32, _P]),

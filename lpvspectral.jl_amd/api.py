@@ -74,13 +74,29 @@ def default_freqs(t_or_n, fs=None, n=None):
         nn = int(t_or_n)
         fs = 1.0 if fs is None else float(fs)
     else:
+        t32 = is_f32(t_or_n)
         t = _host(t_or_n)
         if n is not None:
             t = t[: int(n)]
         nn = len(t)
         if fs is None:
             fs = 1.0 / np.mean(np.diff(t))
+        if t32:   # Float32 time stamps give a Float32 grid (rfftfreq(n, fs::Float32)): multiplier fs / n rounded to Float32, k * multiplier
+            m = np.float32(np.float32(fs) / np.float32(nn))
+            return (np.arange(nn // 2 + 1) * np.float64(m)).astype(np.float32)
     return (np.arange(nn // 2 + 1) * float(fs)) / nn
+
+
+def _all_f32(*arrays):
+    """Julia's eltype promotion for the entry points that take several arrays: Float32 only when every array is."""
+    return all(is_f32(a) for a in arrays)
+
+
+def _host_vec(a):
+    """A host vector in its own float eltype (float32 stays float32: eltype promotion is decided later), anything else float64."""
+    if is_f32(a) and not _lib.is_device_array(a):
+        return np.ravel(np.asarray(a.detach().numpy() if hasattr(a, "detach") else a, dtype=np.float32))
+    return np.ravel(_host(a))
 
 
 def _host(a):
@@ -105,7 +121,7 @@ def check_freq(f):
 
 def get_fourier_regressor(t, f):
     """src/lsfft.jl:26-49 -> ``(A, zerofreq)`` with A an N×Nreg column-major numpy array."""
-    f32 = is_f32(t)                                   # eltype of t decides, as T does in src/lsfft.jl:26
+    f32 = _all_f32(t, f)                              # t and f share the eltype T of src/lsfft.jl:26 (mixed: promoted to Float64 here)
     conv = as_f32 if f32 else as_f64
     kt, pt, N = conv(t)
     kf, pf, Nf = conv(f)
@@ -131,11 +147,11 @@ def basis_activation_func(V, Nv, normalize=True, coulomb=False):
 
 def lpv_regressor(X, V, w, Nv, normalize=True, coulomb=False, permuted=True):
     """Materialised Φ of src/lasso.jl:35-50 (tests / small problems; the solve never forms it)."""
-    f32 = is_f32(X)
+    f32 = _all_f32(X, V, w)                           # the phases w .* X promote (src/lasso.jl:39): Float32 only for an all-Float32 call
     conv = as_f32 if f32 else as_f64
     kx, px, N = conv(X)
     kv, pv, _ = conv(V)
-    kw, pw, Nf = conv(np.ravel(_host(w)) if not _lib.is_device_array(w) else w)
+    kw, pw, Nf = conv(_host_vec(w) if not _lib.is_device_array(w) else w)
     nb = 2 * Nv if coulomb else Nv
     Phi = np.zeros((N, 2 * Nf * nb), order="F", dtype=np.float32 if f32 else np.float64)
     fn = lib().lpvs_lpv_regressor_f32 if f32 else lib().lpvs_lpv_regressor_f64
@@ -162,6 +178,55 @@ def _host_qr_ridge(A, y, lam):
     return np.linalg.lstsq(np.vstack([A, lam * np.eye(n)]), np.concatenate([np.asarray(y, dtype=np.float64), np.zeros(n)]), rcond=None)[0]
 
 
+# --------------------------------------------------------------------------- options (include/lpvspectral.h LPVS_OPT_*)
+def set_default_option(name, value=None):
+    """Thread-local default for handles created / batched-window calls made afterwards: ``set_default_option("storage", "f64")``;
+    ``None`` returns to the library's own choice (which the environment variable of the same name may override)."""
+    oid, vid = _lib.option_ids(name, value)
+    check(lib().lpvs_set_default_option(oid, vid))
+
+
+def get_default_option(name):
+    oid, vals = _lib.OPTIONS[name]
+    v = C.c_int32(0)
+    check(lib().lpvs_get_default_option(oid, C.byref(v)))
+    return {i: k for k, i in vals.items()}.get(int(v.value))
+
+
+class default_options:
+    """``with default_options(storage="f64", iteration="two"): ...`` -- the defaults inside the block, the previous ones after it."""
+
+    def __init__(self, **opts):
+        self.opts = {k: v for k, v in opts.items() if v is not None}
+
+    def __enter__(self):
+        self.prev = {k: get_default_option(k) for k in self.opts}
+        for k, v in self.opts.items():
+            set_default_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_default_option(k, v)
+
+
+def _with_options(fn):
+    """Estimator / driver decorator: option keywords apply, as thread defaults, to everything the call creates."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with default_options(**_pop_options(kwargs)):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+def _pop_options(kwargs):
+    """The option keywords of an estimator call (``storage=``, ``iteration=``, ``gram_form=``, ``nt_loads=``, ``slot_sums=``:
+    extensions, the reference has none of them) taken out of ``kwargs``."""
+    return {k: kwargs.pop(k) for k in list(kwargs) if k in _lib.OPTIONS}
+
+
 # --------------------------------------------------------------------------- device problem handle
 class Problem:
     """Owner of one ``lpvs_problem`` handle (regressor + Gram resident on one MI355X)."""
@@ -179,7 +244,10 @@ class Problem:
     # constructors -----------------------------------------------------------------------
     @classmethod
     def fourier(cls, y, t, f, W=None, device=0):
-        f32 = is_f32(y)
+        # eltype as the reference promotes it: the 3-argument method evaluates the regressor in T = eltype(y) (``T.(t), T.(f)``,
+        # src/lasso.jl:91); the weighted 4-argument method in the eltype of t and f themselves (src/lasso.jl:111 -> src/lsfft.jl:26),
+        # so a Float32 record with Float64 time stamps is a Float64 problem there -- t is never rounded to 24 bits
+        f32 = is_f32(y) if W is None else _all_f32(y, t, f)
         conv = as_f32 if f32 else as_f64
         ky, py, N = conv(y)
         kt, pt, Nt = conv(t)
@@ -196,7 +264,9 @@ class Problem:
 
     @classmethod
     def lpv(cls, y, X, V, w, Nv, normalize=True, coulomb=False, device=0):
-        f32 = is_f32(y)                                  # Y::AbstractVector{S}, src/lasso.jl:27
+        # Y, X, V::AbstractVector{S} (src/lasso.jl:27); the phases w .* X are formed in the promoted type of w and X (:39), so the
+        # Float32 entry points serve only an all-Float32 call -- anything else is widened exactly and runs as a Float64 problem
+        f32 = _all_f32(y, X, V, w)
         conv = as_f32 if f32 else as_f64
         ky, py, N = conv(y)
         kx, px, Nx = conv(X)
@@ -213,7 +283,7 @@ class Problem:
     @classmethod
     def lpv_multi(cls, Y, X, V, w, Nv, normalize=True, coulomb=False, device=0):
         """``Y`` is N x ns (one column per signal / channel) sharing ``X, V, w``: one Gram, ns right-hand sides."""
-        if is_f32(Y) and not _lib.is_device_array(Y):            # Float32 records: the _f32 entry point (float I/O, double arithmetic)
+        if _all_f32(Y, X, V, w) and not _lib.is_device_array(Y):   # an all-Float32 call: the _f32 entry point (float I/O, double arithmetic)
             Yh = np.asfortranarray(np.asarray(Y, dtype=np.float32))
             N, ns = Yh.shape
             kx, px, Nx = as_f32(np.asarray(X, dtype=np.float32))
@@ -250,7 +320,7 @@ class Problem:
         """Partial problem over a ROW SHARD ``(y, X, V)`` of one signal: ``ranges`` =
         ``[min V, max V, max|V|, max|X|]`` over ALL rows.  Its Gram / rhs are partial sums; exchange them with
         :meth:`device_gram` + an all-reduce, then :meth:`gram_modified`."""
-        f32 = is_f32(y) and not _lib.is_device_array(y)       # Float32 record: the _f32 entry point
+        f32 = _all_f32(y, X, V, w) and not _lib.is_device_array(y)       # an all-Float32 call: the _f32 entry point
         conv = as_f32 if f32 else as_f64
         ky, py, N = conv(np.asarray(y, dtype=np.float32) if f32 else y)
         kx, px, Nx = conv(np.asarray(X, dtype=np.float32) if f32 else X)
@@ -306,6 +376,20 @@ class Problem:
 
     def __exit__(self, *exc):
         self.close()
+
+    # options --------------------------------------------------------------------------------
+    def set_option(self, name, value=None):
+        """``storage`` = "mixed" | "split" | "f64", ``iteration`` = "one" | "two", ``nt_loads`` = "on" | "off" (``None``: default);
+        takes effect at the next :meth:`admm_init` / :meth:`admm_run`."""
+        oid, vid = _lib.option_ids(name, value)
+        check(lib().lpvs_problem_set_option(self._h, oid, vid))
+
+    def get_option(self, name):
+        """The value in effect for this handle (explicit, thread default or environment), ``None`` = the library's own choice."""
+        oid, vals = _lib.OPTIONS[name]
+        v = C.c_int32(0)
+        check(lib().lpvs_problem_get_option(self._h, oid, C.byref(v)))
+        return {i: k for k, i in vals.items()}.get(int(v.value))
 
     # accessors ------------------------------------------------------------------------------
     def get_gram(self):
@@ -503,7 +587,7 @@ def ls_spectral(y, t, f=None, W=None, λ=1e-10, verbose=False, device=0):
     frequency grid on an even-length record has one more column than rows) -- identical minimiser, no SVD."""
     f = default_freqs(t) if f is None else f
     if W is None:
-        f32 = is_f32(y)
+        f32 = _all_f32(y, t, f)                                      # get_fourier_regressor(t, f) in their own eltype, src/lsfft.jl:63
         conv = as_f32 if f32 else as_f64
         ky, py, N = conv(y)
         kt, pt, Nt = conv(t)
@@ -558,7 +642,7 @@ def ls_sparse_spectral(y, t, f=None, W=None, init=False, λ=1.0, proxg=None, dev
     (src/lasso.jl:119-121), i.e. the linear term enters with the opposite sign of least squares."""
     f = default_freqs(t) if f is None else f
     proxg = NormL1(λ) if proxg is None else proxg
-    with Problem.fourier(y, t, f, W, device=device) as prob:
+    with default_options(**_pop_options(kwargs)), Problem.fourier(y, t, f, W, device=device) as prob:
         x0 = None
         if init:  # fourier_solve(A,y,zerofreq,λ), src/lasso.jl:92,112 -- UNWEIGHTED in both methods (:112 ignores W)
             zf = check_freq(f)
@@ -583,10 +667,10 @@ def ls_sparse_spectral_lpv(y, X, V, w, Nv, λ=1, coulomb=False, normalize=True, 
     if coulomb:
         raise NotImplementedError("coulomb=true is ill-defined in the reference's sparse LPV path "
                                   "(half of x is never written by prox!, SURVEY.md §2 ‡); use ls_spectral_lpv")
-    w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
+    w = _host_vec(w) if not _lib.is_device_array(w) else w
     Nf = len(w)
     Nv = int(Nv)
-    with Problem.lpv(y, X, V, w, Nv, normalize, False, device=device) as prob:
+    with default_options(**_pop_options(kwargs)), Problem.lpv(y, X, V, w, Nv, normalize, False, device=device) as prob:
         g = SlicedSeparableSum.frequency_groups(λ, Nf, 2 * Nv) if proxg is None else proxg
         try:
             _admm_on_problem(prob, None, g, _lib.LINEAR_LEAST_SQUARES, **kwargs)
@@ -614,7 +698,7 @@ def ls_sparse_spectral_lpv_rowsharded(y, X, V, w, Nv, λ=1, normalize=True, devi
     (src/lasso.jl:136-171) then runs replicated, so every rank returns the same :class:`SpectralExt` as
     :func:`ls_sparse_spectral_lpv` on the whole signal (up to the summation order of the Gram)."""
     from . import sharding
-    w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
+    w = _host_vec(w) if not _lib.is_device_array(w) else w
     Nf, Nv = len(w), int(Nv)
     ranges = sharding.allreduce_ranges(lpv_ranges(X, V), dist)
     with Problem.lpv_rows(y, X, V, w, Nv, ranges, normalize, False, device=device) as prob:
@@ -633,9 +717,9 @@ def ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, λ=1, normalize=True, device=0,
     of ``Y`` (N x ns) are independent signals sharing ``X, V, w``.  One Gram / factorisation, every ADMM kernel
     advances all signals; each signal stops at its own ``‖x−z‖₂ < tol``.  Returns a list of :class:`SpectralExt`
     whose entries equal the single-signal results."""
-    w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
+    w = _host_vec(w) if not _lib.is_device_array(w) else w
     Nf, Nv = len(w), int(Nv)
-    with Problem.lpv_multi(Y, X, V, w, Nv, normalize, False, device=device) as prob:
+    with default_options(**_pop_options(kwargs)), Problem.lpv_multi(Y, X, V, w, Nv, normalize, False, device=device) as prob:
         g = SlicedSeparableSum.frequency_groups(λ, Nf, 2 * Nv) if proxg is None else proxg
         _admm_on_problem(prob, None, g, _lib.LINEAR_LEAST_SQUARES, **kwargs)
         P = prob.params(0)
@@ -654,7 +738,7 @@ def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, devi
     The residual statistics come from the same Gram, with the constant signal as a second right-hand side:
     ``‖e‖² = x'Gx − 2b'x + Y'Y``, ``Σe = (Φ'1)'x − ΣY`` ⇒ ``var(e)``; ``Σ = var(e)·(AA'AA + λI)⁻¹`` (:252-254, λ not
     squared, as written) in the reference's ``[re; im]`` parameter order; the fva warning of :255-256 is issued."""
-    w = np.ravel(_host(w)) if not _lib.is_device_array(w) else w
+    w = _host_vec(w) if not _lib.is_device_array(w) else w
     Nv = int(Nv)
     Yh = _host(Y)
     def ridge(prob):
@@ -766,12 +850,15 @@ def _engine_args(estimator, kwargs, nreg):
 def windows_estimate(Y, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None, device=0):
     """The batched-window engine (``lpvs_windows_estimate_f64``): ``Y`` is a list of signals sharing ``t``; returns
     ``x[ns][nwin][Nf]`` complex and the iteration counts ``[ns][nwin]``."""
-    if all(is_f32(y) and not _lib.is_device_array(y) for y in Y):      # Float32 records: lpvs_windows_estimate_f32
+    # Float32 entry points only when y, t and freqs are ALL Float32: the window drivers call the 4-argument estimator, whose regressor
+    # is evaluated in the eltype of t and freqs (src/lsfft.jl:121 -> src/lasso.jl:111); Float32 y with Float64 t stays exact in t
+    if all(is_f32(y) and not _lib.is_device_array(y) for y in Y) and _all_f32(t, freqs):      # lpvs_windows_estimate_f32
         keep = np.ascontiguousarray(np.stack([np.asarray(y, dtype=np.float32) for y in Y]))
         ns, Ly = keep.shape
         th = np.ascontiguousarray(np.asarray(_host(t), dtype=np.float32)); fh = np.ascontiguousarray(np.asarray(_host(freqs), dtype=np.float32))
         Wh = None if W is None else np.ascontiguousarray(np.asarray(_host(W), dtype=np.float32))
         assert Ly == len(th), "y and t has to be the same length"
+        assert Wh is None or len(Wh) == n, "W must have one weight per window sample"
         k = C.c_int64(0)
         check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
         win_hi = int(k.value) if win_hi is None else int(win_hi)
@@ -818,7 +905,7 @@ def windows_estimate_multi(Y, t, freqs, n, noverlap, W, eng, ngpus=0, devices=No
     """``lpvs_windows_estimate_multi_f64``: ALL windows, split into contiguous ranges over ``ngpus`` devices driven by
     this one process (a host thread per device), the coefficients gathered by one RCCL all-gather.  Same return value as
     :func:`windows_estimate` over the full window range."""
-    f32 = all(is_f32(y) and not _lib.is_device_array(y) for y in Y)      # Float32 records: lpvs_windows_estimate_multi_f32
+    f32 = all(is_f32(y) and not _lib.is_device_array(y) for y in Y) and _all_f32(t, freqs)      # all-Float32 call: lpvs_windows_estimate_multi_f32
     dt = np.float32 if f32 else np.float64
     Ys = [np.ascontiguousarray(np.asarray(_host(y), dtype=dt)) for y in Y]
     ns, Ly = len(Ys), len(Ys[0])
@@ -827,6 +914,7 @@ def windows_estimate_multi(Y, t, freqs, n, noverlap, W, eng, ngpus=0, devices=No
     th = np.ascontiguousarray(np.asarray(_host(t), dtype=dt)); fh = np.ascontiguousarray(np.asarray(_host(freqs), dtype=dt))
     Wh = None if W is None else np.ascontiguousarray(np.asarray(_host(W), dtype=dt))
     assert Ly == len(th), "y and t has to be the same length"
+    assert Wh is None or len(Wh) == n, "W must have one weight per window sample"
     k = C.c_int64(0)
     check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
     k, Nf = int(k.value), len(fh)
@@ -846,7 +934,8 @@ def windows_estimate_multi(Y, t, freqs, n, noverlap, W, eng, ngpus=0, devices=No
 def windowcsd_batched(y, u, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None, device=0):
     """``lpvs_windowcsd_f64``: the accumulators ``(Syu, Syy, Suu)`` over the windows ``[win_lo, win_hi)`` in window order
     (one Gram / factorisation per window, two right-hand sides), plus the per-window ``xy, xu``."""
-    f32 = is_f32(y) and is_f32(u) and not _lib.is_device_array(y) and not _lib.is_device_array(u)   # Float32 records: lpvs_windowcsd_f32
+    f32 = (is_f32(y) and is_f32(u) and not _lib.is_device_array(y) and not _lib.is_device_array(u)
+           and _all_f32(t, freqs))                             # all-Float32 call: lpvs_windowcsd_f32 (see windows_estimate)
     dt = np.float32 if f32 else np.float64
     conv = (lambda a: as_f32(None if a is None else np.asarray(_host(a), dtype=np.float32))) if f32 else as_f64
     ky, py, Ly = conv(y)
@@ -871,6 +960,7 @@ def windowcsd_batched(y, u, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None
     return sre + 1j * sim, syy, suu, x[0], x[1]
 
 
+@_with_options
 def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimator=None, batched=True, **kwargs):
     """``ls_windowpsd(y,t,freqs; nw, noverlap, window_func, estimator=ls_spectral, kwargs...)``
     (src/lsfft.jl:112-126) -> ``(S, freqs)``.  ``estimator`` is any callable ``(y,t,f,W; kw...) -> (x, f)``
@@ -903,6 +993,7 @@ def ls_windowpsd(y, t, freqs=None, nw=8, noverlap=-1, window_func=rect, estimato
     return S / k ** 2, freqs                                        # :125
 
 
+@_with_options
 def ls_windowcsd(y, u, t, freqs=None, nw=10, noverlap=-1, window_func=rect, estimator=None, batched=True, **kwargs):
     """``ls_windowcsd(y,u,t,freqs; nw, noverlap, window_func, estimator=ls_spectral)`` (src/lsfft.jl:140-156):
     cross spectral density, ``S += xy .* conj(xu)`` over the windows, returned as ``S/nw`` (the recomputed window count).
@@ -934,6 +1025,7 @@ def ls_windowcsd(y, u, t, freqs=None, nw=10, noverlap=-1, window_func=rect, esti
     return S / k, freqs
 
 
+@_with_options
 def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, batched=True, **kwargs):
     """``ls_cohere(y,u,t,freqs; nw, noverlap, estimator=ls_spectral)`` (src/lsfft.jl:176-193): magnitude-squared
     coherence over Hann-weighted windows (``Windows3(y,t,u,n,noverlap,hanning)``, :182)."""
@@ -966,6 +1058,7 @@ def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, batched=T
     return abs2(Syu) / (Suu * Syy), freqs
 
 
+@_with_options
 def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, **kwargs):
     """src/lsfft.jl:267-277."""
     w = np.ravel(_host(w))

@@ -2198,9 +2198,9 @@ int32_t launch_pack_tiles_batch(const double *M, int64_t np, int nbatch, double 
 bool fused_ok(const AdmmParams &p);
 
 static void launch_mixed_batch(const AdmmBatch &p, unsigned ntiles, unsigned ns, double *part1, double *part2, const AdmmStatus *status, hipStream_t s) {
-    // non-temporal loads once the inverses of the batch no longer fit the Infinity Cache (LPVS_NT_LOADS=0 / 1 forces either)
-    const char *e = getenv("LPVS_NT_LOADS");
-    const bool nt = e ? e[0] == '1' : (size_t)ntiles * kSplitTileBytes * ns > ((size_t)240 << 20);
+    // non-temporal loads once the inverses of the batch no longer fit the Infinity Cache (LPVS_OPT_NT_LOADS forces either)
+    const int nto = option_in_effect(LPVS_OPT_NT_LOADS, p.opt_nt_loads);
+    const bool nt = nto ? nto == LPVS_NT_ON : (size_t)ntiles * kSplitTileBytes * ns > ((size_t)240 << 20);
     if (nt)
         hipLaunchKernelGGL(symv_tile_mixed_batch_kernel<true>, dim3(ntiles, ns), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types,
                            (size_t)ntiles * kSplitTileBytes, p.rhs, p.np, (int)ntiles, part1, part2, status);
@@ -2217,12 +2217,12 @@ static AdmmParams batch_as_params(const AdmmBatch &p) {   // AdmmParams with ns 
     AdmmParams q{p.M, p.np, p.n, p.b, p.x, p.z, p.u, p.rhs, p.mu, p.tol, p.prox_kind, p.prox_param, p.group_len, p.status,
                  nullptr, p.part, p.Mp, p.nbatch};
     q.xb = p.xb; q.mp_split = p.mp_split; q.mp_types = p.mp_types; q.fi = p.fi; q.fi_base = p.fi_base; q.fi_prefetch_all = p.fi_prefetch_all;
+    q.opt_iteration = p.opt_iteration; q.opt_nt_loads = p.opt_nt_loads;
     return q;
 }
 bool fi_batch_applicable(const AdmmBatch &p) {
-    const char *env = getenv("LPVS_ITERATION");
     const AdmmParams q = batch_as_params(p);
-    return !(env && std::string(env) == "two") && p.fi != nullptr && p.nrhs <= 1 && p.mp_split && p.mp_types != nullptr && p.xb != nullptr && p.part != nullptr &&
+    return option_in_effect(LPVS_OPT_ITERATION, p.opt_iteration) != LPVS_ITERATION_TWO && p.fi != nullptr && p.nrhs <= 1 && p.mp_split && p.mp_types != nullptr && p.xb != nullptr && p.part != nullptr &&
            p.Mp != nullptr && fused_ok(q) && p.np <= 8192 && (int64_t)p.nbatch * p.np * 8 < ((int64_t)1 << 40);
 }
 int32_t launch_fi_batch_setup(const AdmmBatch &p, hipStream_t s) { return launch_fi_setup(batch_as_params(p), 0, true, s); }
@@ -2643,10 +2643,17 @@ __host__ __device__ __forceinline__ FiBufs fi_views(double *fi, int64_t np /* al
     f.qbuf = reinterpret_cast<double *>(f.rec + 2 * nblk); f.consts = f.qbuf + 2 * nprob;
     return f;
 }
+// Worst relative excess of a row sum of |M~| (the packed copy the product streams) over the same row sum of |M|:
+//   single-precision copy (_f32 handles): 2^-24 per element;  float head + 16-bit tail: 2^-40 per element;
+//   36-bit fixed point: <= step/2 per element with step <= 2^-44 max|M| sqrt(8192/np) (pack_tiles_mixed_kernel's admission), so
+//   <= np * step/2 = 2^-45 sqrt(8192 np) max|M| <= 2^-30 max|M| <= 2^-30 R for np <= 49152 (fi_applicable); the clamp to +-(2^35 - 1)
+//   only shrinks.  The bound multiplies two row sums, so (1 + slack)^2 must stay under the 1.000001 the kernel uses.
+constexpr double kFiPackedRowSlack = 0x1p-24 + 0x1p-30;
+static_assert((1.0 + kFiPackedRowSlack) * (1.0 + kFiPackedRowSlack) * (1.0 + 0x1p-40) < 1.000001,
+              "the quantum bound of admm_iter_mixed_kernel no longer covers the rounding of the packed inverse: raise its 1.000001");
 size_t fi_doubles(int64_t np, int64_t nprob) { return (size_t)((4 * np + 6 * (np / TS) + 4) * nprob + 2); }
 bool fi_applicable(const AdmmParams &p) {
-    const char *env = getenv("LPVS_ITERATION");      // (read per call: tests and tools switch it between handles)
-    const bool on = !(env && std::string(env) == "two");
+    const bool on = option_in_effect(LPVS_OPT_ITERATION, p.opt_iteration) != LPVS_ITERATION_TWO;   // (resolved per call: tests and tools switch it between handles)
     return on && p.fi != nullptr && p.ns == 1 && (p.mp_types != nullptr || p.mp_f32) && p.xb != nullptr && p.part != nullptr && p.Mp != nullptr && fused_ok(p) &&
            p.np <= 49152;                            // (six clamped loads per lane cover the block norms / maxima of 384 row blocks)
 }
@@ -2675,8 +2682,11 @@ fi_state_kernel(AdmmParams p, int nblk, long long base, int with_consts) {
     const int64_t voff = (int64_t)sg * p.np;
     __shared__ double sh[3][4];
     double mx = 0, mr = 0, mu_ = 0;
+    int bad = 0;
     for (int64_t e = threadIdx.x; e < p.np; e += 256) {
-        mx = fmax(mx, fabs(p.xb[voff + e])); mr = fmax(mr, fabs(p.rhs[voff + e])); mu_ = fmax(mu_, fabs(p.u[voff + e]));
+        const double a = p.xb[voff + e], b = p.rhs[voff + e], c = p.u[voff + e];
+        mx = fmax(mx, fabs(a)); mr = fmax(mr, fabs(b)); mu_ = fmax(mu_, fabs(c));
+        bad |= !(fabs(b) < 0x1p1000) || !(fabs(c) < 0x1p1000);        // NaN or Inf
     }
     mx = wave_max(mx); mr = wave_max(mr); mu_ = wave_max(mu_);
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = mx; sh[1][threadIdx.x >> 6] = mr; sh[2][threadIdx.x >> 6] = mu_; }
@@ -2684,6 +2694,9 @@ fi_state_kernel(AdmmParams p, int nblk, long long base, int with_consts) {
     mx = fmax(fmax(sh[0][0], sh[0][1]), fmax(sh[0][2], sh[0][3]));
     mr = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
     mu_ = fmax(fmax(sh[2][0], sh[2][1]), fmax(sh[2][2], sh[2][3]));
+    // (fmax drops NaNs: a NaN in the state handed over -- x0, a restored u -- is marked by an infinite maximum instead, which the
+    // iteration kernel's bound turns into NaN iterates; see there)
+    if (__syncthreads_or(bad)) { mr = __longlong_as_double(0x7ff0000000000000ll); mu_ = mr; }
     const int p1 = (int)((base + 1) & 1), p2 = (int)(base & 1);      // parities of base - 1 and base - 2
     const int nbt = nprob * nblk, boff = sg * nblk;
     for (int b = threadIdx.x; b < nblk; b += 256) {
@@ -2891,7 +2904,10 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
                 if (MODE == FI_LAST) p.rhs[voff + e] = rhs_v;
             }
             const double d2 = own && ok ? d * d : 0.0;
-            const double w0 = wave_sum(d2), w1 = wave_max(own ? fabs(rhs_v) : 0.0), w2 = wave_max(own ? fabs(un) : 0.0);
+            // (a NaN would drop out of fmax: it is recorded as an infinite maximum, which makes the next bound infinite and the iterates NaN)
+            const double inf_ = __longlong_as_double(0x7ff0000000000000ll);
+            const double ar = fabs(rhs_v) < inf_ ? fabs(rhs_v) : inf_, au = fabs(un) < inf_ ? fabs(un) : inf_;
+            const double w0 = wave_sum(d2), w1 = wave_max(own ? ar : 0.0), w2 = wave_max(own ? au : 0.0);
             if (lane == 0) { red[0][wave] = w0; red[1][wave] = w1; red[2][wave] = w2; }
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -2905,11 +2921,17 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     if (threadIdx.x < TS) sI[i] = rhs_v; else sJ[i] = rhs_v;
     // ---- this launch's quantum (identical in every workgroup)
     mR = wave_max_nonneg(mR); mU = wave_max_nonneg(mU);
+    // The factor 1.000001: Rrow is the largest absolute row sum of the FULL-PRECISION inverse (fi_rowsum_kernel), the product streams
+    // its packed copy M~, whose row sums may exceed it by kFiPackedRowSlack (relative) -- see the static_assert at its definition.
     double B = Rrow * ((xbmax + Rrow * mR + mU) / p.mu) * 1.000001;
+    // An infinite bound (an overflowed iterate, or fi_state_kernel's marker for a non-finite entry in the state it was given) has no
+    // quantum: NaN then, which the next prologue's x = xb + acc * quantum spreads over every element -- as the two-launch iteration
+    // and the reference's own arithmetic would (a NaN partial converted to an integer would otherwise silently vanish from x).
+    const bool bound_ok = B < 0x1p1000;
     if (!(B > 0x1p-900)) B = 0x1p-900;
     int eb = 0;
-    (void)frexp(B, &eb);                                               // B < 2^eb
-    const double quantum = ldexp(1.0, eb - 62), invq = ldexp(1.0, 62 - eb);
+    (void)frexp(bound_ok ? B : 1.0, &eb);                              // B < 2^eb
+    const double quantum = bound_ok ? ldexp(1.0, eb - 62) : __longlong_as_double(0x7ff8000000000000ll), invq = bound_ok ? ldexp(1.0, 62 - eb) : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) f.qbuf[pg * nprob + sg] = quantum;
     __syncthreads();
     // ---- tile product
@@ -3097,8 +3119,8 @@ static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, s
     LPVS_HIP(hipMemsetAsync(f.acc(0), 0, sizeof(long long) * (size_t)p.np * (size_t)nprob, s));
     const long long base = p.fi_base;
     const bool small = nblk <= 64;                    // one load per lane covers the block norms / maxima
-    const char *nte = getenv("LPVS_NT_LOADS");
-    const bool nt = batch && (nte ? nte[0] == '1' : (size_t)ntiles * kSplitTileBytes * (size_t)nprob > ((size_t)240 << 20));
+    const int nto = option_in_effect(LPVS_OPT_NT_LOADS, p.opt_nt_loads);
+    const bool nt = batch && (nto ? nto == LPVS_NT_ON : (size_t)ntiles * kSplitTileBytes * (size_t)nprob > ((size_t)240 << 20));
     auto launch = [&](int mode, unsigned grid, long long g, int aslot, int uslot, int commit_prev) {
         hipLaunchKernelGGL(fi_kernel(mode, small, batch, nt, prefetch_all, p.mp_f32 != 0), dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
                            commit_prev, mp_stride, prefetch_all ? 1 : 0);

@@ -23,6 +23,39 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- options -----------------------------------------------------------------------------------------------------------
+static thread_local int g_opt[kOptCount] = {0, 0, 0, 0, 0, 0};
+static int option_from_env(int option) {
+    auto is = [](const char *e, const char *v) { return e != nullptr && std::strcmp(e, v) == 0; };
+    switch (option) {
+    case LPVS_OPT_M_STORAGE: { const char *e = getenv("LPVS_M_STORAGE");
+        return is(e, "mixed") ? LPVS_STORAGE_MIXED : is(e, "split") ? LPVS_STORAGE_SPLIT : is(e, "f64") ? LPVS_STORAGE_F64 : 0; }
+    case LPVS_OPT_ITERATION: { const char *e = getenv("LPVS_ITERATION"); return is(e, "two") ? LPVS_ITERATION_TWO : is(e, "one") ? LPVS_ITERATION_ONE : 0; }
+    case LPVS_OPT_GRAM_FORM: { const char *e = getenv("LPVS_GRAM_FORM"); return is(e, "ap") ? LPVS_GRAM_AP : is(e, "krs") ? LPVS_GRAM_KRS : is(e, "kr") ? LPVS_GRAM_KR : 0; }
+    case LPVS_OPT_NT_LOADS: { const char *e = getenv("LPVS_NT_LOADS"); return e == nullptr ? 0 : (e[0] == '1' ? LPVS_NT_ON : LPVS_NT_OFF); }
+    case LPVS_OPT_SLOT_SUMS: { const char *e = getenv("LPVS_NUDFT"); return is(e, "direct") ? LPVS_SLOTS_DIRECT : is(e, "nufft") ? LPVS_SLOTS_NUFFT : 0; }
+    }
+    return 0;
+}
+int option_in_effect(int option, int explicit_value) {
+    if (option <= 0 || option >= kOptCount) return 0;
+    if (explicit_value != 0) return explicit_value;
+    if (g_opt[option] != 0) return g_opt[option];
+    return option_from_env(option);          // (read per call: tests and tools switch it between handles)
+}
+void capture_default_options(int *opt) { for (int i = 0; i < kOptCount; ++i) opt[i] = g_opt[i]; }
+static bool option_value_ok(int option, int value) {
+    if (value == 0) return true;
+    switch (option) {
+    case LPVS_OPT_M_STORAGE: return value >= LPVS_STORAGE_MIXED && value <= LPVS_STORAGE_F64;
+    case LPVS_OPT_ITERATION: return value == LPVS_ITERATION_ONE || value == LPVS_ITERATION_TWO;
+    case LPVS_OPT_GRAM_FORM: return value >= LPVS_GRAM_AP && value <= LPVS_GRAM_KR;
+    case LPVS_OPT_NT_LOADS: return value == LPVS_NT_OFF || value == LPVS_NT_ON;
+    case LPVS_OPT_SLOT_SUMS: return value == LPVS_SLOTS_NUFFT || value == LPVS_SLOTS_DIRECT;
+    }
+    return false;
+}
+
 // ---- caching device allocator -----------------------------------------------------------------------------
 // Work buffers of a solve are tens of GiB (trig table, slabs, panels); hipMalloc/hipFree of that size costs
 // milliseconds to seconds and synchronises the device.  Freed blocks are kept per device and handed out
@@ -270,6 +303,7 @@ struct lpvs_problem {
     EventPair ev[4];          // copies of the bundle's events (owned by `res`)
     StreamBundle *res = nullptr;   // stream, events and the factorisation's side stream, borrowed from the cache
     bool f32 = false;     // created through an _f32 entry point: the ADMM mat-vec streams a single-precision copy of M
+    int opt[kOptCount] = {0, 0, 0, 0, 0, 0};   // LPVS_OPT_*: explicit values of this handle (the creating thread's defaults at creation, then set_option)
     // launch-bound regime (small n): a chunk of ADMM iterations captured once into a hipGraph and replayed
     hipGraphExec_t admm_graph = nullptr;
     int64_t admm_graph_iters = 0;
@@ -300,6 +334,7 @@ int32_t problem_begin(int32_t device, lpvs_problem **out, lpvs_problem **hp) {
     if (!h->res) { delete h; set_error("stream / event creation failed"); return LPVS_EDEVICE; }
     h->stream = h->res->stream;
     for (int i = 0; i < 4; ++i) h->ev[i] = h->res->ev[i];
+    capture_default_options(h->opt);
     *hp = h;
     return LPVS_OK;
 }
@@ -339,10 +374,10 @@ enum { kMpNone = 0, kMpF64 = 1, kMpF32 = 2, kMpSplit = 3, kMpMixed = 4 };
 int mp_mode_for(const lpvs_problem *h) {
     if (h->np < kSymmetricMinNp) return kMpNone;
     if (h->f32) return kMpF32;
-    const char *e = getenv("LPVS_M_STORAGE");
-    if (e && std::string(e) == "f64") return kMpF64;
+    const int st = option_in_effect(LPVS_OPT_M_STORAGE, h->opt[LPVS_OPT_M_STORAGE]);
+    if (st == LPVS_STORAGE_F64) return kMpF64;
     if (h->ns > 1 && h->np > 49152) return kMpF64;   // the streaming multi-signal kernel addresses its partials with 31-bit byte offsets
-    if (h->ns > 1 || (e && std::string(e) == "split")) return kMpSplit;
+    if (h->ns > 1 || st == LPVS_STORAGE_SPLIT) return kMpSplit;
     return kMpMixed;
 }
 
@@ -358,6 +393,7 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.fi = sym && h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && h->fi.p ? h->fi.as<double>() : nullptr;
     p.fi_R = h->fi_R; p.fi_xbmax = h->fi_xbmax;
     p.fi_prefetch_all = sym && h->Mp_mode == kMpMixed && h->Mp_fixed_tiles == (int64_t)(symv_packed_doubles(h->np) / (128 * 128)) ? 1 : 0;
+    p.opt_iteration = h->opt[LPVS_OPT_ITERATION]; p.opt_nt_loads = h->opt[LPVS_OPT_NT_LOADS];
     return p;
 }
 
@@ -453,6 +489,37 @@ int32_t lpvs_release_cached_memory(void) {
     std::vector<StreamBundle *> idle;
     { std::lock_guard<std::mutex> g(g_bundle_mu); idle.swap(g_bundles); }
     for (StreamBundle *b : idle) delete b;           // idle streams / events of destroyed handles
+    return LPVS_OK;
+}
+
+int32_t lpvs_set_default_option(int32_t option, int32_t value) {
+    if (option <= 0 || option >= kOptCount || !option_value_ok(option, value)) { set_error("unknown option %d or value %d", option, value); return LPVS_EARGUMENT; }
+    g_opt[option] = value;
+    return LPVS_OK;
+}
+int32_t lpvs_get_default_option(int32_t option, int32_t *value) {
+    if (option <= 0 || option >= kOptCount || !value) { set_error("unknown option %d or NULL argument", option); return LPVS_EARGUMENT; }
+    *value = g_opt[option];
+    return LPVS_OK;
+}
+int32_t lpvs_problem_set_option(lpvs_problem *h, int32_t option, int32_t value) {
+    if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
+    if (option <= 0 || option >= kOptCount || !option_value_ok(option, value)) { set_error("unknown option %d or value %d", option, value); return LPVS_EARGUMENT; }
+    if (option == LPVS_OPT_GRAM_FORM || option == LPVS_OPT_SLOT_SUMS) {
+        set_error("option %d is chosen when a handle is constructed: set it with lpvs_set_default_option before creating the handle", option);
+        return LPVS_ESTATE;
+    }
+    if (h->opt[option] != value) {
+        h->opt[option] = value;
+        if (option == LPVS_OPT_M_STORAGE) h->inited = false;   // the packed copy is rebuilt by the next lpvs_admm_init
+        h->drop_graph();
+    }
+    return LPVS_OK;
+}
+int32_t lpvs_problem_get_option(lpvs_problem *h, int32_t option, int32_t *value) {
+    if (!h || !value) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (option <= 0 || option >= kOptCount) { set_error("unknown option %d", option); return LPVS_EARGUMENT; }
+    *value = option_in_effect(option, h->opt[option]);
     return LPVS_OK;
 }
 
@@ -649,8 +716,8 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
     //   ap : w is an arithmetic progression up to rounding -> 3Nf-1 non-uniform Fourier sums per activation pair
     //        (nudft.hip); admitted when max|eps_f| * max|x| <= 1e-7 (second-order term <= 5e-15)
     //   krs / kr : dense MFMA contraction for arbitrary w (gram.hip)
-    const char *form_env = getenv("LPVS_GRAM_FORM");
-    const std::string form = form_env ? form_env : "auto";
+    const int form_opt = option_in_effect(LPVS_OPT_GRAM_FORM, h->opt[LPVS_OPT_GRAM_FORM]);
+    const std::string form = form_opt == LPVS_GRAM_AP ? "ap" : form_opt == LPVS_GRAM_KRS ? "krs" : form_opt == LPVS_GRAM_KR ? "kr" : "auto";
     bool use_ap = false;
     ApSlots sl;
     double xam = 0;                                  // max|X| (over all rows of the signal)
@@ -690,7 +757,7 @@ static int32_t create_lpv_impl(const double *y, int64_t ns, const double *X, con
         LPVS_HIP(hipEventRecord(h->ev[1].a, s));
         // merged slot layout: the slot sums are Fourier coefficients at the multiples of ONE step -> non-uniform FFT (nufft.hip);
         // LPVS_NUDFT=direct keeps the direct evaluation of nudft.hip
-        const bool nufft_on = [] { const char *e = getenv("LPVS_NUDFT"); return !(e && std::string(e) == "direct"); }();
+        const bool nufft_on = option_in_effect(LPVS_OPT_SLOT_SUMS, h->opt[LPVS_OPT_SLOT_SUMS]) != LPVS_SLOTS_DIRECT;
         bool nufft = nufft_on && sl.merged && nufft_applicable(N, nsl, P);
         const int nfg = nufft_grid_size(nsl);
         const double xam_ = xam;
@@ -847,8 +914,8 @@ int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_
     DevArg dt, df;
     LPVS_TRY(dt.set(t, N, s)); LPVS_TRY(df.set(f, Nf, s));
     // structured Gram when T(2pi)*f is an arithmetic progression (default_freqs and every grid of the reference's tests)
-    const char *form_env = getenv("LPVS_GRAM_FORM");
-    const std::string form = form_env ? form_env : "auto";
+    const int form_opt = option_in_effect(LPVS_OPT_GRAM_FORM, h->opt[LPVS_OPT_GRAM_FORM]);
+    const std::string form = form_opt == LPVS_GRAM_AP ? "ap" : form_opt == LPVS_GRAM_KRS ? "krs" : form_opt == LPVS_GRAM_KR ? "kr" : "auto";
     if (form == "auto" || form == "ap") {
         std::vector<double> hw;
         LPVS_TRY(fetch_host(hw, f, Nf));
@@ -1411,9 +1478,12 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     LPVS_TRY(dt.set(a.t, a.L, s)); LPVS_TRY(df.set(a.freqs, Nf, s));
     // structured Gram (nudft.hip) when T(2pi)*freqs is an arithmetic progression: no regressor panels at all
     ApSlots sl;
+    int jopt[kOptCount];                             // the caller's options: captured by the entry point, or this thread's own
+    if (a.opt_captured) for (int i = 0; i < kOptCount; ++i) jopt[i] = a.opt[i];
+    else capture_default_options(jopt);
     {
-        const char *form_env = getenv("LPVS_GRAM_FORM");
-        const std::string form = form_env ? form_env : "auto";
+        const int form_opt = option_in_effect(LPVS_OPT_GRAM_FORM, jopt[LPVS_OPT_GRAM_FORM]);
+        const std::string form = form_opt == LPVS_GRAM_AP ? "ap" : form_opt == LPVS_GRAM_KRS ? "krs" : form_opt == LPVS_GRAM_KR ? "kr" : "auto";
         if (form == "auto" || form == "ap") {
             std::vector<double> hw;
             LPVS_TRY(fetch_host(hw, a.freqs, Nf));
@@ -1458,7 +1528,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     const int64_t nprob_max = bw * ns;
     // slot sums by non-uniform FFT (nufft.hip) when one progression serves all slots; LPVS_NUDFT=direct keeps the direct sums
     const bool wnufft = ap && sl.merged && nufft_windows_applicable(n, sl.nsl) &&
-                        [] { const char *e = getenv("LPVS_NUDFT"); return !(e && std::string(e) == "direct"); }();
+                        option_in_effect(LPVS_OPT_SLOT_SUMS, jopt[LPVS_OPT_SLOT_SUMS]) != LPVS_SLOTS_DIRECT;
     const bool wnufft_rhs = wnufft && sl.s0 % 2 == 0 && sl.s0 / 2 + sl.nf8 <= sl.nsl;   // a + f D = mode s0/2 + f (residual delta/2 -> eps)
     const int nfg = wnufft ? nufft_grid_size(sl.nsl) : 0;
     const int64_t wcols = wnufft_rhs ? 1 + ns : 1;
@@ -1499,7 +1569,8 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     }
     const size_t vb = sizeof(double) * (size_t)np * (size_t)nprob_max;
     LPVS_TRY(bvec.alloc(vb)); LPVS_TRY(x.alloc(vb)); LPVS_TRY(z.alloc(vb)); LPVS_TRY(u.alloc(vb)); LPVS_TRY(rhs.alloc(vb));
-    const bool split_storage = sparse && [] { const char *e = getenv("LPVS_M_STORAGE"); return !(e && std::string(e) == "f64"); }();
+    const int storage_opt = option_in_effect(LPVS_OPT_M_STORAGE, jopt[LPVS_OPT_M_STORAGE]);
+    const bool split_storage = sparse && storage_opt != LPVS_STORAGE_F64;
     if (split_storage) LPVS_TRY(xb.alloc(vb));
     LPVS_TRY(istat.alloc(sizeof(int) * (size_t)bw));
     LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)bw));
@@ -1595,13 +1666,14 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         if (sparse) {
             AdmmBatch ab{M.as<double>(), np, nreg, nprob, bvec.as<double>(), x.as<double>(), z.as<double>(), u.as<double>(), rhs.as<double>(),
                          mu, tol, a.prox_kind, a.prox_param, a.group_len, status.as<AdmmStatus>(), part.as<double>(), Mp.as<double>(), (int)ns};
+            ab.opt_iteration = jopt[LPVS_OPT_ITERATION]; ab.opt_nt_loads = jopt[LPVS_OPT_NT_LOADS];
             // 6-byte storage of the packed inverses + offset form of the x-update, as for the single problems (admm.hip); only
             // where the tile-packed path runs at all (LPVS_M_STORAGE=f64: doubles)
             const bool split = split_storage && admm_batch_uses_tiles(ab);
             if (split) {
                 // mixed storage (36-bit fixed-point tiles where a window's inverse is small; the Fourier inverses are nearly diagonal):
                 // tile formats and the per-matrix max|M| live behind the 6-byte slots of the Mp buffer (sized for doubles)
-                const bool mixed = [] { const char *e = getenv("LPVS_M_STORAGE"); return !(e && std::string(e) == "split"); }();
+                const bool mixed = storage_opt != LPVS_STORAGE_SPLIT;
                 const size_t nt = symv_packed_doubles(np) / (128 * 128);
                 unsigned char *types = Mp.as<unsigned char>() + 6 * symv_packed_doubles(np) * (size_t)bw;
                 const size_t types_bytes = ((nt * (size_t)bw + 255) / 256) * 256;

@@ -7,6 +7,9 @@
 // coalesced along the fastest-varying output index.
 #include "lpvs_internal.h"
 
+#include <cstdlib>
+#include <string>
+
 namespace lpvs {
 
 namespace {
@@ -99,6 +102,11 @@ window_panel_kernel(const double *__restrict__ t, const int64_t *__restrict__ to
 
 // ---- a4: trig table T[n][f] = (cos(w_f x_n), -sin(w_f x_n)) --------------------------------
 // conj(exp(i w x)) of src/lasso.jl:39; the minus sign is exact, so T.y * K == -(sin * K).
+// EXACT (diagnostic, LPVS_PHASE=exact): the phase of the REAL product w_f x_n instead of its rounding fl(w_f x_n) -- the
+// rounded product's sincos corrected to first order by the product's exact error d = w x - fl(w x) (|d| <= ulp(w x)/2, the neglected
+// d^2/2 < 1e-19).  The reference rounds (src/lasso.jl:39, exp.(im .* w .* X)); the structured Gram (nudft.hip, nufft.hip) does not,
+// and this knob lets a test separate that half-ulp of phase from everything else the two Gram paths do differently.
+template <bool EXACT>
 __global__ void __launch_bounds__(256)
 trig_table_kernel(const double *__restrict__ X, int64_t N, const double *__restrict__ w, int64_t Nf,
                   double2 *__restrict__ T) {
@@ -108,6 +116,11 @@ trig_table_kernel(const double *__restrict__ X, int64_t N, const double *__restr
     const double phi = w[fn] * X[n];
     double s, c;
     sincos(phi, &s, &c);
+    if (EXACT) {
+        const double d = fma(w[fn], X[n], -phi);
+        const double c2 = fma(-d, s, c), s2 = fma(d, c, s);
+        c = c2; s = s2;
+    }
     T[idx] = make_double2(c, -s);
 }
 
@@ -256,7 +269,11 @@ int32_t launch_window_panels(const double *t, const int64_t *toff_dev, int nbatc
 int32_t launch_trig_table(const double *X, int64_t N, const double *w, int64_t Nf, double2 *T,
                           hipStream_t s) {
     if (N == 0 || Nf == 0) return LPVS_OK;
-    hipLaunchKernelGGL(trig_table_kernel, dim3((unsigned)ceil_div(N * Nf, 256)), dim3(256), 0, s, X, N, w, Nf, T);
+    const char *e = getenv("LPVS_PHASE");            // diagnostic (read per call): "exact" = phases of the unrounded products w x
+    if (e != nullptr && std::string(e) == "exact")
+        hipLaunchKernelGGL(trig_table_kernel<true>, dim3((unsigned)ceil_div(N * Nf, 256)), dim3(256), 0, s, X, N, w, Nf, T);
+    else
+        hipLaunchKernelGGL(trig_table_kernel<false>, dim3((unsigned)ceil_div(N * Nf, 256)), dim3(256), 0, s, X, N, w, Nf, T);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

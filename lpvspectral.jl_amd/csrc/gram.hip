@@ -613,8 +613,6 @@ int32_t launch_gram_krs(const GramPlan &pl, const double2 *T, int64_t Nf, const 
 
 bool gram_krs_fits(int64_t nb) {
     const int64_t P = nb * (nb + 1) / 2;
-    const char *e = getenv("LPVS_GRAM_FORM");   // development knob: "kr" forces the n x n lower-triangle form
-    if (e && e[0] == 'k' && e[1] == 'r' && e[2] == 0) return false;
     return nb >= 2 && gram_lds_bytes(2, 16, nb, P) <= kLdsBudget;
 }
 

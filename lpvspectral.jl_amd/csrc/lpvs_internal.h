@@ -28,6 +28,13 @@ void set_error(const char *fmt, ...);
         if (rc_ != LPVS_OK) return rc_; \
     } while (0)
 
+// ---- options (include/lpvspectral.h LPVS_OPT_*; api.hip) ------------------------------------------------------------
+// value in effect: the explicit value (a handle's, or a job's captured copy of its caller's defaults), else the calling thread's
+// default, else what the environment variable of the same name says, else 0 (the library's own choice)
+constexpr int kOptCount = 6;
+int option_in_effect(int option, int explicit_value = 0);
+void capture_default_options(int *opt /*[kOptCount]*/);   // the calling thread's defaults (for work handed to other threads)
+
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -207,6 +214,7 @@ struct AdmmParams {
     long long fi_base = 0;
     double fi_R = 0, fi_xbmax = 0;   // largest absolute row sum of M (x 1) and max|xb|: host copies of fi's constants (single problems)
     int fi_prefetch_all = 0;         // every tile is in the fixed format: diagonal tiles are requested up front too
+    int opt_iteration = 0, opt_nt_loads = 0;   // LPVS_OPT_ITERATION / LPVS_OPT_NT_LOADS of the handle (0: thread default / environment)
 };
 size_t fi_doubles(int64_t np, int64_t nprob = 1);
 bool fi_applicable(const AdmmParams &p);
@@ -248,6 +256,7 @@ struct AdmmBatch {
     double *fi = nullptr;
     long long fi_base = 0;
     int fi_prefetch_all = 0;
+    int opt_iteration = 0, opt_nt_loads = 0;   // LPVS_OPT_ITERATION / LPVS_OPT_NT_LOADS of the call (0: thread default / environment)
 };
 bool fi_batch_applicable(const AdmmBatch &p);
 int32_t launch_fi_batch_setup(const AdmmBatch &p, hipStream_t s);   // constants and the records of iteration 0 (after launch_admm_batch_init)
@@ -285,6 +294,8 @@ struct WinJob {
     int64_t win_lo, win_hi; int device;
     double t_absmax = -1.0;                       // max|t| over the WHOLE record when (t, L) is only a span of it (< 0: compute)
     bool f32_grid = false;                        // the frequency grid was widened from floats: snap it to the progression it was rounded from
+    int opt[kOptCount] = {0, 0, 0, 0, 0, 0};      // the caller's default options (captured on ITS thread: multi.hip runs the job on workers)
+    bool opt_captured = false;
 };
 // sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations): window order, signals innermost
 typedef std::function<void(int64_t, int64_t, const double *, const double *, int64_t)> WinSink;

@@ -101,6 +101,9 @@ static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double 
     if (!Y || !t || !freqs || ns < 1 || Nf < 1) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    // the calling thread's current device is the caller's business (PyTorch, AMDGPU.jl): whatever this call selects, it puts back
+    struct DeviceRestore { int dev = -1; DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
+                           ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore_device;
     if (ngpus <= 0) ngpus = count;                               // all visible devices
     if (ngpus > count && devices == nullptr) { set_error("ngpus = %d but %d device(s) visible", ngpus, count); return LPVS_EDEVICE; }
     std::vector<int> devs((size_t)ngpus);
@@ -147,6 +150,8 @@ static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double 
         S.hi = S.lo + base + (r < rem ? 1 : 0);
         S.host.assign(slot, 0.0);
     }
+    int copt[kOptCount];
+    capture_default_options(copt);                               // the caller's default options travel to the worker threads with the job
     auto work = [&](int r) {
         Shard &S = sh[(size_t)r];
         if (hipSetDevice(S.device) != hipSuccess) { (void)hipGetLastError(); S.rc = LPVS_EDEVICE; S.err = "hipSetDevice failed"; return; }
@@ -154,6 +159,8 @@ static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double 
                    S.lo, S.hi, S.device};
         job.t_absmax = tam;
         job.f32_grid = f32_grid;
+        for (int i = 0; i < kOptCount; ++i) job.opt[i] = copt[i];
+        job.opt_captured = true;
         double *img = S.host.data();
         S.rc = windows_engine_run(job, [&](int64_t w, int64_t sg, const double *re, const double *im, int64_t its) {
             double *e = img + ((size_t)w * (size_t)ns + (size_t)sg) * (size_t)(2 * Nf + 1);
@@ -190,12 +197,15 @@ static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double 
         std::vector<void *> *comms = nullptr;
         LPVS_TRY(comms_for(devs, &comms));
         Rccl &R = rccl();
+        // nothing returns between GroupStart and GroupEnd: an open group would swallow the process's next collective
         int rc = R.GroupStart();
-        for (int r = 0; r < ngpus && rc == 0; ++r) {
-            LPVS_HIP(hipSetDevice(sh[(size_t)r].device));
+        bool dev_ok = true;
+        for (int r = 0; r < ngpus && rc == 0 && dev_ok; ++r) {
+            if (hipSetDevice(sh[(size_t)r].device) != hipSuccess) { (void)hipGetLastError(); dev_ok = false; break; }
             rc = R.AllGather(sh[(size_t)r].send.p, sh[(size_t)r].recv.p, slot, 8 /* ncclDouble */, (*comms)[(size_t)r], sh[(size_t)r].stream);
         }
         const int rc2 = R.GroupEnd();
+        if (!dev_ok) { set_error("hipSetDevice failed while enqueueing the RCCL all-gather"); return LPVS_EDEVICE; }
         if (rc != 0 || rc2 != 0) { set_error("RCCL all-gather of the window coefficients failed: %s", R.GetErrorString ? R.GetErrorString(rc ? rc : rc2) : "?"); return LPVS_EDEVICE; }
         for (auto &S : sh) { LPVS_HIP(hipSetDevice(S.device)); LPVS_HIP(hipStreamSynchronize(S.stream)); }
         all.resize(slot * (size_t)ngpus);

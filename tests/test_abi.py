@@ -114,3 +114,22 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "oracle" not in txt.lower().replace("(the oracle", ""), f"{fn} mentions the oracle"
+
+
+def test_default_options_roundtrip_without_a_gpu(L):
+    """lpvs_set_default_option / lpvs_get_default_option are host-only bookkeeping (thread-local)."""
+    import threading
+    assert L.get_default_option("storage") is None
+    with L.default_options(storage="f64", iteration="two", nt_loads="on"):
+        assert (L.get_default_option("storage"), L.get_default_option("iteration"), L.get_default_option("nt_loads")) == ("f64", "two", "on")
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(L.get_default_option("storage")))
+        th.start(); th.join()
+        assert seen == [None]                                               # another thread has its own defaults
+    assert L.get_default_option("storage") is None and L.get_default_option("iteration") is None
+    with pytest.raises(ValueError):
+        L.set_default_option("storage", "bf16")
+    with pytest.raises(KeyError):
+        L.set_default_option("precision", "f64")
+    from lpvspectral_jl_amd._lib import lib
+    assert lib().lpvs_set_default_option(99, 1) == -1 and lib().lpvs_set_default_option(1, 7) == -1

@@ -85,41 +85,55 @@ def test_cfg2_fullsize_admm_vs_oracle(L, oracle, equidistant):
 
 
 # ------------------------------------------------------------------ cfg3
+CFG3_PHASE_BOUND = 2e-8      # 2x the measured rel-L2(z) between exact and rounded phases at N = 2^20 (frozen after measurement)
 def test_cfg3_fullsize_structured_vs_dense_end_to_end(L):
     """The benchmarked path (structured Gram -> factorisation -> 2000 iterations at N = 2^20) against the same solve on the
-    dense f64-MFMA Gram (LPVS_GRAM_FORM=krs), which evaluates the reference's own rounded phases fl(w*x).
+    dense f64-MFMA Gram (LPVS_GRAM_FORM=krs), as a three-way experiment that separates WHAT differs between the two Gram paths:
 
-    The structured form uses the phase of the real product w*x, the reference rounds w*x to a double first: per term the
-    phases differ by <= ulp(w*x)/2 <= 2^-53 * max|w x| = 3.7e-10 rad at this size (max|w x| = 3.3e6 rad).  G therefore
-    differs by a few 1e-10 relative (the 1.5e-9 tolerance of test_gpu_fullsize.py), and z -- a Lipschitz function of (G, b)
-    with the conditioning of the group-lasso solution map -- by MEASURED 5.8e-9 rel-L2 after 2000 iterations, with identical
-    support.  That is above SURVEY 8(d)'s 1e-9, and it is a property of the inputs, not of either kernel: a perturbation of
-    the phases by half an ulp of w*x moves the reference's own answer by the same amount.  Frozen bound: 5e-8."""
+      structured    phases of the real products w*x (double-double slot frequencies, FMA-exact products; nudft.hip / nufft.hip)
+      dense-exact   the dense MFMA Gram on a trig table with the same unrounded phases (LPVS_PHASE=exact, basis.hip)
+      dense-rounded the dense MFMA Gram on the reference's own phases fl(w*x) (src/lasso.jl:39 rounds the product first)
+
+    (1) structured vs dense-exact -- the same mathematical problem through two entirely different kernel chains (NUFFT slot sums +
+        assembly vs trig table + matrix-core contraction), then factorisation, mixed storage and 2000 one-launch iterations:
+        SURVEY 8(d)'s 1e-9 in z holds, identical support.
+    (2) dense-exact vs dense-rounded -- ONE kernel chain, the phases perturbed by <= ulp(w*x)/2 = 3.7e-10 rad (max|w x| = 3.3e6):
+        the reference's own answer moves by a few 1e-9.  That is a property of the inputs (the conditioning of the group-lasso
+        solution map at this size), not of either kernel.
+    (3) structured vs dense-rounded is therefore (2)'s size: the excess over 1e-9 against the reference-as-written is its fl(w*x).
+    Bounds frozen at 2x the measured values (printed)."""
     import bench
     y, X, V, w = bench.synth_signal(1 << 20, 512, 0, torch.device("cuda"))
     out = {}
-    for form in ("ap", "krs"):
+    for name, form, phase in (("structured", "ap", None), ("dense-exact", "krs", "exact"), ("dense-rounded", "krs", None)):
         os.environ["LPVS_GRAM_FORM"] = form
+        if phase:
+            os.environ["LPVS_PHASE"] = phase
         try:
             with L.Problem.lpv(y, X, V, w, 8) as p:
                 p.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, 512, 16))
                 p.admm_init(None, μ=0.05, tol=0.0)
+                assert p.matvec_info()["kernel"] == "admm_iter_mixed_kernel"
                 it, nxz, conv = p.admm_run(2000)
                 x, z, u = p.admm_get()
-                out[form] = dict(z=z, x=x, it=it, nxz=nxz, params=p.params(0), form=p.timing()["gram_form"])
+                out[name] = dict(z=z, x=x, it=it, nxz=nxz, form=p.timing()["gram_form"])
         finally:
             del os.environ["LPVS_GRAM_FORM"]
-    assert out["ap"]["form"] in ("ap", "ap-nufft") and out["krs"]["form"] == "krs"   # (slot sums direct or by non-uniform FFT)
-    assert out["ap"]["it"] == out["krs"]["it"] == 2000
-    za, zk = out["ap"]["z"], out["krs"]["z"]
-    ga = np.abs(za).reshape(512, 16).sum(1) > 0
-    gk = np.abs(zk).reshape(512, 16).sum(1) > 0
-    assert np.array_equal(ga, gk) and np.array_equal(za != 0, zk != 0)           # identical support
-    r = rel(za, zk)
-    print(f"cfg3 N=2^20: rel-L2(z structured vs dense) = {r:.3e}, active groups = {int(ga.sum())}, "
-          f"phase bound 2^-53*max|w x| = {2.0 ** -53 * float(w.max() * X.max()):.2e}")
-    assert r <= 5e-8, r
-    assert {40, 204, 409} <= set(np.nonzero(ga)[0])                               # the three true frequencies are active
+            os.environ.pop("LPVS_PHASE", None)
+    assert out["structured"]["form"] in ("ap", "ap-nufft") and out["dense-exact"]["form"] == out["dense-rounded"]["form"] == "krs"
+    assert all(o["it"] == 2000 for o in out.values())
+    zs, ze, zr = out["structured"]["z"], out["dense-exact"]["z"], out["dense-rounded"]["z"]
+    groups = lambda z: np.abs(z).reshape(512, 16).sum(1) > 0
+    assert np.array_equal(groups(zs), groups(ze)) and np.array_equal(groups(zs), groups(zr))
+    assert np.array_equal(zs != 0, ze != 0) and np.array_equal(zs != 0, zr != 0)  # identical support, all three
+    r_se, r_er, r_sr = rel(zs, ze), rel(ze, zr), rel(zs, zr)
+    print(f"cfg3 N=2^20, 2000 iterations, rel-L2(z): structured vs dense-exact {r_se:.3e} | dense-exact vs dense-rounded {r_er:.3e} | "
+          f"structured vs dense-rounded {r_sr:.3e}; active groups {int(groups(zs).sum())}, "
+          f"phase bound 2^-53*max|w x| = {2.0 ** -53 * float(w.max() * X.max()):.2e} rad")
+    assert r_se <= 1e-9, r_se                                                     # (1) SURVEY 8(d) against the same mathematical problem
+    assert r_er > 1e-9 and r_er <= CFG3_PHASE_BOUND, r_er                         # (2) the reference's own sensitivity to fl(w*x)
+    assert r_sr <= CFG3_PHASE_BOUND and 0.5 * r_er <= r_sr <= 2.0 * r_er, (r_sr, r_er)   # (3) = (2)
+    assert {40, 204, 409} <= set(np.nonzero(groups(zs))[0])                       # the three true frequencies are active
 
 
 # ------------------------------------------------------------------ cfg5 at oracle size

@@ -190,3 +190,29 @@ def test_f32_remaining_entry_points(L):
     assert rel(xm, xd) <= 2e-5
     Syu, Syy, Suu, xy, xu = L.windowcsd_batched(ys, us, t, f, 500, 0, W, eng)
     assert Syy.dtype == np.float32 and np.array_equal(xy, xs[0]) and np.array_equal(xu, xs[1])
+
+
+def test_f32_record_with_f64_time_stamps_keeps_t_exact(L):
+    """Eltype promotion as Julia does it (src/lsfft.jl:121 -> src/lasso.jl:111 -> src/lsfft.jl:26: the regressor is evaluated in the
+    eltype of t and freqs): a Float32 record with Float64 time stamps above 2^24 is a Float64 problem -- identical to the widened
+    record, and different from what rounding t to 24 bits would give (time stamps collapsing onto duplicates)."""
+    rng = np.random.default_rng(71)
+    Lh, nw = 1 << 25, 8
+    t = np.arange(Lh, dtype=np.float64)                               # sample indices up to 2^25: odd ones are not floats
+    f = np.arange(1, 25) / 64.0
+    y = (np.sin(2 * np.pi * f[5] * t + 0.3) + 0.2 * rng.standard_normal(Lh)).astype(np.float32)
+    kw = dict(nw=nw, noverlap=0, estimator=L.ls_sparse_spectral, λ=0.1, μ=1e-4, iters=200, tol=0.0)
+    S32, _ = L.ls_windowpsd(y, t, f, **kw)
+    S64, _ = L.ls_windowpsd(y.astype(np.float64), t, f, **kw)
+    assert S32.dtype == np.float64 and np.array_equal(S32, S64)
+    Sr, _ = L.ls_windowpsd(y, t.astype(np.float32), f.astype(np.float32), **kw)      # an all-Float32 call: the _f32 entry points
+    assert rel(Sr, S64) > 1e-6                                        # (that IS a different problem: t rounded to 24 bits)
+    # the dense estimator and the cross-spectral driver promote the same way
+    P32, _ = L.ls_windowpsd(y, t, f, nw=nw, noverlap=0, λ=1e-6)
+    P64, _ = L.ls_windowpsd(y.astype(np.float64), t, f, nw=nw, noverlap=0, λ=1e-6)
+    assert np.array_equal(P32, P64)
+    C32, _ = L.ls_windowcsd(y, y, t, f, nw=nw, noverlap=0, λ=1e-6)
+    C64, _ = L.ls_windowcsd(y.astype(np.float64), y.astype(np.float64), t, f, nw=nw, noverlap=0, λ=1e-6)
+    assert np.array_equal(C32, C64)
+    # default_freqs of Float32 time stamps is a Float32 grid (rfftfreq(n, fs::Float32)); of Float64 ones a Float64 grid
+    assert L.default_freqs(t[:1000].astype(np.float32)).dtype == np.float32 and L.default_freqs(t[:1000]).dtype == np.float64

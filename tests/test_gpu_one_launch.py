@@ -175,3 +175,22 @@ def test_more_than_64_row_blocks(L, monkeypatch):
     assert res["one"][0] == res["two"][0] == 120
     for a, b in zip(res["one"][2:], res["two"][2:]):
         assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1.0), np.abs(a - b).max()
+
+
+def test_non_finite_state_propagates_as_nan(L, problem, monkeypatch):
+    """A NaN in the state handed to the iteration (x0) must come out as NaN iterates, as in the two-launch iteration and in the
+    reference's own arithmetic -- not vanish in the conversion of a tile partial to the fixed-point accumulator."""
+    N, Nf, Nv, y, X, V, w = problem
+    x0 = np.zeros(2 * Nf * Nv); x0[37] = np.nan
+    for mode in ("two", "one"):
+        if mode == "two":
+            monkeypatch.setenv("LPVS_ITERATION", "two")
+        else:
+            monkeypatch.delenv("LPVS_ITERATION", raising=False)
+        with L.Problem.lpv(y, X, V, w, Nv) as p:
+            p.set_prox(L.NormL1(0.5))
+            p.admm_init(x0, μ=0.05, tol=0.0)
+            assert p.matvec_info()["kernel"] == ("symv_tile_mixed_kernel" if mode == "two" else "admm_iter_mixed_kernel")
+            p.admm_run(5)
+            x, z, u = p.admm_get()
+            assert np.isnan(x).all() and np.isnan(u).all(), (mode, np.isnan(x).sum(), np.isnan(u).sum())

@@ -1,0 +1,95 @@
+"""lpvs_problem_set_option / lpvs_set_default_option (include/lpvspectral.h LPVS_OPT_*): the storage of the packed inverse, the
+iteration scheme and the Gram form as API options instead of environment variables -- explicit options win over the environment,
+handles carry their own, the batched-window entry points take the calling thread's defaults.  GPU only."""
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def _signal(N, Nf, rng):
+    X = np.sort(rng.random(N) * (10.0 * N / 500)); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) * 25.0 / Nf
+    y = 2 * V ** 2 * np.cos(w[Nf // 10] * X) + 2 / (5 * V + 1) * np.cos(w[Nf // 3] * X - 0.3) + 0.1 * rng.standard_normal(N)
+    return y, X, V, w
+
+
+@pytest.fixture(scope="module")
+def sig():
+    return _signal(1 << 18, 128, np.random.default_rng(3))     # n = 2048: the smallest size with a packed inverse
+
+
+def test_handle_options_choose_storage_and_iteration(L, sig, monkeypatch):
+    y, X, V, w = sig
+    monkeypatch.delenv("LPVS_M_STORAGE", raising=False); monkeypatch.delenv("LPVS_ITERATION", raising=False)
+    prox = L.SlicedSeparableSum.frequency_groups(2.0, 128, 16)
+    out = {}
+    with L.Problem.lpv(y, X, V, w, 8) as p:
+        p.set_prox(prox)
+        for storage, iteration, kernel in ((None, None, "admm_iter_mixed_kernel"), (None, "two", "symv_tile_mixed_kernel"),
+                                           ("split", None, "symv_tile_split_kernel"), ("f64", None, "symv_tile_kernel<double>"),
+                                           ("mixed", "one", "admm_iter_mixed_kernel")):
+            p.set_option("storage", storage); p.set_option("iteration", iteration)
+            assert p.get_option("storage") == storage and p.get_option("iteration") == iteration
+            p.admm_init(None, μ=0.05, tol=0.0)
+            assert p.matvec_info()["kernel"] == kernel, (storage, iteration, p.matvec_info())
+            p.admm_run(200)
+            out[(storage, iteration)] = p.admm_get()[1]
+        # an explicit option wins over the environment; without one the environment still works (experiments, old scripts)
+        monkeypatch.setenv("LPVS_M_STORAGE", "f64")
+        p.set_option("storage", "split"); p.set_option("iteration", None)
+        p.admm_init(None, μ=0.05, tol=0.0)
+        assert p.matvec_info()["kernel"] == "symv_tile_split_kernel"
+        p.set_option("storage", None)
+        assert p.get_option("storage") == "f64"
+        p.admm_init(None, μ=0.05, tol=0.0)
+        assert p.matvec_info()["kernel"] == "symv_tile_kernel<double>"
+        with pytest.raises(RuntimeError):                                   # constructor-time choices are not handle options
+            p.set_option("gram_form", "krs")
+        with pytest.raises(ValueError):
+            p.set_option("storage", "bf16")
+    ref = out[("f64", None)]
+    for k, z in out.items():
+        assert rel(z, ref) <= 1e-9, (k, rel(z, ref))
+        assert np.array_equal(z != 0, ref != 0)
+
+
+def test_default_options_reach_constructors_estimators_and_the_window_engine(L, sig, monkeypatch):
+    from lpvspectral_jl_amd import api
+    y, X, V, w = sig
+    for v in ("LPVS_M_STORAGE", "LPVS_ITERATION", "LPVS_GRAM_FORM", "LPVS_NUDFT"):
+        monkeypatch.delenv(v, raising=False)
+    N = 20000
+    with L.default_options(gram_form="krs"):
+        assert L.get_default_option("gram_form") == "krs"
+        with L.Problem.lpv(y[:N], X[:N], V[:N], w[:16], 4) as p:
+            assert p.timing()["gram_form"] == "krs"
+    assert L.get_default_option("gram_form") is None
+    with L.Problem.lpv(y[:N], X[:N], V[:N], w[:16], 4) as p:
+        assert p.timing()["gram_form"] in ("ap", "ap-nufft")
+    with L.default_options(slot_sums="direct"):
+        with L.Problem.lpv(y[:N], X[:N], V[:N], w[:16], 4) as p:
+            assert p.timing()["gram_form"] == "ap"
+    # estimator keywords (extensions): same result to the storage's 1e-10
+    kw = dict(λ=2.0, iters=150, tol=0.0, printerval=1000, out=io.StringIO())
+    a = L.ls_sparse_spectral_lpv(y, X, V, w, 8, **kw)
+    b = L.ls_sparse_spectral_lpv(y, X, V, w, 8, storage="f64", iteration="two", **kw)
+    assert L.get_default_option("storage") is None                        # restored
+    assert rel(a.x, b.x) <= 1e-9 and np.array_equal(a.x != 0, b.x != 0)
+    # the batched-window engine has no handle: it takes the calling thread's defaults
+    n, nwin, Nf = 1 << 14, 4, 256
+    t = np.arange(n * nwin, dtype=np.float64); f = np.arange(Nf) / 512.0
+    yw = np.sin(2 * np.pi * f[33] * t) + 0.3 * np.random.default_rng(4).standard_normal(n * nwin)
+    kww = dict(nw=nwin, noverlap=0, estimator=L.ls_sparse_spectral, λ=0.2, μ=1e-4, iters=100, tol=0.0)
+    S1, _ = L.ls_windowpsd(yw, t, f, **kww)
+    assert api.windowpsd_last_timing()["one_launch_iteration"]
+    S2, _ = L.ls_windowpsd(yw, t, f, iteration="two", **kww)
+    assert not api.windowpsd_last_timing()["one_launch_iteration"]
+    S3, _ = L.ls_windowpsd(yw, t, f, storage="f64", ngpus=0, **kww)      # the multi-device driver: options travel to its worker threads
+    assert rel(S2, S1) <= 1e-9 and rel(S3, S1) <= 1e-9
