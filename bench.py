@@ -14,8 +14,16 @@ RCCL is used only for the final gather of the coefficient vectors.
 1024 windows x 2^16 samples, Nf = 256): a step = all 1024 windows, the window range is sharded over the
 ranks (strong scaling), one RCCL all_gather of the per-window coefficients, PSD summed in window order.
 
-`python3 bench.py --gpus N` starts the N ranks itself (a torch.distributed.run child process, before this
-process touches the GPU) when it was not launched by one.
+`--workload cfg2` (ls_sparse_spectral NormL1(0.01), N = 2^18, Nf = 512, 5000 iterations) and `--workload cfg5` (multichannel LPV,
+8 channels per GPU sharing (X, V), N = 2^20, Nf = 1024, Nv = 16 -> n = 32768, IndBallL0(32)) are BASELINE.json's other two GPU
+configurations, each with its own `roofline` and `cpu_baseline`.
+
+With the default workload every run ALSO measures cfg4 with the window range sharded over the ranks and puts it on the same JSON line
+as `cfg4_strong` (windows/s, per-rank window counts, the collective's backend and rank count): the driver's fixed command
+`bench.py --gpus N` thus yields both curves north_star asks for -- independent signals (weak) and batched windows (strong).
+
+`python3 bench.py --gpus N` starts the N ranks itself (a torch.distributed.run CHILD process, started before this process touches
+the GPU) when it was not launched by one; under a profiler preload it refuses to (profile single-rank runs).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with
   roofline     : the dominant kernel (the ADMM mat-vec, HBM-bound) against the HBM peak, from HIP-event
@@ -38,10 +46,21 @@ import torch
 
 LOG2N, NF, NV = 20, 512, 8
 ADMM_ITERS, LAMBDA, MU = 2000, 5.0, 0.05
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s (spec)
+HBM_STREAM_GBS = 6290.0        # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy); tools/stream_read.hip reads this workload's shape at 7.0
 F64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet FP64 matrix; MI355X_MICROARCH.md lists no f64 MFMA row
 # cfg4: L = 2^26 equidistant, 1024 windows of 2^16, freqs (0:255)/512, L1 lam = 0.2, mu = 1e-4, 2000 its
 CFG4 = dict(nwin=1024, log2n=16, Nf=256, lam=0.2, mu=1e-4, iters=2000)
+# cfg2: N = 2^18 non-equidistant t, f = (1:512)/1024 (no zero frequency: n = 1024), NormL1(0.01), mu = 0.05, 5000 iterations, tol = 0
+CFG2 = dict(log2n=18, Nf=512, lam=0.01, mu=0.05, iters=5000)
+# cfg5: channels sharing (X, V), N = 2^20, Nf = 1024, Nv = 16 (n = 32768), IndBallL0(32); 8 channels per GPU
+CFG5 = dict(log2n=20, Nf=1024, Nv=16, r=32, mu=0.05, iters=2000, channels_per_gpu=8)
+
+
+def roof_fracs(achieved_gbs):
+    """Both fractions: against the 8 TB/s datasheet peak (`frac`, the contract's figure) and against the streaming rate the guide
+    measured on this part (6.29 TB/s)."""
+    return {"frac": achieved_gbs / HBM_PEAK_GBS, "frac_of_measured_stream_6290_GBps": achieved_gbs / HBM_STREAM_GBS}
 
 
 def synth_signal(N, Nf, seed, device):
@@ -66,6 +85,32 @@ def synth_windows(nwin, n, Nf, device):
     y = (torch.sin(2 * np.pi * f[33] * t) + 0.5 * torch.sin(2 * np.pi * f[100] * t)
          + 0.3 * torch.randn(Lr, dtype=torch.float64, device=device, generator=g))
     return y.contiguous(), t, f
+
+
+def synth_fourier(N, Nf, device):
+    """cfg2: t = sorted N*U(0,1) (non-equidistant), f = (1:Nf)/(2Nf) (no zero frequency), five sinusoids at
+    f[{17,100,257,300,480}] (1-based) with amplitudes {2,1,.5,.25,.1} + 0.1 N(0,1)."""
+    g = torch.Generator(device=device).manual_seed(0x1B5EC + 2)
+    t = torch.sort(torch.rand(N, dtype=torch.float64, device=device, generator=g) * N).values
+    f = np.arange(1, Nf + 1) / (2.0 * Nf)
+    amp = [(2, 16), (1, 99), (.5, 256), (.25, 299), (.1, 479)]
+    y = sum(a * torch.sin(2 * np.pi * f[min(i, Nf - 1)] * t + 0.3 * i) for a, i in amp)
+    y = y + 0.1 * torch.randn(N, dtype=torch.float64, device=device, generator=g)
+    return y.contiguous(), t.contiguous(), f
+
+
+def synth_channels(N, Nf, ns, device, first=0):
+    """cfg5: ns channels sharing (X, V), 3-6 true frequencies each (channel index first + q decides which)."""
+    g = torch.Generator(device=device).manual_seed(0x1B5EC + 5)
+    X = torch.sort(torch.rand(N, dtype=torch.float64, device=device, generator=g) * (10.0 * N / 500)).values
+    V = torch.linspace(0, 1, N, dtype=torch.float64, device=device)
+    w = torch.tensor(2 * np.pi * (np.arange(Nf) + 1.0) * 25.0 / Nf, dtype=torch.float64, device=device)
+    cols = []
+    for q in range(first, first + ns):
+        gq = torch.Generator(device=device).manual_seed(0x1B5EC + 50 + q)
+        col = sum((1.0 + 0.3 * k) * torch.cos(w[(37 * q + 101 * k) % Nf] * X + 0.1 * k) * (1 + V * (k % 2)) for k in range(3 + q % 4))
+        cols.append(col + 0.1 * torch.randn(N, dtype=torch.float64, device=device, generator=gq))
+    return torch.stack(cols, dim=1).contiguous(), X.contiguous(), V.contiguous(), w.contiguous()
 
 
 def solve(L, y, X, V, w, Nv, iters, device_index):
@@ -95,60 +140,181 @@ def solve_rowsharded(L, ys, Xs, Vs, w, Nv, iters, device_index, dist):
     return params, it, nxz, tm
 
 
-def cpu_baseline(log2n_sample=14, iters=6):
-    """Faithful CPU form (dense Phi in memory, warm-started CG on the lazy Phi'Phi + I/mu, extra Phi*x per
-    iteration) on a bounded sample: N_s = 2^14 rows at the full n = 8192, a few ADMM iterations; the cost
-    per ADMM iteration is a pure N*n stream, so it is extrapolated linearly in N to 2^20 and in iterations
-    to 2000 (optimistic for the CPU: CG needs more iterations as N grows)."""
-    from oracle import oracle as o
-    Ns = 1 << log2n_sample
-    y, X, V, w = [a.cpu().numpy() for a in synth_signal(Ns, NF, 0, "cpu")]
-    t0 = time.time()
-    Phi = o.lpv_regressor(X, V, w, NV)
-    t_asm = time.time() - t0
-    t0 = time.time()
-    r = o.admm_ls(Phi, y, o.GroupL2(LAMBDA, 2 * NV), iters=iters, tol=0.0, mu=MU)
-    t_admm = time.time() - t0
-    scale = float(1 << (LOG2N - log2n_sample))
-    per_iter = t_admm / r["iters"] * scale
-    total = t_asm * scale + per_iter * ADMM_ITERS
-    return {
-        "value": 1.0 / total, "unit": "signals/s", "cores": o.num_threads(), "kind": "port",
-        "sample": f"N=2^{log2n_sample} rows at full n=8192, {r['iters']} ADMM iterations "
-                  f"({r['cg_iters'] / r['iters']:.1f} CG iterations each, {t_admm:.1f} s) + regressor assembly ({t_asm:.1f} s); "
-                  f"extrapolated x{int(scale)} in N and to {ADMM_ITERS} iterations",
-        "admm_iters_per_sec": 1.0 / per_iter,
-    }
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline
+# The CPU port (oracle/, "kind": "port") is timed in a CHILD process so that its OpenMP runtime starts with pinned threads
+# (OMP_PROC_BIND=spread, OMP_PLACES=cores) and no other thread pool of this process competes for the cores: round 1 and round 2 timed
+# the same sample at 23 s and 44 s on "128 cores".  The child first picks the thread count that streams fastest on a small probe
+# (memory-bound gemv stops scaling long before 128 threads, and a GPU box may grant this job a fraction of its cores), then times
+# TWO sample sizes, best of 3 each, so that the linear-in-N law the extrapolation rests on is on the record next to it.
+def _set_threads(o, T):
+    import ctypes
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(T))
+    return o.num_threads()
 
 
-def cpu_baseline_cfg4(n_sample_windows=2, iters=40):
-    """cfg4 on the CPU port: a few windows of the full size (n = 2^16, Nreg = 511), regressor + explicit Gram (as the
-    reference does for the weighted method, src/lasso.jl:118-120) + `iters` CG-based ADMM iterations, extrapolated
-    linearly in windows and iterations."""
+def _cpu_child(which):
     from oracle import oracle as o
-    n, Nf = 1 << CFG4["log2n"], CFG4["Nf"]
-    y, t, f = synth_windows(n_sample_windows, n, Nf, "cpu")
-    y, t = y.numpy(), t.numpy()
+    ncpu = len(os.sched_getaffinity(0))
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
+    rec = {"which": which, "cpus_visible": ncpu}
+    if which == "cfg3":
+        def run(lg, iters):
+            y, X, V, w = [a.numpy() for a in synth_signal(1 << lg, NF, 0, "cpu")]
+            t0 = time.time(); Phi = o.lpv_regressor(X, V, w, NV); t_asm = time.time() - t0
+            t0 = time.time(); r = o.admm_ls(Phi, y, o.GroupL2(LAMBDA, 2 * NV), iters=iters, tol=0.0, mu=MU); t = time.time() - t0
+            return dict(asm_s=t_asm, admm_s=t, iters=r["iters"], cg=r["cg_iters"])
+        probe = {}
+        for T in cands:                                        # one ADMM iteration at N = 2^12 (0.25 GiB regressor) per candidate
+            _set_threads(o, T); run(12, 1); probe[T] = run(12, 1)["admm_s"]
+        T = min(probe, key=probe.get); _set_threads(o, T)
+        rec.update(threads=T, probe_s={str(k): round(v, 3) for k, v in probe.items()}, sizes={})
+        for lg in (13, 14):
+            reps = [run(lg, 2) for _ in range(3)]
+            best = min(reps, key=lambda r: r["admm_s"])
+            rec["sizes"][str(lg)] = dict(best, all_admm_s=[round(r["admm_s"], 3) for r in reps])
+    elif which == "cfg4":
+        n, Nf = 1 << CFG4["log2n"], CFG4["Nf"]
+        def run(iters):
+            y, t, f = synth_windows(1, n, Nf, "cpu")
+            y, t = y.numpy(), t.numpy()
+            t1 = time.time(); A, zf = o.get_fourier_regressor(t, f); Q, q = o.gram(A, y, np.ones(n)); t2 = time.time()
+            r = o.admm_quadratic(Q, q, o.NormL1(CFG4["lam"]), iters=iters, tol=0.0, mu=CFG4["mu"])
+            return dict(gram_s=t2 - t1, admm_s=time.time() - t2, iters=iters, cg=r.get("cg_iters"))
+        probe = {}
+        for T in cands:
+            _set_threads(o, T); probe[T] = (lambda r: r["gram_s"] + r["admm_s"])(run(10))
+        T = min(probe, key=probe.get); _set_threads(o, T)
+        reps = [run(40) for _ in range(3)]
+        rec.update(threads=T, probe_s={str(k): round(v, 3) for k, v in probe.items()},
+                   best=min(reps, key=lambda r: r["gram_s"] + r["admm_s"]), all_s=[round(r["gram_s"] + r["admm_s"], 3) for r in reps])
+    elif which == "cfg2":
+        Nf = CFG2["Nf"]
+        def run(lg, iters):
+            y, t, f = [a.numpy() if hasattr(a, "numpy") else a for a in synth_fourier(1 << lg, Nf, "cpu")]
+            t0 = time.time(); A, zf = o.get_fourier_regressor(t, f); t_asm = time.time() - t0
+            t0 = time.time(); r = o.admm_ls(A, y, o.NormL1(CFG2["lam"]), iters=iters, tol=0.0, mu=CFG2["mu"]); t = time.time() - t0
+            return dict(asm_s=t_asm, admm_s=t, iters=r["iters"], cg=r["cg_iters"])
+        probe = {}
+        for T in cands:
+            _set_threads(o, T); run(13, 2); probe[T] = run(13, 2)["admm_s"]
+        T = min(probe, key=probe.get); _set_threads(o, T)
+        rec.update(threads=T, probe_s={str(k): round(v, 3) for k, v in probe.items()}, sizes={})
+        for lg in (15, 16):
+            reps = [run(lg, 6) for _ in range(3)]
+            best = min(reps, key=lambda r: r["admm_s"])
+            rec["sizes"][str(lg)] = dict(best, all_admm_s=[round(r["admm_s"], 3) for r in reps])
+    elif which == "cfg5":
+        Nf, Nv = CFG5["Nf"], CFG5["Nv"]
+        def run(lg, iters):
+            Y, X, V, w = [a.numpy() for a in synth_channels(1 << lg, Nf, 1, "cpu")]
+            t0 = time.time(); Phi = o.lpv_regressor(X, V, w, Nv); t_asm = time.time() - t0
+            t0 = time.time(); r = o.admm_ls(Phi, Y[:, 0], o.IndBallL0(CFG5["r"]), iters=iters, tol=0.0, mu=CFG5["mu"]); t = time.time() - t0
+            return dict(asm_s=t_asm, admm_s=t, iters=r["iters"], cg=r["cg_iters"])
+        probe = {}
+        for T in cands:
+            _set_threads(o, T); probe[T] = run(10, 1)["admm_s"]
+        T = min(probe, key=probe.get); _set_threads(o, T)
+        rec.update(threads=T, probe_s={str(k): round(v, 3) for k, v in probe.items()}, sizes={})
+        for lg in (11, 12):                                    # 0.5 and 1 GiB of regressor at the full n = 32768
+            reps = [run(lg, 2) for _ in range(2)]
+            best = min(reps, key=lambda r: r["admm_s"])
+            rec["sizes"][str(lg)] = dict(best, all_admm_s=[round(r["admm_s"], 3) for r in reps])
+    print("CPU_BASELINE_JSON " + json.dumps(rec), flush=True)
+
+
+def _run_cpu_child(which):
+    env = dict(os.environ)
+    env.update(OMP_PROC_BIND="spread", OMP_PLACES="cores", OMP_DYNAMIC="false")
+    env.pop("OMP_NUM_THREADS", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
     t0 = time.time()
-    spent_gram, spent_admm = 0.0, 0.0
-    for i in range(n_sample_windows):
-        yi, ti = y[i * n:(i + 1) * n], t[i * n:(i + 1) * n]
-        t1 = time.time()
-        A, zf = o.get_fourier_regressor(ti, f)
-        Q, q = o.gram(A, yi, np.ones(n))
-        t2 = time.time()
-        o.admm_quadratic(Q, q, o.NormL1(CFG4["lam"]), iters=iters, tol=0.0, mu=CFG4["mu"])
-        spent_gram += t2 - t1; spent_admm += time.time() - t2
-    per_window = spent_gram / n_sample_windows + spent_admm / n_sample_windows / iters * CFG4["iters"]
-    return {"value": 1.0 / per_window, "unit": "windows/s", "cores": o.num_threads(), "kind": "port",
-            "sample": f"{n_sample_windows} windows of 2^16 samples at Nf=256: regressor + Gram {spent_gram / n_sample_windows:.2f} s/window, "
-                      f"{iters} ADMM iterations {spent_admm / n_sample_windows:.2f} s/window ({time.time() - t0:.1f} s in all); extrapolated to "
-                      f"{CFG4['iters']} iterations per window"}
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", which], env=env, capture_output=True, text=True, timeout=900)
+    line = next((l for l in out.stdout.splitlines() if l.startswith("CPU_BASELINE_JSON ")), None)
+    if line is None:
+        raise RuntimeError("CPU baseline child failed: " + out.stderr[-2000:])
+    rec = json.loads(line[len("CPU_BASELINE_JSON "):])
+    rec["wall_s"] = round(time.time() - t0, 1)
+    return rec
+
+
+def _linear_law(sizes, unit_rows):
+    """seconds per CG iteration and sample row at each size: equal figures = the cost is a pure N-proportional stream"""
+    return {f"N=2^{lg}": {"ns_per_cg_iteration_per_row": round(r["admm_s"] / max(r["cg"], 1) / (1 << int(lg)) * 1e9, 3),
+                           "cg_iterations_per_admm_iteration": round(r["cg"] / r["iters"], 1), "admm_s_best_of": r["all_admm_s"]} for lg, r in sizes.items()}
+
+
+def cpu_baseline():
+    """cfg3 on the CPU port: the faithful form (dense Phi in memory, warm-started CG on the lazy Phi'Phi + I/mu, the extra Phi*x per
+    iteration) at N_s = 2^13 and 2^14 rows of the full n = 8192; the cost per CG iteration is a pure N*n stream, so the larger sample
+    is extrapolated linearly in N to 2^20 and in iterations to 2000 (optimistic for the CPU: CG needs more iterations as N grows)."""
+    rec = _run_cpu_child("cfg3")
+    big = rec["sizes"]["14"]
+    scale = float(1 << (LOG2N - 14))
+    per_iter = big["admm_s"] / big["iters"] * scale
+    total = big["asm_s"] * scale + per_iter * ADMM_ITERS
+    return {"value": 1.0 / total, "unit": "signals/s", "cores": rec["threads"], "kind": "port",
+            "sample": f"N=2^14 rows at full n=8192, {big['iters']} ADMM iterations ({big['cg'] / big['iters']:.1f} CG iterations each, best of 3: "
+                      f"{big['admm_s']:.1f} s) + regressor assembly ({big['asm_s']:.1f} s); extrapolated x{int(scale)} in N and to {ADMM_ITERS} iterations; "
+                      f"{rec['threads']} pinned OpenMP threads (the fastest of {sorted(int(k) for k in rec['probe_s'])} on a probe; {rec['cpus_visible']} CPUs visible); "
+                      f"{rec['wall_s']} s of CPU work in all",
+            "admm_iters_per_sec": 1.0 / per_iter, "linear_in_N_check": _linear_law(rec["sizes"], None), "thread_probe_s": rec["probe_s"]}
+
+
+def cpu_baseline_cfg4():
+    """cfg4 on the CPU port: one window of the full size (n = 2^16, Nreg = 511), regressor + explicit Gram (as the reference does for
+    the weighted method, src/lasso.jl:118-120) + 40 CG-based ADMM iterations, best of 3, extrapolated linearly in iterations."""
+    rec = _run_cpu_child("cfg4")
+    b = rec["best"]
+    per_window = b["gram_s"] + b["admm_s"] / b["iters"] * CFG4["iters"]
+    return {"value": 1.0 / per_window, "unit": "windows/s", "cores": rec["threads"], "kind": "port",
+            "sample": f"one window of 2^16 samples at Nf=256: regressor + Gram {b['gram_s']:.2f} s, {b['iters']} ADMM iterations {b['admm_s']:.2f} s "
+                      f"(best of 3: {rec['all_s']}); extrapolated to {CFG4['iters']} iterations per window; {rec['threads']} pinned OpenMP threads "
+                      f"({rec['cpus_visible']} CPUs visible); {rec['wall_s']} s of CPU work in all", "thread_probe_s": rec["probe_s"]}
+
+
+def cpu_baseline_cfg2():
+    rec = _run_cpu_child("cfg2")
+    big = rec["sizes"]["16"]
+    scale = float(1 << (CFG2["log2n"] - 16))
+    per_iter = big["admm_s"] / big["iters"] * scale
+    total = big["asm_s"] * scale + per_iter * CFG2["iters"]
+    return {"value": 1.0 / total, "unit": "signals/s", "cores": rec["threads"], "kind": "port",
+            "sample": f"N=2^16 rows at full n=1024, {big['iters']} ADMM iterations ({big['cg'] / big['iters']:.1f} CG iterations each, best of 3: "
+                      f"{big['admm_s']:.2f} s) + regressor assembly ({big['asm_s']:.2f} s); extrapolated x{int(scale)} in N and to {CFG2['iters']} iterations; "
+                      f"{rec['threads']} pinned OpenMP threads ({rec['cpus_visible']} CPUs visible); {rec['wall_s']} s of CPU work in all",
+            "admm_iters_per_sec": 1.0 / per_iter, "linear_in_N_check": _linear_law(rec["sizes"], None), "thread_probe_s": rec["probe_s"]}
+
+
+def cpu_baseline_cfg5():
+    rec = _run_cpu_child("cfg5")
+    big = rec["sizes"]["12"]
+    scale = float(1 << (CFG5["log2n"] - 12))
+    per_iter = big["admm_s"] / big["iters"] * scale
+    total = big["asm_s"] * scale + per_iter * CFG5["iters"]          # per channel (the reference has no shared-regressor batch: every channel pays all of it)
+    return {"value": 1.0 / total, "unit": "signals/s", "cores": rec["threads"], "kind": "port",
+            "sample": f"ONE channel, N=2^12 rows at full n=32768, {big['iters']} ADMM iterations ({big['cg'] / big['iters']:.1f} CG iterations each, best of 2: "
+                      f"{big['admm_s']:.1f} s) + regressor assembly ({big['asm_s']:.1f} s); extrapolated x{int(scale)} in N and to {CFG5['iters']} iterations "
+                      f"(the regressor of the full size, 256 GiB, does not fit a host: SURVEY 8(a) a4); {rec['threads']} pinned OpenMP threads "
+                      f"({rec['cpus_visible']} CPUs visible); {rec['wall_s']} s of CPU work in all",
+            "admm_iters_per_sec": 1.0 / per_iter, "linear_in_N_check": _linear_law(rec["sizes"], None), "thread_probe_s": rec["probe_s"]}
+
+
+def profiler_preloaded():
+    """A rocprofv3 / roctracer preload has already initialised the GPU in THIS process before main() runs."""
+    if any(k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_")) for k in os.environ):
+        return True
+    return any(tag in os.environ.get(v, "") for v in ("LD_PRELOAD", "HSA_TOOLS_LIB") for tag in ("rocprof", "roctracer", "rocprofiler"))
 
 
 def spawn_ranks(args, argv):
-    """`python3 bench.py --gpus N` outside a launcher: start N ranks as a CHILD process tree (torch.distributed.run) before
-    this process has made any HIP call, and exit with its status.  (Nothing is exec'ed and no GPU state is inherited.)"""
+    """`python3 bench.py --gpus N` outside a launcher: start the N ranks as a CHILD process (python -m torch.distributed.run, a plain
+    subprocess of this one, which exits with its status) before this process has made any HIP call, so no GPU state is inherited.
+    Under a profiler preload the GPU IS already initialised here, and starting another program from such a process is what this pool
+    forbids: refuse, and profile single-rank runs (tools/collect_round.sh does)."""
+    if profiler_preloaded():
+        raise SystemExit("bench.py --gpus %d under a profiler preload: the profiler has initialised the GPU in this process, so it must not "
+                         "start the ranks itself.  Profile a single-rank run (--gpus 1), or put the profiler inside each rank." % args.gpus)
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -164,9 +330,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 10 (cfg3) / 3 (cfg4)")
     ap.add_argument("--warmup", type=int, default=None, help="default 2 (cfg3) / 1 (cfg4)")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4"],
-                    help="cfg3 (default, the judged line): one LPV group-lasso signal per GPU per step; cfg4: 1024 batched windows per "
-                         "step, window range sharded over the ranks")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg2", "cfg5"],
+                    help="cfg3 (default, the judged line): one LPV group-lasso signal per GPU per step (+ the cfg4_strong sub-record); cfg4: 1024 "
+                         "batched windows per step, window range sharded over the ranks; cfg2: ls_sparse_spectral NormL1 N=2^18 Nf=512, 5000 "
+                         "iterations; cfg5: multichannel LPV n=32768 IndBallL0(32), 8 channels per GPU")
+    ap.add_argument("--no-cfg4-strong", action="store_true", help="cfg3 runs: skip the cfg4 strong-scaling sub-record")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--channels", type=int, default=CFG5["channels_per_gpu"], help="cfg5: channels per GPU (configured: 8)")
     ap.add_argument("--log2n", type=int, default=LOG2N, help="diagnostic only; the judged size is 20")
     ap.add_argument("--iters", type=int, default=None, help="ADMM iterations (default 2000 for both workloads)")
     ap.add_argument("--nwin", type=int, default=CFG4["nwin"], help="cfg4 diagnostic only; the configured count is 1024")
@@ -186,6 +356,9 @@ def main():
                     help="strong-scaling variant: one signal per step, its sample rows sharded over the ranks (one all-reduce of the Gram)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: map every rank onto the visible GPUs modulo their count")
     args = ap.parse_args()
+    if args.cpu_baseline_child:                           # the CPU port in a child of its own (pinned OpenMP threads); never touches the GPU
+        _cpu_child(args.cpu_baseline_child)
+        return
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -234,12 +407,60 @@ def main():
 
     if args.workload == "cfg4":
         out = run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
+    elif args.workload == "cfg2":
+        out = run_cfg2(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
+    elif args.workload == "cfg5":
+        out = run_cfg5(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
     else:
         out = run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
+        if not args.no_cfg4_strong and not args.row_sharded and args.log2n == LOG2N:
+            # the batched-window configuration, window range sharded over the same ranks (north_star: "near-linear 1->8 on batched windows")
+            sub = measure_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks, steps=3, warmup=1, iters=CFG4["iters"], nwin=CFG4["nwin"])
+            if rank == 0:
+                out["cfg4_strong"] = sub
     if rank == 0:
+        out["backend"] = "none (single process)" if dist is None else ("rccl (torch.distributed nccl)" if args.backend == "nccl" else args.backend)
+        out["rccl_ranks"] = dist.get_world_size() if (dist is not None and args.backend == "nccl") else 0
+        out["collective_ranks"] = 1 if dist is None else dist.get_world_size()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measure_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks, steps, warmup, iters, nwin):
+    """cfg4, the window range sharded over the ranks (strong scaling): the compact record that rides on the cfg3 line."""
+    n, Nf = 1 << CFG4["log2n"], CFG4["Nf"]
+    y, t, f = synth_windows(nwin, n, Nf, dev)
+    lo, hi = L.sharding.shard_range(nwin, world, rank)
+
+    def step():
+        x, S_part, its = L.windowpsd_sparse_batched(y, t, f, n, 0, None, λ=CFG4["lam"], μ=CFG4["mu"], tol=0.0, iters=iters,
+                                                    win_lo=lo, win_hi=hi, device=local)
+        full = L.sharding.gather_units(x, nwin, dist, cdev)   # ONE all_gather of the per-window coefficients (RCCL)
+        return L.sharding.reduce_psd_in_order(full), its
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        S, its = step()
+    sync()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    tm = L.windowpsd_last_timing()
+    del y, t
+    torch.cuda.empty_cache()
+    L._lib.lib().lpvs_release_cached_memory()
+    if rank != 0:
+        return None
+    return {"metric": "windows/sec, ls_windowpsd estimator=ls_sparse_spectral (NormL1), %d windows x N=2^%d, Nf=%d, %d ADMM iters per window"
+                      % (nwin, CFG4["log2n"], Nf, iters),
+            "value": nwin * steps / elapsed, "unit": "windows/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "scaling": "strong", "windows_per_gpu": [L.sharding.shard_range(nwin, world, r)[1] - L.sharding.shard_range(nwin, world, r)[0] for r in range(world)],
+            "final_gather": "none" if world == 1 else ("rccl" if args.backend == "nccl" else args.backend) + " all_gather of per-window coefficients, PSD summed in window order",
+            "one_launch_iteration": bool(tm.get("one_launch_iteration")), "gram_form": tm.get("gram_form"),
+            "phase_ms_rank0": {k: v for k, v in tm.items() if k.endswith("_ms")}, "psd_argmax": int(np.argmax(S)),
+            "iters_min_max": [int(its.min()), int(its.max())]}
 
 
 def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks):
@@ -280,7 +501,7 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         return None
     tm["matvec_us_per_iteration"] = tm_mv.get("matvec_us_per_iteration")
     tm["matvec_windows"] = tm_mv.get("matvec_windows")
-    st = os.environ.get("LPVS_M_STORAGE", "mixed")                 # storage of the packed inverses (admm.hip)
+    st = L.get_default_option("storage") or os.environ.get("LPVS_M_STORAGE", "mixed")   # storage of the packed inverses (admm.hip)
     mv_us = tm.get("matvec_us_per_iteration")
     one_launch = bool(tm_mv.get("one_launch_iteration"))
     mv_only_us = mv_us
@@ -298,7 +519,7 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                  "added into x by 64-bit fixed-point atomics)") if one_launch else
                 "symv_tile_mixed_batch_kernel (6-byte float-head tiles on the diagonal, 36-bit fixed-point tiles elsewhere)")
         roof = {"bound": "hbm", "kernel": kern + ": one tile-packed (Q + I/mu)^-1 per window, all windows of the shard per launch",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": None,
                 "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "windows_per_launch": nmv, "launches_per_step": iters,
                 "matvec_only_launch_us": mv_only_us,
                 "note": ("launch_us = HIP events around the ADMM loop of the last timed step / iterations (one launch per iteration); "
@@ -393,25 +614,21 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         for st in ("f64", "split"):
             if st == "split" and mv_info["kernel"] == "symv_tile_split_kernel":
                 continue
-            os.environ["LPVS_M_STORAGE"] = st
-            try:
-                with L.Problem.lpv(y, X, V, w, NV, True, False, device=local) as p:
-                    p.set_prox(L.SlicedSeparableSum.frequency_groups(LAMBDA, len(w), 2 * NV))
-                    p.admm_init(None, μ=MU, tol=0.0)
-                    a_us, a_bytes = p.time_matvec(300)
-                    rec = {"kernel": p.matvec_info()["kernel"], "launch_us": a_us, "bytes_per_launch": a_bytes,
-                           "achieved_GBps": a_bytes / (a_us * 1e-6) * 1e-9, "frac_of_hbm_peak": a_bytes / (a_us * 1e-6) * 1e-9 / HBM_PEAK_GBS}
-                    if st == "f64":
-                        alt = rec
-                    else:
-                        alt6 = rec
-            finally:
-                del os.environ["LPVS_M_STORAGE"]
+            with L.Problem.lpv(y, X, V, w, NV, True, False, device=local) as p:
+                p.set_option("storage", st)                   # lpvs_problem_set_option(h, LPVS_OPT_M_STORAGE, ...)
+                p.set_prox(L.SlicedSeparableSum.frequency_groups(LAMBDA, len(w), 2 * NV))
+                p.admm_init(None, μ=MU, tol=0.0)
+                a_us, a_bytes = p.time_matvec(300)
+                rec = {"kernel": p.matvec_info()["kernel"], "launch_us": a_us, "bytes_per_launch": a_bytes,
+                       "achieved_GBps": a_bytes / (a_us * 1e-6) * 1e-9, "frac_of_hbm_peak": a_bytes / (a_us * 1e-6) * 1e-9 / HBM_PEAK_GBS}
+                if st == "f64":
+                    alt = rec
+                else:
+                    alt6 = rec
     # ... and the whole step with that storage (a few untimed-for-`value` solves), so that both end-to-end rates are on the record
     alt_step = None
     if alt is not None and not rowsh:
-        os.environ["LPVS_M_STORAGE"] = "f64"
-        try:
+        with L.default_options(storage="f64"):               # lpvs_set_default_option: every handle the runs below create
             run()
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
@@ -420,8 +637,6 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
             torch.cuda.synchronize(dev)
             ms8 = (time.perf_counter() - t1) / 3 * 1e3
             alt_step = {"ms_per_step": ms8, "signals_per_s_per_gpu": 1e3 / ms8, "steps": 3}
-        finally:
-            del os.environ["LPVS_M_STORAGE"]
     mv_only_us = mv_us
     if mv_info.get("one_launch_iteration"):
         # the iteration IS one launch of this kernel (update in its prologue, fixed-point accumulation at its end): its duration inside
@@ -436,14 +651,11 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
     # the timed region (same inputs, LPVS_GRAM_FORM=krs) so both rooflines are on the record.
     general = None
     if not args.no_general_path and not rowsh:
-        os.environ["LPVS_GRAM_FORM"] = "krs"
-        try:
+        with L.default_options(gram_form="krs"):
             gt = None
             for _ in range(2):
                 with L.Problem.lpv(y, X, V, w, NV, True, False, device=local) as p:
                     gt = p.timing()
-        finally:
-            del os.environ["LPVS_GRAM_FORM"]
         g_alg = gt["gram_flops"] / (gt["gram_ms"] * 1e-3) * 1e-12
         g_iss = gt["gram_issued_flops"] / (gt["gram_ms"] * 1e-3) * 1e-12
         general = {"bound": "mfma", "kernel": "gram_kernel<KRS> (v_mfma_f64_16x16x4_f64)", "launch_ms": gt["gram_ms"],
@@ -470,9 +682,15 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                    "final_gather": "none" if (world == 1 or rowsh) else ("rccl" if args.backend == "nccl" else args.backend) + " all_gather"},
         "admm_iters_per_sec": iters / (phase["admm_ms"] * 1e-3),
         "phase_ms": phase,
+        "factor_ms": phase["factor_ms"],
+        "factorisation": {"bound": "mfma", "kernel": "rank_update_kernel + pivot chain (blocked symmetric sweep, v_mfma_f64_16x16x4_f64)",
+                          "flops": float(2 * NF * NV) ** 3, "ms": phase["factor_ms"],
+                          "achieved": float(2 * NF * NV) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": float(2 * NF * NV) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12 / F64_MFMA_PEAK_TFLOPS,
+                          "note": "n^3 flop on the lower triangle for M = (G + I/mu)^-1; whole phase incl. the pivot chains and hand-overs"},
         "final_nxz": nxz,
         "roofline": {"bound": "hbm", "kernel": mv_info["kernel"] + " (ADMM mat-vec with the tile-packed lower triangle of (G + I/mu)^-1)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved),
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": mv_bytes,
                      "launch_us": mv_us, "launches_per_step": iters, "share_of_step": mv_share, "same_matvec_with_8_byte_storage": alt, "same_matvec_with_uniform_6_byte_storage": alt6,
                      "matvec_only_launch_us": mv_only_us,
@@ -488,6 +706,125 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    return out
+
+
+def run_cfg2(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks):
+    """BASELINE.json config 2: ls_sparse_spectral NormL1(0.01), N = 2^18, Nf = 512 (n = 1024), 5000 iterations; one signal per GPU."""
+    steps = 10 if args.steps is None else args.steps
+    warmup = 2 if args.warmup is None else args.warmup
+    iters = CFG2["iters"] if args.iters is None else args.iters
+    N, Nf = 1 << CFG2["log2n"], CFG2["Nf"]
+    y, t, f = synth_fourier(N, Nf, dev)
+    ft = torch.tensor(f, dtype=torch.float64, device=dev)
+
+    def run():
+        with L.Problem.fourier(y, t, ft, None, device=local) as p:
+            p.set_prox(L.NormL1(CFG2["lam"]))
+            p.admm_init(None, μ=CFG2["mu"], tol=0.0)
+            it, nxz, conv = p.admm_run(iters)
+            return p.params(0), it, nxz, p.timing()
+
+    for _ in range(warmup):
+        run()
+    sync()
+    t0 = time.perf_counter()
+    tms = []
+    for _ in range(steps):
+        params, it, nxz, tm = run()
+        tms.append(tm)
+    sync()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return None
+    phase = {k: float(np.mean([q[k] for q in tms])) for k in ("basis_ms", "gram_ms", "reduce_rhs_ms", "factor_ms", "admm_ms")}
+    with L.Problem.fourier(y, t, ft, None, device=local) as p:
+        p.set_prox(L.NormL1(CFG2["lam"]))
+        p.admm_init(None, μ=CFG2["mu"], tol=0.0)
+        mv_us, mv_bytes = p.time_matvec(500)
+        info = p.matvec_info()
+    it_us = phase["admm_ms"] * 1e3 / iters
+    achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
+    out = {"metric": "signals/sec, ls_sparse_spectral NormL1(%g) N=2^%d Nf=%d (%d ADMM iters; iters/sec in admm_iters_per_sec)" % (CFG2["lam"], CFG2["log2n"], Nf, iters),
+           "value": world * steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "cfg2: ls_sparse_spectral NormL1(%g), N=2^%d non-equidistant, Nf=%d (no zero frequency, n=%d), mu=%g, iters=%d, tol=0, one signal per GPU"
+                                  % (CFG2["lam"], CFG2["log2n"], Nf, 2 * Nf, CFG2["mu"], iters), "gram_form": tms[0]["gram_form"], "matvec_storage": info["storage"]},
+           "admm_iters_per_sec": iters / (phase["admm_ms"] * 1e-3), "phase_ms": phase, "final_nxz": nxz,
+           "peaks_1based": sorted((np.argsort(-np.abs(params))[:5] + 1).tolist()),
+           "roofline": {"bound": "hbm", "kernel": info["kernel"] + " (full symmetric (G + I/mu)^-1, n = 1024: 8.4 MB, Infinity-Cache resident)",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": None,
+                        "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "launches_per_step": iters, "iteration_us": it_us,
+                        "note": "launch-latency bound, not bandwidth bound: an iteration is two dependent launches of a few microseconds (mat-vec + prox / "
+                                "dual update), replayed as hipGraph chunks of 50 iterations; iteration_us = HIP events around the ADMM loop / iterations; "
+                                "launch_us = the mat-vec alone, 500 back-to-back launches.  The floor is the dependent-kernel boundary "
+                                "(MI355X_MICROARCH.md: 1.2-1.9 us each), not the 8.4 MB the kernel reads."}}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_cfg2()
+    return out
+
+
+def run_cfg5(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks):
+    """BASELINE.json config 5: multichannel LPV, `channels` channels per GPU sharing (X, V): ONE Gram / factorisation per GPU, every
+    ADMM kernel advances all its channels in one pass over the inverse; IndBallL0(32), n = 32768.  Ranks take disjoint channel ranges
+    (weak scaling: 8 channels per GPU -> 64 on 8 GPUs), no data-path collective, one all_gather of the coefficients."""
+    steps = 2 if args.steps is None else args.steps
+    warmup = 1 if args.warmup is None else args.warmup
+    iters = CFG5["iters"] if args.iters is None else args.iters
+    N, Nf, Nv, ns = 1 << args.log2n, CFG5["Nf"], CFG5["Nv"], args.channels
+    Y, X, V, w = synth_channels(N, Nf, ns, dev, first=rank * ns)
+
+    def run():
+        with L.Problem.lpv_multi(Y, X, V, w, Nv, True, False, device=local) as p:
+            p.set_prox(L.IndBallL0(CFG5["r"]))
+            p.admm_init(None, μ=CFG5["mu"], tol=0.0)
+            it, nxz, conv = p.admm_run(iters)
+            return p.params(0), it, nxz, p.timing()
+
+    for _ in range(warmup):
+        run()
+    sync()
+    t0 = time.perf_counter()
+    tms = []
+    for _ in range(steps):
+        params, it, nxz, tm = run()
+        tms.append(tm)
+    if dist is not None:
+        mine = torch.view_as_real(torch.tensor(np.ascontiguousarray(params.T), device=cdev)).contiguous()
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+    sync()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return None
+    phase = {k: float(np.mean([q[k] for q in tms])) for k in ("basis_ms", "gram_ms", "reduce_rhs_ms", "factor_ms", "admm_ms")}
+    with L.Problem.lpv_multi(Y, X, V, w, Nv, True, False, device=local) as p:
+        p.set_prox(L.IndBallL0(CFG5["r"]))
+        p.admm_init(None, μ=CFG5["mu"], tol=0.0)
+        mv_us, mv_bytes = p.time_matvec(30)
+        info = p.matvec_info()
+    achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
+    n = 2 * Nf * Nv
+    out = {"metric": "signals/sec, multichannel ls_sparse_spectral_lpv IndBallL0(%d) N=2^%d Nf=%d Nv=%d, %d channels per GPU (%d ADMM iters)"
+                     % (CFG5["r"], args.log2n, Nf, Nv, ns, iters),
+           "value": world * ns * steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "cfg5: %d channels per GPU sharing (X, V), N=2^%d, Nf=%d, Nv=%d (n=%d), IndBallL0(%d), mu=%g, iters=%d, tol=0"
+                                  % (ns, args.log2n, Nf, Nv, n, CFG5["r"], CFG5["mu"], iters), "gram_form": tms[0]["gram_form"],
+                      "matvec_storage": info["storage"], "sharding": "disjoint channel ranges per rank", "final_gather": "none" if world == 1 else "all_gather of the coefficients"},
+           "admm_iters_per_sec": iters / (phase["admm_ms"] * 1e-3), "iteration_ms_all_channels": phase["admm_ms"] / iters,
+           "phase_ms": phase, "final_nxz": nxz, "nnz_per_channel": [int(np.count_nonzero(params[:, q])) for q in range(ns)],
+           "factorisation": {"flops": float(n) ** 3, "ms": phase["factor_ms"], "achieved_TFLOPs": float(n) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12,
+                             "frac_of_f64_mfma_peak": float(n) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12 / F64_MFMA_PEAK_TFLOPS},
+           "roofline": {"bound": "hbm", "kernel": info["kernel"] + " (tile product of the packed (G + I/mu)^-1 with all channels on v_mfma_f64_16x16x4_f64)",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": None,
+                        "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "launches_per_step": iters,
+                        "share_of_step": iters * mv_us * 1e-3 / (elapsed / steps * 1e3),
+                        "mfma_flops_per_launch": 4.0 * float(n) * float(n + 128) / 2 * 16 * 2 / 2,
+                        "note": "algorithmic bytes = %s; HIP events around 30 back-to-back launches on the library's stream; the same launch also issues "
+                                "n(n+128)/2 x 16 signal columns x 2 products of f64 MFMA work (with 8 channels half of every MFMA is padding)" % info["bytes_formula"]}}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_cfg5()
     return out
 
 

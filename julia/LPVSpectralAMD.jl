@@ -68,7 +68,7 @@ reshape_params(x, Nf) = reshape(x, Nf, :)                  # src/utilities.jl:77
 psd(se::SpectralExt) = abs2.(sum(reshape_params(copy(se.x), length(se.w)), dims=2))   # src/lsfft.jl:214-217
 
 default_freqs(n::Int, fs=1) = (0:(n >> 1)) .* (fs / n)     # src/lsfft.jl:3-9 (rfftfreq)
-default_freqs(t::AbstractVector, fs=1 / (sum(diff(t)) / (length(t) - 1))) = default_freqs(length(t), fs)
+default_freqs(t::AbstractVector, fs=1/mean(diff(t))) = default_freqs(length(t), fs)
 default_freqs(t::AbstractVector, n::Int) = default_freqs(t[1:n])
 
 rect(n) = ones(n)                                          # DSP.rect
@@ -281,7 +281,8 @@ end
 """`x, z = ADMM(x, proxf, proxg; iters, tol, printerval, cb, μ)` (src/lasso.jl:136-171): `proxf` a
 `ProximalOperators.LeastSquares(A, b; iterative=true)` or `Quadratic(Q, q; iterative=true)`, `proxg` one of the four device
 prox kinds; anything else is not accelerated (call the reference's ADMM)."""
-function ADMM(x::AbstractVector, proxf, proxg; kwargs...)
+function ADMM(x::AbstractArray{T}, proxf, proxg; iters=10000, tol=1e-5, printerval=100, cb=nothing, μ=T(0.05)) where T
+    kwargs = (iters=iters, tol=tol, printerval=printerval, cb=cb, μ=μ)
     pp = proxparams(proxg, length(x))
     pp === nothing && throw(ArgumentError("proxg of type $(typeof(proxg)) has no device kernel"))
     # field names of the iterative variants [PO-recalled]: LeastSquaresIterative(A, b, lambda...), QuadraticIterative(Q, q)

@@ -1,0 +1,44 @@
+"""bench.py's own multi-rank path (the driver launches `bench.py --gpus N`): a bare `python bench.py --gpus 2` starts its two ranks as a
+child process tree before touching the GPU, the ranks rendezvous (gloo here: one shared GPU, no RCCL between two ranks on one device),
+shard the cfg4 windows by range, gather them, and rank 0 prints ONE JSON line with n_gpus = 2 and the cfg4_strong sub-record.  GPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--no-general-path", "--no-alt-storage"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_ranks_and_reports_both_scaling_records():
+    rec = _run(["--log2n", "16", "--iters", "50", "--nwin", "8"])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["scaling"] == "weak" and rec["unit"] == "signals/s"
+    assert rec["collective_ranks"] == 2 and rec["backend"] == "gloo" and rec["rccl_ranks"] == 0
+    assert "cfg4_strong" not in rec                        # (the sub-record rides on the judged size only: --log2n 20)
+    rec4 = _run(["--workload", "cfg4", "--iters", "50", "--nwin", "8"])
+    assert rec4["n_gpus"] == 2 and rec4["scaling"] == "strong" and rec4["config"]["windows_per_gpu"] == [4, 4]
+    assert rec4["psd_argmax"] == 33 and rec4["unit"] == "windows/s"
+
+
+def test_bench_refuses_to_spawn_under_a_profiler_preload():
+    """(CPU test: the refusal happens before anything touches a GPU.)  The marker variable only has to LOOK like a profiler's."""
+    env = dict(os.environ, ROCPROFILER_LPVS_TEST_MARKER="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "profiler preload" in out.stderr

@@ -36,7 +36,12 @@ def lpv_case(L):
     y, X, V, w = _signal(N, Nf, rng)
     with L.Problem.lpv(y, X, V, w, Nv) as p:
         G, b = p.get_gram()
-    return dict(N=N, Nf=Nf, Nv=Nv, y=y, X=X, V=V, w=w, G=G, b=b)
+    # penalties that leave a NON-TRIVIAL support (so that "identical support" can fail): from the data's own scale -- a group / an
+    # element is active at the solution roughly when its correlation with y exceeds the penalty
+    gb = np.linalg.norm(b.reshape(Nf, 2 * Nv), axis=1)
+    xr = np.linalg.solve(G + np.eye(len(b)) / 0.05, b)
+    lams = dict(group=float(np.quantile(gb, 0.7)), l1=float(np.quantile(np.abs(b), 0.7)), l0=float(np.quantile(np.abs(xr), 0.7) ** 2 / (2 * 0.05)))
+    return dict(N=N, Nf=Nf, Nv=Nv, y=y, X=X, V=V, w=w, G=G, b=b, lams=lams)
 
 
 def _device_run(L, case, prox, iters, tol, monkeypatch, mode, f32=False):
@@ -57,17 +62,18 @@ def _device_run(L, case, prox, iters, tol, monkeypatch, mode, f32=False):
     return dict(x=x, z=z, u=u, it=it, nxz=nxz, conv=conv, info=info, G=G, b=b)
 
 
-def _proxes(L, oracle, Nf, Nv):
-    return {"group": (L.SlicedSeparableSum.frequency_groups(2.0, Nf, 2 * Nv), oracle.GroupL2(2.0, 2 * Nv)),
-            "l1": (L.NormL1(0.5), oracle.NormL1(0.5)),
-            "l0": (L.NormL0(0.02), oracle.NormL0(0.02))}
+def _proxes(L, oracle, case):
+    Nf, Nv, lam = case["Nf"], case["Nv"], case["lams"]
+    return {"group": (L.SlicedSeparableSum.frequency_groups(lam["group"], Nf, 2 * Nv), oracle.GroupL2(lam["group"], 2 * Nv)),
+            "l1": (L.NormL1(lam["l1"]), oracle.NormL1(lam["l1"])),
+            "l0": (L.NormL0(lam["l0"]), oracle.NormL0(lam["l0"]))}
 
 
 @pytest.mark.parametrize("kind", ["group", "l1", "l0"])
 @pytest.mark.parametrize("mode,kernel", [("one", "admm_iter_mixed_kernel"), ("two", "symv_tile_mixed_kernel")])
 def test_mixed_storage_iteration_against_oracle(L, oracle, lpv_case, kind, mode, kernel, monkeypatch):
     """300 iterations, tol = 0: the iterates of the benchmarked kernel against oracle.admm_gram on the same G, b."""
-    prox, oprox = _proxes(L, oracle, lpv_case["Nf"], lpv_case["Nv"])[kind]
+    prox, oprox = _proxes(L, oracle, lpv_case)[kind]
     r = _device_run(L, lpv_case, prox, 300, 0.0, monkeypatch, mode)
     assert r["info"]["kernel"] == kernel, r["info"]
     assert r["info"].get("one_launch_iteration", False) == (mode == "one")
@@ -84,7 +90,7 @@ def test_mixed_storage_iteration_against_oracle(L, oracle, lpv_case, kind, mode,
 @pytest.mark.parametrize("mode,kernel", [("one", "admm_iter_mixed_kernel"), ("two", "symv_tile_mixed_kernel")])
 def test_mixed_storage_stopping_iteration_against_oracle(L, oracle, lpv_case, mode, kernel, monkeypatch):
     """tol > 0 (src/lasso.jl:164): the same stopping iteration as the oracle and the iterates of that iteration."""
-    prox, oprox = _proxes(L, oracle, lpv_case["Nf"], lpv_case["Nv"])["l1"]
+    prox, oprox = _proxes(L, oracle, lpv_case)["l1"]
     full = oracle.admm_gram(lpv_case["G"], lpv_case["b"], oprox, iters=600, tol=0.0, mu=0.05, history=True)
     nx = full["nxz"]
     for k0 in (150, 401):                                                    # both parities of the stopping iteration
@@ -103,7 +109,7 @@ def test_mixed_storage_stopping_iteration_against_oracle(L, oracle, lpv_case, mo
 def test_f32_one_launch_iteration_against_oracle(L, oracle, lpv_case, monkeypatch):
     """_f32 handles (single-precision copy of the inverse through the one-launch kernel): against the oracle on the widened inputs'
     Gram, 2e-5 (SURVEY 8(d) asks 1e-3 of a Float32 path)."""
-    prox, oprox = _proxes(L, oracle, lpv_case["Nf"], lpv_case["Nv"])["group"]
+    prox, oprox = _proxes(L, oracle, lpv_case)["group"]
     r = _device_run(L, lpv_case, prox, 300, 0.0, monkeypatch, "one", f32=True)
     assert r["info"]["kernel"] == "admm_iter_mixed_kernel" and r["info"]["one_launch_iteration"], r["info"]
     assert "f32" in r["info"]["storage"]

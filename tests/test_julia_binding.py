@@ -156,3 +156,84 @@ def test_array_arguments_are_preserved_under_the_name_that_is_passed():
             if a.endswith("p") and a[:-1] + "v" in c["preserve"]:
                 continue                                     # a raw pointer derived from a preserved vector (Wp <- Wv, x0p <- x0v)
             assert re.search(r"\b%s\b" % re.escape(a), c["preserve"]), f"{c['name']}: {a} is passed as {t} without GC.@preserve"
+
+
+# ---- the keyword surface of the reference's hot-path methods: names, order and defaults --------------------------------------------
+# tests/golden/reference_signatures.json holds, for every method of the hot-path functions in src/lsfft.jl / src/lasso.jl /
+# src/windows.jl, its positional names (with defaults) and its keywords (with defaults) -- extracted by
+# tests/golden/make_reference_signatures.py.  A user who switches must find the same names with the same defaults.
+def _reference_signatures():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))
+
+
+def test_signature_fixture_matches_the_reference_when_it_is_present():
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("/root/reference is not on this machine (GPU box): the committed fixture stands")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_reference_signatures as mk
+    import json
+    assert json.loads(json.dumps(mk.extract())) == _reference_signatures(), "regenerate tests/golden/reference_signatures.json"
+
+
+def test_julia_wrapper_has_the_references_signatures():
+    """Every reference method has a wrapper method of the same name with the same positional names / defaults, and every reference
+    keyword with the same default; the wrapper may ADD keywords (device, ngpus, storage, ...)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _jlsig import HOT_PATH_FUNCTIONS, parse_methods
+    ref = _reference_signatures()
+    mine = parse_methods(open(JL).read(), HOT_PATH_FUNCTIONS)
+    for name, methods in ref.items():
+        for m in methods:
+            pos = [tuple(p) for p in m["pos"]]
+            cands = [w for w in mine[name] if [p[0] for p in w["pos"]] == [p[0] for p in pos]]
+            assert cands, f"{name}({', '.join(p[0] for p in pos)}) of {m['file']} has no method with these positional arguments in the wrapper"
+            w = cands[0]
+            assert [p[1] for p in w["pos"]] == [p[1] for p in pos], f"{name}: positional defaults {w['pos']} vs reference {pos}"
+            wkw = dict(w["kw"])
+            for k, d in m["kw"]:
+                assert k in wkw, f"{name}: keyword {k} of the reference is missing in the wrapper (has {sorted(wkw)})"
+                assert wkw[k] == d, f"{name}: keyword {k} defaults to {wkw[k]} in the wrapper, {d} in the reference"
+            if m["varkw"]:
+                assert w["varkw"], f"{name}: the reference forwards kwargs..., the wrapper does not"
+
+
+def test_python_mirror_has_the_references_signatures():
+    """The same for lpvspectral.jl_amd/api.py (the host mirror the parity tests call): positional names in order, every reference
+    keyword present with the same default.  Julia defaults that are expressions in earlier arguments (`f=default_freqs(t)`,
+    `proxg=NormL1(λ)`, `estimator=ls_spectral`, `n=length(y)>>3`) are `None` in Python and resolved in the body."""
+    import inspect
+    import sys
+    sys.path.insert(0, ROOT)
+    import lpvspectral_jl_amd as L
+    ref = _reference_signatures()
+    lit = {"false": False, "true": True, "nothing": None, "T(1)": 1.0, "T(0.05)": 0.05, "rect": L.rect}
+    def value(d):
+        if d in lit:
+            return lit[d]
+        try:
+            return float(d) if any(c in d for c in ".e") else int(d)
+        except ValueError:
+            return None                                    # an expression in earlier arguments
+    for name, methods in ref.items():
+        fn = getattr(L, name)
+        sig = inspect.signature(fn.__init__ if inspect.isclass(fn) else fn)
+        params = [p for p in sig.parameters.values() if p.name != "self"]
+        names = [p.name for p in params]
+        for m in methods:
+            pos = [p[0] for p in m["pos"]]
+            if name == "default_freqs":                    # three Julia methods share one Python function (t_or_n, fs, n)
+                continue
+            assert names[:len(pos)] == pos, f"{name}: positional {names[:len(pos)]} vs reference {pos}"
+            for (k, d) in m["pos"]:
+                if d is not None:
+                    assert sig.parameters[k].default == value(d) or value(d) is None, f"{name}: {k} defaults to {sig.parameters[k].default!r}, reference {d}"
+            for k, d in m["kw"]:
+                assert k in sig.parameters, f"{name}: keyword {k} of the reference is missing in api.py"
+                have, want = sig.parameters[k].default, value(d)
+                assert have == want or (want is None and have is None), f"{name}: keyword {k} defaults to {have!r}, reference {d}"
+            if m["varkw"]:
+                assert any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params), f"{name}: the reference forwards kwargs..."
