@@ -31,7 +31,7 @@ static int option_from_env(int option) {
     case LPVS_OPT_M_STORAGE: { const char *e = getenv("LPVS_M_STORAGE");
         return is(e, "mixed") ? LPVS_STORAGE_MIXED : is(e, "split") ? LPVS_STORAGE_SPLIT : is(e, "f64") ? LPVS_STORAGE_F64 : 0; }
     case LPVS_OPT_ITERATION: { const char *e = getenv("LPVS_ITERATION"); return is(e, "two") ? LPVS_ITERATION_TWO : is(e, "one") ? LPVS_ITERATION_ONE : 0; }
-    case LPVS_OPT_GRAM_FORM: { const char *e = getenv("LPVS_GRAM_FORM"); return is(e, "ap") ? LPVS_GRAM_AP : is(e, "krs") ? LPVS_GRAM_KRS : is(e, "kr") ? LPVS_GRAM_KR : 0; }
+    case LPVS_OPT_GRAM_FORM: { const char *e = getenv("LPVS_GRAM_FORM"); return is(e, "ap") ? LPVS_GRAM_AP : (is(e, "krs") || is(e, "panel")) ? LPVS_GRAM_KRS : is(e, "kr") ? LPVS_GRAM_KR : 0; }   // (panel: the Fourier problems' dense form)
     case LPVS_OPT_NT_LOADS: { const char *e = getenv("LPVS_NT_LOADS"); return e == nullptr ? 0 : (e[0] == '1' ? LPVS_NT_ON : LPVS_NT_OFF); }
     case LPVS_OPT_SLOT_SUMS: { const char *e = getenv("LPVS_NUDFT"); return is(e, "direct") ? LPVS_SLOTS_DIRECT : is(e, "nufft") ? LPVS_SLOTS_NUFFT : 0; }
     }

@@ -85,7 +85,7 @@ def test_cfg2_fullsize_admm_vs_oracle(L, oracle, equidistant):
 
 
 # ------------------------------------------------------------------ cfg3
-CFG3_PHASE_BOUND = 2e-8      # 2x the measured rel-L2(z) between exact and rounded phases at N = 2^20 (frozen after measurement)
+CFG3_PHASE_BOUND = 4.5e-9    # 2x the measured rel-L2(z) between exact and rounded phases at N = 2^20 (measured: 2.12e-9 / 1.94e-9; (1): 7.3e-10)
 def test_cfg3_fullsize_structured_vs_dense_end_to_end(L):
     """The benchmarked path (structured Gram -> factorisation -> 2000 iterations at N = 2^20) against the same solve on the
     dense f64-MFMA Gram (LPVS_GRAM_FORM=krs), as a three-way experiment that separates WHAT differs between the two Gram paths:
