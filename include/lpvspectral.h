@@ -311,7 +311,7 @@ int32_t lpvs_merge_f64(const double *yf, int64_t count, int64_t n, int64_t nover
  * sequential loop.  Windows are independent, so ranks of a multi-GPU job take disjoint [win_lo, win_hi).
  *   W          n window weights (NULL = rect/ones); the estimator is always the weighted 4-argument method
  *   linear_sign LPVS_LINEAR_QUADRATIC_AS_WRITTEN reproduces Quadratic(Q, q=+A'Wy) of src/lasso.jl:119-121
- *   prox_kind  L1, L0 or GROUP_L2 (IndBallL0 is not batched)
+ *   prox_kind  L1, L0, GROUP_L2 or BALL_L0 (README.md:79-83; one workgroup per window selects its r largest)
  *   x_re,x_im  (win_hi-win_lo) x Nf, window-major: fourier2complex(z) of each window
  *   S_out      Nf: sum over these windows, in window order, of |x|^2 (NOT yet divided by k^2); may be NULL
  *   iters_out  per-window iteration count (stops per window at ||x-z|| < tol); may be NULL */
@@ -331,11 +331,14 @@ int32_t lpvs_windowpsd_last_timing(double *out, int32_t n_out);
 /* estimator of the batched-window engine */
 #define LPVS_EST_SPARSE 1 /* ls_sparse_spectral(y,t,f,W): Quadratic(Q,q) + ADMM        src/lasso.jl:105-126 */
 #define LPVS_EST_DENSE 2  /* ls_spectral(y,t,f,W): (A'WA + lam I) \ A'Wy               src/lsfft.jl:74-80  */
+#define LPVS_EST_SPARSE_INIT 3 /* ls_sparse_spectral(y,t,f,W; init=true): as LPVS_EST_SPARSE, started from
+                                  fourier_solve(A,y,zerofreq,lam) = (A'A + lam^2 I) \ A'y -- the UNWEIGHTED ridge solution, as written (src/lasso.jl:112) */
 
 /* ---- the engine itself: ns signals sharing the sampling points t (Y is L x ns column-major) --------------------------
  * Every window's Gram A'WA and factorisation are formed ONCE and serve all ns right-hand sides A'W y_s -- the y and u of
  * ls_windowcsd / ls_cohere (src/lsfft.jl:150-151,184-185 call the estimator twice per window on the same t).
- *   estimator   LPVS_EST_SPARSE (prox_*, mu, tol, iters, linear_sign as in lpvs_windowpsd_sparse_f64; lam unused) or
+ *   estimator   LPVS_EST_SPARSE (prox_*, mu, tol, iters, linear_sign as in lpvs_windowpsd_sparse_f64; lam unused),
+ *               LPVS_EST_SPARSE_INIT (the same with init = true: lam = the lambda of the starting ridge solve) or
  *               LPVS_EST_DENSE (lam = ridge; the ADMM arguments are ignored)
  *   x_re, x_im  ns x (win_hi - win_lo) x Nf, signal-major then window-major: fourier2complex of every solution
  *   iters_out   ns x (win_hi - win_lo) iteration counts (0 for the dense estimator); may be NULL.  HOST memory only
@@ -359,6 +362,18 @@ int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const doubl
                                         int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
                                         int64_t iters, int32_t linear_sign, const int32_t *devices, int32_t ngpus, double *x_re,
                                         double *x_im, int64_t *iters_out);
+
+/* ---- multichannel LPV batches over several devices by ONE host process (BASELINE.json config 5) ------
+ * Y is N x ns (one column per channel sharing X, V, w): the channels are split into contiguous ranges over `ngpus` devices
+ * (devices[r], or 0..ngpus-1 when NULL; ngpus <= 0: every visible device), one host thread per device builds its shard's Gram and
+ * factorisation ONCE and advances the shard's channels together (lpvs_problem_create_lpv_multi_f64); every channel stops at its own
+ * ||x-z||_2 < tol.  No data-path collective.  prox as lpvs_problem_set_prox (the reference's ls_sparse_spectral_lpv is
+ * LPVS_PROX_GROUP_L2 with group_len = 2 Nv, src/lasso.jl:53-55; BASELINE's cfg5 asks LPVS_PROX_BALL_L0, an extension).
+ * re_out / im_out: (Nf*Nv) x ns column-major HOST arrays, channel q in column q, parameter index f + (v-1) Nf (src/lasso.jl:67-68);
+ * iters_out: ns iteration counts (HOST, may be NULL).  Inputs may be host or device pointers (staged through the host once). */
+int32_t lpvs_lpv_batch_multi_f64(const double *Y, int64_t ns, const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
+                                 int64_t Nv, int32_t normalize, int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
+                                 int64_t iters, const int32_t *devices, int32_t ngpus, double *re_out, double *im_out, int64_t *iters_out);
 
 /* ---- ls_windowcsd / ls_cohere on the engine                                              src/lsfft.jl:140-156, :176-193
  * Accumulators over the windows [win_lo, win_hi) in window order (NOT yet normalised: ls_windowcsd returns Syu / k,

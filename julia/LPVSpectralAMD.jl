@@ -38,6 +38,7 @@ end
 
 const EST_SPARSE = Int32(1)                               # LPVS_EST_SPARSE
 const EST_DENSE = Int32(2)                                # LPVS_EST_DENSE
+const EST_SPARSE_INIT = Int32(3)                          # LPVS_EST_SPARSE_INIT: init = true, x0 = fourier_solve(A, y, zerofreq, λ)
 
 # ---- ProximalOperators objects -> the four device prox kinds -----------------------------------
 # Field names are those of ProximalOperators.jl 0.10-0.16 (`lambda`, `r`, `fs`, `idxs`) [PO-recalled, SURVEY.md section 8(c)];
@@ -372,9 +373,14 @@ function ls_sparse_spectral_lpv(y::AbstractVector{S}, X::AbstractVector{S}, V::A
 end
 
 function ls_spectral_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer;
-                         λ=1e-8, coulomb=false, normalize=true, device=0)            # src/lsfft.jl:239-259
+                         λ=1e-8, coulomb=false, normalize=true, device=0, covariance=true)   # src/lsfft.jl:239-259
     w = w[:]
     Yv = dense(Float64, Y); N = length(Yv)
+    if !covariance                                          # (extension: ls_windowpsd_lpv reads the parameters only -- no Σ, no second inverse)
+        p1 = lpv_problem(Yv, X, V, w, Nv, normalize, coulomb; device=device)
+        x1 = try solve_ridge(p1, λ^2) catch e; e isa NumericError || rethrow(e); nothing end
+        x1 === nothing || return SpectralExt(Y, X, V, w, Nv, λ, coulomb, normalize, pack(p1, x1), nothing)
+    end
     p = lpv_multi_problem([Yv ones(N)], X, V, w, Nv, normalize, coulomb; device=device)   # second right-hand side: the constant signal
     Nf, nb = length(w), coulomb ? 2Nv : Nv
     local x
@@ -446,7 +452,7 @@ mapwindows(f::Function, args...) = mapwindows(f, Windows2(args...))
 # ---- the batched-window engine: all windows of the drivers below in ONE call ---------------------
 # Which estimator / kwargs combinations the engine covers (everything else runs the reference's sequential loop):
 #   estimator === ls_spectral         (the 4-argument weighted method, src/lsfft.jl:74-80)    kwargs ⊆ (λ,)
-#   estimator === ls_sparse_spectral  (the 4-argument weighted method, src/lasso.jl:105-126)  no cb, no init, device prox
+#   estimator === ls_sparse_spectral  (the 4-argument weighted method, src/lasso.jl:105-126)  no cb; init = true and all four device prox kinds included
 function engine_args(estimator, nreg; kwargs...)
     kw = Dict{Symbol,Any}(kwargs)
     delete!(kw, :device)
@@ -455,14 +461,16 @@ function engine_args(estimator, nreg; kwargs...)
         (get(kw, :verbose, false) || !issubset(keys(kw), (:λ, :verbose))) && return nothing
         return (est=EST_DENSE, lam=Float64(get(kw, :λ, 1e-10)), prox=(Int32(1), 0.0, Int64(0)), μ=0.05, tol=0.0, iters=0, sign=Int32(1))
     elseif estimator === ls_sparse_spectral
-        (get(kw, :cb, nothing) !== nothing || get(kw, :init, false)) && return nothing
+        get(kw, :cb, nothing) !== nothing && return nothing                          # a per-iteration callback needs the host loop
         issubset(keys(kw), (:λ, :proxg, :μ, :tol, :iters, :printerval, :cb, :init)) || return nothing
         g = get(kw, :proxg, PO.NormL1(Float64(get(kw, :λ, 1.0))))
         pp = proxparams(g, nreg)
-        (pp === nothing || pp[1] == Int32(3)) && return nothing                      # IndBallL0 is not batched
+        pp === nothing && return nothing
         μ = Float64(get(kw, :μ, 0.05))
         @assert 0 ≤ μ ≤ 1 "μ should be ≤ 1"
-        return (est=EST_SPARSE, lam=0.0, prox=pp, μ=μ, tol=Float64(get(kw, :tol, 1e-5)), iters=Int(get(kw, :iters, 10000)), sign=Int32(-1))
+        init = Bool(get(kw, :init, false))                                           # src/lasso.jl:112: one batched ridge solve in the engine
+        return (est=init ? EST_SPARSE_INIT : EST_SPARSE, lam=init ? Float64(get(kw, :λ, 1.0)) : 0.0, prox=pp, μ=μ,
+                tol=Float64(get(kw, :tol, 1e-5)), iters=Int(get(kw, :iters, 10000)), sign=Int32(-1))
     end
     nothing
 end
@@ -556,7 +564,7 @@ function ls_windowpsd_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVecto
     S = zeros(length(w))                                                             # src/lsfft.jl:267-277
     windows = Windows3(Y, X, V, length(Y) ÷ nw, noverlap, rect)
     for (y, x, v) in windows
-        se = ls_spectral_lpv(collect(y), collect(x), collect(v), w, Nv; kwargs...)
+        se = ls_spectral_lpv(collect(y), collect(x), collect(v), w, Nv; covariance=false, kwargs...)
         S += vec(abs2.(sum(reshape_params(se.x, length(w)), dims=2)))
     end
     S

@@ -20,7 +20,7 @@ LPVS_EDEVICE, LPVS_EUNSUPPORTED, LPVS_ENUMERIC, LPVS_ESTATE = -5, -6, -7, -8
 
 PROX_L1, PROX_L0, PROX_BALL_L0, PROX_GROUP_L2 = 1, 2, 3, 4
 LINEAR_LEAST_SQUARES, LINEAR_QUADRATIC_AS_WRITTEN = 1, -1
-EST_SPARSE, EST_DENSE = 1, 2
+EST_SPARSE, EST_DENSE, EST_SPARSE_INIT = 1, 2, 3
 # options (include/lpvspectral.h LPVS_OPT_*): name -> (option id, {value name -> value}); None / "default" = 0
 OPTIONS = {
     "storage": (1, {"mixed": 1, "split": 2, "f64": 3}),
@@ -98,6 +98,7 @@ SIGNATURES = {
                                           _I64, _I64, _I32, _P, _P, _P]),
     "lpvs_windows_estimate_multi_f64": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
                                                 _P, _I32, _P, _P, _P]),
+    "lpvs_lpv_batch_multi_f64": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _F64, _I64, _F64, _F64, _I64, _P, _I32, _P, _P, _P]),
     "lpvs_windowcsd_f64": (_I32, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
                                    _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "lpvs_lpv_ranges_f64": (_I32, [_P, _P, _I64, _P]),

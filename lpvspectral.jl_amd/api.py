@@ -825,7 +825,7 @@ def windowpsd_last_timing():
 
 def _engine_args(estimator, kwargs, nreg):
     """Map the reference's estimator + kwargs onto the engine's arguments, or None when that combination has no batched
-    form (user-supplied estimator, callback, init=true, IndBallL0, unknown keywords -> the reference's sequential loop)."""
+    form (user-supplied estimator, per-iteration callback, unknown keywords -> the reference's sequential loop)."""
     kw = dict(kwargs)
     kw.pop("device", None)
     if estimator is ls_spectral:                                       # 4-argument weighted method, src/lsfft.jl:74-80
@@ -834,15 +834,17 @@ def _engine_args(estimator, kwargs, nreg):
         return dict(estimator=_lib.EST_DENSE, lam=float(kw.get("λ", 1e-10)), prox=(_lib.PROX_L1, 0.0, 0), μ=0.05, tol=0.0, iters=0,
                     sign=_lib.LINEAR_LEAST_SQUARES)
     if estimator is ls_sparse_spectral:                                # 4-argument weighted method, src/lasso.jl:105-126
-        if kw.get("cb") is not None or kw.get("init", False) or set(kw) - {"λ", "proxg", "μ", "tol", "iters", "printerval", "cb", "init", "out"}:
-            return None
+        if kw.get("cb") is not None or set(kw) - {"λ", "proxg", "μ", "tol", "iters", "printerval", "cb", "init", "out"}:
+            return None                                                # a per-iteration callback needs the host loop
         pg = kw.get("proxg")
         pg = NormL1(kw.get("λ", 1.0)) if pg is None else pg
-        if not hasattr(pg, "device_params") or isinstance(pg, IndBallL0):
+        if not hasattr(pg, "device_params"):
             return None
         μ = kw.get("μ", 0.05)
         assert 0 <= μ <= 1, "μ should be ≤ 1"                          # src/lasso.jl:143
-        return dict(estimator=_lib.EST_SPARSE, lam=0.0, prox=pg.device_params(nreg), μ=float(μ), tol=float(kw.get("tol", 1e-5)),
+        init = bool(kw.get("init", False))                             # x0 = fourier_solve(A, y, zerofreq, λ): one batched ridge solve (:112)
+        return dict(estimator=_lib.EST_SPARSE_INIT if init else _lib.EST_SPARSE, lam=float(kw.get("λ", 1.0)) if init else 0.0,
+                    prox=pg.device_params(nreg), μ=float(μ), tol=float(kw.get("tol", 1e-5)),
                     iters=int(kw.get("iters", 10000)), sign=_lib.LINEAR_QUADRATIC_AS_WRITTEN)
     return None
 
@@ -1043,10 +1045,12 @@ def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, batched=T
         Syu = np.zeros(len(freqs), dtype=np.complex128)
         for i in range(x.shape[1]):                                 # :183-190, window order
             Syu += _mul_conj(x[0, i], x[1, i]); Syy += abs2(x[0, i]); Suu += abs2(x[1, i])
-        return abs2(Syu) / (Suu * Syy), freqs
+        with np.errstate(invalid="ignore", divide="ignore"):        # 0/0 where neither signal has the frequency: NaN, silently, as in Julia
+            return abs2(Syu) / (Suu * Syy), freqs
     if eng is not None:
         Syu, Syy, Suu, _, _ = windowcsd_batched(y, u, t, freqs, n, windows.noverlap, windows.W, eng, device=kwargs.get("device", 0))
-        return abs2(Syu) / (Suu * Syy), freqs                       # :191
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return abs2(Syu) / (Suu * Syy), freqs                   # :191
     Syy, Suu = np.zeros(len(freqs)), np.zeros(len(freqs))
     Syu = np.zeros(len(freqs), dtype=np.complex128)
     for yi, ti, ui in windows:
@@ -1055,7 +1059,8 @@ def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, batched=T
         Syu += _mul_conj(xy, xu)
         Syy += abs2(xy)
         Suu += abs2(xu)
-    return abs2(Syu) / (Suu * Syy), freqs
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return abs2(Syu) / (Suu * Syy), freqs
 
 
 @_with_options
@@ -1064,6 +1069,7 @@ def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, **kwargs):
     w = np.ravel(_host(w))
     S = np.zeros(len(w))
     windows = Windows3(Y, X, V, len(Y) // nw, noverlap, rect)
+    kwargs.setdefault("covariance", False)                         # the driver reads the parameters only (:273-274): no Σ, no second inverse
     for y, x, v in windows:
         se = ls_spectral_lpv(y, x, v, w, Nv, **kwargs)
         rp = reshape_params(se.x, len(w))

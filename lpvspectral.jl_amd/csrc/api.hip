@@ -1436,16 +1436,18 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     const int64_t n = a.n, Nf = a.Nf, ns = a.ns;
     const int64_t noverlap = a.noverlap < 0 ? n >> 1 : a.noverlap;
     const int64_t win_lo = a.win_lo, win_hi = a.win_hi;
-    const bool sparse = a.estimator == LPVS_EST_SPARSE;
-    if (a.estimator != LPVS_EST_SPARSE && a.estimator != LPVS_EST_DENSE) { set_error("unknown estimator %d", a.estimator); return LPVS_EARGUMENT; }
+    const bool sparse = a.estimator == LPVS_EST_SPARSE || a.estimator == LPVS_EST_SPARSE_INIT;
+    const bool init = a.estimator == LPVS_EST_SPARSE_INIT;       // x0 = fourier_solve(A, y, zerofreq, lam), src/lasso.jl:112
+    if (!sparse && a.estimator != LPVS_EST_DENSE) { set_error("unknown estimator %d", a.estimator); return LPVS_EARGUMENT; }
     if (ns < 1 || ns > 64) { set_error("number of signals %lld outside [1, 64]", (long long)ns); return LPVS_EARGUMENT; }
     if (win_lo < 0 || win_hi > k || win_lo > win_hi) { set_error("window range [%lld,%lld) outside [0,%lld)", (long long)win_lo, (long long)win_hi, (long long)k); return LPVS_EARGUMENT; }
     const double mu = a.mu, tol = a.tol;
     if (sparse) {
         if (!(mu >= 0 && mu <= 1)) { set_error("μ should be ≤ 1"); return LPVS_EASSERT; }
         if (mu == 0) { set_error("mu = 0 makes the x-update singular"); return LPVS_ENUMERIC; }
-        if (a.prox_kind != LPVS_PROX_L1 && a.prox_kind != LPVS_PROX_L0 && a.prox_kind != LPVS_PROX_GROUP_L2) { set_error("prox kind %d is not batched", a.prox_kind); return LPVS_EUNSUPPORTED; }
+        if (a.prox_kind < LPVS_PROX_L1 || a.prox_kind > LPVS_PROX_GROUP_L2) { set_error("unknown prox kind %d", a.prox_kind); return LPVS_EUNSUPPORTED; }
         if (a.prox_kind == LPVS_PROX_GROUP_L2 && a.group_len <= 0) { set_error("group_len must be positive"); return LPVS_EARGUMENT; }
+        if (a.prox_kind == LPVS_PROX_GROUP_L2 && a.group_len > 8192) { set_error("group_len > 8192 is not supported by the device prox"); return LPVS_EUNSUPPORTED; }
         if (a.linear_sign != 1 && a.linear_sign != -1) { set_error("linear_sign must be +1 or -1"); return LPVS_EARGUMENT; }
     }
     int64_t zf = 0;
@@ -1495,7 +1497,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         }
     }
     const bool ap = sl.ok;
-    const int nmat = sparse ? 2 : 3;   // resident np x np matrices per window: M, packed M (sparse) / Q, M, work (dense)
+    const int nmat = (sparse ? 2 : 3) + (init ? 2 : 0);   // resident np x np matrices per window: M, packed M (sparse) / Q, M, work (dense) (+ A'A and its inverse for init)
     if (ap) {   // windows per pass bounded by the matrices: 32 GiB
         bw = (int64_t)(((size_t)32 << 30) / (sizeof(double) * (size_t)np * (size_t)np * (size_t)nmat));
         if (bw < 1) bw = 1;
@@ -1522,7 +1524,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         Wdev = Wp.as<double>();
     }
     PhaseTrace tr(s);
-    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, xb, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb, fibuf;
+    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, xb, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb, fibuf, Q0, M0, b0, x0buf, ballscr;
     ApSlotsDev sd;
     DrainOnExit drain(s);
     const int64_t nprob_max = bw * ns;
@@ -1576,6 +1578,11 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)bw));
     LPVS_TRY(offs.alloc(sizeof(int64_t) * (size_t)bw));
     if (!ap) LPVS_TRY(scr.alloc(rhs_scratch_bytes(n, nreg) * (size_t)bw));
+    if (init) {
+        LPVS_TRY(Q0.alloc(sizeof(double) * (size_t)np * (size_t)np * (size_t)bw)); LPVS_TRY(M0.alloc(sizeof(double) * (size_t)np * (size_t)np * (size_t)bw));
+        LPVS_TRY(b0.alloc(vb)); LPVS_TRY(x0buf.alloc(vb));
+    }
+    if (sparse && a.prox_kind == LPVS_PROX_BALL_L0 && nreg > 8192) LPVS_TRY(ballscr.alloc(2 * vb));   // selection keys of vectors that do not fit the LDS image
 
     tr.mark("alloc");
     std::vector<int64_t> hseg((size_t)3 * (size_t)bw * (size_t)spw);
@@ -1593,55 +1600,79 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         LPVS_HIP(hipMemcpyAsync(offs.p, hoff.data(), sizeof(int64_t) * (size_t)nb_, hipMemcpyHostToDevice, s));
         double *G = sparse ? M.as<double>() : Q.as<double>();                      // where the window Grams are assembled
         LPVS_HIP(hipEventRecord(ev[0].a, s));
-        if (ap) {
-            for (int q = 0; q < nb_; ++q)
-                for (int c = 0; c < spw; ++c) {
-                    int64_t *e = hseg.data() + 3 * ((size_t)q * (size_t)spw + (size_t)c);
-                    e[0] = hoff[q] + (int64_t)c * rpcw;
-                    e[1] = std::min(hoff[q] + n, e[0] + rpcw);
-                    e[2] = hoff[q];
-                }
-            LPVS_TRY(copy_to_device(seg.p, hseg.data(), sizeof(int64_t) * 3 * (size_t)nb_ * (size_t)spw, s));
-            LPVS_HIP(hipMemsetAsync(G, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
-            LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
-            const int64_t gstride = wcols * 2 * (int64_t)nfg;      // doubles per window in wgrids: [column][plain, x-weighted][nfg]
-            if (wnufft) {   // column 0 = the window weights alone (Gram); with it, in the same pass over the samples, signal 0
-                LPVS_TRY(launch_nufft_window_spread(dt.p, Wdev, nullptr, wnufft_rhs ? dys[0].p : nullptr, wnufft_rhs, offs.as<int64_t>(), nb_, n, sl.step.hi[1],
-                                                    sl.step.lo[1], nfg, wgrids.as<double>(), wgrids.as<double>() + 2 * (int64_t)nfg, gstride, s));
-                LPVS_TRY(launch_nufft_window_modes(wgrids.as<double>(), gstride, nb_, nfg, 0, (int)sl.nsl, wscale_g.as<double>(), tab.as<double>(), sl.nsl * 4, s));
-            } else {
-                LPVS_TRY(launch_nudft_windows(dt.p, nullptr, Wdev, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, seg.as<int64_t>(), nb_, spw,
-                                              npart.as<double>(), tab.as<double>(), s));
-            }
-            LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.s0, sl.delta, (int)zf, nreg, G, np, nb_, sl.nsl * 4,
-                                                np * np, s));                                       // Q = A'WA   src/lasso.jl:119
-            tr.mark("gram (structured)");
-            for (int64_t q = 0; q < ns; ++q) {   // q_s = A'W y_s for every signal sharing the window   :120
-                if (wnufft_rhs) {
-                    if (q >= 1 && q % 2 == 1)        // signals 1, 2 | 3, 4 | ... two to a pass
-                        LPVS_TRY(launch_nufft_window_spread(dt.p, Wdev, dys[(size_t)q].p, q + 1 < ns ? dys[(size_t)q + 1].p : nullptr, q + 1 < ns, offs.as<int64_t>(), nb_,
-                                                            n, sl.step.hi[1], sl.step.lo[1], nfg, wgrids.as<double>() + (1 + q) * 2 * (int64_t)nfg,
-                                                            wgrids.as<double>() + (2 + q) * 2 * (int64_t)nfg, gstride, s));
-                    LPVS_TRY(launch_nufft_window_modes(wgrids.as<double>() + (1 + q) * 2 * (int64_t)nfg, gstride, nb_, nfg, (int)(sl.s0 / 2), (int)sl.nf8,
-                                                       wscale_r.as<double>(), tabb.as<double>(), sl.nf8 * 4, s));
+        // Gram A' diag(Wd) A of every window of the pass -> Gdst ([nb_][np][np]) and right-hand sides A' diag(Wd) y_s -> bdst ([nprob][np])
+        auto build_gram = [&](const double *Wd, double *Gdst, double *bdst) -> int32_t {
+            if (ap) {
+                for (int q = 0; q < nb_; ++q)
+                    for (int c = 0; c < spw; ++c) {
+                        int64_t *e = hseg.data() + 3 * ((size_t)q * (size_t)spw + (size_t)c);
+                        e[0] = hoff[q] + (int64_t)c * rpcw;
+                        e[1] = std::min(hoff[q] + n, e[0] + rpcw);
+                        e[2] = hoff[q];
+                    }
+                LPVS_TRY(copy_to_device(seg.p, hseg.data(), sizeof(int64_t) * 3 * (size_t)nb_ * (size_t)spw, s));
+                LPVS_HIP(hipMemsetAsync(Gdst, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
+                LPVS_HIP(hipMemsetAsync(bdst, 0, vb, s));
+                const int64_t gstride = wcols * 2 * (int64_t)nfg;      // doubles per window in wgrids: [column][plain, x-weighted][nfg]
+                if (wnufft) {   // column 0 = the window weights alone (Gram); with it, in the same pass over the samples, signal 0
+                    LPVS_TRY(launch_nufft_window_spread(dt.p, Wd, nullptr, wnufft_rhs ? dys[0].p : nullptr, wnufft_rhs, offs.as<int64_t>(), nb_, n, sl.step.hi[1],
+                                                        sl.step.lo[1], nfg, wgrids.as<double>(), wgrids.as<double>() + 2 * (int64_t)nfg, gstride, s));
+                    LPVS_TRY(launch_nufft_window_modes(wgrids.as<double>(), gstride, nb_, nfg, 0, (int)sl.nsl, wscale_g.as<double>(), tab.as<double>(), sl.nsl * 4, s));
                 } else {
-                    LPVS_TRY(launch_nudft_windows(dt.p, dys[(size_t)q].p, Wdev, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, seg.as<int64_t>(),
-                                                  nb_, spw, npart.as<double>(), tabb.as<double>(), s));
+                    LPVS_TRY(launch_nudft_windows(dt.p, nullptr, Wd, sd.hi.as<double>(), sd.lo.as<double>(), (int)sl.nsl, sl.step, seg.as<int64_t>(), nb_, spw,
+                                                  npart.as<double>(), tab.as<double>(), s));
                 }
-                LPVS_TRY(launch_ap_rhs_fourier(tabb.as<double>(), wnufft_rhs ? wepsr.as<double>() : sd.eps.as<double>(), Nf, (int)zf, bvec.as<double>() + q * np, nb_,
-                                               sl.nf8 * 4, ns * np, s));
+                LPVS_TRY(launch_ap_assemble_fourier(tab.as<double>(), sd.eps.as<double>(), Nf, sl.s0, sl.delta, (int)zf, nreg, Gdst, np, nb_, sl.nsl * 4,
+                                                    np * np, s));                                       // Q = A'WA   src/lasso.jl:119
+                tr.mark("gram (structured)");
+                for (int64_t q = 0; q < ns; ++q) {   // q_s = A'W y_s for every signal sharing the window   :120
+                    if (wnufft_rhs) {
+                        if (q >= 1 && q % 2 == 1)        // signals 1, 2 | 3, 4 | ... two to a pass
+                            LPVS_TRY(launch_nufft_window_spread(dt.p, Wd, dys[(size_t)q].p, q + 1 < ns ? dys[(size_t)q + 1].p : nullptr, q + 1 < ns, offs.as<int64_t>(), nb_,
+                                                                n, sl.step.hi[1], sl.step.lo[1], nfg, wgrids.as<double>() + (1 + q) * 2 * (int64_t)nfg,
+                                                                wgrids.as<double>() + (2 + q) * 2 * (int64_t)nfg, gstride, s));
+                        LPVS_TRY(launch_nufft_window_modes(wgrids.as<double>() + (1 + q) * 2 * (int64_t)nfg, gstride, nb_, nfg, (int)(sl.s0 / 2), (int)sl.nf8,
+                                                           wscale_r.as<double>(), tabb.as<double>(), sl.nf8 * 4, s));
+                    } else {
+                        LPVS_TRY(launch_nudft_windows(dt.p, dys[(size_t)q].p, Wd, sd.rhi.as<double>(), sd.rlo.as<double>(), (int)sl.nf8, sl.step, seg.as<int64_t>(),
+                                                      nb_, spw, npart.as<double>(), tabb.as<double>(), s));
+                    }
+                    LPVS_TRY(launch_ap_rhs_fourier(tabb.as<double>(), wnufft_rhs ? wepsr.as<double>() : sd.eps.as<double>(), Nf, (int)zf, bdst + q * np, nb_,
+                                                   sl.nf8 * 4, ns * np, s));
+                }
+            } else {
+                LPVS_TRY(launch_window_panels(dt.p, offs.as<int64_t>(), nb_, n, nrows, df.p, Nf, (int)zf, P.as<double>(), ld, s));
+                tr.mark("panels");
+                LPVS_TRY(launch_gram_panel_batch(pl, nb_, P.as<double>(), nrows * ld, ld, Wd, slab.as<double>(), s));
+                tr.mark("gram");
+                LPVS_HIP(hipMemsetAsync(Gdst, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
+                LPVS_HIP(hipMemsetAsync(bdst, 0, vb, s));
+                LPVS_TRY(launch_gram_reduce_batch(pl, nb_, slab.as<double>(), Gdst, np, s));                  // Q = A'WA   src/lasso.jl:119
+                for (int64_t q = 0; q < ns; ++q)
+                    LPVS_TRY(launch_rhs_panel_batch(nb_, P.as<double>(), nrows * ld, ld, nreg, Wd, dys[(size_t)q].p, offs.as<int64_t>(), n,
+                                                    bdst + q * np, ns * np, scr.as<double>(), scr.bytes, s));   // q = A'Wy   :120
             }
-        } else {
-            LPVS_TRY(launch_window_panels(dt.p, offs.as<int64_t>(), nb_, n, nrows, df.p, Nf, (int)zf, P.as<double>(), ld, s));
-            tr.mark("panels");
-            LPVS_TRY(launch_gram_panel_batch(pl, nb_, P.as<double>(), nrows * ld, ld, Wdev, slab.as<double>(), s));
-            tr.mark("gram");
-            LPVS_HIP(hipMemsetAsync(G, 0, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, s));
-            LPVS_HIP(hipMemsetAsync(bvec.p, 0, vb, s));
-            LPVS_TRY(launch_gram_reduce_batch(pl, nb_, slab.as<double>(), G, np, s));                  // Q = A'WA   src/lasso.jl:119
-            for (int64_t q = 0; q < ns; ++q)
-                LPVS_TRY(launch_rhs_panel_batch(nb_, P.as<double>(), nrows * ld, ld, nreg, Wdev, dys[(size_t)q].p, offs.as<int64_t>(), n,
-                                                bvec.as<double>() + q * np, ns * np, scr.as<double>(), scr.bytes, s));   // q = A'Wy   :120
+            return LPVS_OK;
+        };
+        LPVS_TRY(build_gram(Wdev, G, bvec.as<double>()));
+        if (init) {
+            // x0 = fourier_solve(A, y, zerofreq, lam) = (A'A + lam^2 I) \ A'y per window and signal -- the UNWEIGHTED problem, whatever W is
+            // (src/lasso.jl:112 passes A and y, not Wd): with a window function its own Gram / right-hand sides, otherwise those just built
+            if (Wdev != nullptr) LPVS_TRY(build_gram(nullptr, Q0.as<double>(), b0.as<double>()));
+            else {
+                LPVS_HIP(hipMemcpyAsync(Q0.p, G, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, hipMemcpyDeviceToDevice, s));
+                LPVS_HIP(hipMemcpyAsync(b0.p, bvec.p, sizeof(double) * (size_t)np * (size_t)nprob, hipMemcpyDeviceToDevice, s));
+            }
+            LPVS_HIP(hipMemcpyAsync(M0.p, Q0.p, sizeof(double) * (size_t)np * (size_t)np * (size_t)nb_, hipMemcpyDeviceToDevice, s));
+            LPVS_TRY(launch_add_diag_batch(M0.as<double>(), np, nreg, a.lam * a.lam, nb_, s));
+            LPVS_TRY(spd_inverse_inplace_batch(M0.as<double>(), np, nb_, work.as<double>(), istat.as<int>(), s));
+            LPVS_HIP(hipMemcpyAsync(hist_.data(), istat.p, sizeof(int) * (size_t)nb_, hipMemcpyDeviceToHost, s));
+            LPVS_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < nb_; ++q)
+                if (hist_[q] != 0) { set_error("window %lld: init = true needs (A'A + %.3g I) positive definite", (long long)(win_lo + w0 + q), a.lam * a.lam); return LPVS_ENUMERIC; }
+            LPVS_TRY(launch_batch_ridge_solve(Q0.as<double>(), M0.as<double>(), np, nreg, nprob, (int)ns, b0.as<double>(), a.lam * a.lam, 2, x0buf.as<double>(),
+                                              z.as<double>(), u.as<double>(), s));   // (z, u: scratch here; the ADMM init below rewrites them)
+            tr.mark("init (ridge)");
         }
         LPVS_HIP(hipEventRecord(ev[0].b, s));
         if (sparse && a.linear_sign < 0) {  // Quadratic(Q, +q): the x-update's linear term is -q
@@ -1667,6 +1698,8 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
             AdmmBatch ab{M.as<double>(), np, nreg, nprob, bvec.as<double>(), x.as<double>(), z.as<double>(), u.as<double>(), rhs.as<double>(),
                          mu, tol, a.prox_kind, a.prox_param, a.group_len, status.as<AdmmStatus>(), part.as<double>(), Mp.as<double>(), (int)ns};
             ab.opt_iteration = jopt[LPVS_OPT_ITERATION]; ab.opt_nt_loads = jopt[LPVS_OPT_NT_LOADS];
+            ab.scratch = ballscr.p ? ballscr.as<double>() : nullptr;
+            ab.x0 = init ? x0buf.as<double>() : nullptr;
             // 6-byte storage of the packed inverses + offset form of the x-update, as for the single problems (admm.hip); only
             // where the tile-packed path runs at all (LPVS_M_STORAGE=f64: doubles)
             const bool split = split_storage && admm_batch_uses_tiles(ab);

@@ -231,7 +231,10 @@ template <int W>
 __global__ void __launch_bounds__(((W / 8) * (W / 8 + 1) / 2 + 63) / 64 * 64)
 pivot_inverse_kernel(const double *__restrict__ A, int64_t np, int64_t k0, double *__restrict__ P, int *status) {
     constexpr int G = W / 8, NBLK = G * (G + 1) / 2;
-    __shared__ double w[W];
+    // the published pivot column is double-buffered by pivot parity: ONE barrier per pivot (a thread that is done reading pivot p's
+    // column publishes pivot p+1's into the other buffer; nobody overwrites buffer p & 1 before the barrier of pivot p+1, which a
+    // thread reaches only after its reads of pivot p)
+    __shared__ double wbuf[2][W];
     const int t = threadIdx.x;
     const bool live = t < NBLK;
     int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -255,6 +258,7 @@ pivot_inverse_kernel(const double *__restrict__ A, int64_t np, int64_t k0, doubl
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
             const int p = 8 * pb + pp;
+            double *w = wbuf[pp & 1];            // (8 pivots per pb: the parity of p is the parity of pp)
             if (live && tj == pb) {            // block column pb: rows 8ti .. 8ti+7 of column p
 #pragma unroll
                 for (int a = 0; a < 8; ++a) w[8 * ti + a] = v[a][pp];
@@ -266,14 +270,13 @@ pivot_inverse_kernel(const double *__restrict__ A, int64_t np, int64_t k0, doubl
             const double d = w[p];
             if (t == 0 && !(d > 0)) atomicOr(status, 1);
             const double inv = 1.0 / d;
-            double rj[8];
+            double rj[8], wi[8];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) rj[b] = w[8 * tj + b] * inv;
+            for (int b = 0; b < 8; ++b) { rj[b] = w[8 * tj + b] * inv; wi[b] = w[8 * ti + b]; }
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-                const double wi = w[8 * ti + a];
 #pragma unroll
-                for (int b = 0; b < 8; ++b) v[a][b] = fma(-wi, rj[b], v[a][b]);
+                for (int b = 0; b < 8; ++b) v[a][b] = fma(-wi[a], rj[b], v[a][b]);
             }
             if (ti == pb) {                    // row p of the block
 #pragma unroll
@@ -281,10 +284,9 @@ pivot_inverse_kernel(const double *__restrict__ A, int64_t np, int64_t k0, doubl
             }
             if (tj == pb) {                    // column p of the block
 #pragma unroll
-                for (int a = 0; a < 8; ++a) v[a][pp] = w[8 * ti + a] * inv;
+                for (int a = 0; a < 8; ++a) v[a][pp] = wi[a] * inv;
             }
             if (ti == pb && tj == pb) v[pp][pp] = -inv;
-            __syncthreads();
         }
     }
     if (!live) return;
@@ -508,6 +510,216 @@ rank_update_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, 
             }
 }
 
+// ---- the tail of a pivot chain in ONE launch (kw = 128): gather + panel GEMM + write-back -------------------------------------
+// One workgroup = 16 matrix rows R0 .. R0+15 against all 128 pivot columns:
+//   S[q][r] = B[R0+r][q] (B = A[:, pivot columns] read from the lower triangle; zero in the pivot rows) through 16 KB of LDS,
+//   Bk[q][R] = S (k-major panel for the trailing update),  C' = P S on the matrix cores (wave w: pivot columns 32w .. 32w+31),
+//   Ck = -C',  A[:, k] = C (lower-triangle positions),  A_kk = -P.
+// 16 KB of LDS and < 128 registers: the kernel is resident NEXT TO two trailing-update workgroups of a CU (2 x 64 KB of LDS, 2 x ~190
+// registers per SIMD lane) instead of waiting for one of them to retire -- the separate gather (33 KB of LDS) and GEMM kernels took
+// 68 + 66 us of a step's pivot chain that way.  Rows above the pivot band are read as rows of A (coalesced as they stand); rows below
+// it are 1 KB row segments, transposed on the way into the LDS image (XOR swizzle: conflict-free both ways).
+__global__ void __launch_bounds__(256, 5)          // <= 96 registers: one of its waves fits a SIMD next to two trailing-update waves
+panel_fused_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, const double *__restrict__ P,
+                   double *__restrict__ Bk, double *__restrict__ Ck) {
+    constexpr int KWF = 128, RS = 16;
+    __shared__ __attribute__((aligned(16))) double S[KWF * RS];       // S[q][r ^ (q & 15)]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t R0 = (int64_t)blockIdx.x * RS;
+    const bool pad = R0 >= np, band = !pad && R0 >= k0 && R0 < k0 + KWF, low = !pad && R0 < k0;
+    if (pad || band) {
+        for (int e = tid; e < KWF * RS; e += 256) {                   // no contribution: zero panels
+            const int q = e >> 4, r = e & 15;
+            Bk[(int64_t)q * ldp + R0 + r] = 0.0; Ck[(int64_t)q * ldp + R0 + r] = 0.0;
+        }
+        if (band)
+            for (int e = tid; e < KWF * RS; e += 256) {               // A_kk = -P
+                const int r = e >> 7, c = e & 127;
+                A[(R0 + r) * np + k0 + c] = -P[(R0 + r - k0) * KWF + c];
+            }
+        return;
+    }
+    if (low) {                                                        // B[R][q] = A[k0+q][R]: rows of A are rows of the panel
+#pragma unroll
+        for (int i = 0; i < KWF * RS / 256; ++i) {
+            const int e = tid + 256 * i, q = e >> 4, r = e & 15;
+            S[q * RS + (r ^ (q & 15))] = A[(k0 + q) * np + R0 + r];
+        }
+    } else {                                                          // B[R][q] = A[R][k0+q]: 1 KB per row, transposed into S
+#pragma unroll
+        for (int i = 0; i < KWF * RS / 256; ++i) {
+            const int e = tid + 256 * i, r = e >> 7, q = e & 127;
+            S[q * RS + (r ^ (q & 15))] = A[(R0 + r) * np + k0 + q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KWF * RS / 256; ++i) {                        // the k-major panel of B
+        const int e = tid + 256 * i, q = e >> 4, r = e & 15;
+        Bk[(int64_t)q * ldp + R0 + r] = S[q * RS + (r ^ (q & 15))];
+    }
+    // C'[c][r] = sum_q P[c][q] S[q][r]:  A operand = P[q][c] (P symmetric: lanes walk c), B operand = S[q][r]
+    const int li = lane & 15, lk = lane >> 4;
+    f64x4 acc[2] = {(f64x4){0.0, 0.0, 0.0, 0.0}, (f64x4){0.0, 0.0, 0.0, 0.0}};
+    const double *pa = P + (int64_t)lk * KWF + 32 * wave + li;
+    constexpr int CH = 4;                                             // k-steps per chunk: two chunks in flight (P comes from L2)
+    double opA[2][CH][2];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) { opA[0][k][0] = pa[(int64_t)(4 * k) * KWF]; opA[0][k][1] = pa[(int64_t)(4 * k) * KWF + 16]; }
+#pragma unroll
+    for (int ch = 0; ch < 32 / CH; ++ch) {
+        if (ch + 1 < 32 / CH) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                opA[(ch + 1) & 1][k][0] = pa[(int64_t)(4 * (CH * (ch + 1) + k)) * KWF];
+                opA[(ch + 1) & 1][k][1] = pa[(int64_t)(4 * (CH * (ch + 1) + k)) * KWF + 16];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int q = 4 * (CH * ch + k) + lk;
+            const double b = S[q * RS + (li ^ (q & 15))];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[ch & 1][k][0], b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[ch & 1][k][1], b, acc[1], 0, 0, 0);
+        }
+    }
+    // D: col = lane & 15 = r, row = lk + 4 reg = pivot column within the 16-block
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Ck[(int64_t)(32 * wave + 16 * b + lk + 4 * rg) * ldp + R0 + li] = -acc[b][rg];   // the update adds A + (-C) B'
+    if (low) {                                                        // A[k0+c][R] = C[R][c]: coalesced as it stands
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) A[(k0 + 32 * wave + 16 * b + lk + 4 * rg) * np + R0 + li] = acc[b][rg];
+        return;
+    }
+    __syncthreads();                                                  // every wave is done reading S
+    // A[R][k0+c] = C[R][c]: through LDS as T[r][c ^ (2 r)] so that a row leaves as one 1 KB segment
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int c = 32 * wave + 16 * b + lk + 4 * rg;
+            S[li * KWF + (c ^ (2 * li))] = acc[b][rg];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KWF * RS / 256; ++i) {
+        const int e = tid + 256 * i, r = e >> 7, c = e & 127;
+        A[(R0 + r) * np + k0 + c] = S[r * KWF + (c ^ (2 * r))];
+    }
+}
+
+// ---- trailing update with TWO pivot panels in one pass (pairs of 128-wide steps) ------------------------------------------------
+// A tile receives  A += Ck1' Bk1 + Ck2' Bk2  (Ck = -C') in ONE read-modify-write: 256 pivots per pass instead of 128 -- half the
+// passes over A per flop (at depth 128 a step moves 0.54 GB for 8.6 GFLOP) and half the accumulator loads / stores per matrix
+// instruction.  Which panels a 64 x 64 block takes follows from where it lies: a block inside a panel's own pivot band (its row or
+// its column range is the band) is not touched by that panel; blocks inside `skip` bands are left to other launches.
+//   select = 0: every tile of the list;  1: the tiles of the bands [e0, e0 + 128 * nslices) enumerated directly (band launches).
+struct RuPanel { const double *Ck, *Bk; int64_t k0; int kw; };        // kw = 0: no such panel
+__global__ void __launch_bounds__(RU_THREADS, 2)
+rank_update2_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuPanel p1, RuPanel p2, const int2 *__restrict__ tiles, int ntiles,
+                    int select, int band_tile, int nslices, int64_t skipA0, int skipAw, int64_t skipB0, int skipBw) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave / RU_WN, wb = wave % RU_WN;
+    int2 tt;
+    if (select == 1) {
+        const int nr = (int)(np / RU_TM);
+        const int bsl = blockIdx.x / nr, e = blockIdx.x - bsl * nr, bt = band_tile + bsl;
+        if (bsl + 1 < nslices && e == bt + 1) return;               // tile (bt + 1, bt) belongs to the next slice
+        tt = e <= bt ? make_int2(bt, e) : make_int2(e, bt);
+    } else {
+        const int bq = ntiles / 8, br = ntiles % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;
+        const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
+        tt = tiles[item];
+    }
+    const int64_t a0 = (int64_t)tt.x * RU_TM, b0 = (int64_t)tt.y * RU_TN;
+    auto in_band = [&](int64_t lo, int64_t start, int64_t width) { return width > 0 && lo >= start && lo < start + width; };
+    // (tile level: bands are 128-aligned, so the four 64 x 64 blocks of a tile share these answers)
+    if (in_band(a0, skipA0, skipAw) || in_band(b0, skipA0, skipAw) || in_band(a0, skipB0, skipBw) || in_band(b0, skipB0, skipBw)) return;
+    const bool use1 = p1.kw > 0 && !in_band(a0, p1.k0, p1.kw) && !in_band(b0, p1.k0, p1.kw);
+    const bool use2 = p2.kw > 0 && !in_band(a0, p2.k0, p2.kw) && !in_band(b0, p2.k0, p2.kw);
+    if (!use1 && !use2) return;
+    const int64_t r_lo = a0 + wa * 64, c_lo = b0 + wb * 64;
+    const bool skip_wave = c_lo > r_lo + 63 || c_lo >= np;          // above the diagonal: nothing to maintain
+    // the stages of this tile: panel 1's pivots (if it applies), then panel 2's
+    const int n1s = use1 ? p1.kw / RU_BK : 0, nstages = n1s + (use2 ? p2.kw / RU_BK : 0);
+
+    constexpr int ROW = RU_TM + RU_TN, STAGE = RU_BK * ROW;
+    double *buf0 = lds, *buf1 = lds + STAGE;
+    auto stage_load = [&](double *buf, int st) {
+        const bool first = st < n1s;
+        const double *Ck = first ? p1.Ck : p2.Ck, *Bk = first ? p1.Bk : p2.Bk;
+        const int s0 = (first ? st : st - n1s) * RU_BK;
+        for (int p = wave; p < RU_BK * 2; p += RU_THREADS / 64) {     // piece = (pivot, part): 128 panel values
+            const int k = p >> 1, part = p & 1;
+            const double *src = part == 0 ? Ck + (int64_t)(s0 + k) * ldp + a0 : Bk + (int64_t)(s0 + k) * ldp + b0;
+            glds16(src + 2 * lane, buf + p * 128);
+        }
+    };
+    const int li = lane & 15, lk = lane >> 4;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { offA[t] = wa * 64 + t * 16 + li; offB[t] = RU_TM + wb * 64 + t * 16 + li; }
+    stage_load(buf0, 0);
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r_lo + i * 16 + lk + 4 * r, col = c_lo + j * 16 + li;
+                acc[i][j][r] = (!skip_wave && col <= row) ? A[row * np + col] : 0.0;
+            }
+    __syncthreads();
+    double rA[4], rB[4];
+    auto fetch = [&](const double *img, int kk) {
+        const double *row = img + (kk * 4 + lk) * ROW;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { rA[t] = row[offA[t]]; rB[t] = row[offB[t]]; }
+    };
+#pragma unroll 1
+    for (int s = 0; s < nstages; ++s) {
+        double *cur = (s & 1) ? buf1 : buf0, *nxt = (s & 1) ? buf0 : buf1;
+        if (s + 1 < nstages) stage_load(nxt, s + 1);
+        if (!skip_wave) {
+            fetch(cur, 0);
+#pragma unroll
+            for (int kk = 0; kk < RU_BK / 4; ++kk) {
+                double opA[4], opB[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { opA[t] = rA[t]; opB[t] = rB[t]; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < RU_BK / 4) fetch(cur, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    if (skip_wave) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r_lo + i * 16 + lk + 4 * r, col = c_lo + j * 16 + li;
+                if (col <= row) A[row * np + col] = acc[i][j][r];
+            }
+}
+
 // diag(M) += shift on the valid part; the pad block becomes the identity
 __global__ void __launch_bounds__(256) add_diag_kernel(double *__restrict__ Mall, int64_t np, int64_t n, double shift) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -623,10 +835,25 @@ int32_t SweepAux::ensure() {
     LPVS_HIP(hipEventCreateWithFlags(&rest, hipEventDisableTiming));
     LPVS_HIP(hipEventCreateWithFlags(&band, hipEventDisableTiming));
     LPVS_HIP(hipEventCreateWithFlags(&second, hipEventDisableTiming));
+    LPVS_HIP(hipEventCreateWithFlags(&bulkdone, hipEventDisableTiming));
+    // The pair schedule's trailing updates fill every CU with two workgroups of ~208 registers per lane: the one-workgroup pivot
+    // inverse (304 registers per lane) then waits for a workgroup to retire, and once resident shares its SIMDs with a stream of f64
+    // matrix instructions that its own vector instructions cannot overlap (measured: 235 us instead of 80).  The updates therefore run
+    // on a stream whose CU mask leaves a few CUs (LPVS_RESERVE_CUS, default 8 of 256; 0 = no mask) to the side stream's chains.
+    const int reserve = [] { const char *e = getenv("LPVS_RESERVE_CUS"); return e ? atoi(e) : 8; }();
+    int dev = 0, cus = 0;
+    if (reserve > 0 && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        cus > 4 * reserve) {
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+        for (int c = reserve; c < cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+        if (hipExtStreamCreateWithCUMask(&bulk, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); bulk = nullptr; }
+    }
     return LPVS_OK;
 }
 SweepAux::~SweepAux() {
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (bulk) { (void)hipStreamSynchronize(bulk); (void)hipStreamDestroy(bulk); }
+    if (bulkdone) (void)hipEventDestroy(bulkdone);
     if (panel) (void)hipEventDestroy(panel);
     if (rest) (void)hipEventDestroy(rest);
     if (band) (void)hipEventDestroy(band);
@@ -683,6 +910,79 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
         hipLaunchKernelGGL(rank_update_kernel, dim3(grid), dim3(RU_THREADS), lds, st, A, np, ldp, k0,
                            kw, Ck, Bk, tiles, (int)ht.size(), which, n0, nw, band_tile, n1, nw1);
     };
+
+    // ---- pairs of 128-wide steps: the trailing update takes TWO panels per pass (rank_update2_kernel) -----------------------------
+    // Per pair p (pivot blocks k1 = 2p, k2 = 2p + 1; n1, n2 the next pair's):
+    //   side:  band k2 += panel k1  ->  chain k2  ->  [event panelB]          ... [wait prio]  chain n1  ->  [event panelA]
+    //   main:  [wait panelB]  bands n1, n2 += panels k1, k2 (the next pair's pivot bands first)  ->  [event prio]  ->  every other tile
+    // Band k2's tiles received the earlier panels as "bands n1, n2" of the previous pair; a tile inside band k1 takes panel k2 only,
+    // a tile inside band k2 panel k1 only (that is the side stream's band launch) -- rank_update2_kernel decides per tile.  Panels
+    // rotate through four slots: chain n1 of pair p writes slot (2p + 2) & 3 = pair p - 1's first slot, whose last reader (the
+    // update of pair p - 1) precedes this pair's priority launch on the main stream, which the chain waits for.
+    const bool pairs_on = [] { const char *e = getenv("LPVS_FACTOR_SCHEME"); return !(e && std::string(e) == "steps"); }();
+    const bool fused_chain = [] { const char *e = getenv("LPVS_CHAIN"); return !(e && std::string(e) == "split"); }();
+    if (la && pairs_on && single_wg_pivot && kw_outer == 128 && np >= 2048 && np % 128 == 0 && ldp == np) {
+        hipStream_t side = aux->side;
+        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rank_update2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        auto slotB = [&](int64_t k0) { return work + ((k0 / 128) & 3) * (2 * 128 * ldp); };
+        auto slotC = [&](int64_t k0) { return slotB(k0) + 128 * ldp; };
+        auto chain128 = [&](int64_t k0, hipStream_t st) {
+            hipLaunchKernelGGL(pivot_inverse_kernel<128>, dim3(1), dim3(192), 0, st, A, np, k0, P, status_dev);
+            if (fused_chain) {
+                hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(ldp / 16)), dim3(256), 0, st, A, np, ldp, k0, (const double *)P, slotB(k0), slotC(k0));
+            } else {
+                hipLaunchKernelGGL(panel_gather_kernel, dim3((unsigned)(ldp / 64)), dim3(256), 0, st, A, np, ldp, k0, 128, slotB(k0));
+                hipLaunchKernelGGL(panel_gemm_kernel, dim3((unsigned)(ldp / 64)), dim3(256), 0, st, A, np, ldp, k0, 128, P, slotB(k0), slotC(k0));
+            }
+        };
+        auto panel = [&](int64_t k0) { return k0 < np ? RuPanel{slotC(k0), slotB(k0), k0, 128} : RuPanel{nullptr, nullptr, 0, 0}; };
+        const int nr = (int)(np / RU_TM);
+        auto update_bands = [&](hipStream_t st, int64_t e0, int nsl, RuPanel a, RuPanel b, int64_t skip0, int skipw) {
+            hipLaunchKernelGGL(rank_update2_kernel, dim3((unsigned)(nr * nsl)), dim3(RU_THREADS), lds, st, A, np, ldp, a, b, tiles, (int)ht.size(), 1,
+                               (int)(e0 / RU_TM), nsl, skip0, skipw, (int64_t)0, 0);
+        };
+        auto update_rest = [&](hipStream_t st, RuPanel a, RuPanel b, int64_t sA0, int sAw, int64_t sB0, int sBw) {
+            hipLaunchKernelGGL(rank_update2_kernel, dim3((unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, a, b, tiles, (int)ht.size(), 0,
+                               0, 0, sA0, sAw, sB0, sBw);
+        };
+        hipStream_t mb = aux->bulk ? aux->bulk : s;             // the trailing updates' stream (CU-masked: see SweepAux::ensure)
+        LPVS_HIP(hipEventRecord(aux->rest, s));                 // A is ready on the caller's stream
+        LPVS_HIP(hipStreamWaitEvent(side, aux->rest, 0));
+        if (mb != s) LPVS_HIP(hipStreamWaitEvent(mb, aux->rest, 0));
+        chain128(0, side);
+        LPVS_HIP(hipEventRecord(aux->panel, side));             // panelA
+        for (int64_t k1 = 0; k1 < np; k1 += 256) {
+            const int64_t k2 = k1 + 128, n1 = k1 + 256;
+            if (k2 >= np) {                                      // an odd last step: one panel, every tile outside its band
+                LPVS_HIP(hipStreamWaitEvent(mb, aux->panel, 0));
+                update_rest(mb, panel(k1), panel(np), 0, 0, 0, 0);
+                break;
+            }
+            update_bands(side, k2, 1, panel(k1), panel(np), 0, 0);      // band k2 += panel k1 (its tile inside band k1 is dead)
+            chain128(k2, side);
+            LPVS_HIP(hipEventRecord(aux->band, side));          // panelB (implies panelA: same stream)
+            LPVS_HIP(hipStreamWaitEvent(mb, aux->band, 0));
+            const int nsl = n1 >= np ? 0 : (n1 + 256 <= np ? 2 : 1);
+            if (nsl > 0) {
+                update_bands(mb, n1, nsl, panel(k1), panel(k2), k2, 128);    // the next pair's pivot bands first (band k2 is the side stream's)
+                LPVS_HIP(hipEventRecord(aux->second, mb));      // prio
+            }
+            update_rest(mb, panel(k1), panel(k2), k2, 128, n1, 128 * nsl);
+            if (nsl > 0) {
+                LPVS_HIP(hipStreamWaitEvent(side, aux->second, 0));
+                chain128(n1, side);
+                LPVS_HIP(hipEventRecord(aux->panel, side));     // panelA of the next pair
+            }
+            LPVS_HIP(hipGetLastError());
+        }
+        if (mb != s) {
+            LPVS_HIP(hipEventRecord(aux->bulkdone, mb));
+            LPVS_HIP(hipStreamWaitEvent(s, aux->bulkdone, 0));
+        }
+        LPVS_HIP(hipEventRecord(aux->rest, side));              // neither helper stream has anything pending when the caller goes on
+        LPVS_HIP(hipStreamWaitEvent(s, aux->rest, 0));
+        return LPVS_OK;
+    }
 
     if (!la) {
         for (int64_t k0 = 0; k0 < np; k0 += kw_outer) {

@@ -167,7 +167,8 @@ int32_t launch_ap_rhs(const double *tab, const double *eps, int64_t Nf, int64_t 
 // (high-priority) stream while the bulk of the current trailing update runs on the caller's stream.
 struct SweepAux {
     hipStream_t side = nullptr;
-    hipEvent_t panel = nullptr, rest = nullptr, band = nullptr, second = nullptr;
+    hipStream_t bulk = nullptr;   // trailing updates of the pair schedule: a stream whose CU mask leaves a few CUs to the pivot chains (or nullptr)
+    hipEvent_t panel = nullptr, rest = nullptr, band = nullptr, second = nullptr, bulkdone = nullptr;
     int32_t ensure();
     ~SweepAux();
 };
@@ -257,6 +258,8 @@ struct AdmmBatch {
     long long fi_base = 0;
     int fi_prefetch_all = 0;
     int opt_iteration = 0, opt_nt_loads = 0;   // LPVS_OPT_ITERATION / LPVS_OPT_NT_LOADS of the call (0: thread default / environment)
+    double *scratch = nullptr;                 // IndBallL0 with n > 8192: 2 * np doubles per problem (selection keys), else unused
+    const double *x0 = nullptr;                // init = true: the starting point of every problem ([nbatch][np]); nullptr: zeros
 };
 bool fi_batch_applicable(const AdmmBatch &p);
 int32_t launch_fi_batch_setup(const AdmmBatch &p, hipStream_t s);   // constants and the records of iteration 0 (after launch_admm_batch_init)

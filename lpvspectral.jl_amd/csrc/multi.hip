@@ -244,6 +244,83 @@ int32_t lpvs_windows_estimate_multi_f64(const double *Y, int64_t ns, const doubl
                                   linear_sign, devices, ngpus, x_re, x_im, iters_out, false);
 }
 
+// ---- multichannel LPV batches over several devices (SURVEY.md section 8(b)(4) "lpvs_lpv_batch", BASELINE.json config 5) ------------------
+// ns channels sharing (X, V, w): contiguous channel ranges go to the devices, one host thread per device builds ITS shard's handle
+// (one Gram / factorisation per device, every ADMM kernel advances the shard's channels in one pass over the inverse), runs the
+// iterations and writes the shard's columns of the outputs.  No data-path collective; the coefficients (ns x Nf*Nv complex) come back
+// through each device's own copy engine -- a host-process API returns host arrays, there is nothing to gather onto one device first.
+int32_t lpvs_lpv_batch_multi_f64(const double *Y, int64_t ns, const double *X, const double *V, int64_t N, const double *w, int64_t Nf,
+                                 int64_t Nv, int32_t normalize, int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
+                                 int64_t iters, const int32_t *devices, int32_t ngpus, double *re_out, double *im_out, int64_t *iters_out) {
+    if (!Y || !X || !V || !w || !re_out || !im_out || ns < 1 || N < 1 || Nf < 1 || Nv < 1) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    if (is_device_ptr(re_out) || is_device_ptr(im_out)) { set_error("lpvs_lpv_batch_multi: outputs are host arrays"); return LPVS_EARGUMENT; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    struct DeviceRestore { int dev = -1; DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
+                           ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore_device;
+    if (ngpus <= 0) ngpus = count;
+    if (ngpus > count && devices == nullptr) { set_error("ngpus = %d but %d device(s) visible", ngpus, count); return LPVS_EDEVICE; }
+    if ((int64_t)ngpus > ns) ngpus = (int32_t)ns;                 // no more shards than channels
+    std::vector<int> devs((size_t)ngpus);
+    for (int r = 0; r < ngpus; ++r) {
+        devs[(size_t)r] = devices ? devices[r] : r;
+        if (devs[(size_t)r] < 0 || devs[(size_t)r] >= count) { set_error("device %d out of range [0,%d)", devs[(size_t)r], count); return LPVS_EDEVICE; }
+    }
+    std::vector<double> hY, hX, hV, hw;
+    auto host_of = [&](const double *p, int64_t cnt, std::vector<double> &stage) -> const double * {
+        if (!is_device_ptr(p)) return p;
+        stage.resize((size_t)cnt);
+        if (hipMemcpy(stage.data(), p, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return stage.data();
+    };
+    const double *Yh = host_of(Y, N * ns, hY), *Xh = host_of(X, N, hX), *Vh = host_of(V, N, hV), *wh = host_of(w, Nf, hw);
+    if (!Yh || !Xh || !Vh || !wh) { set_error("staging of device arguments failed"); return LPVS_EDEVICE; }
+    const int64_t m = Nf * Nv;                                    // complex parameters per channel
+    struct ChShard { int device; int64_t lo, hi; int32_t rc = LPVS_OK; std::string err; };
+    std::vector<ChShard> sh((size_t)ngpus);
+    const int64_t base = ns / ngpus, rem = ns % ngpus;
+    for (int r = 0; r < ngpus; ++r) {
+        sh[(size_t)r].device = devs[(size_t)r];
+        sh[(size_t)r].lo = r * base + (r < rem ? r : rem);
+        sh[(size_t)r].hi = sh[(size_t)r].lo + base + (r < rem ? 1 : 0);
+    }
+    int copt[kOptCount];
+    capture_default_options(copt);
+    auto work = [&](int r) {
+        ChShard &S = sh[(size_t)r];
+        const int64_t cnt = S.hi - S.lo;
+        for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, copt[o]);   // the caller's default options on this worker thread
+        lpvs_problem *h = nullptr;
+        auto fail = [&](int32_t rc) { S.rc = rc; S.err = lpvs_last_error(); if (h) lpvs_problem_destroy(h); };
+        int32_t rc = lpvs_problem_create_lpv_multi_f64(Yh + S.lo * N, cnt, Xh, Vh, N, wh, Nf, Nv, normalize, 0, S.device, &h);
+        if (rc != LPVS_OK) return fail(rc);
+        if ((rc = lpvs_problem_set_prox(h, prox_kind, prox_param, group_len)) != LPVS_OK) return fail(rc);
+        if ((rc = lpvs_admm_init_f64(h, nullptr, mu, tol, LPVS_LINEAR_LEAST_SQUARES)) != LPVS_OK) return fail(rc);
+        int64_t done = 0; double nxz = 0; int32_t conv = 0;
+        if ((rc = lpvs_admm_run(h, iters, &done, &nxz, &conv)) != LPVS_OK) return fail(rc);
+        if ((rc = lpvs_problem_get_params_f64(h, 0, re_out + S.lo * m, im_out + S.lo * m)) != LPVS_OK) return fail(rc);
+        if (iters_out)
+            for (int64_t q = 0; q < cnt; ++q) {
+                int64_t it = 0;
+                if ((rc = lpvs_admm_status(h, q, &it, nullptr, nullptr)) != LPVS_OK) return fail(rc);
+                iters_out[S.lo + q] = it;
+            }
+        lpvs_problem_destroy(h);
+    };
+    if (ngpus == 1) {
+        int saved[kOptCount];
+        capture_default_options(saved);
+        work(0);
+        for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, saved[o]);
+    } else {
+        std::vector<std::thread> th_;
+        for (int r = 0; r < ngpus; ++r) th_.emplace_back(work, r);
+        for (auto &q : th_) q.join();
+    }
+    for (auto &S : sh) if (S.rc != LPVS_OK) { set_error("device %d (channels [%lld,%lld)): %s", S.device, (long long)S.lo, (long long)S.hi, S.err.c_str()); return S.rc; }
+    return LPVS_OK;
+}
+
 // Float32 records (host or device): widened on the host, float grids snapped to their progression, coefficients returned as floats
 int32_t lpvs_windows_estimate_multi_f32(const float *Y, int64_t ns, const float *t, int64_t L, int64_t n, int64_t noverlap,
                                         const float *W, const float *freqs, int64_t Nf, int32_t estimator, double lam,

@@ -190,3 +190,44 @@ def test_mixed_vs_split_windows(L, monkeypatch):
     for st in ("mixed", "split"):
         assert np.array_equal(out[st][1], out["f64"][1])
         assert rel(out[st][0], out["f64"][0]) <= 1e-9, (st, rel(out[st][0], out["f64"][0]))
+
+
+@pytest.mark.parametrize("zero", [True, False])
+def test_indball_and_init_through_the_engine_vs_oracle(L, oracle, zero):
+    """The two estimator options that used to fall back to the sequential loop now run in the batch: proxg = IndBallL0(r)
+    (README.md:79-83: one workgroup per window selects its r largest) and init = true (src/lasso.jl:112: x0 = fourier_solve(A, y,
+    zerofreq, lam), the UNWEIGHTED ridge solution whatever the window function).  Per window against oracle.admm_quadratic on the
+    window's own Q, q (read back from a single-window handle) started from the oracle's own fourier_solve, and against the
+    sequential device loop."""
+    from lpvspectral_jl_amd import api
+    y, u, t, f = two_signals(4000, 21, zero)
+    n, noverlap, k = 500, 0, 8
+    W = L.hanning(n)
+    nreg = 2 * len(f) - (1 if zero else 0)
+    for name, proxg, oproxg, init in (("ball", L.IndBallL0(6), oracle.IndBallL0(6), False), ("ball+init", L.IndBallL0(6), oracle.IndBallL0(6), True),
+                                      ("l1+init", L.NormL1(0.5), oracle.NormL1(0.5), True)):
+        kw = dict(λ=0.7, proxg=proxg, μ=0.05, tol=0.0, iters=400, init=init)
+        eng = api._engine_args(L.ls_sparse_spectral, kw, nreg)
+        assert eng is not None and eng["estimator"] == (3 if init else 1), eng
+        x, its = api.windows_estimate([y], t, f, n, noverlap, W, eng)
+        assert x.shape == (1, k, len(f)) and np.all(its == 400)
+        for i in range(k):
+            yi, ti = y[i * n:(i + 1) * n], t[i * n:(i + 1) * n]
+            with L.Problem.fourier(yi, ti, f, W) as p:
+                Q, q = p.get_gram()
+            x0 = None
+            if init:
+                A, zf = oracle.get_fourier_regressor(ti, f)
+                p0 = oracle.fourier_solve(A, yi, zf, 0.7)                     # UNWEIGHTED, as written
+                x0 = np.concatenate([p0.real, p0.imag[1:] if zf else p0.imag])
+            ro = oracle.admm_quadratic(Q, q, oproxg, x0=x0, iters=400, tol=0.0, mu=0.05)
+            zo = oracle.fourier2complex(ro["z"], 1 if zero else None)
+            assert rel(x[0, i], zo) <= 1e-8, (name, i, rel(x[0, i], zo))
+            assert np.array_equal(x[0, i] != 0, zo != 0), (name, i)
+            if "ball" in name:
+                assert np.count_nonzero(ro["z"]) == 6
+        # the drivers take the engine for these keywords now, and agree with the reference's sequential loop on the device
+        S, _ = L.ls_windowpsd(y, t, f, nw=k, noverlap=0, window_func=L.hanning, estimator=L.ls_sparse_spectral, **kw)
+        assert api.windowpsd_last_timing()["windows"] == k
+        Sseq, _ = L.ls_windowpsd(y, t, f, nw=k, noverlap=0, window_func=L.hanning, estimator=L.ls_sparse_spectral, batched=False, printerval=100000, **kw)
+        assert rel(S, Sseq) <= 1e-8, (name, rel(S, Sseq))
