@@ -372,6 +372,26 @@ function ls_sparse_spectral_lpv(y::AbstractVector{S}, X::AbstractVector{S}, V::A
     end
 end
 
+# Multichannel batch over several devices (extension; BASELINE.json config 5): the columns of Y (N x ns) share X, V, w; contiguous
+# channel ranges go to `ngpus` devices driven by this one process (ngpus = 0: every visible device).  proxg = nothing gives the
+# reference's frequency-grouped lasso (src/lasso.jl:53-55) per channel.  Returns a Vector of SpectralExt.
+function ls_sparse_spectral_lpv(Y::AbstractMatrix{S}, X::AbstractVector{S}, V::AbstractVector{S}, w, Nv::Integer;
+                                λ=1, normalize=true, proxg=nothing, iters=10000, tol=1e-5, μ=0.05, ngpus=0) where S
+    @assert 0 ≤ μ ≤ 1 "μ should be ≤ 1"
+    w = w[:]
+    Ym = Matrix{Float64}(Y); Xv, Vv, wv = dense(Float64, X), dense(Float64, V), dense(Float64, w)
+    N, ns = size(Ym); Nf = length(wv); m = Nf * Nv
+    @assert N == length(Xv) == length(Vv) "Y, X and V has to have the same number of samples"
+    pp = proxg === nothing ? (Int32(4), Float64(λ), Int64(2Nv)) : proxparams(proxg, 2Nf * Nv)
+    pp === nothing && throw(ArgumentError("proxg of type $(typeof(proxg)) has no device kernel"))
+    re, im_ = zeros(m, ns), zeros(m, ns); its = zeros(Int64, ns)
+    GC.@preserve Ym Xv Vv wv re im_ its check(@ccall LIB.lpvs_lpv_batch_multi_f64(Ym::Ptr{Float64}, Int64(ns)::Int64, Xv::Ptr{Float64}, Vv::Ptr{Float64},
+        Int64(N)::Int64, wv::Ptr{Float64}, Int64(Nf)::Int64, Int64(Nv)::Int64, Int32(normalize)::Int32, pp[1]::Int32, pp[2]::Float64, pp[3]::Int64,
+        Float64(μ)::Float64, Float64(tol)::Float64, Int64(iters)::Int64, C_NULL::Ptr{Int32}, Int32(ngpus)::Int32, re::Ptr{Float64}, im_::Ptr{Float64},
+        its::Ptr{Int64})::Int32)
+    [SpectralExt(Ym[:, q], X, V, w, Nv, λ, false, normalize, complex.(re[:, q], im_[:, q]), nothing) for q in 1:ns]
+end
+
 function ls_spectral_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer;
                          λ=1e-8, coulomb=false, normalize=true, device=0, covariance=true)   # src/lsfft.jl:239-259
     w = w[:]

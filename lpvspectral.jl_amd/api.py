@@ -730,6 +730,32 @@ def ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, λ=1, normalize=True, device=0,
             for q in range(ns)]
 
 
+def lpv_batch_multi(Y, X, V, w, Nv, proxg=None, λ=1, normalize=True, μ=0.05, tol=1e-5, iters=10000, ngpus=0, devices=None):
+    """``lpvs_lpv_batch_multi_f64``: the channels (columns of ``Y``, N x ns) split into contiguous ranges over ``ngpus`` devices driven
+    by this one process (a host thread per device: one Gram / factorisation per device, its channels advanced together).  Returns
+    ``(params [Nf*Nv x ns complex], iters [ns])``; no progress lines / callbacks (use :func:`ls_sparse_spectral_lpv_multi` per device
+    for those)."""
+    assert 0 <= μ <= 1, "μ should be ≤ 1"                             # src/lasso.jl:143
+    w = _host_vec(w).astype(np.float64)
+    Yh = np.asfortranarray(_host(Y))
+    N, ns = Yh.shape
+    Xh, Vh = np.ascontiguousarray(_host(X)), np.ascontiguousarray(_host(V))
+    assert N == len(Xh) == len(Vh), "Y, X and V has to have the same number of samples"
+    Nf, Nv = len(w), int(Nv)
+    g = SlicedSeparableSum.frequency_groups(λ, Nf, 2 * Nv) if proxg is None else proxg
+    kind, param, glen = g.device_params(2 * Nf * Nv)
+    dv = None if devices is None else np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+    if dv is not None:
+        ngpus = len(dv)
+    m = Nf * Nv
+    re, im = np.zeros((m, ns), order="F"), np.zeros((m, ns), order="F")
+    its = np.zeros(ns, dtype=np.int64)
+    check(lib().lpvs_lpv_batch_multi_f64(out_ptr(Yh), ns, out_ptr(Xh), out_ptr(Vh), N, out_ptr(w), Nf, Nv, int(bool(normalize)), int(kind), float(param),
+                                         int(glen), float(μ), float(tol), int(iters), None if dv is None else out_ptr(dv), int(ngpus),
+                                         out_ptr(re), out_ptr(im), out_ptr(its)))
+    return re + 1j * im, its
+
+
 def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, device=0, covariance=True):
     """``ls_spectral_lpv(Y,X,V,w,Nv; λ, coulomb, normalize)`` (src/lsfft.jl:239-259) -> :class:`SpectralExt`.
 

@@ -302,6 +302,133 @@ pivot_inverse_kernel(const double *__restrict__ A, int64_t np, int64_t k0, doubl
         }
 }
 
+// ---- the same inverse on the matrix cores: 16 x 16 sub-blocks, the lower triangle's 36 blocks as accumulators in registers -------
+// The register kernel above spends ~1.1 us per pivot (two LDS round trips and 64 dependent FMAs per thread and pivot: 147 us for
+// 128 pivots once the trailing update keeps every other CU's matrix pipe busy).  Here the SAME blocked sweep that the large matrix
+// uses is applied inside the pivot block with 16-wide sub-blocks: per sub-step k
+//   publish the column panel B = S[:, k] and the pivot sub-block D = S_kk (LDS, 17-double rows: conflict-free operand reads),
+//   P = D^-1 by ONE wave (16 symmetric sweeps through lane shuffles: lane (r, q) holds D[r][4q .. 4q+3]),
+//   C = B P on the owners of the panel's blocks (4 MFMAs each; block (k, j), j < k, takes the transposed product P B_j'),
+//   S_ij -= C_i B_j' on the owners of the other blocks (4 MFMAs each),  S_kk = -P.
+// Wave w owns blocks b = w, w + 4, ... (b = i (i + 1) / 2 + j): nine f64x4 accumulators that never leave its registers.  ~140
+// matrix instructions and one 16 x 16 inverse per sub-step instead of 16 x (2 barriers + 64 FMAs).  After 8 sub-steps the blocks
+// hold -inv(A_kk); negated and mirrored on the way out (exactly symmetric).  status |= 1 on a non-positive pivot.
+__global__ void __launch_bounds__(256)
+pivot_inverse_mfma_kernel(const double *__restrict__ A, int64_t np, int64_t k0, double *__restrict__ P, int *status) {
+    constexpr int W = 128, NB16 = W / 16, PS = 17, NOWN = 9;
+    __shared__ double Bp[W * PS], Cn[W * PS], Db[16 * PS], Pb[16 * PS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    f64x4 acc[NOWN];
+    int bi[NOWN], bj[NOWN];
+#pragma unroll
+    for (int n = 0; n < NOWN; ++n) {
+        const int b = wave + 4 * n;
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= b) ++i;                       // (scalar: b is wave-uniform)
+        bi[n] = i; bj[n] = b - i * (i + 1) / 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = 16 * bi[n] + lk + 4 * r, col = 16 * bj[n] + li;
+            if (col > row) { const int t = row; row = col; col = t; }   // diagonal blocks: only the lower triangle of A is current
+            acc[n][r] = A[(k0 + row) * np + k0 + col];
+        }
+    }
+    for (int k = 0; k < NB16; ++k) {
+        // ---- publish the column panel B[R][q] = S[R][16k + q] (R outside the pivot rows) and the pivot sub-block
+#pragma unroll
+        for (int n = 0; n < NOWN; ++n) {
+            if (bi[n] == k && bj[n] == k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Db[(lk + 4 * r) * PS + li] = acc[n][r];
+            } else if (bj[n] == k) {                                  // block (i, k), i > k: rows of the panel as they stand
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Bp[(16 * bi[n] + lk + 4 * r) * PS + li] = acc[n][r];
+            } else if (bi[n] == k) {                                  // block (k, j), j < k: S[16k + q][16j + c] = B[16j + c][q]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Bp[(16 * bj[n] + li) * PS + lk + 4 * r] = acc[n][r];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // P = D^-1: the symmetric sweep operator applied 16 times, lane (r = lane & 15, qg = lane >> 4) holds D[r][4qg .. 4qg+3]
+            const int r = li, qg = lk;
+            double e[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) e[m] = Db[r * PS + 4 * qg + m];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int ps = p & 3, pq = p >> 2;
+                double prow[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) prow[m] = __shfl(e[m], p + 16 * qg, 64);   // D[p][4qg + m]
+                const double pcol = __shfl(e[ps], r + 16 * pq, 64);                     // D[r][p]
+                const double d = __shfl(e[ps], p + 16 * pq, 64);                        // D[p][p]
+                if (lane == 0 && !(d > 0)) atomicOr(status, 1);
+                const double inv = 1.0 / d, ci = pcol * inv;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int c = 4 * qg + m;
+                    double nv = fma(-ci, prow[m], e[m]);
+                    if (r == p) nv = prow[m] * inv;
+                    if (c == p) nv = ci;
+                    if (r == p && c == p) nv = -inv;
+                    e[m] = nv;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) Pb[r * PS + 4 * qg + m] = -e[m];                // the sweeps leave -D^-1
+        }
+        __syncthreads();
+        // ---- the panel's blocks: C = B P (and S_kk = -P); the negated panel Cn[R][q] = -C[R][q] goes to LDS for the update
+#pragma unroll
+        for (int n = 0; n < NOWN; ++n) {
+            if (bi[n] == k && bj[n] == k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[n][r] = -Pb[(lk + 4 * r) * PS + li];
+            } else if (bj[n] == k) {                                  // (i, k): C_i[r][c] = sum_q B[16i + r][q] P[q][c]
+                f64x4 c = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(Bp[(16 * bi[n] + li) * PS + 4 * kk + lk], Pb[(4 * kk + lk) * PS + li], c, 0, 0, 0);
+                acc[n] = c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cn[(16 * bi[n] + lk + 4 * r) * PS + li] = -c[r];
+            } else if (bi[n] == k) {                                  // (k, j): new[r][c] = C[16j + c][r] = sum_q P[r][q] B[16j + c][q]
+                f64x4 c = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(Pb[li * PS + 4 * kk + lk], Bp[(16 * bj[n] + li) * PS + 4 * kk + lk], c, 0, 0, 0);
+                acc[n] = c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cn[(16 * bj[n] + li) * PS + lk + 4 * r] = -c[r];
+            }
+        }
+        __syncthreads();
+        // ---- every other block: S_ij += (-C_i) B_j'
+#pragma unroll
+        for (int n = 0; n < NOWN; ++n) {
+            if (bi[n] != k && bj[n] != k) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cn[(16 * bi[n] + li) * PS + 4 * kk + lk], Bp[(16 * bj[n] + li) * PS + 4 * kk + lk], acc[n], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                              // the panels are rewritten by the next sub-step
+    }
+#pragma unroll
+    for (int n = 0; n < NOWN; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * bi[n] + lk + 4 * r, col = 16 * bj[n] + li;
+            if (col > row) continue;
+            const double o = -acc[n][r];
+            P[(int64_t)row * W + col] = o;
+            P[(int64_t)col * W + row] = o;
+        }
+}
+
 // k-major panel Bk[c][R] = B[R][c]: B = A[:, pivot columns] read from the lower triangle, pivot rows and pad columns zero
 __global__ void __launch_bounds__(256)
 panel_gather_kernel(const double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, int kw, double *__restrict__ Bk) {
@@ -613,16 +740,27 @@ panel_fused_kernel(double *__restrict__ A, int64_t np, int64_t ldp, int64_t k0, 
     }
 }
 
-// ---- trailing update with TWO pivot panels in one pass (pairs of 128-wide steps) ------------------------------------------------
-// A tile receives  A += Ck1' Bk1 + Ck2' Bk2  (Ck = -C') in ONE read-modify-write: 256 pivots per pass instead of 128 -- half the
-// passes over A per flop (at depth 128 a step moves 0.54 GB for 8.6 GFLOP) and half the accumulator loads / stores per matrix
-// instruction.  Which panels a 64 x 64 block takes follows from where it lies: a block inside a panel's own pivot band (its row or
-// its column range is the band) is not touched by that panel; blocks inside `skip` bands are left to other launches.
-//   select = 0: every tile of the list;  1: the tiles of the bands [e0, e0 + 128 * nslices) enumerated directly (band launches).
-struct RuPanel { const double *Ck, *Bk; int64_t k0; int kw; };        // kw = 0: no such panel
+// ---- trailing update with SEVERAL pivot panels in one pass (groups of 128-wide steps) ---------------------------------------------
+// A tile receives  A += sum_i Ck_i' Bk_i  (Ck = -C') for a RANGE of the group's panels in ONE read-modify-write.  Fitted on this
+// kernel's own timings (one panel per pass: 56.4 us per workgroup, two: 93.8 us): a workgroup costs 19 us + 0.29 us per pivot -- the
+// accumulator load / store, the first stage and the lock-step of the two workgroups of a CU weigh as much as 65 pivots of matrix
+// instructions -- so the passes over A are made as deep as the dependencies allow: kMaxGroup = 4 panels (512 pivots) per pass.
+// Which panels a tile takes follows from where it lies.  With jr / jc = the group-local index of the pivot band that holds the
+// tile's row / column block (-1: none; jc <= jr on the lower triangle), every panel i outside {jr, jc} is applied EXACTLY ONCE:
+//   band launch j (tiles of band j, before chain j reads them):  i in [jc + 1 if 0 <= jc < j else 0,  j)
+//   priority / rest launches (after the group's last chain):     i in (max(jr, jc), mg)          (all of them when jr = jc = -1)
+// -- a tile inside band jc was overwritten with C by chain jc: panels before jc went into that chain's input, panels after it
+// update the stored C (the Gauss-Jordan sweep keeps updating the columns of earlier pivots).
+constexpr int kMaxGroup = 4;
+struct RuGroup {
+    const double *Ck[kMaxGroup], *Bk[kMaxGroup];    // panel i of the group (k-major, ldp apart per pivot)
+    int kb, mg;                                      // first pivot block of the group, panels in it
+};
+// select = 0: the tiles of the list, except those inside the blocks [skip0, skip0 + nskip) (the next group's bands);
+//          1: the tiles of the bands [e0, e0 + nslices) enumerated directly; band >= 0: a band launch for that group-local band
 __global__ void __launch_bounds__(RU_THREADS, 2)
-rank_update2_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuPanel p1, RuPanel p2, const int2 *__restrict__ tiles, int ntiles,
-                    int select, int band_tile, int nslices, int64_t skipA0, int skipAw, int64_t skipB0, int skipBw) {
+rank_updatem_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuGroup g, const int2 *__restrict__ tiles, int ntiles,
+                    int select, int e0, int nslices, int band, int skip0, int nskip) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -630,32 +768,33 @@ rank_update2_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuPanel p1,
     int2 tt;
     if (select == 1) {
         const int nr = (int)(np / RU_TM);
-        const int bsl = blockIdx.x / nr, e = blockIdx.x - bsl * nr, bt = band_tile + bsl;
-        if (bsl + 1 < nslices && e == bt + 1) return;               // tile (bt + 1, bt) belongs to the next slice
+        const int bsl = blockIdx.x / nr, e = blockIdx.x - bsl * nr, bt = e0 + bsl;
+        if (e > bt && e < e0 + nslices) return;                      // tile (e, bt) with e a later slice: enumerated there as (e, bt)
         tt = e <= bt ? make_int2(bt, e) : make_int2(e, bt);
     } else {
         const int bq = ntiles / 8, br = ntiles % 8, xcd = blockIdx.x % 8, bm = blockIdx.x / 8;
         const int item = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bm;
         tt = tiles[item];
+        if ((tt.x >= skip0 && tt.x < skip0 + nskip) || (tt.y >= skip0 && tt.y < skip0 + nskip)) return;
     }
+    const int jr = (tt.x >= g.kb && tt.x < g.kb + g.mg) ? tt.x - g.kb : -1, jc = (tt.y >= g.kb && tt.y < g.kb + g.mg) ? tt.y - g.kb : -1;
+    int lo, hi;
+    if (band >= 0) { lo = (jc >= 0 && jc < band) ? jc + 1 : 0; hi = band; }
+    else { lo = (jr > jc ? jr : jc) + 1; hi = g.mg; }
+    if (lo >= hi) return;
     const int64_t a0 = (int64_t)tt.x * RU_TM, b0 = (int64_t)tt.y * RU_TN;
-    auto in_band = [&](int64_t lo, int64_t start, int64_t width) { return width > 0 && lo >= start && lo < start + width; };
-    // (tile level: bands are 128-aligned, so the four 64 x 64 blocks of a tile share these answers)
-    if (in_band(a0, skipA0, skipAw) || in_band(b0, skipA0, skipAw) || in_band(a0, skipB0, skipBw) || in_band(b0, skipB0, skipBw)) return;
-    const bool use1 = p1.kw > 0 && !in_band(a0, p1.k0, p1.kw) && !in_band(b0, p1.k0, p1.kw);
-    const bool use2 = p2.kw > 0 && !in_band(a0, p2.k0, p2.kw) && !in_band(b0, p2.k0, p2.kw);
-    if (!use1 && !use2) return;
     const int64_t r_lo = a0 + wa * 64, c_lo = b0 + wb * 64;
     const bool skip_wave = c_lo > r_lo + 63 || c_lo >= np;          // above the diagonal: nothing to maintain
-    // the stages of this tile: panel 1's pivots (if it applies), then panel 2's
-    const int n1s = use1 ? p1.kw / RU_BK : 0, nstages = n1s + (use2 ? p2.kw / RU_BK : 0);
+    constexpr int SPP = 128 / RU_BK;                                 // stages per panel
+    const int nstages = (hi - lo) * SPP;
 
     constexpr int ROW = RU_TM + RU_TN, STAGE = RU_BK * ROW;
     double *buf0 = lds, *buf1 = lds + STAGE;
     auto stage_load = [&](double *buf, int st) {
-        const bool first = st < n1s;
-        const double *Ck = first ? p1.Ck : p2.Ck, *Bk = first ? p1.Bk : p2.Bk;
-        const int s0 = (first ? st : st - n1s) * RU_BK;
+        const int pi = lo + st / SPP, s0 = (st % SPP) * RU_BK;
+        const double *Ck = nullptr, *Bk = nullptr;                   // (selected without indexing the kernel-argument arrays dynamically)
+#pragma unroll
+        for (int i = 0; i < kMaxGroup; ++i) if (i == pi) { Ck = g.Ck[i]; Bk = g.Bk[i]; }
         for (int p = wave; p < RU_BK * 2; p += RU_THREADS / 64) {     // piece = (pivot, part): 128 panel values
             const int k = p >> 1, part = p & 1;
             const double *src = part == 0 ? Ck + (int64_t)(s0 + k) * ldp + a0 : Bk + (int64_t)(s0 + k) * ldp + b0;
@@ -789,7 +928,7 @@ size_t spd_inverse_work_bytes(int64_t np) {
     size_t d = sweep64_work_doubles(np);
     if (np >= kTwoLevelMinNp) {
         const int64_t ldp = round_up(np, RU_TN);
-        const size_t two = (size_t)(6 * KW * ldp + KW * KW) + sweep64_work_doubles(KW) + ru_tile_capacity(np);   // int2 = one double
+        const size_t two = (size_t)(8 * KW * ldp + KW * KW) + sweep64_work_doubles(KW) + ru_tile_capacity(np);   // 8 panel slots (groups of four steps, two groups in flight)   // int2 = one double
         if (two > d) d = two;
     }
     return sizeof(double) * d;
@@ -868,7 +1007,7 @@ SweepAux::~SweepAux() {
 static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *status_dev, hipStream_t s, SweepAux *aux) {
     const int64_t ldp = round_up(np, RU_TN);
     double *panelbuf[3] = {work, work + 2 * KW * ldp, work + 4 * KW * ldp};   // {Bk, Ck} x 3 (depth-2 look-ahead rotates three)
-    double *P = work + 6 * KW * ldp, *inner = P + KW * KW;
+    double *P = work + 8 * KW * ldp, *inner = P + KW * KW;
     int2 *tiles = reinterpret_cast<int2 *>(inner + sweep64_work_doubles(KW));
     const std::vector<int2> &ht = ru_tiles(np);   // persistent host copy: the async upload may outlive this call
     LPVS_HIP(hipMemcpyAsync(tiles, ht.data(), sizeof(int2) * ht.size(), hipMemcpyHostToDevice, s));
@@ -879,7 +1018,9 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     // 128-wide pivot blocks (one-workgroup inverse) up to np ~ 12k; beyond, the bulk update is long enough to hide the
     // 256-wide chain (pivot block by the 64-wide sweep) and the deeper update runs closer to the MFMA peak
     const int kw_env = [] { const char *e = getenv("LPVS_KW"); return e ? atoi(e) : 0; }();
-    const int kw_outer = kw_env == 128 || kw_env == 256 ? kw_env : (np >= 12288 ? 256 : 128);
+    // (the group schedule below runs 128-wide steps: 39.9 ms against 47.5 with 256-wide steps at np = 12288, 89.5 / 93.5 at 16384, equal at 32768)
+    const bool steps_scheme = [] { const char *e = getenv("LPVS_FACTOR_SCHEME"); return e && std::string(e) == "steps"; }();
+    const int kw_outer = kw_env == 128 || kw_env == 256 ? kw_env : ((steps_scheme && np >= 12288) ? 256 : 128);
     const bool la = lookahead_on && aux != nullptr && np > kw_outer;
     if (la) LPVS_TRY(aux->ensure());
 
@@ -911,69 +1052,81 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
                            kw, Ck, Bk, tiles, (int)ht.size(), which, n0, nw, band_tile, n1, nw1);
     };
 
-    // ---- pairs of 128-wide steps: the trailing update takes TWO panels per pass (rank_update2_kernel) -----------------------------
-    // Per pair p (pivot blocks k1 = 2p, k2 = 2p + 1; n1, n2 the next pair's):
-    //   side:  band k2 += panel k1  ->  chain k2  ->  [event panelB]          ... [wait prio]  chain n1  ->  [event panelA]
-    //   main:  [wait panelB]  bands n1, n2 += panels k1, k2 (the next pair's pivot bands first)  ->  [event prio]  ->  every other tile
-    // Band k2's tiles received the earlier panels as "bands n1, n2" of the previous pair; a tile inside band k1 takes panel k2 only,
-    // a tile inside band k2 panel k1 only (that is the side stream's band launch) -- rank_update2_kernel decides per tile.  Panels
-    // rotate through four slots: chain n1 of pair p writes slot (2p + 2) & 3 = pair p - 1's first slot, whose last reader (the
-    // update of pair p - 1) precedes this pair's priority launch on the main stream, which the chain waits for.
-    const bool pairs_on = [] { const char *e = getenv("LPVS_FACTOR_SCHEME"); return !(e && std::string(e) == "steps"); }();
+    // ---- groups of up to four 128-wide steps: the trailing update takes the group's panels in ONE pass (rank_updatem_kernel) --------
+    // Per group (pivot blocks kb .. kb + mg - 1; panel kb is ready when the group starts; the next group starts at block nb0):
+    //   side:  for j = 1 .. mg-1:  band j += panels [.., j)  ->  chain kb+j        ->  [event panels]
+    //          [wait: previous group's rest]  the NEXT group's bands += this group's panels (priority)  ->  chain nb0  (the next group's first panel)
+    //   main:  [wait panels]  every tile outside the next group's bands += this group's panels                 ->  [event rest]
+    // The side stream (high priority) thus owns everything the pivot chains wait for -- its priority launch shares the chip with the
+    // main stream's pass instead of running ahead of it --, and the main stream is one deep pass per group.  Band / priority tiles are
+    // disjoint from the rest launch's; the priority tiles were last written by the previous group's rest launch (hence the wait).
+    // Panels live in 2 x kMaxGroup slots (slot = pivot block mod 8): chain nb0 and the next group's chains write the other half
+    // while this group's launches still read theirs; a half is rewritten two groups later, behind the events above.
+    const int group_env = [] { const char *e = getenv("LPVS_FACTOR_GROUP"); return e ? atoi(e) : 0; }();   // 1 .. 4 panels per pass (diagnostic)
+    // Measured at np = 8192 (tools/factor_ab3.sh): 1 panel per pass 16.2 ms, 2: 14.0, 3: 15.0, 4: 15.4 (round 2's schedule: 17.8).  Deeper
+    // passes amortise the per-tile overhead further, but the side stream's share of the matrix work grows with the group (bands of
+    // depth 128 .. 128 (mg - 1) and a priority launch of mg bands: 15 % of the flops at mg = 2, 30 % at mg = 4) and its workgroups
+    // queue behind 170-us workgroups of the main pass: from mg = 3 the side stream is the critical path again.
+    const int mgmax = group_env >= 1 && group_env <= kMaxGroup ? group_env : 2;
+    const bool groups_on = [] { const char *e = getenv("LPVS_FACTOR_SCHEME"); return !(e && std::string(e) == "steps"); }();
     const bool fused_chain = [] { const char *e = getenv("LPVS_CHAIN"); return !(e && std::string(e) == "split"); }();
-    if (la && pairs_on && single_wg_pivot && kw_outer == 128 && np >= 2048 && np % 128 == 0 && ldp == np) {
+    const bool mfma_pivot = [] { const char *e = getenv("LPVS_PIVOT"); return !(e && std::string(e) == "regs"); }();   // regs: the register kernel
+    if (la && groups_on && single_wg_pivot && kw_outer == 128 && np >= 2048 && np % 128 == 0 && ldp == np) {
         hipStream_t side = aux->side;
-        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rank_update2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        auto slotB = [&](int64_t k0) { return work + ((k0 / 128) & 3) * (2 * 128 * ldp); };
-        auto slotC = [&](int64_t k0) { return slotB(k0) + 128 * ldp; };
-        auto chain128 = [&](int64_t k0, hipStream_t st) {
-            hipLaunchKernelGGL(pivot_inverse_kernel<128>, dim3(1), dim3(192), 0, st, A, np, k0, P, status_dev);
+        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rank_updatem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int nblocks = (int)(np / 128);
+        auto slotB = [&](int blk) { return work + (int64_t)(blk & (2 * kMaxGroup - 1)) * (2 * 128 * ldp); };
+        auto slotC = [&](int blk) { return slotB(blk) + 128 * ldp; };
+        auto chain128 = [&](int blk, hipStream_t st) {
+            const int64_t k0 = (int64_t)blk * 128;
+            if (mfma_pivot) hipLaunchKernelGGL(pivot_inverse_mfma_kernel, dim3(1), dim3(256), 0, st, A, np, k0, P, status_dev);
+            else hipLaunchKernelGGL(pivot_inverse_kernel<128>, dim3(1), dim3(192), 0, st, A, np, k0, P, status_dev);
             if (fused_chain) {
-                hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(ldp / 16)), dim3(256), 0, st, A, np, ldp, k0, (const double *)P, slotB(k0), slotC(k0));
+                hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(ldp / 16)), dim3(256), 0, st, A, np, ldp, k0, (const double *)P, slotB(blk), slotC(blk));
             } else {
-                hipLaunchKernelGGL(panel_gather_kernel, dim3((unsigned)(ldp / 64)), dim3(256), 0, st, A, np, ldp, k0, 128, slotB(k0));
-                hipLaunchKernelGGL(panel_gemm_kernel, dim3((unsigned)(ldp / 64)), dim3(256), 0, st, A, np, ldp, k0, 128, P, slotB(k0), slotC(k0));
+                hipLaunchKernelGGL(panel_gather_kernel, dim3((unsigned)(ldp / 64)), dim3(256), 0, st, A, np, ldp, k0, 128, slotB(blk));
+                hipLaunchKernelGGL(panel_gemm_kernel, dim3((unsigned)(ldp / 64)), dim3(256), 0, st, A, np, ldp, k0, 128, P, slotB(blk), slotC(blk));
             }
         };
-        auto panel = [&](int64_t k0) { return k0 < np ? RuPanel{slotC(k0), slotB(k0), k0, 128} : RuPanel{nullptr, nullptr, 0, 0}; };
+        auto group_of = [&](int kb, int mg) {
+            RuGroup g{};
+            for (int i = 0; i < kMaxGroup; ++i) { g.Ck[i] = slotC(kb + (i < mg ? i : 0)); g.Bk[i] = slotB(kb + (i < mg ? i : 0)); }
+            g.kb = kb; g.mg = mg;
+            return g;
+        };
         const int nr = (int)(np / RU_TM);
-        auto update_bands = [&](hipStream_t st, int64_t e0, int nsl, RuPanel a, RuPanel b, int64_t skip0, int skipw) {
-            hipLaunchKernelGGL(rank_update2_kernel, dim3((unsigned)(nr * nsl)), dim3(RU_THREADS), lds, st, A, np, ldp, a, b, tiles, (int)ht.size(), 1,
-                               (int)(e0 / RU_TM), nsl, skip0, skipw, (int64_t)0, 0);
+        auto launch_bands = [&](hipStream_t st, const RuGroup &g, int e0, int nsl, int band) {   // the tiles of bands e0 .. e0 + nsl - 1
+            hipLaunchKernelGGL(rank_updatem_kernel, dim3((unsigned)(nr * nsl)), dim3(RU_THREADS), lds, st, A, np, ldp, g, tiles, (int)ht.size(), 1, e0, nsl, band, 0, 0);
         };
-        auto update_rest = [&](hipStream_t st, RuPanel a, RuPanel b, int64_t sA0, int sAw, int64_t sB0, int sBw) {
-            hipLaunchKernelGGL(rank_update2_kernel, dim3((unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, a, b, tiles, (int)ht.size(), 0,
-                               0, 0, sA0, sAw, sB0, sBw);
+        auto launch_rest = [&](hipStream_t st, const RuGroup &g, int skip0, int nskip) {
+            hipLaunchKernelGGL(rank_updatem_kernel, dim3((unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, g, tiles, (int)ht.size(), 0, 0, 0, -1, skip0, nskip);
         };
-        hipStream_t mb = aux->bulk ? aux->bulk : s;             // the trailing updates' stream (CU-masked: see SweepAux::ensure)
+        hipStream_t mb = aux->bulk ? aux->bulk : s;             // the deep passes' stream (CU-masked: see SweepAux::ensure)
         LPVS_HIP(hipEventRecord(aux->rest, s));                 // A is ready on the caller's stream
         LPVS_HIP(hipStreamWaitEvent(side, aux->rest, 0));
         if (mb != s) LPVS_HIP(hipStreamWaitEvent(mb, aux->rest, 0));
         chain128(0, side);
-        LPVS_HIP(hipEventRecord(aux->panel, side));             // panelA
-        for (int64_t k1 = 0; k1 < np; k1 += 256) {
-            const int64_t k2 = k1 + 128, n1 = k1 + 256;
-            if (k2 >= np) {                                      // an odd last step: one panel, every tile outside its band
-                LPVS_HIP(hipStreamWaitEvent(mb, aux->panel, 0));
-                update_rest(mb, panel(k1), panel(np), 0, 0, 0, 0);
-                break;
+        bool rest_pending = false;                               // a rest launch of an earlier group is recorded in aux->second
+        for (int kb = 0; kb < nblocks;) {
+            const int mg = nblocks - kb < mgmax ? nblocks - kb : mgmax, nb0 = kb + mg;
+            const int mgn = nblocks - nb0 < mgmax ? nblocks - nb0 : mgmax;       // bands of the next group (0: this is the last)
+            const RuGroup g = group_of(kb, mg);
+            for (int j = 1; j < mg; ++j) {
+                launch_bands(side, g, kb + j, 1, j);             // band j += the group's earlier panels, then its chain
+                chain128(kb + j, side);
             }
-            update_bands(side, k2, 1, panel(k1), panel(np), 0, 0);      // band k2 += panel k1 (its tile inside band k1 is dead)
-            chain128(k2, side);
-            LPVS_HIP(hipEventRecord(aux->band, side));          // panelB (implies panelA: same stream)
-            LPVS_HIP(hipStreamWaitEvent(mb, aux->band, 0));
-            const int nsl = n1 >= np ? 0 : (n1 + 256 <= np ? 2 : 1);
-            if (nsl > 0) {
-                update_bands(mb, n1, nsl, panel(k1), panel(k2), k2, 128);    // the next pair's pivot bands first (band k2 is the side stream's)
-                LPVS_HIP(hipEventRecord(aux->second, mb));      // prio
+            LPVS_HIP(hipEventRecord(aux->panel, side));         // the group's panels are complete
+            LPVS_HIP(hipStreamWaitEvent(mb, aux->panel, 0));
+            launch_rest(mb, g, nb0, mgn);
+            if (mgn > 0) {
+                if (rest_pending) LPVS_HIP(hipStreamWaitEvent(side, aux->second, 0));   // the previous group's rest wrote the tiles of these bands
+                launch_bands(side, g, nb0, mgn, -1);             // priority: the next group's pivot bands
+                chain128(nb0, side);
             }
-            update_rest(mb, panel(k1), panel(k2), k2, 128, n1, 128 * nsl);
-            if (nsl > 0) {
-                LPVS_HIP(hipStreamWaitEvent(side, aux->second, 0));
-                chain128(n1, side);
-                LPVS_HIP(hipEventRecord(aux->panel, side));     // panelA of the next pair
-            }
+            LPVS_HIP(hipEventRecord(aux->second, mb));          // this group's rest
+            rest_pending = true;
             LPVS_HIP(hipGetLastError());
+            kb = nb0;
         }
         if (mb != s) {
             LPVS_HIP(hipEventRecord(aux->bulkdone, mb));

@@ -210,3 +210,27 @@ def test_window_shards_reproduce_the_whole_dense_form(L, monkeypatch):
     x, S, its = L.windowpsd_sparse_batched(y, t, f, n, 0, None, **kw)
     parts = [L.windowpsd_sparse_batched(y, t, f, n, 0, None, win_lo=lo, win_hi=hi, **kw)[0] for lo, hi in ((0, 1), (1, 12), (12, 23))]
     assert np.array_equal(np.vstack(parts), x)
+
+
+def test_lpv_batch_multi_equals_single_channel_solves(L, monkeypatch):
+    """lpvs_lpv_batch_multi_f64 (channels over devices, one host thread per device): with one device, with three shards
+    sharing the device (a rehearsal of three GPUs: each shard its own handle, Gram and factorisation), and against the per-channel
+    single-signal solves -- same coefficients, same per-channel stopping iterations."""
+    rng = np.random.default_rng(77)
+    N, Nf, Nv, ns = 6000, 24, 4, 5
+    X = np.sort(rng.random(N) * 80); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) / 6
+    Y = np.stack([np.cos(w[(5 * q + 2) % Nf] * X) * (1 + q * V) + 0.5 * np.cos(w[(3 * q + 7) % Nf] * X + q) + 0.05 * rng.standard_normal(N) for q in range(ns)], axis=1)
+    kw = dict(proxg=L.IndBallL0(6), μ=0.05, tol=1e-7, iters=3000)
+    P1, it1 = L.lpv_batch_multi(Y, X, V, w, Nv, ngpus=1, **kw)
+    P3, it3 = L.lpv_batch_multi(Y, X, V, w, Nv, devices=[0, 0, 0], **kw)
+    assert P1.shape == (Nf * Nv, ns) and len(set(it1.tolist())) > 1 and it1.min() < 3000      # every channel stops on its own (or runs out of iterations)
+    assert np.array_equal(it1, it3) and np.abs(P1 - P3).max() <= 1e-12 * np.abs(P1).max()
+    import io
+    for q in range(ns):
+        se = L.ls_sparse_spectral_lpv(Y[:, q], X, V, w, Nv, proxg=L.IndBallL0(6), μ=0.05, tol=1e-7, iters=3000, printerval=100000, out=io.StringIO())
+        assert np.abs(se.x - P1[:, q]).max() <= 1e-10 * np.abs(se.x).max(), q
+        assert np.array_equal(se.x != 0, P1[:, q] != 0) and np.count_nonzero(np.concatenate([se.x.real, se.x.imag])) == 6
+    G, _ = L.lpv_batch_multi(Y, X, V, w, Nv, λ=3.0, ngpus=0, μ=0.05, tol=0.0, iters=200)    # the reference's group lasso, every visible device
+    S = L.ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, λ=3.0, μ=0.05, tol=0.0, iters=200, printerval=100000, out=io.StringIO())
+    assert all(np.abs(G[:, q] - S[q].x).max() <= 1e-10 * np.abs(S[q].x).max() for q in range(ns))
