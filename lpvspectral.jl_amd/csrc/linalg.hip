@@ -758,7 +758,9 @@ struct RuGroup {
 };
 // select = 0: the tiles of the list, except those inside the blocks [skip0, skip0 + nskip) (the next group's bands);
 //          1: the tiles of the bands [e0, e0 + nslices) enumerated directly; band >= 0: a band launch for that group-local band
-__global__ void __launch_bounds__(RU_THREADS, 2)
+// BK = pivots per LDS stage, WGS = workgroups per CU the register budget is set for (BK = 16: 64 KB of LDS, two; BK = 8: 32 KB, three)
+template <int BK, int WGS>
+__global__ void __launch_bounds__(RU_THREADS, WGS)
 rank_updatem_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuGroup g, const int2 *__restrict__ tiles, int ntiles,
                     int select, int e0, int nslices, int band, int skip0, int nskip) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -785,17 +787,17 @@ rank_updatem_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuGroup g, 
     const int64_t a0 = (int64_t)tt.x * RU_TM, b0 = (int64_t)tt.y * RU_TN;
     const int64_t r_lo = a0 + wa * 64, c_lo = b0 + wb * 64;
     const bool skip_wave = c_lo > r_lo + 63 || c_lo >= np;          // above the diagonal: nothing to maintain
-    constexpr int SPP = 128 / RU_BK;                                 // stages per panel
+    constexpr int SPP = 128 / BK;                                 // stages per panel
     const int nstages = (hi - lo) * SPP;
 
-    constexpr int ROW = RU_TM + RU_TN, STAGE = RU_BK * ROW;
+    constexpr int ROW = RU_TM + RU_TN, STAGE = BK * ROW;
     double *buf0 = lds, *buf1 = lds + STAGE;
     auto stage_load = [&](double *buf, int st) {
-        const int pi = lo + st / SPP, s0 = (st % SPP) * RU_BK;
+        const int pi = lo + st / SPP, s0 = (st % SPP) * BK;
         const double *Ck = nullptr, *Bk = nullptr;                   // (selected without indexing the kernel-argument arrays dynamically)
 #pragma unroll
         for (int i = 0; i < kMaxGroup; ++i) if (i == pi) { Ck = g.Ck[i]; Bk = g.Bk[i]; }
-        for (int p = wave; p < RU_BK * 2; p += RU_THREADS / 64) {     // piece = (pivot, part): 128 panel values
+        for (int p = wave; p < BK * 2; p += RU_THREADS / 64) {     // piece = (pivot, part): 128 panel values
             const int k = p >> 1, part = p & 1;
             const double *src = part == 0 ? Ck + (int64_t)(s0 + k) * ldp + a0 : Bk + (int64_t)(s0 + k) * ldp + b0;
             glds16(src + 2 * lane, buf + p * 128);
@@ -807,15 +809,30 @@ rank_updatem_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuGroup g, 
     for (int t = 0; t < 4; ++t) { offA[t] = wa * 64 + t * 16 + li; offB[t] = RU_TM + wb * 64 + t * 16 + li; }
     stage_load(buf0, 0);
     f64x4 acc[4][4];
+    // accumulator addresses = a wave-uniform pointer per (i, r, j) + ONE 32-bit lane offset (saddr + voffset form: no 64-bit vector
+    // arithmetic per element); a wave strictly below the diagonal takes every element, so its 64 loads / stores carry no predicate
+    const unsigned voffb = (unsigned)((lk * np + li) * 8);          // byte offset of the lane inside a 4-row x 16-column patch (< 2^32: np < 2^26)
+    const bool below = c_lo + 63 <= r_lo;                            // (wave-uniform) col <= row for every element of the wave's 64 x 64 block
+    if (!skip_wave && below) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t row = r_lo + i * 16 + lk + 4 * r, col = c_lo + j * 16 + li;
-                acc[i][j][r] = (!skip_wave && col <= row) ? A[row * np + col] : 0.0;
+                const double *sp = A + (r_lo + i * 16 + 4 * r) * np + c_lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][r] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(sp + j * 16) + voffb);
             }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = r_lo + i * 16 + lk + 4 * r, col = c_lo + j * 16 + li;
+                    acc[i][j][r] = (!skip_wave && col <= row) ? A[row * np + col] : 0.0;
+                }
+    }
     __syncthreads();
     double rA[4], rB[4];
     auto fetch = [&](const double *img, int kk) {
@@ -830,12 +847,12 @@ rank_updatem_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuGroup g, 
         if (!skip_wave) {
             fetch(cur, 0);
 #pragma unroll
-            for (int kk = 0; kk < RU_BK / 4; ++kk) {
+            for (int kk = 0; kk < BK / 4; ++kk) {
                 double opA[4], opB[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { opA[t] = rA[t]; opB[t] = rB[t]; }
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < RU_BK / 4) fetch(cur, kk + 1);
+                if (kk + 1 < BK / 4) fetch(cur, kk + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -848,6 +865,17 @@ rank_updatem_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuGroup g, 
         __syncthreads();
     }
     if (skip_wave) return;
+    if (below) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double *sp = A + (r_lo + i * 16 + 4 * r) * np + c_lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<double *>(reinterpret_cast<char *>(sp + j * 16) + voffb) = acc[i][j][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1067,13 +1095,21 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     // passes amortise the per-tile overhead further, but the side stream's share of the matrix work grows with the group (bands of
     // depth 128 .. 128 (mg - 1) and a priority launch of mg bands: 15 % of the flops at mg = 2, 30 % at mg = 4) and its workgroups
     // queue behind 170-us workgroups of the main pass: from mg = 3 the side stream is the critical path again.
-    const int mgmax = group_env >= 1 && group_env <= kMaxGroup ? group_env : 2;
+    // From np = 12288 the main pass is long enough to cover a four-step side chain: 84.5 ms with groups of four (and the 8-pivot
+    // stages below) against 89.6 with pairs at np = 16384 (tools/factor_ab4.sh).
+    const int mgmax = group_env >= 1 && group_env <= kMaxGroup ? group_env : (np >= 12288 ? 4 : 2);
     const bool groups_on = [] { const char *e = getenv("LPVS_FACTOR_SCHEME"); return !(e && std::string(e) == "steps"); }();
     const bool fused_chain = [] { const char *e = getenv("LPVS_CHAIN"); return !(e && std::string(e) == "split"); }();
     const bool mfma_pivot = [] { const char *e = getenv("LPVS_PIVOT"); return !(e && std::string(e) == "regs"); }();   // regs: the register kernel
     if (la && groups_on && single_wg_pivot && kw_outer == 128 && np >= 2048 && np % 128 == 0 && ldp == np) {
         hipStream_t side = aux->side;
-        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rank_updatem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // LPVS_RU_STAGE=8: 8-pivot LDS stages (32 KB per workgroup) and a register budget for three workgroups per CU
+        // (np = 8192: 14.65 ms against 13.3 with 16-pivot stages and two workgroups per CU; np = 16384: 84.5 against 86.5 -- default from 12288)
+        const int stage_env = [] { const char *e = getenv("LPVS_RU_STAGE"); return e ? atoi(e) : 0; }();
+        const bool bk8 = stage_env == 8 || (stage_env != 16 && np >= 12288);
+        const size_t ldsm = bk8 ? lds / 2 : lds;
+        auto ru_kernel = bk8 ? rank_updatem_kernel<8, 3> : rank_updatem_kernel<16, 2>;
+        LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ru_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
         const int nblocks = (int)(np / 128);
         auto slotB = [&](int blk) { return work + (int64_t)(blk & (2 * kMaxGroup - 1)) * (2 * 128 * ldp); };
         auto slotC = [&](int blk) { return slotB(blk) + 128 * ldp; };
@@ -1096,10 +1132,10 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
         };
         const int nr = (int)(np / RU_TM);
         auto launch_bands = [&](hipStream_t st, const RuGroup &g, int e0, int nsl, int band) {   // the tiles of bands e0 .. e0 + nsl - 1
-            hipLaunchKernelGGL(rank_updatem_kernel, dim3((unsigned)(nr * nsl)), dim3(RU_THREADS), lds, st, A, np, ldp, g, tiles, (int)ht.size(), 1, e0, nsl, band, 0, 0);
+            hipLaunchKernelGGL(ru_kernel, dim3((unsigned)(nr * nsl)), dim3(RU_THREADS), ldsm, st, A, np, ldp, g, tiles, (int)ht.size(), 1, e0, nsl, band, 0, 0);
         };
         auto launch_rest = [&](hipStream_t st, const RuGroup &g, int skip0, int nskip) {
-            hipLaunchKernelGGL(rank_updatem_kernel, dim3((unsigned)ht.size()), dim3(RU_THREADS), lds, st, A, np, ldp, g, tiles, (int)ht.size(), 0, 0, 0, -1, skip0, nskip);
+            hipLaunchKernelGGL(ru_kernel, dim3((unsigned)ht.size()), dim3(RU_THREADS), ldsm, st, A, np, ldp, g, tiles, (int)ht.size(), 0, 0, 0, -1, skip0, nskip);
         };
         hipStream_t mb = aux->bulk ? aux->bulk : s;             // the deep passes' stream (CU-masked: see SweepAux::ensure)
         LPVS_HIP(hipEventRecord(aux->rest, s));                 // A is ready on the caller's stream

@@ -75,7 +75,7 @@ def test_empty_and_mismatched_inputs_raise(L):
 @pytest.mark.parametrize("knobs", [{}, {"LPVS_KW": "256"}, {"LPVS_KW": "256", "LPVS_LOOKAHEAD": "0"}, {"LPVS_LOOKAHEAD": "0"},
                                    {"LPVS_PIVOT": "sweep64"}, {"LPVS_FACTOR": "sweep64"}, {"LPVS_FACTOR_SCHEME": "steps"},
                                    {"LPVS_CHAIN": "split"}, {"LPVS_PIVOT": "regs"}, {"LPVS_FACTOR_GROUP": "1"}, {"LPVS_FACTOR_GROUP": "2"},
-                                   {"LPVS_FACTOR_GROUP": "3"}, {"LPVS_RESERVE_CUS": "0"}])
+                                   {"LPVS_FACTOR_GROUP": "3"}, {"LPVS_FACTOR_GROUP": "4", "LPVS_RU_STAGE": "8"}, {"LPVS_RESERVE_CUS": "0"}])
 @pytest.mark.parametrize("n", [1024, 2100, 2300, 2500])
 def test_factorisation_variants_give_the_inverse(L, knobs, n, monkeypatch):
     """Every factorisation variant (128 / 256-wide outer blocks incl. the ragged last block, with and without look-ahead,
