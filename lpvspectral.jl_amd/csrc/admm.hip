@@ -1379,7 +1379,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int WS_NS = 16;                            // signal columns of the LDS images = the MFMA's N
 constexpr size_t symv_ws_lds() { return sizeof(double) * 2 * ((size_t)MT_ROWS * MT_RS + (size_t)MT_ROWS * WS_NS + (size_t)TS * WS_NS); }
 
-struct StreamVisit { int t, pass, I, J; };          // one (tile, signal pass): four 32-row stages
+struct StreamVisit { int t, pass, I, J, k, end; };  // one (tile, signal pass): four 32-row stages; RUNS: of segment k = [.., end)
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_f64(double v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
@@ -1387,17 +1387,29 @@ __device__ __forceinline__ void store_f64(double v, __amdgpu_buffer_rsrc_t rsrc,
     __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, voffset, soffset, 0);
 }
 
-template <bool SPLIT>
+// Q4 (ns <= 8): the products run on v_mfma_f64_4x4x4_4b_f64 instead -- four independent 4x4x4 blocks per instruction (lane layout
+// probed by tools/mfma_4x4x4_layout.hip: A[blk][i][k] in lane 16k + 4blk + i, B[blk][k][j] in lane 16k + 4blk + j, D[blk][i][j] in lane
+// 16i + 4blk + j).  With the four blocks on four row quads (P1) or four column quads (P2) the TILE operand has exactly the lane layout
+// of the 16x16x4 form, and the small operand is a 4 x 4 block of right-hand sides repeated in every block: signals 0-3 and 4-7 are two
+// instructions on the same tile registers -- 8 signal columns cost 2 x 16 cycles where the 16-column instruction costs 64 with half of
+// it padding.  The right-hand-side images hold 8 signals per row, ordered (s & 3) * 2 + (s >> 2): a lane's two quads are one 16-byte read.
+// RUNS: the row-major triangle is cut into nseg SEGMENTS of consecutive tiles, segment k = [k ntiles / nseg, (k+1) ntiles / nseg)
+// (about 8 tiles), workgroup g walks the segments g, g + G, ... -- at any moment the workgroups still stream one contiguous stretch of
+// M between them, as with single tiles -- and the P1 waves keep the sums of a row block in registers over a RUN of tiles of the same
+// row I within a segment: one record (id I + k: at most nseg + nblk of them) per run instead of one per tile -- most of one half of the
+// partials (270 MB of 539 MB per launch at cfg5) is never written and never read back.  The consumers find row block I's records as
+// [I + k(I,0), I + k(I,I)] (part1_range below).
+template <bool SPLIT, bool Q4, bool RUNS>
 __global__ void __launch_bounds__(512, 1)
 symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
-                         double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+                         double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status, int nseg) {
     if (status != nullptr) {
         bool all = true;
         for (int q = 0; q < ns; ++q) all = all && status[q].converged;
         if (all) return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int NS = WS_NS, NQ = TS / MT_ROWS;
+    constexpr int NS = Q4 ? 8 : WS_NS, NQ = TS / MT_ROWS;
     static_assert(NQ == 4, "a tile is four stages: ring slot = stage, LDS parity = stage & 1");
     constexpr unsigned kStgB = MT_ROWS * MT_RS * 8, kRiB = MT_ROWS * NS * 8, kRjB = TS * NS * 8;   // bytes of one image
     unsigned char *stg = lds_raw;                    // [2][32][MT_RS]   32 rows of a tile, by stage parity
@@ -1413,18 +1425,32 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
     // not all ask for the same quarter of their (power-of-two sized) tiles at the same time.
     const int q0 = blockIdx.x & (NQ - 1);
     const int npass = (ns + NS - 1) / NS, nvalid = ns < NS ? ns : NS, s0max = ns > NS ? ns - NS : 0;
-    if ((int)blockIdx.x >= ntiles) return;
+    constexpr int tend_unused = 0; (void)tend_unused;
+    const int tend = ntiles;
+    auto seg_begin = [&](int k) -> int { return (int)(((unsigned long long)(unsigned)k * (unsigned)ntiles) / (unsigned)nseg); };
+    if ((int)blockIdx.x >= (RUNS ? nseg : ntiles)) return;
     auto next = [&](StreamVisit v) -> StreamVisit {  // scalar only; t >= ntiles after the workgroup's last visit
         if (++v.pass == npass) {
             v.pass = 0;
-            v.t += G;
-            v.J += G;                                // t = I(I+1)/2 + J, 0 <= J <= I
-            while (v.J > v.I) { v.J -= v.I + 1; ++v.I; }
+            if constexpr (RUNS) {
+                if (++v.t < v.end) {
+                    if (++v.J > v.I) { v.J = 0; ++v.I; }
+                } else if ((v.k += G) < nseg) {      // the workgroup's next segment
+                    v.t = __builtin_amdgcn_readfirstlane(seg_begin(v.k)); v.end = __builtin_amdgcn_readfirstlane(seg_begin(v.k + 1));
+                    tile_index(v.t, v.I, v.J);
+                    v.I = __builtin_amdgcn_readfirstlane(v.I); v.J = __builtin_amdgcn_readfirstlane(v.J);
+                } else v.t = ntiles;
+            } else {
+                v.t += G;
+                v.J += G;                            // t = I(I+1)/2 + J, 0 <= J <= I
+                while (v.J > v.I) { v.J -= v.I + 1; ++v.I; }
+            }
         }
         return v;
     };
     auto s0_of = [&](const StreamVisit &v) -> int { const int s0 = v.pass * NS; return s0 < s0max ? s0 : s0max; };
-    StreamVisit cv{(int)blockIdx.x, 0, 0, 0};        // the visit being multiplied
+    StreamVisit cv{RUNS ? seg_begin(blockIdx.x) : (int)blockIdx.x, 0, 0, 0, (int)blockIdx.x, RUNS ? seg_begin(blockIdx.x + 1) : 0};   // the visit being multiplied
+    cv.t = __builtin_amdgcn_readfirstlane(cv.t); cv.end = __builtin_amdgcn_readfirstlane(cv.end);
     tile_index(cv.t, cv.I, cv.J);
     cv.I = __builtin_amdgcn_readfirstlane(cv.I); cv.J = __builtin_amdgcn_readfirstlane(cv.J);
     int tp = 0;                                      // parity of the visit count
@@ -1446,13 +1472,13 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
         for (int k = 0; k < RI; ++k) {
             const int e = ltid + 256 * k, sq = e >> 5, i = e & 31;
             go_ri[k] = (int)(((int64_t)(sq < ns ? sq : ns - 1) * np + i) * 8);
-            wo_ri[k] = (i * NS + sq) * 8;
+            wo_ri[k] = (i * NS + (Q4 ? (sq & 3) * 2 + (sq >> 2) : sq)) * 8;
         }
 #pragma unroll
         for (int k = 0; k < RJ; ++k) {
             const int e = ltid + 256 * k, sq = e >> 7, i = e & 127;
             go_rj[k] = (int)(((int64_t)(sq < ns ? sq : ns - 1) * np + i) * 8);
-            wo_rj[k] = (i * NS + sq) * 8;
+            wo_rj[k] = (i * NS + (Q4 ? (sq & 3) * 2 + (sq >> 2) : sq)) * 8;
         }
         const unsigned wo_stg = SPLIT ? (r * MT_RS + 4 * c) * 8 : (r * MT_RS + 2 * c) * 8;
         // Every load of a step is unconditional (past the last visit an earlier one is requested again): a load under a
@@ -1526,20 +1552,20 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
         fetch(integral_constant<int, 2>{}, cv);
         fetch(integral_constant<int, 3>{}, cv);
         put(integral_constant<int, 0>{}, 0);
-        fetch(integral_constant<int, 0>{}, v1.t < ntiles ? v1 : cv);
+        fetch(integral_constant<int, 0>{}, v1.t < tend ? v1 : cv);
         __syncthreads();
 #pragma unroll 1
         for (;;) {
             // while the MFMA waves multiply step q of the current visit, stage step q + 1 and refill its slot from the next visit
-            const StreamVisit src = v1.t < ntiles ? v1 : cv;
+            const StreamVisit src = v1.t < tend ? v1 : cv;
             put(integral_constant<int, 1>{}, tp); fetch(integral_constant<int, 1>{}, src); __syncthreads();
             put(integral_constant<int, 2>{}, tp); fetch(integral_constant<int, 2>{}, src); __syncthreads();
             put(integral_constant<int, 3>{}, tp); fetch(integral_constant<int, 3>{}, src); __syncthreads();
             const StreamVisit v2 = next(v1);
-            if (v1.t < ntiles) put(integral_constant<int, 0>{}, tp ^ 1);
-            fetch(integral_constant<int, 0>{}, v2.t < ntiles ? v2 : cv);
+            if (v1.t < tend) put(integral_constant<int, 0>{}, tp ^ 1);
+            fetch(integral_constant<int, 0>{}, v2.t < tend ? v2 : cv);
             __syncthreads();
-            if (v1.t >= ntiles) break;
+            if (v1.t >= tend) break;
             cv = v1; v1 = v2; tp ^= 1;
         }
         return;
@@ -1547,11 +1573,16 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
 
     // ---- MFMA waves: loop-invariant lane offsets (bytes)
     const bool p1 = wave < 2;
-    const unsigned a_lane = p1 ? ((16 * wave + li) * MT_RS + lk) * 8 : (lk * NS + li) * 8;                 // P1: A = tile rows; P2: A = ri
-    const unsigned b_lane = p1 ? (lk * NS + li) * 8 : (lk * MT_RS + 64 * (wave - 2) + li) * 8;             // P1: B = rj;        P2: B = tile rows
+    const unsigned small_lane = Q4 ? (lk * NS + (li & 3) * 2) * 8 : (lk * NS + li) * 8;                     // the right-hand-side operand (Q4: two quads = 16 bytes)
+    const unsigned a_lane = p1 ? ((16 * wave + li) * MT_RS + lk) * 8 : small_lane;                         // P1: A = tile rows; P2: A = ri
+    const unsigned b_lane = p1 ? small_lane : (lk * MT_RS + 64 * (wave - 2) + li) * 8;                     // P1: B = rj;        P2: B = tile rows
     // partials: buffer stores, a lane whose signal is beyond the pass's valid ones gets an out-of-range offset (store dropped)
-    const int s_lane = p1 ? (li < nvalid ? (int)(((int64_t)li * ntiles * TS + 16 * wave + lk) * 8) : (int)0x80000000u)     // part1: [signal li][tile][row lk + 4k]
-                          : (int)(((int64_t)lk * ntiles * TS + 64 * (wave - 2) + li) * 8);                                   // part2: [signal lk + 4k][tile][col 16u + li]
+    //   16x16x4: part1 [signal li][tile][row lk + 4k], part2 [signal lk + 4k][tile][col 16u + li]
+    //   Q4:      part1 [signal (li & 3) + 4h][tile][row 4 (li >> 2) + lk], part2 [signal lk + 4h][tile][col 16u + li]
+    const int s_lane = Q4 ? (p1 ? (int)(((int64_t)(li & 3) * ntiles * TS + 16 * wave + 4 * (li >> 2) + lk) * 8) : (int)(((int64_t)lk * ntiles * TS + 64 * (wave - 2) + li) * 8))
+                          : (p1 ? (li < nvalid ? (int)(((int64_t)li * ntiles * TS + 16 * wave + lk) * 8) : (int)0x80000000u)
+                                : (int)(((int64_t)lk * ntiles * TS + 64 * (wave - 2) + li) * 8));
+    const bool hi_valid = Q4 && (p1 ? (li & 3) + 4 : lk + 4) < nvalid, lo_valid = !Q4 || (p1 ? (li & 3) : lk) < nvalid;
     const int64_t pass_bytes = (int64_t)nvalid * ntiles * TS * 8;
     const int part_records = (int)(pass_bytes < 0x7fffffff ? pass_bytes : 0x7fffffff);
     f64x4 acc2[4];                                   // waves 2-3: P2 blocks, columns 64*(wave-2) + 16*u .., over the tile's stages
@@ -1562,27 +1593,49 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
     // right after it, so the matrix pipe does not drain at step boundaries.
     if (p1) {
         // P1: rows 16*wave .. of a stage, all 128 columns.  A[i = li][k = lk], B[k = lk][j = s = li]
-        double A[2][8], B[2][8];
+        using BT = std::conditional_t<Q4, f64x2, double>;
+        double A[2][8]; BT B[2][8];
         auto load = [&](auto gc, unsigned par, int vtp, int buf) {      // operands of group G of the stage with parity par
             constexpr int g = decltype(gc)::value;
             const unsigned char *ap = stg + par * kStgB + a_lane, *bp = rj + vtp * kRjB + b_lane;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 A[buf][j] = *reinterpret_cast<const double *>(ap + 32 * (8 * g + j));
-                B[buf][j] = *reinterpret_cast<const double *>(bp + 4 * NS * 8 * (8 * g + j));
+                B[buf][j] = *reinterpret_cast<const BT *>(bp + 4 * NS * 8 * (8 * g + j));
             }
         };
         using std::integral_constant;
         load(integral_constant<int, 0>{}, 0, 0, 0);
+        f64x4 run0[RUNS ? NQ : 1], run1[RUNS && !Q4 ? NQ : 1];   // RUNS: the sums of a run of tiles of one row block, step by step
+        bool fresh = true;                           // (scalar) the visit starts a run
+        auto store1 = [&](const f64x4 &a0, const f64x4 &a1, int so) {   // a stage's 16 rows of this wave; a converged signal's partials are never read
+            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part1_all + (int64_t)s0_of(cv) * ntiles * TS, 0, part_records, 0x00020000);
+            if constexpr (Q4) {                      // D: row = 4 (li >> 2) + lk, signal = (li & 3) + 4h
+                store_f64(a0[0] + a0[2], pr, lo_valid ? s_lane : (int)0x80000000u, so);
+                store_f64(a0[1] + a0[3], pr, hi_valid ? s_lane : (int)0x80000000u, so + 4 * ntiles * TS * 8);
+            } else {                                 // D: col = li = s, row = lk + 4*reg
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store_f64(a0[k] + a1[k], pr, s_lane + 32 * k, so);
+            }
+        };
         auto step = [&](auto qc, int next_tp) {
             constexpr int Q = decltype(qc)::value;
             constexpr unsigned par = Q & 1;
-            f64x4 a0 = (f64x4){0.0, 0.0, 0.0, 0.0}, a1 = a0;
+            f64x4 t0 = (f64x4){0.0, 0.0, 0.0, 0.0}, t1 = t0;
+            if constexpr (RUNS) { if (fresh) { run0[RUNS ? Q : 0] = t0; if constexpr (!Q4) run1[RUNS && !Q4 ? Q : 0] = t0; } }
+            f64x4 &a0 = RUNS ? run0[RUNS ? Q : 0] : t0, &a1 = (RUNS && !Q4) ? run1[RUNS && !Q4 ? Q : 0] : t1;   // (Q4: elements 0/1 = signals lo/hi of the even k steps, 2/3 of the odd ones)
             auto mul = [&](int buf) {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j], B[buf][j], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j + 1], B[buf][j + 1], a1, 0, 0, 0);
+                    if constexpr (Q4) {
+                        a0[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j], B[buf][j][0], a0[0], 0, 0, 0);
+                        a0[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j], B[buf][j][1], a0[1], 0, 0, 0);
+                        a0[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j + 1], B[buf][j + 1][0], a0[2], 0, 0, 0);
+                        a0[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j + 1], B[buf][j + 1][1], a0[3], 0, 0, 0);
+                    } else {
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j], B[buf][j], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j + 1], B[buf][j + 1], a1, 0, 0, 0);
+                    }
                 }
             };
             load(integral_constant<int, 1>{}, par, tp, 1); __builtin_amdgcn_sched_barrier(0); mul(0); __builtin_amdgcn_sched_barrier(0);
@@ -1590,11 +1643,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             load(integral_constant<int, 3>{}, par, tp, 1); __builtin_amdgcn_sched_barrier(0); mul(0); __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                         // the next step is staged; this step's images are free
             load(integral_constant<int, 0>{}, par ^ 1, next_tp, 0); __builtin_amdgcn_sched_barrier(0); mul(1); __builtin_amdgcn_sched_barrier(0);
-            // D: col = li = s, row = lk + 4*reg   (a converged signal's partials are never read)
-            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part1_all + (int64_t)s0_of(cv) * ntiles * TS, 0, part_records, 0x00020000);
-            const int so = (cv.t * TS + MT_ROWS * ((Q + q0) & (NQ - 1))) * 8;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) store_f64(a0[k] + a1[k], pr, s_lane + 32 * k, so);
+            if constexpr (!RUNS) store1(a0, a1, (cv.t * TS + MT_ROWS * ((Q + q0) & (NQ - 1))) * 8);
         };
 #pragma unroll 1
         for (;;) {
@@ -1602,19 +1651,30 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             step(integral_constant<int, 1>{}, tp);
             step(integral_constant<int, 2>{}, tp);
             step(integral_constant<int, 3>{}, tp ^ 1);
-            cv = next(cv);
-            if (cv.t >= ntiles) break;
+            const StreamVisit nv = next(cv);
+            if constexpr (RUNS) {
+                fresh = nv.t >= tend || nv.I != cv.I || nv.k != cv.k;   // the run ends with this tile: record I + k
+                if (fresh) {
+                    const int rec = cv.I + cv.k;
+#pragma unroll
+                    for (int Q = 0; Q < NQ; ++Q) store1(run0[Q], run1[Q4 ? 0 : Q], (rec * TS + MT_ROWS * ((Q + q0) & (NQ - 1))) * 8);
+                }
+            }
+            cv = nv;
+            if (cv.t >= tend) break;
             tp ^= 1;
         }
     } else {
         // P2: columns 64*(wave-2) + 16*u .., the 32 rows of a stage.  A[s = li][k = lk], B[k = lk][j = c = li]
-        double A[2][2], B[2][8];
+        using AT = std::conditional_t<Q4, f64x2, double>;
+        AT A[2][2]; double B[2][8];
+        f64x2 acc4[4];                               // Q4: P2 blocks of signals lo/hi, columns 64*(wave-2) + 16*u ..
         auto load = [&](auto gc, unsigned par, int buf) {
             constexpr int g = decltype(gc)::value;
             const unsigned char *ap = ri + par * kRiB + a_lane, *bp = stg + par * kStgB + b_lane;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                A[buf][j] = *reinterpret_cast<const double *>(ap + 4 * NS * 8 * (2 * g + j));
+                A[buf][j] = *reinterpret_cast<const AT *>(ap + 4 * NS * 8 * (2 * g + j));
 #pragma unroll
                 for (int u = 0; u < 4; ++u) B[buf][4 * j + u] = *reinterpret_cast<const double *>(bp + 4 * MT_RS * 8 * (2 * g + j) + 128 * u);
             }
@@ -1629,8 +1689,14 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const f64x4 cin = (first && j == 0) ? (f64x4){0.0, 0.0, 0.0, 0.0} : acc2[u];   // a tile's first product starts the sums
-                        acc2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j], B[buf][4 * j + u], cin, 0, 0, 0);
+                        if constexpr (Q4) {
+                            const f64x2 cin = (first && j == 0) ? (f64x2){0.0, 0.0} : acc4[u];
+                            acc4[u][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j][0], B[buf][4 * j + u], cin[0], 0, 0, 0);
+                            acc4[u][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j][1], B[buf][4 * j + u], cin[1], 0, 0, 0);
+                        } else {
+                            const f64x4 cin = (first && j == 0) ? (f64x4){0.0, 0.0, 0.0, 0.0} : acc2[u];   // a tile's first product starts the sums
+                            acc2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j], B[buf][4 * j + u], cin, 0, 0, 0);
+                        }
                     }
             };
             load(integral_constant<int, 1>{}, par, 1); __builtin_amdgcn_sched_barrier(0); mul(0, Q == 0); __builtin_amdgcn_sched_barrier(0);
@@ -1645,7 +1711,10 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
                     for (int k = 0; k < NS / 4; ++k) {
                         const int so = (int)(((int64_t)4 * k * ntiles + cv.t) * TS * 8);   // (beyond the pass's valid signals: out of range, dropped)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) store_f64(acc2[u][k], pr, s_lane + 128 * u, so);
+                        for (int u = 0; u < 4; ++u) {
+                            if constexpr (Q4) store_f64(acc4[u][k], pr, (k ? hi_valid : lo_valid) ? s_lane + 128 * u : (int)0x80000000u, so);
+                            else store_f64(acc2[u][k], pr, s_lane + 128 * u, so);
+                        }
                     }
                 }
             }
@@ -1657,7 +1726,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             step(integral_constant<int, 2>{});
             step(integral_constant<int, 3>{});
             cv = next(cv);
-            if (cv.t >= ntiles) break;
+            if (cv.t >= tend) break;
         }
     }
 }
@@ -1725,23 +1794,33 @@ symv_tile_batch_kernel(const double *__restrict__ Mp_all, int64_t mp_stride, con
     }
 }
 
+// The part1 records of row block I: the tiles (I, 0..I) -- or, when the multi-signal kernel wrote one record per RUN (runs_G = its
+// number of segments), the records I + k for the segments k = [k ntiles / nseg, (k+1) ntiles / nseg) that meet the row.
+struct Part1Range { int first, count; };
+__device__ __forceinline__ Part1Range part1_range(int I, int ntiles, int runs_G) {
+    const int t0 = I * (I + 1) / 2;
+    if (runs_G == 0) return {t0, I + 1};
+    const int g0 = (int)((((int64_t)t0 + 1) * runs_G - 1) / ntiles), g1 = (int)((((int64_t)t0 + I + 1) * runs_G - 1) / ntiles);
+    return {I + g0, g1 - g0 + 1};
+}
+
 // x[I*128+i] = sum_{J<=I} part1[(I,J)][i] + sum_{K>I} part2[(K,I)][i]; both sums in fixed order.
 // 256 threads: 0..127 walk part1, 128..255 walk part2, 16 independent loads in flight each.
 __device__ __forceinline__ double gather_x(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, int I,
-                                           double *sh /*[128]*/) {
+                                           double *sh /*[128]*/, Part1Range r1) {
     const int i = threadIdx.x & 127, half = threadIdx.x >> 7;
     double s = 0;
     if (half == 0) {
-        const double *p = part1 + ((int64_t)I * (I + 1) / 2) * TS + i;
+        const double *p = part1 + (int64_t)r1.first * TS + i;
         int J = 0;
-        for (; J + 16 <= I + 1; J += 16) {
+        for (; J + 16 <= r1.count; J += 16) {
             double a[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) a[q] = p[(int64_t)(J + q) * TS];
 #pragma unroll
             for (int q = 0; q < 16; ++q) s += a[q];
         }
-        for (; J <= I; ++J) s += p[(int64_t)J * TS];
+        for (; J < r1.count; ++J) s += p[(int64_t)J * TS];
     } else {
         int K = I + 1;
         for (; K + 16 <= nblk; K += 16) {
@@ -1785,11 +1864,12 @@ __device__ __forceinline__ double gather_x4(const double *__restrict__ part1, co
 
 __global__ void __launch_bounds__(256)
 symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ part2, int nblk, int ntiles, int64_t np,
-                   double *__restrict__ x, const AdmmStatus *status, const double *__restrict__ xb) {
+                   double *__restrict__ x, const AdmmStatus *status, const double *__restrict__ xb, int runs_G) {
     const int sg = blockIdx.y;
     if (status != nullptr && status[sg].converged) return;
     __shared__ double sh[TS];
-    const double s = gather_x(part1 + (int64_t)sg * ntiles * TS, part2 + (int64_t)sg * ntiles * TS, nblk, blockIdx.x, sh);
+    const double s = gather_x(part1 + (int64_t)sg * ntiles * TS, part2 + (int64_t)sg * ntiles * TS, nblk, blockIdx.x, sh,
+                              part1_range(blockIdx.x, ntiles, runs_G));
     if (threadIdx.x < TS) {
         const int64_t gi = (int64_t)sg * np + (int64_t)blockIdx.x * TS + threadIdx.x;
         x[gi] = xb ? xb[gi] + s : s;
@@ -1903,7 +1983,7 @@ __device__ __forceinline__ double pending_norm(const double *__restrict__ bn, in
 
 __global__ void __launch_bounds__(512)
 admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk,
-                          int ntiles, double *__restrict__ blocknorm_all, int parity, int commit_prev) {
+                          int ntiles, double *__restrict__ blocknorm_all, int parity, int commit_prev, int runs_G) {
     const int sg = blockIdx.y;
     AdmmStatus *status = p.status + sg;
     __shared__ double sh[3 * TS], sq[TS], gs[TS], slot;
@@ -1920,17 +2000,21 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     const int conv_flag = __builtin_nontemporal_load(&status->converged);
     const double u_raw = p.u[gi], b_raw = (offset_form ? p.xb : p.b)[gi];
     const int gq = threadIdx.x >> 7;
-    const int per = (nblk + 3) / 4, e0 = gq * per, e1 = e0 + per < nblk ? e0 + per : nblk;
+    // the row block's contributions as one list: its part1 records (tiles (I, 0..I), or the runs of the multi-signal kernel), then part2 of tiles (K > I, I)
+    const Part1Range r1 = part1_range(I, ntiles, runs_G);
+    const int nent = r1.count + nblk - 1 - I, eshift = I + 1 - r1.count;      // (runs_G == 0: nent = nblk, eshift = 0)
+    const int per = (nent + 3) / 4, e0 = gq * per, e1 = e0 + per < nent ? e0 + per : nent;
     // (32-bit element offsets from part1: both partial arrays live in one buffer, part2 behind part1; the 64-bit form of this
     // address arithmetic was 300 instructions ahead of the first load)
     const unsigned p2off = (unsigned)(part2 - part1);
-    const unsigned rowoff = (unsigned)(I * (I + 1) / 2) * TS + i;
+    const unsigned rowoff = (unsigned)r1.first * TS + i;
     auto at = [&](int e) -> const double * {
-        return part1 + (e <= I ? rowoff + (unsigned)e * TS : p2off + ((unsigned)(e * (e + 1) / 2 + I)) * TS + i);
+        const int K = e + eshift;
+        return part1 + (e < r1.count ? rowoff + (unsigned)e * TS : p2off + ((unsigned)(K * (K + 1) / 2 + I)) * TS + i);
     };
     double pre[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) pre[q] = *at(e0 + q < nblk ? e0 + q : nblk - 1);
+    for (int q = 0; q < 16; ++q) pre[q] = *at(e0 + q < nent ? e0 + q : nent - 1);
     const int lane64 = threadIdx.x & 63;
     const double bn_raw = bn_prev[lane64 < nblk ? lane64 : nblk - 1];
     // (a use of every loaded value BEFORE the early exit: otherwise the compiler tests the flag first and sinks the loads below
@@ -2256,7 +2340,7 @@ int32_t launch_admm_batch_iterations(const AdmmBatch &p, int64_t iters, hipStrea
             if (!fusable) {
                 // IndBallL0 (the top-r selection needs the whole vector) and group lengths that do not divide 128: gather x from the tile
                 // partials, then one workgroup per problem (radix select in LDS / block soft-threshold) -- the kernels of the single handles
-                hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb);
+                hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, 0);
                 hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, q);
             } else if (nblk <= 8)
                 hipLaunchKernelGGL(admm_window_update_kernel, dim3(ns), dim3((unsigned)(TS * nblk)), 0, s, q, part1, part2, nblk, (int)ntiles);
@@ -2448,22 +2532,53 @@ static void launch_split(const unsigned char *Mp, const unsigned char *types, co
 
 // persistent grid of the wave-specialised multi-signal kernel: one workgroup per CU, evened out over the rounds so that
 // every workgroup walks the same number of tiles (+-1)
-static unsigned stream_grid(unsigned ntiles) {
+static unsigned stream_cus() {
     static const unsigned slots = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
         return (unsigned)cus;
     }();
-    const unsigned rounds = (ntiles + slots - 1) / slots;
+    return slots;
+}
+static unsigned stream_grid(unsigned ntiles) {
+    const unsigned slots = stream_cus(), rounds = (ntiles + slots - 1) / slots;
     return (ntiles + rounds - 1) / rounds;
 }
+static int stream_runs(const AdmmParams &p);
 
-template <bool SPLIT>
+template <bool SPLIT, bool Q4, bool RUNS>
 static void launch_mfma_stream(const AdmmParams &p, unsigned ntiles, double *part1, double *part2, const AdmmStatus *status, hipStream_t s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_ws_kernel<SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)symv_ws_lds());   // per device; cheap
-    hipLaunchKernelGGL((symv_tile_mfma_ws_kernel<SPLIT>), dim3(stream_grid(ntiles)), dim3(512), symv_ws_lds(), s,
-                       reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
+    const int nseg = RUNS ? stream_runs(p) : 0;
+    hipLaunchKernelGGL((symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS>), dim3(RUNS ? std::min(stream_cus(), (unsigned)nseg) : stream_grid(ntiles)), dim3(512), symv_ws_lds(), s,
+                       reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status, nseg);
+}
+
+// multi-signal handles: stream (default: persistent, register-staged MFMA kernel), dma (LDS-DMA staged MFMA kernel, 8-byte
+// storage only), valu (no matrix cores)
+static int multi_matvec_choice() {
+    static const int multi = [] {
+        const char *e = getenv("LPVS_MULTI_MATVEC");
+        return !e ? 2 : (std::string(e) == "valu" ? 0 : (std::string(e) == "dma" ? 1 : 2));
+    }();
+    return multi;
+}
+static bool uses_stream_kernel(const AdmmParams &p) {
+    return p.ns > 1 && !p.mp_f32 && p.Mp != nullptr && (p.mp_split || (multi_matvec_choice() == 2 && p.np <= 49152));   // (31-bit byte offsets into the partials: np <= 49152)
+}
+// The stream kernel's number of segments when it writes its P1 partials per RUN of tiles (one signal pass; every workgroup the same
+// number of segments of about L tiles; room for nseg + nblk records in the per-tile record area), else 0: the consumers of the partials
+// (symv_reduce_kernel, admm_fused_update2_kernel) take it as `runs_G`.  LPVS_MULTI_RUNS=L sets the segment length (default 8), 0 keeps
+// one record per tile.
+static int stream_runs(const AdmmParams &p) {
+    const unsigned L = [] { const char *e = getenv("LPVS_MULTI_RUNS"); const int v = e ? atoi(e) : 8; return (unsigned)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();   // (read per call: tests switch it)
+    if (L < 2 || !uses_stream_kernel(p) || p.ns > WS_NS) return 0;
+    const int nblk = (int)(p.np / TS);
+    const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), cus = stream_cus();
+    if (ntiles < 2 * cus * L) return 0;              // (small matrices: a tile per visit)
+    const unsigned rounds = (ntiles + cus * L - 1) / (cus * L), nseg = cus * rounds;
+    return nseg + (unsigned)nblk <= ntiles ? (int)nseg : 0;
 }
 
 // the mat-vec of one iteration on the packed symmetric form (tile partials -> part1 / part2)
@@ -2472,15 +2587,17 @@ static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hip
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
     const unsigned ns = (unsigned)p.ns;
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
-    // multi-signal handles: stream (default: persistent, register-staged MFMA kernel), dma (LDS-DMA staged MFMA kernel, 8-byte
-    // storage only), valu (no matrix cores)
-    static const int multi = [] {
-        const char *e = getenv("LPVS_MULTI_MATVEC");
-        return !e ? 2 : (std::string(e) == "valu" ? 0 : (std::string(e) == "dma" ? 1 : 2));
-    }();
-    if (p.ns > 1 && !p.mp_f32 && (p.mp_split || (multi == 2 && p.np <= 49152))) {   // (31-bit byte offsets into the partials: np <= 49152)
-        if (p.mp_split) launch_mfma_stream<true>(p, ntiles, part1, part2, status, s);
-        else launch_mfma_stream<false>(p, ntiles, part1, part2, status, s);
+    const int multi = multi_matvec_choice();
+    if (uses_stream_kernel(p)) {
+        // up to 8 signals: the 4x4x4 four-block MFMA (no padded columns); LPVS_MULTI_MFMA=16 keeps the 16-column instruction
+        const bool q4_off = [] { const char *e = getenv("LPVS_MULTI_MFMA"); return e && std::string(e) == "16"; }();
+        const bool q4 = p.ns <= 8 && !q4_off, runs = stream_runs(p) != 0;
+        auto go = [&](auto split, auto q4c, auto runsc) {
+            launch_mfma_stream<decltype(split)::value, decltype(q4c)::value, decltype(runsc)::value>(p, ntiles, part1, part2, status, s);
+        };
+        using T = std::true_type; using F = std::false_type;
+        if (p.mp_split) { if (q4) { if (runs) go(T{}, T{}, T{}); else go(T{}, T{}, F{}); } else { if (runs) go(T{}, F{}, T{}); else go(T{}, F{}, F{}); } }
+        else            { if (q4) { if (runs) go(F{}, T{}, T{}); else go(F{}, T{}, F{}); } else { if (runs) go(F{}, F{}, T{}); else go(F{}, F{}, F{}); } }
     } else if (p.ns > 8 && !p.mp_f32 && multi == 1) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)symv_mfma_lds<16>());   // per device; cheap
@@ -2512,9 +2629,9 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
     launch_sym_matvec(p, p.status, s);
     if (fused_ok(p)) {
-        hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0);
+        hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0, stream_runs(p));
     } else {
-        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb);
+        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, stream_runs(p));
         hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
     }
 }

@@ -671,3 +671,36 @@ def test_tls_spectral_known_answer_and_oracle(L, oracle):
     x2, _ = L.tls_spectral(y2, t2, f2)
     xo, _ = oracle.tls_spectral(y2, t2, f2)
     assert rel(x2, xo) <= 1e-9
+
+
+@pytest.mark.parametrize("ns,prox", [(3, "ball"), (8, "group"), (8, "ball"), (12, "group")])
+def test_multi_signal_tile_product_variants_agree(L, ns, prox, monkeypatch):
+    """The multi-signal tile product (symv_tile_mfma_ws_kernel) in its variants -- 4x4x4 four-block MFMA (ns <= 8) or the 16-column MFMA,
+    one P1 record per tile or per run of tiles (segments of 2 / 4 tiles here; 8 at cfg5) -- through both consumers of the partials
+    (symv_reduce_kernel for IndBallL0, admm_fused_update2_kernel for the group prox): same supports, same stopping iterations, iterates
+    equal to summation order."""
+    rng = np.random.default_rng(31)
+    N, Nf, Nv = 3000, 192, 16                                   # n = 6144: 48 row blocks, 1176 tiles
+    X = np.sort(10 * rng.random(N)); V = np.linspace(0, 1, N)
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) * 25 / Nf
+    Y = np.stack([np.cos(w[(3 * q + 1) % Nf] * X) * (1 + q * V) + 0.3 * np.sin(w[(5 * q + 2) % Nf] * X) + 0.05 * rng.standard_normal(N)
+                  for q in range(ns)], axis=1)
+    g = L.IndBallL0(6) if prox == "ball" else None
+    kw = dict(λ=3.0, iters=300, tol=1e-6, μ=0.05, printerval=100000, proxg=g)
+    out = {}
+    for name, env in (("tiles", {"LPVS_MULTI_RUNS": "0"}), ("runs2", {"LPVS_MULTI_RUNS": "2"}), ("runs4", {"LPVS_MULTI_RUNS": "4"}),
+                      ("mfma16/tiles", {"LPVS_MULTI_RUNS": "0", "LPVS_MULTI_MFMA": "16"}), ("mfma16/runs2", {"LPVS_MULTI_RUNS": "2", "LPVS_MULTI_MFMA": "16"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ses = L.ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, **kw)
+        for k in env:
+            monkeypatch.delenv(k)
+        out[name] = np.stack([se.x for se in ses], axis=1)
+    ref = out["mfma16/tiles"]                                    # (round 2's kernel)
+    assert 0 < np.count_nonzero(ref) < ref.size
+    for name, x in out.items():
+        assert np.array_equal(x != 0, ref != 0), name
+        assert rel(x, ref) <= 1e-11, (name, rel(x, ref))
+    q = ns - 1
+    se = L.ls_sparse_spectral_lpv(Y[:, q].copy(), X, V, w, Nv, **kw)     # and the single-signal solve of the last column (scalar tile product)
+    assert np.array_equal(se.x != 0, out["runs2"][:, q] != 0) and rel(out["runs2"][:, q], se.x) <= 1e-9
