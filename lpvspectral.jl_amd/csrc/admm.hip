@@ -187,10 +187,10 @@ __device__ void topr_threshold(const double *v, int64_t n, int64_t r, unsigned l
 // index first on ties) and the winners are marked in an LDS bitmap.  Returns false (nothing written) when there
 // are more than 1024 candidates -- the caller then falls back to the 64-bit select.
 //   keep(i) = key32[i] > thr32  ||  bit i of `mark`
-__device__ bool topr_float_keys(const double *__restrict__ X, const double *__restrict__ U, int64_t n, long long r,
-                                unsigned int *key32 /*[n] LDS*/, unsigned int *mark /*[1024] LDS words*/,
-                                unsigned int *hist /*[256]*/, long long *shll /*[3]*/, int *scan /*[1024] LDS*/,
-                                unsigned int *thr_out) {
+__device__ bool topr_float_keys_radix(const double *__restrict__ X, const double *__restrict__ U, int64_t n, long long r,
+                                      unsigned int *key32 /*[n] LDS*/, unsigned int *mark /*[1024] LDS words*/,
+                                      unsigned int *hist /*[256]*/, long long *shll /*[3]*/, int *scan /*[1024] LDS*/,
+                                      unsigned int *thr_out) {
     const int lane = threadIdx.x & 63;
     for (int64_t i = threadIdx.x; i < n; i += 1024) key32[i] = __float_as_uint((float)fabs(X[i] + U[i]));   // monotone in |v|
     for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
@@ -266,6 +266,85 @@ __device__ bool topr_float_keys(const double *__restrict__ X, const double *__re
     return true;
 }
 
+// The same selection in ONE histogram pass (what cfg5 runs every iteration: n = 32768, r = 32): the float keys go to LDS and, on the
+// way, into a histogram of their top 11 bits (exponent + 3 mantissa bits: plain LDS atomics -- the keys of a wave spread over tens of
+// bins; the four byte-wise passes above cost a ballot loop per distinct bin each); a suffix scan of the 2048 counts finds the bin of the
+// r-th largest; the (few) elements of that bin are ranked exactly on their 64-bit keys held in LDS (lowest index first on ties).
+//   keep(i) = key32[i] > *thr_out  ||  bit i of `mark`          (*thr_out = the bin's largest float key)
+// More than 1023 elements in the threshold bin: the byte-wise select above decides (and may hand on to the 64-bit one).
+__device__ bool topr_float_keys(const double *__restrict__ X, const double *__restrict__ U, int64_t n, long long r,
+                                unsigned int *key32 /*[n] LDS*/, unsigned int *mark /*[1024] LDS words*/,
+                                unsigned int *hist /*[256]*/, unsigned int *hist11 /*[2048]*/, unsigned long long *ckey /*[1024]*/,
+                                long long *shll /*[3]*/, int *scan /*[1024] LDS*/, unsigned int *thr_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2048; i += 1024) hist11[i] = 0;
+    mark[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < n; c0 += 8192) {          // eight elements per thread in flight
+        double xv[8], uv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = c0 + threadIdx.x + 1024 * k;
+            xv[k] = i < n ? X[i] : 0.0; uv[k] = i < n ? U[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = c0 + threadIdx.x + 1024 * k;
+            if (i < n) {
+                const unsigned int key = __float_as_uint((float)fabs(xv[k] + uv[k]));   // monotone in |v|
+                key32[i] = key;
+                atomicAdd(&hist11[key >> 20], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    {   // suffix sums over the 2048 bins: thread t owns bins 2t, 2t + 1
+        const unsigned int c0 = hist11[2 * threadIdx.x], c1 = hist11[2 * threadIdx.x + 1], tot = c0 + c1;
+        unsigned int sfx = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_down(sfx, o, 64);
+            if (lane + o < 64) sfx += t;
+        }
+        if (lane == 0) scan[wave] = (int)sfx;           // the wave's total
+        __syncthreads();
+        unsigned int above = sfx - tot;                  // counts in higher bins of this wave ...
+        for (int w2 = wave + 1; w2 < 16; ++w2) above += (unsigned int)scan[w2];   // ... and of the higher waves
+        const unsigned int S1 = above + c1, S0 = S1 + c0;
+        if ((long long)S1 >= r && (long long)above < r) { shll[0] = 2 * threadIdx.x + 1; shll[1] = r - above; shll[2] = c1; }
+        if ((long long)S0 >= r && (long long)S1 < r) { shll[0] = 2 * threadIdx.x; shll[1] = r - S1; shll[2] = c0; }
+        __syncthreads();
+    }
+    const unsigned int bin = (unsigned int)shll[0];
+    const long long need = shll[1], ncand = shll[2];      // keep `need` of the `ncand` elements of the bin
+    if (ncand > 1023) {                                   // (uniform)
+        __syncthreads();
+        return topr_float_keys_radix(X, U, n, r, key32, mark, hist, shll, scan, thr_out);
+    }
+    *thr_out = (bin << 20) | 0xFFFFFu;
+    if (threadIdx.x == 0) scan[0] = 0;
+    __syncthreads();
+    int *cidx = scan + 1;
+    for (int64_t i = threadIdx.x; i < n; i += 1024)
+        if ((key32[i] >> 20) == bin) cidx[atomicAdd(&scan[0], 1)] = (int)i;
+    __syncthreads();
+    if ((long long)threadIdx.x < ncand) { const int me = cidx[threadIdx.x]; ckey[threadIdx.x] = abs_key(X[me] + U[me]); }
+    __syncthreads();
+    if ((long long)threadIdx.x < ncand) {                 // exact rank among the candidates: 64-bit key descending, index ascending
+        const int me = cidx[threadIdx.x];
+        const unsigned long long km = ckey[threadIdx.x];
+        int rank = 0;
+        for (int c = 0; c < (int)ncand; ++c) {
+            const int o = cidx[c];
+            const unsigned long long ko = ckey[c];
+            rank += (ko > km) || (ko == km && o < me);
+        }
+        if (rank < need) atomicOr(&mark[me >> 5], 1u << (me & 31));
+    }
+    __syncthreads();
+    return true;
+}
+
 // Elements are processed in coalesced passes of 1024 threads x EPT elements: all loads of a pass are
 // issued before any store (no aliasing-serialised round trips); group norms go through LDS.
 constexpr int EPT = 8;                 // elements per thread per pass
@@ -279,6 +358,8 @@ admm_prox_kernel(AdmmParams p) {
     __shared__ int scan[1024];
     __shared__ double lds2[2 * PASS];  // 128 KiB: group prox uses it as sq / gscale, IndBallL0 as float keys or v cache
     __shared__ unsigned int mark[1024];
+    __shared__ unsigned int hist11[2048];
+    __shared__ unsigned long long ckey[1024];
     double *sq = lds2;                 // v^2 of the current pass (group prox)
     double *gscale = lds2 + PASS;      // per-group scale of the current pass
     const int sg = blockIdx.x;         // one workgroup per signal
@@ -310,7 +391,7 @@ admm_prox_kernel(AdmmParams p) {
     unsigned int thr32 = 0;
     bool ball_fast = false;                                // two-level selection with float keys in LDS succeeded
     if (kind == LPVS_PROX_BALL_L0 && ball_r > 0 && ball_r < n) {
-        if (n <= 4 * PASS) ball_fast = topr_float_keys(X, U, n, ball_r, key32, mark, hist, shll, scan, &thr32);
+        if (n <= 4 * PASS) ball_fast = topr_float_keys(X, U, n, ball_r, key32, mark, hist, hist11, ckey, shll, scan, &thr32);
         if (!ball_fast) {
             __syncthreads();
             for (int64_t i = threadIdx.x; i < n; i += 1024) vbuf[i] = X[i] + U[i];
@@ -1876,6 +1957,50 @@ symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ 
     }
 }
 
+// The same for the multi-signal kernel's partials per RUN: a row block has a few part1 records and up to nblk - 1 part2 tiles, so the
+// contributions are taken as ONE list and summed by eight groups of 128 lanes, a contiguous eighth each (16 loads in flight per lane),
+// then combined in fixed order.
+__global__ void __launch_bounds__(1024)
+symv_reduce_runs_kernel(const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk, int ntiles, int64_t np,
+                        double *__restrict__ x, const AdmmStatus *status, const double *__restrict__ xb, int runs_G) {
+    const int sg = blockIdx.y, I = blockIdx.x;
+    if (status != nullptr && status[sg].converged) return;
+    __shared__ double sh[7 * TS];
+    const double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
+    const int i = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const Part1Range r1 = part1_range(I, ntiles, runs_G);
+    const int nent = r1.count + nblk - 1 - I, eshift = I + 1 - r1.count;
+    const int per = (nent + 7) / 8, e0 = g * per, e1 = e0 + per < nent ? e0 + per : nent;
+    auto at = [&](int e) -> const double * {
+        const int K = e + eshift;
+        return e < r1.count ? part1 + ((int64_t)r1.first + e) * TS + i : part2 + ((int64_t)K * (K + 1) / 2 + I) * TS + i;
+    };
+    double s = 0;
+    int e = e0;
+    for (; e + 16 <= e1; e += 16) {
+        double a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = *at(e + q);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += a[q];
+    }
+    {   // the remainder, also in one batch (clamped addresses, masked values)
+        double a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = *at(e + q < e1 ? e + q : (nent > 0 ? nent - 1 : 0));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += e + q < e1 ? a[q] : 0.0;
+    }
+    if (g > 0) sh[(g - 1) * TS + i] = s;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) s += sh[q * TS + i];
+        const int64_t gi = (int64_t)sg * np + (int64_t)I * TS + i;
+        x[gi] = xb ? xb[gi] + s : s;
+    }
+}
+
 // ---- fused: gather x from the tile partials + prox_g + dual update + next rhs, one workgroup per
 // 128-row block; ||x-z||^2 is combined by the last-arriving workgroup in fixed block order (deterministic).
 // Valid for element-wise prox (L1, L0) and for group prox with 128 % group_len == 0, n % group_len == 0.
@@ -2631,7 +2756,10 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     if (fused_ok(p)) {
         hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0, stream_runs(p));
     } else {
-        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, stream_runs(p));
+        if (const int runs = stream_runs(p))
+            hipLaunchKernelGGL(symv_reduce_runs_kernel, dim3((unsigned)nblk, ns), dim3(1024), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, runs);
+        else
+            hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, 0);
         hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
     }
 }
