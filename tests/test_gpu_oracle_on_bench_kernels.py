@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 
 
 def rel(a, b):
-    return np.linalg.norm(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) / max(np.linalg.norm(np.asarray(b, dtype=np.float64)), 1e-300)
+    a, b = np.asarray(a), np.asarray(b)                      # (complex spectra stay complex: both parts are compared)
+    dt = np.complex128 if np.iscomplexobj(a) or np.iscomplexobj(b) else np.float64
+    a, b = a.astype(dt), b.astype(dt)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
 def _signal(N, Nf, rng):
