@@ -266,6 +266,16 @@ static StreamBundle *bundle_acquire(int device) {
         for (size_t i = 0; i < g_bundles.size(); ++i)
             if (g_bundles[i]->device == device) { StreamBundle *b = g_bundles[i]; g_bundles.erase(g_bundles.begin() + (long)i); return b; }
     }
+    // Idle bundles are destroyed by an exit handler registered HERE, i.e. after the HIP runtime's own: it runs before the runtime is
+    // torn down (a CU-masked stream still alive at that point crashed the process at exit under rocprofv3).
+    static std::once_flag exit_hook;
+    std::call_once(exit_hook, [] {
+        (void)atexit([] {
+            std::lock_guard<std::mutex> g(g_bundle_mu);
+            for (StreamBundle *q : g_bundles) { (void)hipSetDevice(q->device); delete q; }
+            g_bundles.clear();
+        });
+    });
     StreamBundle *b = new (std::nothrow) StreamBundle();
     if (!b) return nullptr;
     b->device = device;

@@ -2,7 +2,6 @@
 # HBM traffic of the bench's kernels from PMC counters, collected as the guide prescribes: separate --pmc
 # passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only.  Run on the GPU box:
 #   bash tools/collect_pmc.sh <outdir>
-set -e
 OUT=${1:-gpurun_out/pmc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/$OUT"

@@ -19,6 +19,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gp
 cd "$R"
 for k in k3 k4 k5 k2; do F=$(find gpurun_out/prof/$k -name "*kernel_stats.csv" | head -1); python tools/trim_stats.py "$F" gpurun_out/prof/${k}_kernel_stats.csv > /dev/null; rm -rf gpurun_out/prof/$k; done
 bash tools/collect_pmc.sh gpurun_out/prof/pmc > gpurun_out/prof/pmc.log 2>&1
-rm -rf gpurun_out/prof/pmc/FETCH_SIZE gpurun_out/prof/pmc/WRITE_SIZE
 bash tools/collect_factor_pmc.sh gpurun_out/prof/pmc_factor 8192 > gpurun_out/prof/pmc_factor.log 2>&1
 ls -la gpurun_out/prof gpurun_out/prof/pmc
