@@ -1113,9 +1113,16 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
         const int nblocks = (int)(np / 128);
         auto slotB = [&](int blk) { return work + (int64_t)(blk & (2 * kMaxGroup - 1)) * (2 * 128 * ldp); };
         auto slotC = [&](int blk) { return slotB(blk) + 128 * ldp; };
+        // The one-workgroup pivot inverse asks for the rest of a CU's LDS (unused): it can then only be placed on a CU that holds no other
+        // workgroup -- one of those the deep passes' CU mask leaves out -- and nothing joins it there (np = 8192: 13.5 -> 13.2 ms; with three
+        // update workgroups per CU, from np = 12288, it waits too long for an empty CU: 84.5 -> 86.3 ms at 16384).  LPVS_PIVOT_ALONE=0/1.
+        const int alone_env = [] { const char *e = getenv("LPVS_PIVOT_ALONE"); return e ? atoi(e) : -1; }();
+        const bool pivot_alone = alone_env >= 0 ? alone_env != 0 : np < 12288;
+        const size_t pivot_pad = (pivot_alone && aux->bulk) ? (size_t)(160 * 1024 - 40 * 1024) : 0;
+        if (pivot_pad) LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pivot_inverse_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pivot_pad));
         auto chain128 = [&](int blk, hipStream_t st) {
             const int64_t k0 = (int64_t)blk * 128;
-            if (mfma_pivot) hipLaunchKernelGGL(pivot_inverse_mfma_kernel, dim3(1), dim3(256), 0, st, A, np, k0, P, status_dev);
+            if (mfma_pivot) hipLaunchKernelGGL(pivot_inverse_mfma_kernel, dim3(1), dim3(256), pivot_pad, st, A, np, k0, P, status_dev);
             else hipLaunchKernelGGL(pivot_inverse_kernel<128>, dim3(1), dim3(192), 0, st, A, np, k0, P, status_dev);
             if (fused_chain) {
                 hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(ldp / 16)), dim3(256), 0, st, A, np, ldp, k0, (const double *)P, slotB(blk), slotC(blk));
