@@ -683,7 +683,7 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         "admm_iters_per_sec": iters / (phase["admm_ms"] * 1e-3),
         "phase_ms": phase,
         "factor_ms": phase["factor_ms"],
-        "factorisation": {"bound": "mfma", "kernel": "rank_update_kernel + pivot chain (blocked symmetric sweep, v_mfma_f64_16x16x4_f64)",
+        "factorisation": {"bound": "mfma", "kernel": "rank_updatem_kernel + pivot chain (blocked symmetric sweep, two 128-wide steps per pass over A, v_mfma_f64_16x16x4_f64)",
                           "flops": float(2 * NF * NV) ** 3, "ms": phase["factor_ms"],
                           "achieved": float(2 * NF * NV) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": float(2 * NF * NV) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12 / F64_MFMA_PEAK_TFLOPS,
@@ -816,13 +816,15 @@ def run_cfg5(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
            "phase_ms": phase, "final_nxz": nxz, "nnz_per_channel": [int(np.count_nonzero(params[:, q])) for q in range(ns)],
            "factorisation": {"flops": float(n) ** 3, "ms": phase["factor_ms"], "achieved_TFLOPs": float(n) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12,
                              "frac_of_f64_mfma_peak": float(n) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12 / F64_MFMA_PEAK_TFLOPS},
-           "roofline": {"bound": "hbm", "kernel": info["kernel"] + " (tile product of the packed (G + I/mu)^-1 with all channels on v_mfma_f64_16x16x4_f64)",
+           "roofline": {"bound": "hbm", "kernel": info["kernel"] + " (tile product of the packed (G + I/mu)^-1 with all channels on %s)" % info.get("mfma", "the matrix cores"),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": None,
                         "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "launches_per_step": iters,
                         "share_of_step": iters * mv_us * 1e-3 / (elapsed / steps * 1e3),
-                        "mfma_flops_per_launch": 4.0 * float(n) * float(n + 128) / 2 * 16 * 2 / 2,
-                        "note": "algorithmic bytes = %s; HIP events around 30 back-to-back launches on the library's stream; the same launch also issues "
-                                "n(n+128)/2 x 16 signal columns x 2 products of f64 MFMA work (with 8 channels half of every MFMA is padding)" % info["bytes_formula"]}}
+                        "mfma_flops_per_launch": 4.0 * float(n) * float(n + 128) / 2 * info.get("signals_per_pass", 16) * 2 / 2,
+                        "note": "algorithmic bytes = %s (+ the tile partials the launch writes: one record per run of tiles for the row sums, one per tile "
+                                "for the column sums: 34 + 270 MB at n = 32768, not counted); HIP events around 30 back-to-back launches on the library's stream; "
+                                "the same launch also issues n(n+128)/2 x %d signal columns x 2 products of f64 MFMA work; launch time varies by ~10 %% with the "
+                                "box and with where the 3.2 GB buffer landed (DESIGN.md 4.5.1)" % (info["bytes_formula"], info.get("signals_per_pass", 16))}}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_cfg5()
     return out

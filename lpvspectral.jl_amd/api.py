@@ -10,6 +10,7 @@ in HBM).  There is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import logging
 import sys
 from dataclasses import dataclass
@@ -492,8 +493,11 @@ class Problem:
                         bytes_formula="98304 B per 6-byte tile, 74240 B per fixed-point tile (np = %d; 8-byte form %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2))
         if self.ns > 1 and int(k.value) in (1, 3):
             elt = 8 if int(k.value) == 1 else 6
+            q4 = self.ns <= 8 and os.environ.get("LPVS_MULTI_MFMA") != "16"
             return dict(kernel="symv_tile_mfma_ws_kernel", storage="tile-packed lower triangle, %s" % ("f64 (8 B)" if elt == 8 else "float head + 16-bit tail (6 B, 40 significant bits)"),
-                        bytes_formula="%d B x np(np+128)/2 (np = %d), streamed once per 16 signals" % (elt, np_))
+                        mfma="v_mfma_f64_4x4x4_4b_f64 (8 signal columns per pass, none padded)" if q4 else "v_mfma_f64_16x16x4_f64 (16 signal columns per pass)",
+                        signals_per_pass=8 if q4 else 16,
+                        bytes_formula="%d B x np(np+128)/2 (np = %d), streamed once per %d signals" % (elt, np_, 8 if q4 else 16))
         return {0: dict(kernel="symv_kernel", storage="full symmetric f64", bytes_formula="8 B x np^2"),
                 1: dict(kernel="symv_tile_kernel<double>", storage="tile-packed lower triangle, f64 (8 B)",
                         bytes_formula="8 B x np(np+128)/2 (np = %d)" % np_),
