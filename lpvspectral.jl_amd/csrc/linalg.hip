@@ -887,6 +887,130 @@ rank_updatem_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuGroup g, 
             }
 }
 
+// ---- band launches on 64 x 64 tiles ------------------------------------------------------------------------------------------------
+// A band launch (the tiles of one or a few 128-wide bands) has fewer tiles than the chip has workgroup slots: it lasts as long as ONE
+// tile at the pass's depth (19 us + 0.29 us per pivot on 128 x 128 tiles), and it sits on the pivot chains' critical path.  The same
+// update on 64 x 64 tiles -- four times the workgroups, a quarter of the matrix instructions each (a wave owns 32 x 32: four
+// accumulators), half the LDS stage (a pivot's 64 + 64 panel values are ONE 1-KB LDS-DMA piece: lanes 0-31 fetch Ck, lanes 32-63 Bk) --
+// applies the same panels to the same elements in the same order per element (bit-identical results).
+// Tile rules as rank_updatem_kernel with select = 1.
+template <int BK>
+__global__ void __launch_bounds__(256, 4)
+rank_updateb_kernel(double *__restrict__ A, int64_t np, int64_t ldp, RuGroup g, int e0, int nslices, int band) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 1, wb = wave & 1;
+    const int sub = blockIdx.x & 3, bidx = blockIdx.x >> 2, sx = sub >> 1, sy = sub & 1;
+    const int nr = (int)(np / 128);
+    const int bsl = bidx / nr, e = bidx - bsl * nr, bt = e0 + bsl;
+    if (e > bt && e < e0 + nslices) return;                          // tile (e, bt) with e a later slice: enumerated there as (e, bt)
+    const int2 tt = e <= bt ? make_int2(bt, e) : make_int2(e, bt);
+    if (tt.x == tt.y && sy > sx) return;                             // quarter above the diagonal
+    const int jr = (tt.x >= g.kb && tt.x < g.kb + g.mg) ? tt.x - g.kb : -1, jc = (tt.y >= g.kb && tt.y < g.kb + g.mg) ? tt.y - g.kb : -1;
+    int lo, hi;
+    if (band >= 0) { lo = (jc >= 0 && jc < band) ? jc + 1 : 0; hi = band; }
+    else { lo = (jr > jc ? jr : jc) + 1; hi = g.mg; }
+    if (lo >= hi) return;
+    const int64_t a0 = (int64_t)tt.x * 128 + sx * 64, b0 = (int64_t)tt.y * 128 + sy * 64;
+    const int64_t r_lo = a0 + wa * 32, c_lo = b0 + wb * 32;
+    const bool skip_wave = c_lo > r_lo + 31;                         // above the diagonal: nothing to maintain
+    constexpr int SPP = 128 / BK;                                    // stages per panel
+    const int nstages = (hi - lo) * SPP;
+    constexpr int ROW = 128, STAGE = BK * ROW;
+    double *buf0 = lds, *buf1 = lds + STAGE;
+    auto stage_load = [&](double *buf, int st) {
+        const int pi = lo + st / SPP, s0 = (st % SPP) * BK;
+        const double *Ck = nullptr, *Bk = nullptr;
+#pragma unroll
+        for (int i = 0; i < kMaxGroup; ++i) if (i == pi) { Ck = g.Ck[i]; Bk = g.Bk[i]; }
+        for (int k = wave; k < BK; k += 4) {                         // piece = pivot: [64 of Ck | 64 of Bk]
+            const double *src = lane < 32 ? Ck + (int64_t)(s0 + k) * ldp + a0 + 2 * lane : Bk + (int64_t)(s0 + k) * ldp + b0 + 2 * (lane - 32);
+            glds16(src, buf + k * ROW);
+        }
+    };
+    const int li = lane & 15, lk = lane >> 4;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { offA[t] = wa * 32 + t * 16 + li; offB[t] = 64 + wb * 32 + t * 16 + li; }
+    stage_load(buf0, 0);
+    f64x4 acc[2][2];
+    const unsigned voffb = (unsigned)((lk * np + li) * 8);
+    const bool below = c_lo + 31 <= r_lo;                            // (wave-uniform) col <= row for every element of the wave's 32 x 32 block
+    if (!skip_wave && below) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double *sp = A + (r_lo + i * 16 + 4 * r) * np + c_lo;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j][r] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(sp + j * 16) + voffb);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = r_lo + i * 16 + lk + 4 * r, col = c_lo + j * 16 + li;
+                    acc[i][j][r] = (!skip_wave && col <= row) ? A[row * np + col] : 0.0;
+                }
+    }
+    __syncthreads();
+    double rA[2], rB[2];
+    auto fetch = [&](const double *img, int kk) {
+        const double *row = img + (kk * 4 + lk) * ROW;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { rA[t] = row[offA[t]]; rB[t] = row[offB[t]]; }
+    };
+#pragma unroll 1
+    for (int s = 0; s < nstages; ++s) {
+        double *cur = (s & 1) ? buf1 : buf0, *nxt = (s & 1) ? buf0 : buf1;
+        if (s + 1 < nstages) stage_load(nxt, s + 1);
+        if (!skip_wave) {
+            fetch(cur, 0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double opA[2], opB[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { opA[t] = rA[t]; opB[t] = rB[t]; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < BK / 4) fetch(cur, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[i], opB[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    if (skip_wave) return;
+    if (below) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double *sp = A + (r_lo + i * 16 + 4 * r) * np + c_lo;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) *reinterpret_cast<double *>(reinterpret_cast<char *>(sp + j * 16) + voffb) = acc[i][j][r];
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r_lo + i * 16 + lk + 4 * r, col = c_lo + j * 16 + li;
+                if (col <= row) A[row * np + col] = acc[i][j][r];
+            }
+}
+
 // diag(M) += shift on the valid part; the pad block becomes the identity
 __global__ void __launch_bounds__(256) add_diag_kernel(double *__restrict__ Mall, int64_t np, int64_t n, double shift) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1138,8 +1262,16 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
             return g;
         };
         const int nr = (int)(np / RU_TM);
+        // band launches on 64 x 64 tiles (rank_updateb_kernel) below np = 8192: 4.31 -> 3.98 ms at 4096; from 8192 the deep pass is the
+        // critical path either way (side chain 445 -> 390 us per pair against a 393-us deep pass; 12.9-13.1 ms with 128 x 128 band tiles,
+        // 13.1-13.3 with 64 x 64).  LPVS_BAND_TILE=64|128 forces one.
+        const int band_env = [] { const char *e = getenv("LPVS_BAND_TILE"); return e ? atoi(e) : 0; }();
+        const bool band64 = band_env == 64 || (band_env != 128 && np < 8192);
         auto launch_bands = [&](hipStream_t st, const RuGroup &g, int e0, int nsl, int band) {   // the tiles of bands e0 .. e0 + nsl - 1
-            hipLaunchKernelGGL(ru_kernel, dim3((unsigned)(nr * nsl)), dim3(RU_THREADS), ldsm, st, A, np, ldp, g, tiles, (int)ht.size(), 1, e0, nsl, band, 0, 0);
+            if (band64)
+                hipLaunchKernelGGL(rank_updateb_kernel<16>, dim3((unsigned)(4 * nr * nsl)), dim3(256), 2 * 16 * 128 * sizeof(double), st, A, np, ldp, g, e0, nsl, band);
+            else
+                hipLaunchKernelGGL(ru_kernel, dim3((unsigned)(nr * nsl)), dim3(RU_THREADS), ldsm, st, A, np, ldp, g, tiles, (int)ht.size(), 1, e0, nsl, band, 0, 0);
         };
         auto launch_rest = [&](hipStream_t st, const RuGroup &g, int skip0, int nskip) {
             hipLaunchKernelGGL(ru_kernel, dim3((unsigned)ht.size()), dim3(RU_THREADS), ldsm, st, A, np, ldp, g, tiles, (int)ht.size(), 0, 0, 0, -1, skip0, nskip);

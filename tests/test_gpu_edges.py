@@ -75,7 +75,8 @@ def test_empty_and_mismatched_inputs_raise(L):
 @pytest.mark.parametrize("knobs", [{}, {"LPVS_KW": "256"}, {"LPVS_KW": "256", "LPVS_LOOKAHEAD": "0"}, {"LPVS_LOOKAHEAD": "0"},
                                    {"LPVS_PIVOT": "sweep64"}, {"LPVS_FACTOR": "sweep64"}, {"LPVS_FACTOR_SCHEME": "steps"},
                                    {"LPVS_CHAIN": "split"}, {"LPVS_PIVOT": "regs"}, {"LPVS_FACTOR_GROUP": "1"}, {"LPVS_FACTOR_GROUP": "2"},
-                                   {"LPVS_FACTOR_GROUP": "3"}, {"LPVS_FACTOR_GROUP": "4", "LPVS_RU_STAGE": "8"}, {"LPVS_RESERVE_CUS": "0"}])
+                                   {"LPVS_FACTOR_GROUP": "3"}, {"LPVS_FACTOR_GROUP": "4", "LPVS_RU_STAGE": "8"}, {"LPVS_RESERVE_CUS": "0"},
+                                   {"LPVS_BAND_TILE": "128"}, {"LPVS_BAND_TILE": "64", "LPVS_FACTOR_GROUP": "4"}, {"LPVS_PIVOT_ALONE": "0"}])
 @pytest.mark.parametrize("n", [1024, 2100, 2300, 2500])
 def test_factorisation_variants_give_the_inverse(L, knobs, n, monkeypatch):
     """Every factorisation variant (128 / 256-wide outer blocks incl. the ragged last block, with and without look-ahead,
@@ -83,7 +84,8 @@ def test_factorisation_variants_give_the_inverse(L, knobs, n, monkeypatch):
     panels per pass of the trailing update, pivot block inverted on the matrix cores, fused pivot-chain tail: np = 2176 is 17 pivot
     blocks (groups 4 + 4 + 4 + 4 + 1), 2304 = 18, 2560 = 20; LPVS_FACTOR_GROUP = 1 / 2 / 3 panels per pass, LPVS_PIVOT=regs the
     register kernel for the pivot block, LPVS_FACTOR_SCHEME=steps / LPVS_CHAIN=split the one-panel schedule / the separate gather +
-    GEMM kernels, LPVS_RESERVE_CUS=0 no CU mask) returns (G + I/mu)^-1: |M H - I| at rounding level."""
+    GEMM kernels, LPVS_RESERVE_CUS=0 no CU mask, LPVS_BAND_TILE=64|128 the band launches' tile size, LPVS_PIVOT_ALONE=0 the pivot
+    kernel without its LDS padding) returns (G + I/mu)^-1: |M H - I| at rounding level."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(n)
@@ -98,7 +100,7 @@ def test_factorisation_variants_give_the_inverse(L, knobs, n, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [{}, {"LPVS_LOOKAHEAD": "1"}, {"LPVS_KW": "256"}, {"LPVS_FACTOR_SCHEME": "steps"}, {"LPVS_CHAIN": "split"},
-                                   {"LPVS_FACTOR_GROUP": "3"}, {"LPVS_PIVOT": "regs"}])
+                                   {"LPVS_FACTOR_GROUP": "3"}, {"LPVS_PIVOT": "regs"}, {"LPVS_BAND_TILE": "128"}])
 def test_deep_lookahead_factorisation_gives_the_inverse(L, knobs, monkeypatch):
     """np >= 6144 takes the depth-2 look-ahead schedule (three panel buffers, second band of the trailing update); a ragged
     size just above that threshold must agree with the depth-one schedule and with the definition of the inverse."""
