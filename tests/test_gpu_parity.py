@@ -674,7 +674,7 @@ def test_tls_spectral_known_answer_and_oracle(L, oracle):
 
 
 @pytest.mark.parametrize("ns,prox", [(3, "ball"), (8, "group"), (8, "ball"), (12, "group")])
-def test_multi_signal_tile_product_variants_agree(L, ns, prox, monkeypatch):
+def test_multi_signal_tile_product_variants_agree(L, oracle, ns, prox, monkeypatch):
     """The multi-signal tile product (symv_tile_mfma_ws_kernel) in its variants -- 4x4x4 four-block MFMA (ns <= 8) or the 16-column MFMA,
     one P1 record per tile or per run of tiles (segments of 2 / 4 tiles here; 8 at cfg5) -- through both consumers of the partials
     (symv_reduce_kernel for IndBallL0, admm_fused_update2_kernel for the group prox): same supports, same stopping iterations, iterates
@@ -704,3 +704,19 @@ def test_multi_signal_tile_product_variants_agree(L, ns, prox, monkeypatch):
     q = ns - 1
     se = L.ls_sparse_spectral_lpv(Y[:, q].copy(), X, V, w, Nv, **kw)     # and the single-signal solve of the last column (scalar tile product)
     assert np.array_equal(se.x != 0, out["runs2"][:, q] != 0) and rel(out["runs2"][:, q], se.x) <= 1e-9
+    if ns == 8 and prox == "ball":
+        # ... and the ORACLE on the kernel cfg5 runs (4x4x4 MFMA, partials per run, one-pass top-r selection): Gram-form ADMM on the
+        # device Gram at equal iteration counts, every channel: rel-L2 <= 1e-9, identical support, identical stopping iteration
+        monkeypatch.setenv("LPVS_MULTI_RUNS", "2")
+        with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
+            G, _ = p.get_gram(); B = p.get_rhs()
+            p.set_prox(L.IndBallL0(6))
+            p.admm_init(None, μ=0.05, tol=1e-6)
+            assert p.matvec_info()["kernel"] == "symv_tile_mfma_ws_kernel" and p.matvec_info()["signals_per_pass"] == 8
+            p.admm_run(300)
+            per = [p.admm_status(c) for c in range(ns)]
+            _, z, _ = p.admm_get()
+        for c in (0, 5):
+            ro = oracle.admm_gram(G, B[:, c], oracle.IndBallL0(6), iters=300, tol=1e-6, mu=0.05)
+            assert ro["iters"] == per[c][0], (c, ro["iters"], per[c])
+            assert np.array_equal(ro["z"] != 0, z[:, c] != 0) and rel(z[:, c], ro["z"]) <= 1e-9, (c, rel(z[:, c], ro["z"]))
