@@ -7,7 +7,7 @@ mkdir -p "$R/$OUT"
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv \
-    -d "$R/$OUT/sq" -o bench -- python3 "$R/bench.py" --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --no-general-path --no-cfg4-strong > "$R/$OUT/sq.log" 2>&1
+    -d "$R/$OUT/sq" -o bench -- python3 "$R/bench.py" --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --no-general-path --no-cfg4-strong --no-concurrent > "$R/$OUT/sq.log" 2>&1
 echo "rc=$?"
 cd "$R"
 python3 - "$OUT" <<'PY'

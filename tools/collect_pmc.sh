@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/$OUT/$C" -o bench -- \
-      python3 "$R/bench.py" --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --no-general-path --no-cfg4-strong > "$R/$OUT/$C.log" 2>&1
+      python3 "$R/bench.py" --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --no-general-path --no-cfg4-strong --no-concurrent > "$R/$OUT/$C.log" 2>&1
   echo "$C rc=$?"
 done
 cd "$R"

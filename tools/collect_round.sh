@@ -12,7 +12,7 @@ timeout -k 10 300 python bench.py --workload cfg2 > gpurun_out/prof/bench_cfg2.j
 timeout -k 10 400 python bench.py --workload cfg5 > gpurun_out/prof/bench_cfg5.json 2> gpurun_out/prof/bench_cfg5.err
 timeout -k 10 300 python bench.py --dtype f32 --no-cpu-baseline --no-general-path --no-cfg4-strong > gpurun_out/prof/bench_cfg3_f32.json 2> gpurun_out/prof/bench_cfg3_f32.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k3" -o bench -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-general-path --no-alt-storage --no-cfg4-strong > "$R/gpurun_out/prof/k3.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k3" -o bench -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-general-path --no-alt-storage --no-cfg4-strong --no-concurrent > "$R/gpurun_out/prof/k3.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k4" -o bench -- python3 "$R/bench.py" --workload cfg4 --steps 1 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof/k4.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k5" -o bench -- python3 "$R/bench.py" --workload cfg5 --steps 1 --warmup 0 --iters 500 --no-cpu-baseline > "$R/gpurun_out/prof/k5.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k2" -o bench -- python3 "$R/bench.py" --workload cfg2 --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof/k2.log" 2>&1
