@@ -387,9 +387,10 @@ int32_t lpvs_windowcsd_f64(const double *y, const double *u, const double *t, in
 
 /* ---- storage of the inverse the ADMM mat-vec streams (after lpvs_admm_init) ------------------------------------------
  * *kind = 0 full symmetric doubles (n < 2048), 1 tile-packed lower triangle in doubles, 2 in floats (_f32 handles),
- * 3 in 6-byte elements (float head + 16-bit tail = 40 significant bits; _f64 handles with several right-hand sides, or
- * LPVS_M_STORAGE=split), 4 mixed: as 3, but tiles whose entries are all small against max|M| are 36-bit fixed point with a
- * per-row step (the default of _f64 handles with one right-hand side; lpvs_admm_time_matvec reports the bytes a launch reads);
+ * 3 in 6-byte elements (float head + 16-bit tail = 40 significant bits; LPVS_M_STORAGE=split, or a matrix of which fewer than
+ * half of the tiles qualify for 4), 4 mixed: as 3, but tiles whose entries are all small against max|M| are 36-bit fixed point with a
+ * per-row step (the default of _f64 handles -- with several right-hand sides the diagonal tiles always stay in the 6-byte format;
+ * lpvs_admm_time_matvec reports the bytes a launch reads);
  * LPVS_M_STORAGE=f64 selects 1.  Bit 4 (+16) is set when, with the prox operator currently set, the ADMM iteration runs as ONE
  * launch (kind 4, one right-hand side, L1 / L0 / group prox whose groups divide 128: the tile partials are added into x with 64-bit
  * fixed-point atomics -- exact and order-independent -- and the next launch's tile workgroups apply prox and dual update in their

@@ -491,6 +491,15 @@ class Problem:
                                 "36-bit fixed point with per-row steps (4.53 B) for tiles of small entries; tile partials added into x by 64-bit "
                                 "fixed-point atomics, prox / dual update in the next launch's prologue",
                         bytes_formula="98304 B per 6-byte tile, 74240 B per fixed-point tile (np = %d; 8-byte form %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2))
+        if self.ns > 1 and int(k.value) == 4:                              # fixed-point tiles below the diagonal, float-head tiles on it
+            q4 = self.ns <= 8 and os.environ.get("LPVS_MULTI_MFMA") != "16"
+            nb = np_ // 128
+            return dict(kernel="symv_tile_mfma_ws_kernel", storage="tile-packed lower triangle, mixed: 36-bit fixed point with per-row steps (4.53 B) for the "
+                        "tiles below the diagonal, float head + 16-bit tail (6 B) for the diagonal tiles",
+                        mfma="v_mfma_f64_4x4x4_4b_f64 (8 signal columns per pass, none padded)" if q4 else "v_mfma_f64_16x16x4_f64 (16 signal columns per pass)",
+                        signals_per_pass=8 if q4 else 16,
+                        bytes_formula="74240 B x %d tiles below the diagonal + 98304 B x %d diagonal tiles (np = %d), streamed once per %d signals"
+                                      % (nb * (nb - 1) // 2, nb, np_, 8 if q4 else 16))
         if self.ns > 1 and int(k.value) in (1, 3):
             elt = 8 if int(k.value) == 1 else 6
             q4 = self.ns <= 8 and os.environ.get("LPVS_MULTI_MFMA") != "16"

@@ -780,7 +780,7 @@ absmax_kernel(const double *__restrict__ M, int64_t count, unsigned long long *_
 // mixed packing: tile blockIdx.x of matrix blockIdx.y -> float-head format or fixed point; types[matrix][tile] says which
 __global__ void __launch_bounds__(256)
 pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char *__restrict__ Mp, unsigned char *__restrict__ types,
-                        const unsigned long long *__restrict__ absmax_bits, double step_scale) {
+                        const unsigned long long *__restrict__ absmax_bits, double step_scale, int diag_float /* diagonal tiles always in the float-head format */) {
     int I, J;
     tile_index(blockIdx.x, I, J);
     M += (int64_t)blockIdx.y * np * np;              // blockIdx.y = matrix of a batch
@@ -792,7 +792,7 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
     __shared__ float rowstep[TS];
     __shared__ int bad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) bad = 0;
+    if (threadIdx.x == 0) bad = (diag_float && I == J) ? 1 : 0;
     __syncthreads();
     {
         const double limit = __longlong_as_double((long long)*absmax_bits) * step_scale;     // largest admissible step
@@ -1480,10 +1480,17 @@ __device__ __forceinline__ void store_f64(double v, __amdgpu_buffer_rsrc_t rsrc,
 // row I within a segment: one record (id I + k: at most nseg + nblk of them) per run instead of one per tile -- most of one half of the
 // partials (270 MB of 539 MB per launch at cfg5) is never written and never read back.  The consumers find row block I's records as
 // [I + k(I,0), I + k(I,I)] (part1_range below).
-template <bool SPLIT, bool Q4, bool RUNS>
+// FIX (with SPLIT): the mixed storage -- tiles whose format byte is non-zero are 36-bit fixed point (74 240 of the slot's 98 304 bytes: the
+// same 64 KB of leading dwords, then 8 KB of nibbles and a float step per row), the others (all diagonal tiles among them) float-head.
+// A visit's format byte is requested (scalar load) a whole visit before its first stage is fetched.  Both formats' loads are issued for
+// every stage, through buffer descriptors of size zero for the format the tile does not have (those loads are dropped: no load under a
+// branch); a fixed-point element decodes in four vector instructions (bit-field extract, two integer instructions that assemble
+// 2^52 + q, one FMA with the row's step).
+template <bool SPLIT, bool Q4, bool RUNS, bool FIX>
 __global__ void __launch_bounds__(512, 1)
 symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
-                         double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status, int nseg) {
+                         double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status, int nseg,
+                         const unsigned char *__restrict__ types /* FIX: per-tile formats */) {
     if (status != nullptr) {
         bool all = true;
         for (int q = 0; q < ns; ++q) all = all && status[q].converged;
@@ -1541,7 +1548,12 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
         //   split:  two 16-byte pieces of heads (columns 4c.., 64+4c..) and one of tails per row (pack_tiles_split_kernel's layout)
         //   double: four 16-byte pieces per row (columns 32j + 2c, 2c+1)
         const int r = ltid >> 4, c = ltid & 15;
-        constexpr int NRAW = SPLIT ? 6 : 8, RI = MT_ROWS * NS / 256, RJ = TS * NS / 256;
+        static_assert(!FIX || SPLIT, "fixed-point tiles live in the 6-byte slots");
+        constexpr int NRAW = SPLIT ? (FIX ? 7 : 6) : 8, RI = MT_ROWS * NS / 256, RJ = TS * NS / 256;
+        // fixed-point tiles: the dwords of this thread's two rows' nibbles and steps (pack_tiles_mixed_kernel's layout: row 32 w + 4 rg + g,
+        // lane (g, c); this thread's rows are w = stage, rg = r >> 2 and (r >> 2) + 4, g = r & 3)
+        const int lo_nib = (int)kFixHeadBytes + ((((r & 3) * 16 + c) * 8) + (r >> 2)) * 4;
+        const int lo_stp = (int)(kFixHeadBytes + kFixNibBytes) + (((r & 3) * 8) + (r >> 2)) * 4;
         u32x4 raw[NQ][NRAW];                          // ring slot = step of the tile
         double pri[NQ][RI], prj[RJ];                 // (the J slice travels with step 0)
         // loop-invariant lane offsets (bytes)
@@ -1565,18 +1577,33 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
         // Every load of a step is unconditional (past the last visit an earlier one is requested again): a load under a
         // branch, or registers that differ between two paths into the loop, make the compiler wait for the prefetch right
         // where it was issued.  Buffer loads: scalar descriptor + scalar offset + loop-invariant lane offset.
-        auto fetch = [&](auto qc, const StreamVisit &v) {
+        auto type_of = [&](const StreamVisit &v) -> unsigned {   // (scalar load of the dword that holds the tile's format byte)
+            if constexpr (!FIX) return 0u;
+            const int t = v.t < tend ? v.t : tend - 1;
+            return (reinterpret_cast<const unsigned int *>(types)[t >> 2] >> (8 * (t & 3))) & 255u;
+        };
+        auto fetch = [&](auto qc, const StreamVisit &v, unsigned ty) {
             constexpr int Q = decltype(qc)::value;
             const int qp = (Q + q0) & (NQ - 1);
             const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Mp + (size_t)v.t * kTileBytes), 0, (int)kTileBytes, 0x00020000);
             if constexpr (SPLIT) {
                 const int oh = qp * (MT_ROWS * TS * 4), ot = TS * TS * 4 + qp * (MT_ROWS * TS * 2);
+                // (FIX: the tails exist in a diagonal tile only, nibbles and steps below the diagonal only -- descriptors of size zero drop the rest)
+                const bool fx = FIX && ty != 0;
+                const __amdgpu_buffer_rsrc_t tails = FIX ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Mp + (size_t)v.t * kTileBytes), 0, fx ? 0 : (int)kTileBytes, 0x00020000) : tile;
                 raw[Q][0] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a, oh, 0);
                 raw[Q][1] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + 256, oh, 0);
-                raw[Q][2] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_t, ot, 0);
+                raw[Q][2] = __builtin_amdgcn_raw_buffer_load_b128(tails, lo_t, ot, 0);
                 raw[Q][3] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a, oh + 16 * TS * 4, 0);
                 raw[Q][4] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + 256, oh + 16 * TS * 4, 0);
-                raw[Q][5] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_t, ot + 16 * TS * 2, 0);
+                raw[Q][5] = __builtin_amdgcn_raw_buffer_load_b128(tails, lo_t, ot + 16 * TS * 2, 0);
+                if constexpr (FIX) {
+                    const __amdgpu_buffer_rsrc_t aux = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Mp + (size_t)v.t * kTileBytes), 0, fx ? (int)kMixedFixedTileBytes : 0, 0x00020000);
+                    raw[Q][6][0] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_nib, qp * (64 * 8 * 4), 0);
+                    raw[Q][6][1] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_nib + 16, qp * (64 * 8 * 4), 0);
+                    raw[Q][6][2] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_stp, qp * (4 * 8 * 4), 0);
+                    raw[Q][6][3] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_stp + 16, qp * (4 * 8 * 4), 0);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
@@ -1597,11 +1624,29 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
                 for (int k = 0; k < RJ; ++k) prj[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, go_rj[k], oJ, 0));
             }
         };
-        auto put = [&](auto qc, int vtp) {           // step's registers -> the LDS images of parity Q & 1 (J slice: visit parity)
+        auto put = [&](auto qc, int vtp, bool fx) {  // step's registers -> the LDS images of parity Q & 1 (J slice: visit parity); fx: a fixed-point tile
             constexpr int Q = decltype(qc)::value;
             constexpr unsigned par = Q & 1;
             unsigned char *sp = stg + par * kStgB + wo_stg;
-            if constexpr (SPLIT) {
+            if (FIX && fx) {                         // (uniform)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const u32x4 ha = raw[Q][3 * k], hb = raw[Q][3 * k + 1];
+                    const unsigned int nw = raw[Q][FIX ? 6 : 0][k];
+                    const double step = (double)__uint_as_float(raw[Q][FIX ? 6 : 0][2 + k]), off = -(0x1p52 + 0x1p35) * step;
+                    auto dec = [&](unsigned int hi, int j) -> double {      // (2^52 + q) * step - (2^52 + 2^35) * step, exact
+                        const unsigned int top = __builtin_amdgcn_alignbit(0x04330000u, hi, 28);
+                        unsigned int lo = (nw >> (4 * j)) & 15u;
+                        asm("v_lshl_or_b32 %0, %1, 4, %0" : "+v"(lo) : "v"(hi));
+                        return fma(__hiloint2double((int)top, (int)lo), step, off);
+                    };
+                    f64x2 *row = reinterpret_cast<f64x2 *>(sp + k * (16 * MT_RS * 8));
+                    row[0] = (f64x2){dec(ha.x, 0), dec(ha.y, 1)};
+                    row[1] = (f64x2){dec(ha.z, 2), dec(ha.w, 3)};
+                    row[32] = (f64x2){dec(hb.x, 4), dec(hb.y, 5)};
+                    row[33] = (f64x2){dec(hb.z, 6), dec(hb.w, 7)};
+                }
+            } else if constexpr (SPLIT) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const u32x4 ha = raw[Q][3 * k], hb = raw[Q][3 * k + 1], lq = raw[Q][3 * k + 2];
@@ -1627,27 +1672,31 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
         };
         using std::integral_constant;
         StreamVisit v1 = next(cv);                   // the visit after the current one; `src` = the visit the ring is refilled from
+        unsigned tyc = type_of(cv), ty1 = type_of(v1);   // formats of the current and the next visit's tiles (scalar)
         // prologue: the first visit's four steps in flight, step 0 staged, slot 0 refilled from the next visit
-        fetch(integral_constant<int, 0>{}, cv);
-        fetch(integral_constant<int, 1>{}, cv);
-        fetch(integral_constant<int, 2>{}, cv);
-        fetch(integral_constant<int, 3>{}, cv);
-        put(integral_constant<int, 0>{}, 0);
-        fetch(integral_constant<int, 0>{}, v1.t < tend ? v1 : cv);
+        fetch(integral_constant<int, 0>{}, cv, tyc);
+        fetch(integral_constant<int, 1>{}, cv, tyc);
+        fetch(integral_constant<int, 2>{}, cv, tyc);
+        fetch(integral_constant<int, 3>{}, cv, tyc);
+        put(integral_constant<int, 0>{}, 0, tyc != 0);
+        fetch(integral_constant<int, 0>{}, v1.t < tend ? v1 : cv, v1.t < tend ? ty1 : tyc);
         __syncthreads();
 #pragma unroll 1
         for (;;) {
             // while the MFMA waves multiply step q of the current visit, stage step q + 1 and refill its slot from the next visit
+            const StreamVisit v2 = next(v1);         // (its format byte is requested here and used at the end of this visit)
+            const unsigned ty2 = type_of(v2);
             const StreamVisit src = v1.t < tend ? v1 : cv;
-            put(integral_constant<int, 1>{}, tp); fetch(integral_constant<int, 1>{}, src); __syncthreads();
-            put(integral_constant<int, 2>{}, tp); fetch(integral_constant<int, 2>{}, src); __syncthreads();
-            put(integral_constant<int, 3>{}, tp); fetch(integral_constant<int, 3>{}, src); __syncthreads();
-            const StreamVisit v2 = next(v1);
-            if (v1.t < tend) put(integral_constant<int, 0>{}, tp ^ 1);
-            fetch(integral_constant<int, 0>{}, v2.t < tend ? v2 : cv);
+            const unsigned tys = v1.t < tend ? ty1 : tyc;
+            const bool fxc = tyc != 0;
+            put(integral_constant<int, 1>{}, tp, fxc); fetch(integral_constant<int, 1>{}, src, tys); __syncthreads();
+            put(integral_constant<int, 2>{}, tp, fxc); fetch(integral_constant<int, 2>{}, src, tys); __syncthreads();
+            put(integral_constant<int, 3>{}, tp, fxc); fetch(integral_constant<int, 3>{}, src, tys); __syncthreads();
+            if (v1.t < tend) put(integral_constant<int, 0>{}, tp ^ 1, ty1 != 0);
+            fetch(integral_constant<int, 0>{}, v2.t < tend ? v2 : cv, v2.t < tend ? ty2 : tyc);
             __syncthreads();
             if (v1.t >= tend) break;
-            cv = v1; v1 = v2; tp ^= 1;
+            cv = v1; v1 = v2; tyc = ty1; ty1 = ty2; tp ^= 1;
         }
         return;
     }
@@ -2612,20 +2661,21 @@ int32_t launch_pack_tiles_split_batch(const double *M, int64_t np, int nbatch, u
 }
 
 // mixed packing (single matrix): types = ntiles bytes after the tile slots; absmax = 8 bytes of device scratch
-int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s) {
-    return launch_pack_tiles_mixed_batch(M, np, 1, Mp, types, absmax, s);
+int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s,
+                                bool diag_float) {
+    return launch_pack_tiles_mixed_batch(M, np, 1, Mp, types, absmax, s, diag_float);
 }
 
 // ... of nbatch matrices: types = [nbatch][ntiles] bytes, absmax = nbatch * 8 bytes of device scratch
 int32_t launch_pack_tiles_mixed_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, unsigned char *types, unsigned long long *absmax,
-                                      hipStream_t s) {
+                                      hipStream_t s, bool diag_float) {
     const int nblk = (int)(np / TS);
     LPVS_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned long long) * (size_t)nbatch, s));
     const int64_t count = np * np;
     const unsigned gx = (unsigned)std::min<int64_t>(1024, ceil_div(count, 256 * 8));
     hipLaunchKernelGGL(absmax_kernel, dim3(gx, (unsigned)nbatch), dim3(256), 0, s, M, count, absmax);
     const double step_scale = 0x1p-44 * std::sqrt(8192.0 / (double)np);
-    hipLaunchKernelGGL(pack_tiles_mixed_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2), (unsigned)nbatch), dim3(256), 0, s, M, np, Mp, types, absmax, step_scale);
+    hipLaunchKernelGGL(pack_tiles_mixed_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2), (unsigned)nbatch), dim3(256), 0, s, M, np, Mp, types, absmax, step_scale, diag_float ? 1 : 0);
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -2671,13 +2721,13 @@ static unsigned stream_grid(unsigned ntiles) {
 }
 static int stream_runs(const AdmmParams &p);
 
-template <bool SPLIT, bool Q4, bool RUNS>
+template <bool SPLIT, bool Q4, bool RUNS, bool FIX>
 static void launch_mfma_stream(const AdmmParams &p, unsigned ntiles, double *part1, double *part2, const AdmmStatus *status, hipStream_t s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS, FIX>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)symv_ws_lds());   // per device; cheap
     const int nseg = RUNS ? stream_runs(p) : 0;
-    hipLaunchKernelGGL((symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS>), dim3(RUNS ? std::min(stream_cus(), (unsigned)nseg) : stream_grid(ntiles)), dim3(512), symv_ws_lds(), s,
-                       reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status, nseg);
+    hipLaunchKernelGGL((symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS, FIX>), dim3(RUNS ? std::min(stream_cus(), (unsigned)nseg) : stream_grid(ntiles)), dim3(512), symv_ws_lds(), s,
+                       reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status, nseg, FIX ? p.mp_types : nullptr);
 }
 
 // multi-signal handles: stream (default: persistent, register-staged MFMA kernel), dma (LDS-DMA staged MFMA kernel, 8-byte
@@ -2689,6 +2739,8 @@ static int multi_matvec_choice() {
     }();
     return multi;
 }
+// (api.hip: may a handle with several right-hand sides keep its off-diagonal tiles in the fixed-point format?  Only the stream kernel reads them.)
+bool multi_signal_fixed_tiles_ok(int64_t np) { return multi_matvec_choice() == 2 && np <= 49152; }
 static bool uses_stream_kernel(const AdmmParams &p) {
     return p.ns > 1 && !p.mp_f32 && p.Mp != nullptr && (p.mp_split || (multi_matvec_choice() == 2 && p.np <= 49152));   // (31-bit byte offsets into the partials: np <= 49152)
 }
@@ -2718,7 +2770,10 @@ static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hip
         const bool q4_off = [] { const char *e = getenv("LPVS_MULTI_MFMA"); return e && std::string(e) == "16"; }();
         const bool q4 = p.ns <= 8 && !q4_off, runs = stream_runs(p) != 0;
         auto go = [&](auto split, auto q4c, auto runsc) {
-            launch_mfma_stream<decltype(split)::value, decltype(q4c)::value, decltype(runsc)::value>(p, ntiles, part1, part2, status, s);
+            if constexpr (decltype(split)::value) {
+                if (p.mp_types != nullptr) { launch_mfma_stream<true, decltype(q4c)::value, decltype(runsc)::value, true>(p, ntiles, part1, part2, status, s); return; }
+            }
+            launch_mfma_stream<decltype(split)::value, decltype(q4c)::value, decltype(runsc)::value, false>(p, ntiles, part1, part2, status, s);
         };
         using T = std::true_type; using F = std::false_type;
         if (p.mp_split) { if (q4) { if (runs) go(T{}, T{}, T{}); else go(T{}, T{}, F{}); } else { if (runs) go(T{}, F{}, T{}); else go(T{}, F{}, F{}); } }

@@ -377,18 +377,19 @@ int32_t copy_state_in(lpvs_problem *h, void *dev, const double *src) {
 // storage of the tile-packed inverse streamed by the ADMM mat-vec of large problems
 enum { kMpNone = 0, kMpF64 = 1, kMpF32 = 2, kMpSplit = 3, kMpMixed = 4 };
 // LPVS_M_STORAGE = mixed (default) | split | f64: how a double-precision handle stores the tile-packed inverse its mat-vec streams.
-// split = float head + 16-bit tail (6 bytes, 40 significant bits, admm.hip); mixed (single-signal handles) = the same, except that
+// split = float head + 16-bit tail (6 bytes, 40 significant bits, admm.hip); mixed = the same, except that
 // tiles whose entries are all small against max|M| (the off-diagonal tiles of the LPV / Fourier inverses) are 36-bit fixed point
-// (4.53 bytes per element); _f32 handles always stream floats.  Handles with several right-hand sides decode 6-byte tiles on
-// the way into the LDS image their matrix-core tile product reads.
+// (4.53 bytes per element); _f32 handles always stream floats.  Handles with several right-hand sides decode either format on
+// the way into the LDS image their matrix-core tile product reads (their diagonal tiles always stay 6-byte).
 int mp_mode_for(const lpvs_problem *h) {
     if (h->np < kSymmetricMinNp) return kMpNone;
     if (h->f32) return kMpF32;
     const int st = option_in_effect(LPVS_OPT_M_STORAGE, h->opt[LPVS_OPT_M_STORAGE]);
     if (st == LPVS_STORAGE_F64) return kMpF64;
     if (h->ns > 1 && h->np > 49152) return kMpF64;   // the streaming multi-signal kernel addresses its partials with 31-bit byte offsets
-    if (h->ns > 1 || st == LPVS_STORAGE_SPLIT) return kMpSplit;
-    return kMpMixed;
+    if (st == LPVS_STORAGE_SPLIT) return kMpSplit;
+    if (h->ns > 1 && !multi_signal_fixed_tiles_ok(h->np)) return kMpSplit;
+    return kMpMixed;   // (several right-hand sides: diagonal tiles always float-head; lpvs_admm_init)
 }
 
 AdmmParams make_params(const lpvs_problem *h) {
@@ -1125,7 +1126,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         else if (mode == kMpMixed) {
             unsigned char *types = h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np);
             LPVS_TRY(launch_pack_tiles_mixed(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), types,
-                                             reinterpret_cast<unsigned long long *>(types + ((ntiles + 255) / 256) * 256), s));
+                                             reinterpret_cast<unsigned long long *>(types + ((ntiles + 255) / 256) * 256), s, /*diag_float=*/h->ns > 1));
             std::vector<unsigned char> ht(ntiles);
             LPVS_HIP(hipMemcpyAsync(ht.data(), types, ntiles, hipMemcpyDeviceToHost, s));
             LPVS_HIP(hipStreamSynchronize(s));
@@ -1133,6 +1134,8 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
             for (unsigned char t : ht) { h->Mp_fixed_tiles += t != 0; ndiag += t == 2; }
             h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)kMixedFixedTileBytes + (double)ndiag * 1024.0 +
                                  (double)(ntiles - (size_t)h->Mp_fixed_tiles) * (double)kMixedFloatTileBytes;
+            const size_t nblk_ = (size_t)(h->np / 128);
+            if (getenv("LPVS_TRACE")) fprintf(stderr, "[lpvs] mixed packing: %lld of %zu tiles fixed point (%zu diagonal), ns = %lld\n", (long long)h->Mp_fixed_tiles, ntiles, nblk_, (long long)h->ns);
             if (2 * (size_t)h->Mp_fixed_tiles < ntiles) {
                 // not a diagonally dominant inverse: the mixed kernel (three workgroups per CU, float-head tiles in two halves) would
                 // only lose against the plain 6-byte kernel -- store every tile in the float-head format

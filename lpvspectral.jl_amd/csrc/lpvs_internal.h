@@ -204,7 +204,7 @@ struct AdmmParams {
     int ns;            // right-hand sides sharing M (signals of a shared-regressor batch); vectors are [ns][np]
     int mp_f32 = 0;    // Mp holds float (the _f32 entry points: M is streamed in single precision, arithmetic stays double)
     int mp_split = 0;  // Mp holds 6-byte elements (float head + 16-bit tail, 40 significant bits; see admm.hip)
-    const unsigned char *mp_types = nullptr;   // mixed storage (single signal): per-tile format, 1 = 36-bit fixed point (admm.hip)
+    const unsigned char *mp_types = nullptr;   // mixed storage: per-tile format, 1 = 36-bit fixed point (admm.hip); several right-hand sides: diagonal tiles always 0
     // offset form of the x-update (single-problem tile-packed path): x = xb + M (z-u)/mu with xb = M b computed once from
     // the full-precision inverse; the per-iteration product then never multiplies the large constant vector b by the
     // reduced-precision copy of M (its rounding would otherwise be amplified by cond(G + I/mu)).  nullptr: x = M (b + (z-u)/mu).
@@ -226,9 +226,11 @@ size_t symv_packed_doubles(int64_t np);
 int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s);
 int32_t launch_pack_tiles_f32(const double *M, int64_t np, float *Mp, hipStream_t s);
 int32_t launch_pack_tiles_split(const double *M, int64_t np, unsigned char *Mp, hipStream_t s);   // 6 * symv_packed_doubles(np) bytes
-int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s);
+int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s,
+                                bool diag_float = false);   // diag_float: diagonal tiles always in the float-head format (multi-signal handles)
+bool multi_signal_fixed_tiles_ok(int64_t np);               // the multi-signal tile product in use reads fixed-point off-diagonal tiles
 int32_t launch_pack_tiles_mixed_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, unsigned char *types, unsigned long long *absmax,
-                                      hipStream_t s);
+                                      hipStream_t s, bool diag_float = false);
 constexpr size_t kMixedFixedTileBytes = 128 * 128 * 4 + 128 * 128 / 2 + 128 * 4, kMixedFloatTileBytes = 128 * 128 * 6;
 // element conversions for the _f32 entry points (device buffers)
 int32_t launch_cvt_f32_f64(const float *src, double *dst, int64_t count, hipStream_t s);

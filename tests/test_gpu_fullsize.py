@@ -180,15 +180,12 @@ def test_cfg4_window_shards_reproduce_the_whole(L):
 
 
 def test_cfg5_shape_multichannel_equals_single_channel(L):
-    """cfg5 shape (Nf = 1024, Nv = 16 -> n = 32768, IndBallL0(32)) at N = 2^17 rows, 3 channels sharing (X, V): every channel of the
+    """cfg5 shape (Nf = 1024, Nv = 16 -> n = 32768, IndBallL0(32)) at N = 2^20 rows, 3 channels sharing (X, V): every channel of the
     multi-signal solve (matrix-core tile product) equals its own single-signal solve (scalar tile product) to summation
     order, with the same support of 32 coefficients."""
     import bench
-    N, Nf, Nv, ns = 1 << 17, 1024, 16, 3
-    _, X, V, w = bench.synth_signal(N, Nf, 0, torch.device("cuda"))
-    g = torch.Generator(device="cuda").manual_seed(55)
-    Y = torch.stack([(1 + q) * torch.cos(w[(37 * q + 11) % Nf] * X) * (1 + V) + 0.5 * torch.cos(w[(91 * q + 400) % Nf] * X)
-                     + 0.1 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g) for q in range(ns)], dim=1)
+    N, Nf, Nv, ns = 1 << 20, 1024, 16, 3                          # (the bench's own cfg5 inputs: two thirds of its inverse's tiles qualify for fixed point)
+    Y, X, V, w = bench.synth_channels(N, Nf, ns, torch.device("cuda"))
     kw = dict(proxg=L.IndBallL0(32), iters=40, tol=0.0, μ=0.05, printerval=100000)
     ses = L.ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, **kw)
     q = 1
@@ -196,6 +193,18 @@ def test_cfg5_shape_multichannel_equals_single_channel(L):
     assert np.count_nonzero(se.x) <= 32 and np.count_nonzero(se.x) > 0
     assert np.array_equal(np.abs(ses[q].x) > 0, np.abs(se.x) > 0)
     assert rel(ses[q].x, se.x) <= 1e-10
+    # the multi-signal handle streams the MIXED storage here (36-bit fixed-point tiles wherever a tile's rows are small, decoded by the
+    # loader waves of the matrix-core tile product); with uniform 6-byte tiles (storage="split") and with doubles the same iterates
+    with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
+        p.set_prox(L.IndBallL0(32))
+        p.admm_init(None, μ=0.05, tol=0.0)
+        info = p.matvec_info()
+        assert info["kernel"] == "symv_tile_mfma_ws_kernel" and "36-bit fixed point" in info["storage"], info
+        us, nbytes = p.time_matvec(3)
+        assert nbytes < 0.95 * 6 * 32768 * (32768 + 128) / 2          # fewer bytes than uniform 6-byte tiles
+    for st, bound in (("split", 1e-10), ("f64", 1e-10)):
+        sa = L.ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, storage=st, **kw)
+        assert np.array_equal(np.abs(sa[q].x) > 0, np.abs(ses[q].x) > 0) and rel(ses[q].x, sa[q].x) <= bound, (st, rel(ses[q].x, sa[q].x))
 
 
 def test_window_shards_reproduce_the_whole_dense_form(L, monkeypatch):

@@ -215,3 +215,31 @@ def test_window_batch_nontemporal_loads_are_bit_identical(L, monkeypatch):
             out[(nt, mode)] = x
     assert np.array_equal(out[("0", "one")], out[("1", "one")])
     assert np.array_equal(out[("0", "two")], out[("1", "two")])
+
+
+@pytest.mark.parametrize("kind", ["ball", "group"])
+def test_multi_signal_mixed_storage_against_oracle(L, oracle, lpv_case, kind):
+    """The cfg5 kernel on the storage cfg5 streams: several channels sharing (X, V, w), the matrix-core tile product
+    (symv_tile_mfma_ws_kernel, 4x4x4 MFMA) reading 36-bit fixed-point tiles below the diagonal and float-head tiles on it.  Every channel
+    against oracle.admm_gram on the device Gram at equal iteration counts: rel-L2 <= 1e-9, identical support."""
+    c = lpv_case
+    rng = np.random.default_rng(5)
+    ns = 3
+    Y = np.stack([c["y"], c["y"][::-1].copy(), 0.5 * c["y"] + np.cos(c["w"][7] * c["X"]) * (1 + c["V"])], axis=1) + 0.01 * rng.standard_normal((c["N"], ns))
+    prox, oprox = {"ball": (L.IndBallL0(40), oracle.IndBallL0(40)),
+                   "group": (L.SlicedSeparableSum.frequency_groups(c["lams"]["group"], c["Nf"], 2 * c["Nv"]), oracle.GroupL2(c["lams"]["group"], 2 * c["Nv"]))}[kind]
+    with L.Problem.lpv_multi(Y, c["X"], c["V"], c["w"], c["Nv"]) as p:
+        G, _ = p.get_gram(); B = p.get_rhs()
+        p.set_prox(prox)
+        p.admm_init(None, μ=0.05, tol=0.0)
+        info = p.matvec_info()
+        assert info["kernel"] == "symv_tile_mfma_ws_kernel" and "36-bit fixed point" in info["storage"] and info["signals_per_pass"] == 8, info
+        it, _, _ = p.admm_run(300)
+        x, z, u = p.admm_get()
+    assert it == 300 and rel(G, c["G"]) <= 1e-13
+    for q in range(ns):
+        ro = oracle.admm_gram(G, B[:, q], oprox, iters=300, tol=0.0, mu=0.05)
+        errs = {k: rel(v[:, q], ro[k]) for k, v in (("x", x), ("z", z), ("u", u))}
+        print(f"multi/{kind} channel {q}: rel-L2 vs oracle x {errs['x']:.2e} z {errs['z']:.2e} u {errs['u']:.2e}; nnz {np.count_nonzero(ro['z'])}")
+        assert max(errs.values()) <= 1e-9, (q, errs)
+        assert np.array_equal(z[:, q] != 0, ro["z"] != 0) and 0 < np.count_nonzero(ro["z"]) < ro["z"].size
