@@ -580,11 +580,28 @@ function ls_cohere(y, u, t, freqs=nothing; nw=10, noverlap=-1, estimator=ls_spec
     abs2.(Syu) ./ (Suu .* Syy), freqs
 end
 
-function ls_windowpsd_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer, nw::Int=10, noverlap=0; kwargs...)
+# The windows' regressors share nothing, so every window is a device solve of its own; `in_flight` of them (an extension; needs
+# `julia -t N`) run concurrently, each on its own handle and stream -- statically scheduled, so a solve stays on the thread whose
+# thread-local option defaults and error string it uses (defaults set with `set_default_option` on the calling thread do not reach the
+# others: pass options as keywords).  The sum is taken in window order either way (src/lsfft.jl:274).
+function ls_windowpsd_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer, nw::Int=10, noverlap=0; in_flight::Int=2, kwargs...)
     S = zeros(length(w))                                                             # src/lsfft.jl:267-277
-    windows = Windows3(Y, X, V, length(Y) ÷ nw, noverlap, rect)
-    for (y, x, v) in windows
-        se = ls_spectral_lpv(collect(y), collect(x), collect(v), w, Nv; covariance=false, kwargs...)
+    windows = collect(Windows3(Y, X, V, length(Y) ÷ nw, noverlap, rect))
+    solve((y, x, v)) = ls_spectral_lpv(collect(y), collect(x), collect(v), w, Nv; covariance=false, kwargs...)
+    ses = Vector{Any}(undef, length(windows))
+    if in_flight > 1 && Threads.nthreads() > 1 && length(windows) > 1
+        nt = min(in_flight, Threads.nthreads())
+        Threads.@threads :static for k in 1:nt
+            for i in k:nt:length(windows)
+                ses[i] = solve(windows[i])
+            end
+        end
+    else
+        for i in eachindex(windows)
+            ses[i] = solve(windows[i])
+        end
+    end
+    for se in ses
         S += vec(abs2.(sum(reshape_params(se.x, length(w)), dims=2)))
     end
     S

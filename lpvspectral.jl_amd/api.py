@@ -1103,14 +1103,27 @@ def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, batched=T
 
 
 @_with_options
-def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, **kwargs):
-    """src/lsfft.jl:267-277."""
+def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, in_flight=2, **kwargs):
+    """src/lsfft.jl:267-277.  The windows' regressors share nothing (each has its own samples of X and V), so every window is a
+    device solve of its own (Gram, factorisation, ridge solve with refinement); ``in_flight`` of them run concurrently, each on its
+    own handle and stream (an extension; 1 = one after the other) -- the latency-bound stretches of one solve hide under the other.
+    The sum over windows is taken in window order either way (:274), so the result does not depend on ``in_flight``."""
     w = np.ravel(_host(w))
     S = np.zeros(len(w))
-    windows = Windows3(Y, X, V, len(Y) // nw, noverlap, rect)
+    windows = list(Windows3(Y, X, V, len(Y) // nw, noverlap, rect))
     kwargs.setdefault("covariance", False)                         # the driver reads the parameters only (:273-274): no Σ, no second inverse
-    for y, x, v in windows:
-        se = ls_spectral_lpv(y, x, v, w, Nv, **kwargs)
+    solve = lambda win: ls_spectral_lpv(win[0], win[1], win[2], w, Nv, **kwargs)
+    if in_flight > 1 and len(windows) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        opts = {k: get_default_option(k) for k in _lib.OPTIONS}    # (the option defaults are thread-local: carried into the workers)
+        def worker(win):
+            with default_options(**opts):
+                return solve(win)
+        with ThreadPoolExecutor(max_workers=int(in_flight)) as pool:
+            ses = list(pool.map(worker, windows))                  # (ctypes releases the GIL inside the library; results in window order)
+    else:
+        ses = [solve(win) for win in windows]
+    for se in ses:
         rp = reshape_params(se.x, len(w))
         S = S + abs2(rp.sum(axis=1))
     return S

@@ -341,6 +341,11 @@ def test_ls_spectral_lpv_top3(L, oracle):
     assert rel(se.x, xo) <= 1e-6
     Sw = L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02)
     assert set(np.argsort(-Sw)[:3] + 1) == {1, 5, 10}
+    # its windows two in flight (the default) or one after the other: the same solves, summed in window order
+    assert np.array_equal(Sw, L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02, in_flight=1))
+    with L.default_options(gram_form="krs"):                     # option defaults reach the worker threads
+        Sk = L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02, in_flight=3)
+    assert rel(Sk, Sw) <= 1e-8
     # covariance (src/lsfft.jl:252-254) against a direct numpy evaluation in the reference's [re; im] order
     Ar = oracle.lpv_regressor(X, V, w_test, 50, permuted=False)
     xr = np.concatenate([se.x.real, se.x.imag])
