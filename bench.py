@@ -618,6 +618,19 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         e2 = time.perf_counter() - t2
         two_in_flight = {"value": nst / e2, "unit": "signals/s", "steps": nst, "ms_per_signal": e2 / nst * 1e3, "host_threads": 2,
                          "admm_launch_us_under_contention": float(np.mean([r[3]["admm_ms"] for r in res2])) * 1e3 / iters}
+        if args.dtype == "f64":
+            # ... and the same through ONE call of the C-ABI's batch driver (lpvs_lpv_signals_multi_f64: a single-threaded host, the
+            # library's own worker threads), device-resident column-major inputs
+            col = lambda v: torch.stack([v] * nst, dim=0).T
+            Ym, Xm, Vm = col(y), col(X), col(V)
+            prox = L.SlicedSeparableSum.frequency_groups(LAMBDA, len(w), 2 * NV)
+            call = lambda: L.lpv_signals_multi(Ym, Xm, Vm, w, NV, proxg=prox, μ=MU, tol=0.0, iters=iters, devices=[local], in_flight=2)
+            sync()
+            t3 = time.perf_counter()
+            Pm, itm = call()
+            e3 = time.perf_counter() - t3
+            two_in_flight["through_lpvs_lpv_signals_multi_f64"] = {"value": nst / e3, "ms_per_signal": e3 / nst * 1e3, "signals": nst, "in_flight": 2,
+                                                                   "same_coefficients_as_the_timed_steps": bool(np.array_equal(Pm[:, 0], np.asarray(params).ravel()))}
     # ---- dominant kernel of the step: the ADMM mat-vec (one launch per iteration, HBM-bound: it streams the
     # tile-packed lower triangle of M once).  Launch duration measured live with HIP events on the library's stream.
     with L.Problem.lpv(y, X, V, w, NV, True, False, device=local) as p:

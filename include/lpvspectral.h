@@ -375,6 +375,19 @@ int32_t lpvs_lpv_batch_multi_f64(const double *Y, int64_t ns, const double *X, c
                                  int64_t Nv, int32_t normalize, int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
                                  int64_t iters, const int32_t *devices, int32_t ngpus, double *re_out, double *im_out, int64_t *iters_out);
 
+/* ---- independent LPV signals, several devices, several solves in flight per device (extension: BASELINE.json config 3 as a batch)
+ * The loop  [ls_sparse_spectral_lpv(Y[:,q], X[:,q], V[:,q], w, Nv; ...) for q in 1:nsig]  (src/lasso.jl:27-70 per signal) inside the
+ * library: every signal has its OWN X and V (N x nsig column-major, like Y), hence its own Gram, factorisation and ADMM run.
+ * Contiguous signal ranges go to the devices (ngpus <= 0: every visible device; devices may be NULL); per device `in_flight` host
+ * threads (1 .. 8) each solve one signal at a time on a handle and stream of their own -- the matrix-core-bound Gram and factorisation
+ * of one solve run under the HBM-bound iterations of another (one MI355X at N = 2^20, n = 8192: 13.9 signals/s with in_flight = 1,
+ * 16.4-16.8 with 2).  No collective.  Results do not depend on ngpus / in_flight.  re_out / im_out: (Nf*Nv) x nsig column-major HOST
+ * arrays (signal q in column q, parameter index f + (v-1) Nf); iters_out: nsig iteration counts (HOST, may be NULL). */
+int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const double *V, int64_t N, int64_t nsig, const double *w, int64_t Nf,
+                                   int64_t Nv, int32_t normalize, int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
+                                   int64_t iters, const int32_t *devices, int32_t ngpus, int32_t in_flight, double *re_out, double *im_out,
+                                   int64_t *iters_out);
+
 /* ---- ls_windowcsd / ls_cohere on the engine                                              src/lsfft.jl:140-156, :176-193
  * Accumulators over the windows [win_lo, win_hi) in window order (NOT yet normalised: ls_windowcsd returns Syu / k,
  * ls_cohere |Syu|^2 / (Suu Syy)):  Syu += xy .* conj.(xu),  Syy += abs2.(xy),  Suu += abs2.(xu).  Any output may be NULL;

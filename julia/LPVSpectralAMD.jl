@@ -392,6 +392,27 @@ function ls_sparse_spectral_lpv(Y::AbstractMatrix{S}, X::AbstractVector{S}, V::A
     [SpectralExt(Ym[:, q], X, V, w, Nv, λ, false, normalize, complex.(re[:, q], im_[:, q]), nothing) for q in 1:ns]
 end
 
+# Independent signals (extension; BASELINE.json config 3 as a batch): column q of Y, X and V (all N x nsig) is one signal with its own
+# samples, i.e. the loop [ls_sparse_spectral_lpv(Y[:,q], X[:,q], V[:,q], w, Nv; ...) for q] inside the library -- contiguous signal
+# ranges over `ngpus` devices, `in_flight` solves at a time per device, each on its own handle and stream (the matrix-core-bound Gram /
+# factorisation of one solve under the HBM-bound iterations of another).  Returns a Vector of SpectralExt.
+function ls_sparse_spectral_lpv(Y::AbstractMatrix{S}, X::AbstractMatrix{S}, V::AbstractMatrix{S}, w, Nv::Integer;
+                                λ=1, normalize=true, proxg=nothing, iters=10000, tol=1e-5, μ=0.05, ngpus=0, in_flight=2) where S
+    @assert 0 ≤ μ ≤ 1 "μ should be ≤ 1"
+    w = w[:]
+    Ym, Xm, Vm = Matrix{Float64}(Y), Matrix{Float64}(X), Matrix{Float64}(V); wv = dense(Float64, w)
+    N, nsig = size(Ym); Nf = length(wv); m = Nf * Nv
+    @assert size(Xm) == size(Vm) == (N, nsig) "Y, X and V has to have the same number of samples"
+    pp = proxg === nothing ? (Int32(4), Float64(λ), Int64(2Nv)) : proxparams(proxg, 2Nf * Nv)
+    pp === nothing && throw(ArgumentError("proxg of type $(typeof(proxg)) has no device kernel"))
+    re, im_ = zeros(m, nsig), zeros(m, nsig); its = zeros(Int64, nsig)
+    GC.@preserve Ym Xm Vm wv re im_ its check(@ccall LIB.lpvs_lpv_signals_multi_f64(Ym::Ptr{Float64}, Xm::Ptr{Float64}, Vm::Ptr{Float64},
+        Int64(N)::Int64, Int64(nsig)::Int64, wv::Ptr{Float64}, Int64(Nf)::Int64, Int64(Nv)::Int64, Int32(normalize)::Int32, pp[1]::Int32, pp[2]::Float64,
+        pp[3]::Int64, Float64(μ)::Float64, Float64(tol)::Float64, Int64(iters)::Int64, C_NULL::Ptr{Int32}, Int32(ngpus)::Int32, Int32(in_flight)::Int32,
+        re::Ptr{Float64}, im_::Ptr{Float64}, its::Ptr{Int64})::Int32)
+    [SpectralExt(Ym[:, q], Xm[:, q], Vm[:, q], w, Nv, λ, false, normalize, complex.(re[:, q], im_[:, q]), nothing) for q in 1:nsig]
+end
+
 function ls_spectral_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer;
                          λ=1e-8, coulomb=false, normalize=true, device=0, covariance=true)   # src/lsfft.jl:239-259
     w = w[:]

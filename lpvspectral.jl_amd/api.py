@@ -769,6 +769,42 @@ def lpv_batch_multi(Y, X, V, w, Nv, proxg=None, λ=1, normalize=True, μ=0.05, t
     return re + 1j * im, its
 
 
+def lpv_signals_multi(Y, X, V, w, Nv, proxg=None, λ=1, normalize=True, μ=0.05, tol=1e-5, iters=10000, ngpus=0, devices=None, in_flight=2):
+    """``lpvs_lpv_signals_multi_f64``: the loop ``[ls_sparse_spectral_lpv(Y[:, q], X[:, q], V[:, q], w, Nv; ...) for q]`` inside the
+    library -- every signal its own samples of X and V (all three N x nsig), contiguous signal ranges over ``ngpus`` devices,
+    ``in_flight`` solves at a time per device (each on its own handle and stream).  Returns ``(params [Nf*Nv x nsig complex],
+    iters [nsig])``; the results do not depend on ``ngpus`` / ``in_flight``."""
+    assert 0 <= μ <= 1, "μ should be ≤ 1"                             # src/lasso.jl:143
+    w = _host_vec(w).astype(np.float64)
+    dev_in = all(_lib.is_device_array(a) for a in (Y, X, V))
+    if dev_in:                                                        # resident inputs (column-major N x nsig on the device) are used in place
+        Yh, Xh, Vh = Y, X, V
+        N, nsig = int(Y.shape[0]), int(Y.shape[1])
+        assert tuple(X.shape) == tuple(V.shape) == (N, nsig), "Y, X and V has to have the same number of samples"
+        assert all(a.stride(0) == 1 and a.stride(1) == N for a in (Y, X, V)), "device inputs must be column-major (N x nsig, e.g. A.T.contiguous().T)"
+    else:
+        Yh, Xh, Vh = (np.asfortranarray(_host(a), dtype=np.float64) for a in (Y, X, V))
+        N, nsig = Yh.shape
+        assert Xh.shape == Vh.shape == (N, nsig), "Y, X and V has to have the same number of samples"
+    Nf, Nv = len(w), int(Nv)
+    g = SlicedSeparableSum.frequency_groups(λ, Nf, 2 * Nv) if proxg is None else proxg
+    kind, param, glen = g.device_params(2 * Nf * Nv)
+    dv = None if devices is None else np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+    if dv is not None:
+        ngpus = len(dv)
+    m = Nf * Nv
+    re, im = np.zeros((m, nsig), order="F"), np.zeros((m, nsig), order="F")
+    its = np.zeros(nsig, dtype=np.int64)
+    ptr = (lambda a: C.c_void_p(a.data_ptr())) if dev_in else out_ptr
+    if dev_in:
+        import torch
+        torch.cuda.current_stream(Y.device).synchronize()             # the library works on its own streams
+    check(lib().lpvs_lpv_signals_multi_f64(ptr(Yh), ptr(Xh), ptr(Vh), N, nsig, out_ptr(w), Nf, Nv, int(bool(normalize)), int(kind), float(param),
+                                           int(glen), float(μ), float(tol), int(iters), None if dv is None else out_ptr(dv), int(ngpus), int(in_flight),
+                                           out_ptr(re), out_ptr(im), out_ptr(its)))
+    return re + 1j * im, its
+
+
 def ls_spectral_lpv(Y, X, V, w, Nv, λ=1e-8, coulomb=False, normalize=True, device=0, covariance=True):
     """``ls_spectral_lpv(Y,X,V,w,Nv; λ, coulomb, normalize)`` (src/lsfft.jl:239-259) -> :class:`SpectralExt`.
 

@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -318,6 +319,84 @@ int32_t lpvs_lpv_batch_multi_f64(const double *Y, int64_t ns, const double *X, c
         for (auto &q : th_) q.join();
     }
     for (auto &S : sh) if (S.rc != LPVS_OK) { set_error("device %d (channels [%lld,%lld)): %s", S.device, (long long)S.lo, (long long)S.hi, S.err.c_str()); return S.rc; }
+    return LPVS_OK;
+}
+
+// ---- independent LPV signals over several devices, several in flight per device (BASELINE.json config 3 as a batch) ---------------------
+// nsig signals, each with its OWN samples of X and V (so nothing is shared: one Gram, one factorisation, one ADMM run per signal) --
+// the loop  [ls_sparse_spectral_lpv(Y[:,q], X[:,q], V[:,q], w, Nv; ...) for q]  of a host program.  Contiguous signal ranges go to the
+// devices; per device `in_flight` host threads pull signals from the device's range, each solve on its own handle and stream: the
+// matrix-core-bound Gram / factorisation of one solve runs under the HBM-bound iterations of another (cfg3 on one MI355X: 13.9 signals/s
+// one at a time, 16.4-16.8 with two in flight, nothing more with three).  No collective.
+int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const double *V, int64_t N, int64_t nsig, const double *w, int64_t Nf,
+                                   int64_t Nv, int32_t normalize, int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
+                                   int64_t iters, const int32_t *devices, int32_t ngpus, int32_t in_flight, double *re_out, double *im_out,
+                                   int64_t *iters_out) {
+    if (!Y || !X || !V || !w || !re_out || !im_out || nsig < 1 || N < 1 || Nf < 1 || Nv < 1) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    if (is_device_ptr(re_out) || is_device_ptr(im_out)) { set_error("lpvs_lpv_signals_multi: outputs are host arrays"); return LPVS_EARGUMENT; }
+    if (in_flight < 1 || in_flight > 8) { set_error("in_flight = %d: 1 .. 8 solves per device", in_flight); return LPVS_EARGUMENT; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    struct DeviceRestore { int dev = -1; DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
+                           ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore_device;
+    if (ngpus <= 0) ngpus = count;
+    if (ngpus > count && devices == nullptr) { set_error("ngpus = %d but %d device(s) visible", ngpus, count); return LPVS_EDEVICE; }
+    if ((int64_t)ngpus > nsig) ngpus = (int32_t)nsig;
+    std::vector<int> devs((size_t)ngpus);
+    for (int r = 0; r < ngpus; ++r) {
+        devs[(size_t)r] = devices ? devices[r] : r;
+        if (devs[(size_t)r] < 0 || devs[(size_t)r] >= count) { set_error("device %d out of range [0,%d)", devs[(size_t)r], count); return LPVS_EDEVICE; }
+    }
+    // (device inputs are used in place when they live on the solving device; the constructors stage anything else themselves)
+    const int64_t m = Nf * Nv;                                    // complex parameters per signal
+    struct Range { int device; int64_t lo, hi; std::atomic<int64_t> next{0}; };
+    std::vector<Range> rg((size_t)ngpus);
+    const int64_t base = nsig / ngpus, rem = nsig % ngpus;
+    for (int r = 0; r < ngpus; ++r) {
+        rg[(size_t)r].device = devs[(size_t)r];
+        rg[(size_t)r].lo = r * base + (r < rem ? r : rem);
+        rg[(size_t)r].hi = rg[(size_t)r].lo + base + (r < rem ? 1 : 0);
+        rg[(size_t)r].next.store(rg[(size_t)r].lo);
+    }
+    int copt[kOptCount];
+    capture_default_options(copt);
+    std::mutex err_mu;
+    int32_t first_rc = LPVS_OK; std::string first_err; int64_t first_sig = -1;
+    auto work = [&](int r) {
+        Range &R = rg[(size_t)r];
+        for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, copt[o]);   // the caller's default options on this worker thread
+        for (;;) {
+            const int64_t q = R.next.fetch_add(1);
+            if (q >= R.hi) return;
+            { std::lock_guard<std::mutex> g(err_mu); if (first_rc != LPVS_OK) return; }
+            lpvs_problem *h = nullptr;
+            auto fail = [&](int32_t rc) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (first_rc == LPVS_OK) { first_rc = rc; first_err = lpvs_last_error(); first_sig = q; }
+                if (h) lpvs_problem_destroy(h);
+            };
+            int32_t rc = lpvs_problem_create_lpv_f64(Y + q * N, X + q * N, V + q * N, N, w, Nf, Nv, normalize, 0, R.device, &h);
+            if (rc != LPVS_OK) return fail(rc);
+            if ((rc = lpvs_problem_set_prox(h, prox_kind, prox_param, group_len)) != LPVS_OK) return fail(rc);
+            if ((rc = lpvs_admm_init_f64(h, nullptr, mu, tol, LPVS_LINEAR_LEAST_SQUARES)) != LPVS_OK) return fail(rc);
+            int64_t done = 0; double nxz = 0; int32_t conv = 0;
+            if ((rc = lpvs_admm_run(h, iters, &done, &nxz, &conv)) != LPVS_OK) return fail(rc);
+            if ((rc = lpvs_problem_get_params_f64(h, 0, re_out + q * m, im_out + q * m)) != LPVS_OK) return fail(rc);
+            if (iters_out) iters_out[q] = done;
+            lpvs_problem_destroy(h);
+        }
+    };
+    int saved[kOptCount];
+    capture_default_options(saved);
+    if (ngpus == 1 && in_flight == 1) work(0);
+    else {
+        std::vector<std::thread> th_;
+        for (int r = 0; r < ngpus; ++r)
+            for (int k = 0; k < in_flight; ++k) th_.emplace_back(work, r);
+        for (auto &q : th_) q.join();
+    }
+    for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, saved[o]);
+    if (first_rc != LPVS_OK) { set_error("signal %lld: %s", (long long)first_sig, first_err.c_str()); return first_rc; }
     return LPVS_OK;
 }
 

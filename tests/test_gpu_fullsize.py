@@ -243,3 +243,30 @@ def test_lpv_batch_multi_equals_single_channel_solves(L, monkeypatch):
     G, _ = L.lpv_batch_multi(Y, X, V, w, Nv, λ=3.0, ngpus=0, μ=0.05, tol=0.0, iters=200)    # the reference's group lasso, every visible device
     S = L.ls_sparse_spectral_lpv_multi(Y, X, V, w, Nv, λ=3.0, μ=0.05, tol=0.0, iters=200, printerval=100000, out=io.StringIO())
     assert all(np.abs(G[:, q] - S[q].x).max() <= 1e-10 * np.abs(S[q].x).max() for q in range(ns))
+
+
+def test_lpv_signals_multi_equals_the_loop_over_signals(L):
+    """lpvs_lpv_signals_multi_f64 (independent signals, each with its own X and V; contiguous ranges over devices, several solves in
+    flight per device): the same coefficients and stopping iterations as the loop of single-signal calls, whatever the sharding --
+    one solve at a time, three in flight, two shards sharing the device with two in flight each; host and device-resident inputs."""
+    rng = np.random.default_rng(91)
+    N, Nf, Nv, nsig = 5000, 160, 8, 5                              # n = 2560: the tile-packed path, one launch per iteration
+    w = 2 * np.pi * (np.arange(Nf) + 1.0) / 8
+    X = np.sort(rng.random((N, nsig)) * 60, axis=0); V = np.tile(np.linspace(0, 1, N)[:, None], (1, nsig)) ** np.arange(1, nsig + 1)
+    Y = np.stack([np.cos(w[(7 * q + 3) % Nf] * X[:, q]) * (1 + q * V[:, q]) + 0.4 * np.cos(w[(11 * q + 50) % Nf] * X[:, q] + q)
+                  + 0.05 * rng.standard_normal(N) for q in range(nsig)], axis=1)
+    kw = dict(λ=2.0, μ=0.05, tol=1e-6, iters=800)
+    ref = [L.ls_sparse_spectral_lpv(Y[:, q].copy(), X[:, q].copy(), V[:, q].copy(), w, Nv, printerval=100000, **kw).x for q in range(nsig)]
+    assert all(0 < np.count_nonzero(r) < r.size for r in ref)
+    P1, it1 = L.lpv_signals_multi(Y, X, V, w, Nv, ngpus=1, in_flight=1, **kw)
+    P3, it3 = L.lpv_signals_multi(Y, X, V, w, Nv, ngpus=1, in_flight=3, **kw)
+    P22, it22 = L.lpv_signals_multi(Y, X, V, w, Nv, devices=[0, 0], in_flight=2, **kw)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a.T), device="cuda").T       # column-major N x nsig on the device
+    Pd, itd = L.lpv_signals_multi(dev(Y), dev(X), dev(V), w, Nv, ngpus=1, in_flight=2, **kw)
+    for q in range(nsig):
+        assert np.array_equal(P1[:, q], ref[q]), q
+    for P, it in ((P3, it3), (P22, it22), (Pd, itd)):
+        assert np.array_equal(P, P1) and np.array_equal(it, it1)
+    assert len(set(it1.tolist())) > 1 and it1.max() <= 800          # every signal stops on its own
+    with pytest.raises(ValueError):
+        L.lpv_signals_multi(Y, X, V, w, Nv, in_flight=0, **kw)
