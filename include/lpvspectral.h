@@ -85,7 +85,7 @@ int32_t lpvs_release_cached_memory(void);
 #define LPVS_OPT_M_STORAGE 1  /* LPVS_STORAGE_*  : packed inverse of n >= 2048 handles / window batches */
 #define LPVS_OPT_ITERATION 2  /* LPVS_ITERATION_*: one launch per ADMM iteration (where applicable) or mat-vec + update launches */
 #define LPVS_OPT_GRAM_FORM 3  /* LPVS_GRAM_*     : structured Gram for arithmetic-progression grids, or the dense MFMA forms */
-#define LPVS_OPT_NT_LOADS 4   /* LPVS_NT_*       : non-temporal tile loads in window batches (default: beyond 240 MiB of inverses) */
+#define LPVS_OPT_NT_LOADS 4   /* LPVS_NT_*       : non-temporal tile loads (default: when a launch streams more than 240 MiB of inverses -- window batches, single problems from n = 10752) */
 #define LPVS_OPT_SLOT_SUMS 5  /* LPVS_SLOTS_*    : slot sums of the structured Gram by non-uniform FFT or by direct evaluation */
 #define LPVS_STORAGE_MIXED 1  /* float head + 16-bit tail (40 bits) for tiles with large entries, 36-bit fixed point elsewhere */
 #define LPVS_STORAGE_SPLIT 2  /* float head + 16-bit tail everywhere (6 bytes, 40 significant bits) */

@@ -3418,6 +3418,8 @@ static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa, bo
         return pa ? fi_kernel_mode<1, true, false, true>(mode) : fi_kernel_mode<1, true, false, false>(mode);
     }
     if (small) return pa ? fi_kernel_mode<1, false, false, true>(mode) : fi_kernel_mode<1, false, false, false>(mode);
+    // (more than 64 row blocks: np >= 8320.  A single inverse beyond the Infinity Cache -- np >= 10752 -- streams with non-temporal loads)
+    if (nt) return pa ? fi_kernel_mode<6, false, true, true>(mode) : fi_kernel_mode<6, false, true, false>(mode);
     return pa ? fi_kernel_mode<6, false, false, true>(mode) : fi_kernel_mode<6, false, false, false>(mode);
 }
 static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, size_t mp_stride, bool prefetch_all, hipStream_t s) {
@@ -3429,7 +3431,9 @@ static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, s
     const long long base = p.fi_base;
     const bool small = nblk <= 64;                    // one load per lane covers the block norms / maxima
     const int nto = option_in_effect(LPVS_OPT_NT_LOADS, p.opt_nt_loads);
-    const bool nt = batch && (nto ? nto == LPVS_NT_ON : (size_t)ntiles * kSplitTileBytes * (size_t)nprob > ((size_t)240 << 20));
+    // (single problems: the bytes the launch really reads -- the fixed-point tiles are shorter than their slots; only the kernel for more than 64 row blocks has the variant)
+    const size_t stream_bytes = batch ? (size_t)ntiles * kSplitTileBytes * (size_t)nprob : (size_t)ntiles * kMixedFixedTileBytes;
+    const bool nt = (batch || !small) && !p.mp_f32 && (nto ? nto == LPVS_NT_ON : stream_bytes > ((size_t)240 << 20));
     auto launch = [&](int mode, unsigned grid, long long g, int aslot, int uslot, int commit_prev) {
         hipLaunchKernelGGL(fi_kernel(mode, small, batch, nt, prefetch_all, p.mp_f32 != 0), dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
                            commit_prev, mp_stride, prefetch_all ? 1 : 0);

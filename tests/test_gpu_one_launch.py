@@ -175,6 +175,18 @@ def test_more_than_64_row_blocks(L, monkeypatch):
     assert res["one"][0] == res["two"][0] == 120
     for a, b in zip(res["one"][2:], res["two"][2:]):
         assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1.0), np.abs(a - b).max()
+    # this inverse (348 MB in the mixed storage) is larger than the Infinity Cache: the one-launch kernel streams it with non-temporal
+    # loads by default; with plain loads (option nt_loads="off") the same bits
+    with L.default_options(nt_loads="off"):
+        with L.Problem.lpv(y, X, V, w, Nv) as p:
+            p.set_prox(L.SlicedSeparableSum.frequency_groups(2.0, Nf, 2 * Nv))
+            p.admm_init(None, μ=0.05, tol=0.0)
+            for c in (60, 1, 59):
+                it, nxz, conv = p.admm_run(c)
+            plain = (it, nxz) + p.admm_get()
+    assert plain[0] == 120 and plain[1] == res["one"][1]
+    for a, b in zip(plain[2:], res["one"][2:]):
+        assert np.array_equal(a, b)
 
 
 def test_non_finite_state_propagates_as_nan(L, problem, monkeypatch):
