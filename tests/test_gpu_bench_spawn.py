@@ -35,6 +35,36 @@ def test_bench_spawns_its_ranks_and_reports_both_scaling_records():
     assert rec4["psd_argmax"] == 33 and rec4["unit"] == "windows/s"
 
 
+def _run1(extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--no-cpu-baseline"] + extra, env=env,
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_lines_of_every_workload():
+    """One rank, reduced sizes / iteration counts: every workload prints ONE line with the contract's fields, a roofline record and the
+    sub-records the full-size runs carry (two solves in flight through Python threads and through lpvs_lpv_signals_multi_f64)."""
+    need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+    r3 = _run1(["--log2n", "16", "--iters", "60", "--no-general-path", "--no-alt-storage"])
+    assert need <= set(r3) and r3["n_gpus"] == 1 and r3["roofline"]["bound"] == "hbm"
+    # (at N = 2^16 the inverse is not diagonally dominant enough for the mixed storage: the uniform 6-byte kernel runs)
+    assert r3["roofline"]["kernel"].split(" ")[0] in ("admm_iter_mixed_kernel", "symv_tile_split_kernel", "symv_tile_mixed_kernel")
+    two = r3["config"]["two_solves_in_flight"]
+    assert two["value"] > 0 and two["through_lpvs_lpv_signals_multi_f64"]["same_coefficients_as_the_timed_steps"] is True
+    r2 = _run1(["--workload", "cfg2", "--iters", "200"])
+    assert need <= set(r2) and r2["unit"] == "signals/s" and r2["roofline"]["launch_us"] > 0
+    r5 = _run1(["--workload", "cfg5", "--log2n", "17", "--iters", "30", "--channels", "3", "--steps", "1"])
+    assert need <= set(r5) and r5["roofline"]["kernel"].startswith("symv_tile_mfma_ws_kernel") and "4x4x4" in r5["roofline"]["kernel"]
+    assert len(r5["nnz_per_channel"]) == 3 and r5["factorisation"]["ms"] > 0
+
+
 def test_bench_refuses_to_spawn_under_a_profiler_preload():
     """(CPU test: the refusal happens before anything touches a GPU.)  The marker variable only has to LOOK like a profiler's."""
     env = dict(os.environ, ROCPROFILER_LPVS_TEST_MARKER="1")
