@@ -1723,19 +1723,23 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
     // right after it, so the matrix pipe does not drain at step boundaries.
     if (p1) {
         // P1: rows 16*wave .. of a stage, all 128 columns.  A[i = li][k = lk], B[k = lk][j = s = li]
+        // Q4: the right-hand-side operand (B: the J slice, 32 pivot steps x two signal quads) does not change over the four steps of a
+        // visit -- it is read from LDS with step 0's groups only and kept in registers (128 of them): the LDS operand reads of the four
+        // MFMA waves cost as much time as their matrix instructions, and these were a third of them
         using BT = std::conditional_t<Q4, f64x2, double>;
-        double A[2][8]; BT B[2][8];
-        auto load = [&](auto gc, unsigned par, int vtp, int buf) {      // operands of group G of the stage with parity par
+        double A[2][8]; BT B[Q4 ? 1 : 2][8]; BT Bv[Q4 ? 32 : 1];
+        auto load = [&](auto gc, unsigned par, int vtp, int buf, bool with_b) {      // operands of group G of the stage with parity par
             constexpr int g = decltype(gc)::value;
             const unsigned char *ap = stg + par * kStgB + a_lane, *bp = rj + vtp * kRjB + b_lane;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 A[buf][j] = *reinterpret_cast<const double *>(ap + 32 * (8 * g + j));
-                B[buf][j] = *reinterpret_cast<const BT *>(bp + 4 * NS * 8 * (8 * g + j));
+                if constexpr (Q4) { if (with_b) Bv[Q4 ? 8 * g + j : 0] = *reinterpret_cast<const BT *>(bp + 4 * NS * 8 * (8 * g + j)); }
+                else B[Q4 ? 0 : buf][j] = *reinterpret_cast<const BT *>(bp + 4 * NS * 8 * (8 * g + j));
             }
         };
         using std::integral_constant;
-        load(integral_constant<int, 0>{}, 0, 0, 0);
+        load(integral_constant<int, 0>{}, 0, 0, 0, true);
         f64x4 run0[RUNS ? NQ : 1], run1[RUNS && !Q4 ? NQ : 1];   // RUNS: the sums of a run of tiles of one row block, step by step
         bool fresh = true;                           // (scalar) the visit starts a run
         auto store1 = [&](const f64x4 &a0, const f64x4 &a1, int so) {   // a stage's 16 rows of this wave; a converged signal's partials are never read
@@ -1754,25 +1758,27 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             f64x4 t0 = (f64x4){0.0, 0.0, 0.0, 0.0}, t1 = t0;
             if constexpr (RUNS) { if (fresh) { run0[RUNS ? Q : 0] = t0; if constexpr (!Q4) run1[RUNS && !Q4 ? Q : 0] = t0; } }
             f64x4 &a0 = RUNS ? run0[RUNS ? Q : 0] : t0, &a1 = (RUNS && !Q4) ? run1[RUNS && !Q4 ? Q : 0] : t1;   // (Q4: elements 0/1 = signals lo/hi of the even k steps, 2/3 of the odd ones)
-            auto mul = [&](int buf) {
+            auto mul = [&](int buf, auto gc) {
+                constexpr int g = decltype(gc)::value;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
                     if constexpr (Q4) {
-                        a0[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j], B[buf][j][0], a0[0], 0, 0, 0);
-                        a0[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j], B[buf][j][1], a0[1], 0, 0, 0);
-                        a0[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j + 1], B[buf][j + 1][0], a0[2], 0, 0, 0);
-                        a0[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j + 1], B[buf][j + 1][1], a0[3], 0, 0, 0);
+                        a0[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j], Bv[Q4 ? 8 * g + j : 0][0], a0[0], 0, 0, 0);
+                        a0[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j], Bv[Q4 ? 8 * g + j : 0][1], a0[1], 0, 0, 0);
+                        a0[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j + 1], Bv[Q4 ? 8 * g + j + 1 : 0][0], a0[2], 0, 0, 0);
+                        a0[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[buf][j + 1], Bv[Q4 ? 8 * g + j + 1 : 0][1], a0[3], 0, 0, 0);
                     } else {
-                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j], B[buf][j], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j + 1], B[buf][j + 1], a1, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j], B[Q4 ? 0 : buf][j], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[buf][j + 1], B[Q4 ? 0 : buf][j + 1], a1, 0, 0, 0);
                     }
                 }
             };
-            load(integral_constant<int, 1>{}, par, tp, 1); __builtin_amdgcn_sched_barrier(0); mul(0); __builtin_amdgcn_sched_barrier(0);
-            load(integral_constant<int, 2>{}, par, tp, 0); __builtin_amdgcn_sched_barrier(0); mul(1); __builtin_amdgcn_sched_barrier(0);
-            load(integral_constant<int, 3>{}, par, tp, 1); __builtin_amdgcn_sched_barrier(0); mul(0); __builtin_amdgcn_sched_barrier(0);
+            constexpr bool first = Q == 0, last = Q == NQ - 1;   // (B is read with the groups of a visit's step 0; group 0 of step 0 rides on the previous step 3)
+            load(integral_constant<int, 1>{}, par, tp, 1, first); __builtin_amdgcn_sched_barrier(0); mul(0, integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0);
+            load(integral_constant<int, 2>{}, par, tp, 0, first); __builtin_amdgcn_sched_barrier(0); mul(1, integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0);
+            load(integral_constant<int, 3>{}, par, tp, 1, first); __builtin_amdgcn_sched_barrier(0); mul(0, integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                         // the next step is staged; this step's images are free
-            load(integral_constant<int, 0>{}, par ^ 1, next_tp, 0); __builtin_amdgcn_sched_barrier(0); mul(1); __builtin_amdgcn_sched_barrier(0);
+            load(integral_constant<int, 0>{}, par ^ 1, next_tp, 0, last); __builtin_amdgcn_sched_barrier(0); mul(1, integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0);
             if constexpr (!RUNS) store1(a0, a1, (cv.t * TS + MT_ROWS * ((Q + q0) & (NQ - 1))) * 8);
         };
 #pragma unroll 1
