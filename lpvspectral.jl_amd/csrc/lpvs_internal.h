@@ -304,7 +304,7 @@ struct WinJob {
 };
 // sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations): window order, signals innermost
 typedef std::function<void(int64_t, int64_t, const double *, const double *, int64_t)> WinSink;
-int32_t windows_engine_run(const WinJob &job, const WinSink &sink);
+int32_t windows_engine_run(const WinJob &job, const WinSink &sink, bool chunked = false);   // chunked: in cache-sized chunks, two parts of a chunk in flight (api.hip)
 void windows_last_timing(double *out10);          // the calling thread's last engine call
 void windows_set_timing(const double *in10);
 

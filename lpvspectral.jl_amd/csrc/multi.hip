@@ -168,7 +168,7 @@ static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double 
             memcpy(e, re, sizeof(double) * (size_t)Nf);
             memcpy(e + Nf, im, sizeof(double) * (size_t)Nf);
             e[2 * Nf] = (double)its;
-        });
+        }, /*chunked=*/true);
         if (S.rc != LPVS_OK) { S.err = lpvs_last_error(); return; }
         windows_last_timing(S.timing);
         if (use_rccl) {   // the shard's slot goes to its device for the gather

@@ -231,3 +231,32 @@ def test_indball_and_init_through_the_engine_vs_oracle(L, oracle, zero):
         assert api.windowpsd_last_timing()["windows"] == k
         Sseq, _ = L.ls_windowpsd(y, t, f, nw=k, noverlap=0, window_func=L.hanning, estimator=L.ls_sparse_spectral, batched=False, printerval=100000, **kw)
         assert rel(S, Sseq) <= 1e-8, (name, rel(S, Sseq))
+
+
+@pytest.mark.parametrize("knobs", [{"LPVS_WINDOW_CHUNK_MB": "3", "LPVS_WINDOWS_IN_FLIGHT": "2"}, {"LPVS_WINDOW_CHUNK_MB": "0", "LPVS_WINDOWS_IN_FLIGHT": "3"},
+                                   {"LPVS_WINDOW_CHUNK_MB": "5", "LPVS_WINDOWS_IN_FLIGHT": "1"}, {}])
+def test_chunked_engine_is_bit_identical_to_the_uncut_one(L, knobs, monkeypatch):
+    """The engine in cache-sized chunks with several parts of a chunk in flight (windows_engine_chunked): coefficients, iteration counts
+    and every accumulation over windows (S of ls_windowpsd, the csd sums) equal the uncut call bit for bit -- here with chunks of a few
+    windows, ragged last chunks, two or three parts, the sparse estimator on one and on two signals."""
+    rng = np.random.default_rng(12)
+    n, nwin, Nf = 1 << 10, 83, 96                              # (0.092 MB of packed inverse per window: chunks of 32 / 54 windows)
+    t = np.arange(nwin * n, dtype=np.float64)
+    f = np.arange(1, Nf + 1) / 250.0
+    y = np.sin(2 * np.pi * f[20] * t) * (1 + 0.3 * np.sin(2 * np.pi * t / (7 * n))) + 0.3 * rng.standard_normal(nwin * n)
+    u = 0.7 * np.sin(2 * np.pi * f[20] * t + 0.5) + 0.4 * np.cos(2 * np.pi * f[55] * t) + 0.3 * rng.standard_normal(nwin * n)
+    kw = dict(λ=0.3, μ=1e-3, tol=0.0, iters=150)
+    def run():
+        x, S, its = L.windowpsd_sparse_batched(y, t, f, n, 0, None, **kw)
+        eng = dict(estimator=L._lib.EST_SPARSE, lam=0.0, prox=L.NormL1(0.3).device_params(2 * Nf), μ=1e-3, tol=0.0, iters=150, sign=1)
+        acc = L.windowcsd_batched(y, u, t, f, n, 0, None, eng)
+        return x, S, its, acc
+    monkeypatch.setenv("LPVS_WINDOW_CHUNK_MB", "0"); monkeypatch.setenv("LPVS_WINDOWS_IN_FLIGHT", "1")
+    x0, S0, its0, acc0 = run()
+    monkeypatch.delenv("LPVS_WINDOW_CHUNK_MB"); monkeypatch.delenv("LPVS_WINDOWS_IN_FLIGHT")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    x1, S1, its1, acc1 = run()
+    assert np.array_equal(x1, x0) and np.array_equal(S1, S0) and np.array_equal(its1, its0)
+    for a, b in zip(acc1, acc0):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
