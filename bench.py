@@ -529,7 +529,7 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                          "in flight on two streams, one launch per iteration and half: a chunk's inverses are re-read from the 256 MiB Infinity Cache "
                          "iteration after iteration, which is why `achieved` may exceed the HBM stream rate (LPVS_WINDOW_CHUNK_MB=0 "
                          "LPVS_WINDOWS_IN_FLIGHT=1: every window in one launch per iteration, HBM-bound: 126 us = 6.06 TB/s); "
-                         "matvec_only_launch_us = 200 back-to-back launches of the two-launch scheme's stand-alone batch mat-vec, summed likewise") if one_launch else
+                         "matvec_only_launch_us = 200 back-to-back launches of the two-launch scheme's stand-alone batch mat-vec over ALL the shard's windows in one launch (uncut: HBM-bound)") if one_launch else
                         "HIP events around 200 back-to-back launches of the batch mat-vec on the library's stream (rank 0's shard)"}
     out = {
         "metric": "windows/sec, ls_windowpsd estimator=ls_sparse_spectral (NormL1), %d windows x N=2^%d, Nf=%d, %d ADMM iters per window"
