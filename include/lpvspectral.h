@@ -388,6 +388,17 @@ int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const doubl
                                    int64_t iters, const int32_t *devices, int32_t ngpus, int32_t in_flight, double *re_out, double *im_out,
                                    int64_t *iters_out);
 
+/* ---- ls_windowpsd_lpv                                                                    src/lsfft.jl:267-277
+ * S[Nf] = sum over the windows of Windows3(Y, X, V, n, noverlap, rect), in window order, of abs2.(sum(reshape_params(x_i, Nf), dims=2))
+ * with x_i = ls_spectral_lpv(y_i, x_i, v_i, w, Nv; lam, coulomb, normalize).x (:239-250: every window its own basis centres, Gram,
+ * factorisation and ridge solve on the device; no covariance -- the driver never reads it).  The windows share nothing: `in_flight`
+ * (1 .. 8) of them are solved at a time on handles and streams of their own.  n = length(Y) / nw as the caller computes it (:269).
+ * LPVS_ENUMERIC when a window's normal equations are singular to working precision (the reference's QR route is the wrapper's).
+ * S_out: HOST array. */
+int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V, int64_t N, const double *w, int64_t Nf, int64_t Nv,
+                               int64_t n, int64_t noverlap, double lam, int32_t normalize, int32_t coulomb, int32_t device, int32_t in_flight,
+                               double *S_out);
+
 /* ---- ls_windowcsd / ls_cohere on the engine                                              src/lsfft.jl:140-156, :176-193
  * Accumulators over the windows [win_lo, win_hi) in window order (NOT yet normalised: ls_windowcsd returns Syu / k,
  * ls_cohere |Syu|^2 / (Suu Syy)):  Syu += xy .* conj.(xu),  Syy += abs2.(xy),  Suu += abs2.(xu).  Any output may be NULL;

@@ -607,6 +607,23 @@ end
 # others: pass options as keywords).  The sum is taken in window order either way (src/lsfft.jl:274).
 function ls_windowpsd_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer, nw::Int=10, noverlap=0; in_flight::Int=2, kwargs...)
     S = zeros(length(w))                                                             # src/lsfft.jl:267-277
+    # the library's own driver (the same device solves on the library's worker threads: no `julia -t` needed) whenever the call has only
+    # what it takes; a singular window (NumericError) sends the call down the per-window path below, which has the host-QR route
+    if all(k in (:λ, :coulomb, :normalize, :device) for k in keys(kwargs))
+        @assert length(Y) == length(X) == length(V) "y, t and v has to be the same length"
+        Yv, Xv, Vv, wv = dense(Float64, Y), dense(Float64, X), dense(Float64, V), dense(Float64, w[:])
+        kw = (; kwargs...)
+        try
+            GC.@preserve Yv Xv Vv wv S check(@ccall LIB.lpvs_windowpsd_lpv_f64(Yv::Ptr{Float64}, Xv::Ptr{Float64}, Vv::Ptr{Float64}, length(Yv)::Int64,
+                wv::Ptr{Float64}, length(wv)::Int64, Int64(Nv)::Int64, Int64(length(Yv) ÷ nw)::Int64, Int64(noverlap)::Int64, Float64(get(kw, :λ, 1e-8))::Float64,
+                Int32(get(kw, :normalize, true))::Int32, Int32(get(kw, :coulomb, false))::Int32, Int32(get(kw, :device, 0))::Int32,
+                Int32(clamp(in_flight, 1, 8))::Int32, S::Ptr{Float64})::Int32)
+            return S
+        catch e
+            e isa NumericError || rethrow()
+            fill!(S, 0.0)
+        end
+    end
     windows = collect(Windows3(Y, X, V, length(Y) ÷ nw, noverlap, rect))
     solve((y, x, v)) = ls_spectral_lpv(collect(y), collect(x), collect(v), w, Nv; covariance=false, kwargs...)
     ses = Vector{Any}(undef, length(windows))

@@ -1146,6 +1146,20 @@ def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, in_flight=2, **kwargs):
     The sum over windows is taken in window order either way (:274), so the result does not depend on ``in_flight``."""
     w = np.ravel(_host(w))
     S = np.zeros(len(w))
+    # the library's own driver (lpvs_windowpsd_lpv_f64: the same device solves, the library's worker threads) whenever the call has only
+    # what it takes; a singular window (LPVS_ENUMERIC) sends the whole call down the per-window path below, which has the host-QR route
+    if set(kwargs) <= {"λ", "coulomb", "normalize", "device"} and not any(_lib.is_device_array(a) for a in (Y, X, V)) and not _all_f32(Y, X, V):
+        Yh, Xh, Vh = (np.ascontiguousarray(_host(a), dtype=np.float64) for a in (Y, X, V))
+        assert len(Yh) == len(Xh) == len(Vh), "y, t and v has to be the same length"   # src/windows.jl:96
+        wv = np.ascontiguousarray(w, dtype=np.float64)
+        try:
+            check(lib().lpvs_windowpsd_lpv_f64(out_ptr(Yh), out_ptr(Xh), out_ptr(Vh), len(Yh), out_ptr(wv), len(wv), int(Nv), len(Yh) // int(nw), int(noverlap),
+                                               float(kwargs.get("λ", 1e-8)), int(bool(kwargs.get("normalize", True))), int(bool(kwargs.get("coulomb", False))),
+                                               int(kwargs.get("device", 0)), max(1, min(8, int(in_flight))), out_ptr(S)))
+            return S
+        except _lib.NumericError as e:
+            log.info("ls_windowpsd_lpv: %s; per-window path", e)
+            S = np.zeros(len(w))
     windows = list(Windows3(Y, X, V, len(Y) // nw, noverlap, rect))
     kwargs.setdefault("covariance", False)                         # the driver reads the parameters only (:273-274): no Σ, no second inverse
     solve = lambda win: ls_spectral_lpv(win[0], win[1], win[2], w, Nv, **kwargs)

@@ -400,6 +400,80 @@ int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const doubl
     return LPVS_OK;
 }
 
+// ---- ls_windowpsd_lpv (src/lsfft.jl:267-277) inside the library ------------------------------------------------------------------
+// Windows3(Y, X, V, n, noverlap, rect): every window is a dense LPV estimate of its own (ls_spectral_lpv, :239-250: basis centres from
+// the WINDOW's range of V, Gram, factorisation of G + lam^2 I, ridge solve with refinement) -- the windows share nothing, so they are
+// separate device solves, `in_flight` of them at a time on handles and streams of their own (host threads of the library).
+// S = sum over windows, IN WINDOW ORDER (:274), of abs2.(sum(reshape_params(x, Nf), dims = 2)).  A window whose normal equations are
+// singular to working precision returns LPVS_ENUMERIC (the wrapper then takes the reference's QR route per window on the host).
+int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V, int64_t N, const double *w, int64_t Nf, int64_t Nv,
+                               int64_t n, int64_t noverlap, double lam, int32_t normalize, int32_t coulomb, int32_t device, int32_t in_flight,
+                               double *S_out) {
+    if (!Y || !X || !V || !w || !S_out || N < 1 || Nf < 1 || Nv < 1 || n < 1) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
+    if (in_flight < 1 || in_flight > 8) { set_error("in_flight = %d: 1 .. 8 solves at a time", in_flight); return LPVS_EARGUMENT; }
+    if (is_device_ptr(S_out)) { set_error("lpvs_windowpsd_lpv: S_out is a host array"); return LPVS_EARGUMENT; }
+    int64_t k = 0;
+    LPVS_TRY(lpvs_window_count(N, n, noverlap, &k));
+    for (int64_t f = 0; f < Nf; ++f) S_out[f] = 0.0;
+    if (k == 0) return LPVS_OK;
+    std::vector<int64_t> offs((size_t)k);
+    int64_t kk = 0;
+    LPVS_TRY(lpvs_window_offsets(N, n, noverlap, offs.data(), k, &kk));
+    struct DeviceRestore { int dev = -1; DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
+                           ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore_device;
+    const int64_t nb = coulomb ? 2 * Nv : Nv, m = Nf * nb;
+    std::vector<double> Sw((size_t)k * (size_t)Nf, 0.0);         // per-window contributions, summed in window order afterwards
+    int copt[kOptCount];
+    capture_default_options(copt);
+    std::atomic<int64_t> next{0};
+    std::mutex err_mu;
+    int32_t first_rc = LPVS_OK; std::string first_err; int64_t first_win = -1;
+    auto work = [&]() {
+        for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, copt[o]);
+        std::vector<double> x, re((size_t)m), im((size_t)m);
+        for (;;) {
+            const int64_t q = next.fetch_add(1);
+            if (q >= k) return;
+            { std::lock_guard<std::mutex> g(err_mu); if (first_rc != LPVS_OK) return; }
+            lpvs_problem *h = nullptr;
+            auto fail = [&](int32_t rc) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (first_rc == LPVS_OK) { first_rc = rc; first_err = lpvs_last_error(); first_win = q; }
+                if (h) lpvs_problem_destroy(h);
+            };
+            const int64_t o = offs[(size_t)q];
+            int32_t rc = lpvs_problem_create_lpv_f64(Y + o, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
+            if (rc != LPVS_OK) return fail(rc);
+            int64_t nn = 0;
+            if ((rc = lpvs_problem_size(h, &nn)) != LPVS_OK) return fail(rc);
+            x.assign((size_t)nn, 0.0);
+            if ((rc = lpvs_problem_solve_ridge_f64(h, lam * lam, x.data())) != LPVS_OK) return fail(rc);   // real_complex_bs, src/utilities.jl:49-54
+            if ((rc = lpvs_problem_pack_params_f64(h, x.data(), re.data(), im.data())) != LPVS_OK) return fail(rc);
+            lpvs_problem_destroy(h);
+            double *sw = Sw.data() + (size_t)q * (size_t)Nf;
+            for (int64_t f = 0; f < Nf; ++f) {                    // abs2(sum over the basis functions of frequency f), parameter index f + (v-1) Nf
+                double sr = 0.0, si = 0.0;
+                for (int64_t v = 0; v < nb; ++v) { sr += re[(size_t)(f + v * Nf)]; si += im[(size_t)(f + v * Nf)]; }
+                sw[f] = sr * sr + si * si;
+            }
+        }
+    };
+    int saved[kOptCount];
+    capture_default_options(saved);
+    const int nth = (int)std::min<int64_t>(in_flight, k);
+    if (nth == 1) work();
+    else {
+        std::vector<std::thread> th_;
+        for (int t = 0; t < nth; ++t) th_.emplace_back(work);
+        for (auto &q : th_) q.join();
+    }
+    for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, saved[o]);
+    if (first_rc != LPVS_OK) { set_error("window %lld: %s", (long long)first_win, first_err.c_str()); return first_rc; }
+    for (int64_t q = 0; q < k; ++q)
+        for (int64_t f = 0; f < Nf; ++f) S_out[f] += Sw[(size_t)q * (size_t)Nf + (size_t)f];                     // S += ..., window order (:274)
+    return LPVS_OK;
+}
+
 // Float32 records (host or device): widened on the host, float grids snapped to their progression, coefficients returned as floats
 int32_t lpvs_windows_estimate_multi_f32(const float *Y, int64_t ns, const float *t, int64_t L, int64_t n, int64_t noverlap,
                                         const float *W, const float *freqs, int64_t Nf, int32_t estimator, double lam,

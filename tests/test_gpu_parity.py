@@ -341,8 +341,22 @@ def test_ls_spectral_lpv_top3(L, oracle):
     assert rel(se.x, xo) <= 1e-6
     Sw = L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02)
     assert set(np.argsort(-Sw)[:3] + 1) == {1, 5, 10}
-    # its windows two in flight (the default) or one after the other: the same solves, summed in window order
+    # its windows two in flight (the default) or one after the other: the same solves, summed in window order; the call above went through
+    # the library's own driver (lpvs_windowpsd_lpv_f64), with `covariance=False` spelled out it takes the wrapper's per-window loop
     assert np.array_equal(Sw, L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02, in_flight=1))
+    assert np.array_equal(Sw, L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02, covariance=False))
+    So = sum(np.abs(oracle.ls_spectral_lpv(Y[i * 50:(i + 1) * 50], X[i * 50:(i + 1) * 50], V[i * 50:(i + 1) * 50], w_test, 50, lam=0.02).reshape(-1, len(w_test)).sum(axis=0)) ** 2
+             for i in range(10))
+    assert rel(Sw, So) <= 1e-6
+    # a well-posed case (125 samples per window, 96 unknowns): the library's driver with 1, 2 and 5 windows in flight, the wrapper's
+    # per-window loop and the oracle
+    S4 = L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, in_flight=2)
+    assert np.array_equal(S4, L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, in_flight=1))
+    assert np.array_equal(S4, L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, in_flight=5))
+    assert np.array_equal(S4, L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, covariance=False))
+    So4 = sum(np.abs(oracle.ls_spectral_lpv(Y[i * 125:(i + 1) * 125], X[i * 125:(i + 1) * 125], V[i * 125:(i + 1) * 125], w_test, 4, lam=1e-4).reshape(-1, len(w_test)).sum(axis=0)) ** 2
+              for i in range(4))
+    assert rel(S4, So4) <= 1e-6
     with L.default_options(gram_form="krs"):                     # option defaults reach the worker threads
         Sk = L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02, in_flight=3)
     assert rel(Sk, Sw) <= 1e-8
