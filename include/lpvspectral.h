@@ -79,7 +79,9 @@ int32_t lpvs_release_cached_memory(void);
  * tests/test_gpu_nufft.py); M_STORAGE trades bytes per iteration against 1e-10 in the iterates (see the header comment).
  *   lpvs_set_default_option:  thread-local default for handles created and batched-window calls made AFTERWARDS by the calling
  *                             thread (the batched-window entry points have no handle to carry options);
- *   lpvs_problem_set_option:  one handle.  M_STORAGE / ITERATION / NT_LOADS take effect at the next lpvs_admm_init / lpvs_admm_run;
+ *   lpvs_problem_set_option:  one handle.  ITERATION / NT_LOADS take effect at the next lpvs_admm_run; a CHANGED M_STORAGE
+ *                             invalidates the iteration state (the packed copy is rebuilt): lpvs_admm_init must follow, an
+ *                             lpvs_admm_run without it returns LPVS_ESTATE;
  *                             GRAM_FORM and SLOT_SUMS are constructor-time choices (LPVS_ESTATE on a handle: set the default). */
 #define LPVS_OPT_DEFAULT 0
 #define LPVS_OPT_M_STORAGE 1  /* LPVS_STORAGE_*  : packed inverse of n >= 2048 handles / window batches */
@@ -382,7 +384,9 @@ int32_t lpvs_lpv_batch_multi_f64(const double *Y, int64_t ns, const double *X, c
  * threads (1 .. 8) each solve one signal at a time on a handle and stream of their own -- the matrix-core-bound Gram and factorisation
  * of one solve run under the HBM-bound iterations of another (one MI355X at N = 2^20, n = 8192: 13.9 signals/s with in_flight = 1,
  * 16.4-16.8 with 2).  No collective.  Results do not depend on ngpus / in_flight.  re_out / im_out: (Nf*Nv) x nsig column-major HOST
- * arrays (signal q in column q, parameter index f + (v-1) Nf); iters_out: nsig iteration counts (HOST, may be NULL). */
+ * arrays (signal q in column q, parameter index f + (v-1) Nf); iters_out: nsig iteration counts (HOST, may be NULL).
+ * Y, X, V may be host or device pointers; a signal whose columns live on a device other than the one that solves it is copied there
+ * (peer copy) by the constructor -- kernels never read another device's memory (this holds for every lpvs_problem_create_*). */
 int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const double *V, int64_t N, int64_t nsig, const double *w, int64_t Nf,
                                    int64_t Nv, int32_t normalize, int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol,
                                    int64_t iters, const int32_t *devices, int32_t ngpus, int32_t in_flight, double *re_out, double *im_out,

@@ -778,6 +778,13 @@ def lpv_signals_multi(Y, X, V, w, Nv, proxg=None, λ=1, normalize=True, μ=0.05,
     w = _host_vec(w).astype(np.float64)
     dev_in = all(_lib.is_device_array(a) for a in (Y, X, V))
     if dev_in:                                                        # resident inputs (column-major N x nsig on the device) are used in place
+        import torch
+        if not all(a.dtype == torch.float64 for a in (Y, X, V)):     # the _f64 entry point reads 8-byte elements: never reinterpret
+            raise TypeError("lpv_signals_multi: device inputs must be float64 tensors (got %s)" % ", ".join(str(a.dtype) for a in (Y, X, V)))
+        if not (Y.device == X.device == V.device):
+            raise ValueError("lpv_signals_multi: Y, X and V must live on the same device (got %s, %s, %s)" % (Y.device, X.device, V.device))
+        if Y.dim() != 2:
+            raise ValueError("lpv_signals_multi: device inputs are N x nsig matrices")
         Yh, Xh, Vh = Y, X, V
         N, nsig = int(Y.shape[0]), int(Y.shape[1])
         assert tuple(X.shape) == tuple(V.shape) == (N, nsig), "Y, X and V has to have the same number of samples"

@@ -153,6 +153,14 @@ bool is_device_ptr(const void *p) {
     return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
 }
 
+int device_of_ptr(const void *p) {   // owning device of a device / managed allocation, -1 for host memory
+    if (p == nullptr) return -1;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) ? at.device : -1;
+}
+
 int32_t copy_to_device(void *dst_dev, const void *src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return LPVS_OK;
     LPVS_HIP(hipMemcpyAsync(dst_dev, src, bytes, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
@@ -166,13 +174,21 @@ int32_t copy_from_device(void *dst, const void *src_dev, size_t bytes, hipStream
     return LPVS_OK;
 }
 
-// A read-only argument made device-resident: aliases the caller's pointer when it already is.
+// A read-only argument made device-resident: aliases the caller's pointer when it already lives on the CURRENT device (the one the
+// handle computes on); memory of another device is staged like host memory (a peer copy) -- kernels never dereference it.
 struct DevArg {
     DevBuf own;
     const double *p = nullptr;
     int32_t set(const double *src, int64_t count, hipStream_t s) {
-        if (is_device_ptr(src)) { p = src; return LPVS_OK; }
+        const int owner = device_of_ptr(src);
+        int cur = -1;
+        if (owner >= 0) LPVS_HIP(hipGetDevice(&cur));
+        if (owner >= 0 && owner == cur) { p = src; return LPVS_OK; }
         LPVS_TRY(own.alloc(sizeof(double) * (size_t)count));
+        if (owner >= 0) {
+            LPVS_HIP(hipMemcpyPeerAsync(own.p, cur, src, owner, sizeof(double) * (size_t)count, s));
+            LPVS_HIP(hipStreamSynchronize(s));
+        } else
         LPVS_TRY(copy_to_device(own.p, src, sizeof(double) * (size_t)count, s));
         p = own.as<double>();
         return LPVS_OK;
@@ -1117,6 +1133,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     const bool demoted = mode == kMpMixed && h->Mp_mode == kMpSplit && h->Mp_demoted;   // mixed was tried for this M and found no small tiles
     if (h->np >= kSymmetricMinNp && (!h->Mp_valid || (h->Mp_mode != mode && !demoted))) {   // tile-packed lower triangle for the half-traffic mat-vec
         h->Mp_demoted = false;
+        bool just_demoted = false;   // set only by the demotion a few lines down: the handle's OLD (Mp_mode, Mp_valid) must not be mistaken for it
         const size_t elt = mode == kMpF32 ? 4 : (mode == kMpSplit || mode == kMpMixed ? 6 : 8);
         const size_t ntiles = symv_packed_doubles(h->np) / (128 * 128);
         const size_t need = elt * symv_packed_doubles(h->np) + (mode == kMpMixed ? ((ntiles + 255) / 256) * 256 + 256 : 0);   // + tile types + max|M|
@@ -1144,10 +1161,10 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
                 LPVS_TRY(launch_pack_tiles_split(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), s));
                 h->Mp_fixed_tiles = 0;
                 h->Mp_stream_bytes = 6.0 * (double)symv_packed_doubles(h->np);
-                h->Mp_valid = true; h->Mp_mode = kMpSplit; h->Mp_demoted = true;
+                h->Mp_valid = true; h->Mp_mode = kMpSplit; h->Mp_demoted = true; just_demoted = true;
             }
         } else LPVS_TRY(launch_pack_tiles(h->M.as<double>(), h->np, h->Mp.as<double>(), s));
-        if (!(mode == kMpMixed && h->Mp_mode == kMpSplit && h->Mp_valid)) { h->Mp_valid = true; h->Mp_mode = mode; }
+        if (!just_demoted) { h->Mp_valid = true; h->Mp_mode = mode; }
     }
     LPVS_HIP(hipMemsetAsync(h->part.p, 0, h->part.bytes, s));   // zero the ticket / block norms
     h->mu = mu; h->tol = tol; h->sign = linear_sign;

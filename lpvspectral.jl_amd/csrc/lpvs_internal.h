@@ -53,6 +53,7 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 bool is_device_ptr(const void *p);
+int device_of_ptr(const void *p);   // owning device, -1 for host memory
 // dst device <- src (host or device); dst (host or device) <- src device
 int32_t copy_to_device(void *dst_dev, const void *src, size_t bytes, hipStream_t s);
 int32_t copy_from_device(void *dst, const void *src_dev, size_t bytes, hipStream_t s);

@@ -60,6 +60,31 @@ def test_handle_options_choose_storage_and_iteration(L, sig, monkeypatch):
         assert np.array_equal(z != 0, ref != 0)
 
 
+def test_storage_switches_on_one_handle_repack_and_rebind(L, sig, monkeypatch):
+    """split -> mixed and split -> default on ONE handle with the same mu (so the factorisation is cached and
+    only the packed copy changes).  The stale (Mp_mode, Mp_valid) of the split packing used to be taken for a demotion that had just
+    happened: the buffer was repacked in the mixed layout and then decoded by the split kernel."""
+    y, X, V, w = sig
+    monkeypatch.delenv("LPVS_M_STORAGE", raising=False); monkeypatch.delenv("LPVS_ITERATION", raising=False)
+    prox = L.SlicedSeparableSum.frequency_groups(2.0, 128, 16)
+    seq = (("f64", "symv_tile_kernel<double>"), ("split", "symv_tile_split_kernel"), ("mixed", "admm_iter_mixed_kernel"),
+           ("split", "symv_tile_split_kernel"), (None, "admm_iter_mixed_kernel"), ("split", "symv_tile_split_kernel"), ("mixed", "admm_iter_mixed_kernel"),
+           ("f64", "symv_tile_kernel<double>"), (None, "admm_iter_mixed_kernel"))
+    zs = []
+    with L.Problem.lpv(y, X, V, w, 8) as p:
+        p.set_prox(prox)
+        for storage, kernel in seq:
+            p.set_option("storage", storage)
+            p.admm_init(None, μ=0.05, tol=0.0)
+            assert p.matvec_info()["kernel"] == kernel, (storage, p.matvec_info())
+            p.admm_run(200)
+            zs.append((storage, p.admm_get()[1]))
+    ref = zs[0][1]
+    for storage, z in zs[1:]:
+        assert rel(z, ref) <= 1e-9, (storage, rel(z, ref))
+        assert np.array_equal(z != 0, ref != 0), storage
+
+
 def test_default_options_reach_constructors_estimators_and_the_window_engine(L, sig, monkeypatch):
     from lpvspectral_jl_amd import api
     y, X, V, w = sig
