@@ -1458,6 +1458,7 @@ namespace {
 // phase times (ms) of the calling thread's last engine call: [0] Gram + rhs, [1] inverse (+ pack), [2] ADMM iterations or dense
 // solves, [3] windows, [4] batch mat-vec microseconds per launch (LPVS_WINDOW_MATVEC_TIMING=1 only, last pass), [5] windows of
 // that pass, [6] passes, [7] 1 if the structured Gram was used
+thread_local double g_win_multi[2] = {0, 0};   // last several-device call of this thread: ranks of the RCCL communicator that gathered (0: no collective), devices driven
 thread_local double g_win_timing[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] = bytes of packed inverses one timed mat-vec launch reads
 
 // sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations) is called in window order, signals innermost
@@ -1485,6 +1486,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
     int64_t zf = 0;
     LPVS_TRY(lpvs_check_freq_f64(a.freqs, Nf, &zf));
     for (double &v : g_win_timing) v = 0;
+    g_win_multi[0] = g_win_multi[1] = 0;
     const int64_t nwin = win_hi - win_lo;
     if (nwin == 0) return LPVS_OK;
     int count = 0;
@@ -1928,6 +1930,7 @@ int32_t windows_engine_run(const WinJob &job, const WinSink &sink, bool chunked)
 }
 void windows_last_timing(double *out10) { for (int i = 0; i < 10; ++i) out10[i] = g_win_timing[i]; }
 void windows_set_timing(const double *in10) { for (int i = 0; i < 10; ++i) g_win_timing[i] = in10[i]; }
+void windows_set_multi_info(int rccl_ranks, int devices) { g_win_multi[0] = rccl_ranks; g_win_multi[1] = devices; }
 }  // namespace lpvs
 
 extern "C" {
@@ -1935,6 +1938,7 @@ extern "C" {
 int32_t lpvs_windowpsd_last_timing(double *out, int32_t n_out) {
     if (!out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     for (int i = 0; i < n_out && i < 10; ++i) out[i] = g_win_timing[i];
+    for (int i = 10; i < n_out && i < 12; ++i) out[i] = g_win_multi[i - 10];
     return LPVS_OK;
 }
 

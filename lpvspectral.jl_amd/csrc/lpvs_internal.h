@@ -308,5 +308,6 @@ typedef std::function<void(int64_t, int64_t, const double *, const double *, int
 int32_t windows_engine_run(const WinJob &job, const WinSink &sink, bool chunked = false);   // chunked: in cache-sized chunks, two parts of a chunk in flight (api.hip)
 void windows_last_timing(double *out10);          // the calling thread's last engine call
 void windows_set_timing(const double *in10);
+void windows_set_multi_info(int rccl_ranks, int devices);   // out[10], out[11] of lpvs_windowpsd_last_timing
 
 }  // namespace lpvs

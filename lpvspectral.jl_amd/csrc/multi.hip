@@ -191,6 +191,7 @@ static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double 
         for (auto &S : sh) for (int i = 0; i < 10; ++i) if (S.timing[i] > tmax[i]) tmax[i] = S.timing[i];
         tmax[3] = (double)k;
         windows_set_timing(tmax);
+        windows_set_multi_info(0, ngpus);
     }
     std::vector<double> all;
     const double *img_all = nullptr;
@@ -209,6 +210,7 @@ static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double 
         if (!dev_ok) { set_error("hipSetDevice failed while enqueueing the RCCL all-gather"); return LPVS_EDEVICE; }
         if (rc != 0 || rc2 != 0) { set_error("RCCL all-gather of the window coefficients failed: %s", R.GetErrorString ? R.GetErrorString(rc ? rc : rc2) : "?"); return LPVS_EDEVICE; }
         for (auto &S : sh) { LPVS_HIP(hipSetDevice(S.device)); LPVS_HIP(hipStreamSynchronize(S.stream)); }
+        windows_set_multi_info((int)comms->size(), ngpus);          // the communicator that gathered: one rank per device
         all.resize(slot * (size_t)ngpus);
         LPVS_HIP(hipSetDevice(sh[0].device));
         LPVS_HIP(hipMemcpy(all.data(), sh[0].recv.p, sizeof(double) * all.size(), hipMemcpyDeviceToHost));   // devices[0] holds every window

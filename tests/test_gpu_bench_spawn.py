@@ -11,8 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra):
-    env = dict(os.environ)
+def _run(extra, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "1", "--warmup", "0",
@@ -33,6 +33,44 @@ def test_bench_spawns_its_ranks_and_reports_both_scaling_records():
     rec4 = _run(["--workload", "cfg4", "--iters", "50", "--nwin", "8"])
     assert rec4["n_gpus"] == 2 and rec4["scaling"] == "strong" and rec4["config"]["windows_per_gpu"] == [4, 4]
     assert rec4["psd_argmax"] == 33 and rec4["unit"] == "windows/s"
+
+
+@pytest.mark.gpu
+def test_bench_sub_records_cannot_cost_the_main_line():
+    """(a) a rank whose local part of cfg4_strong raises -> the ranks stay in lock-step, the main line prints
+    with cfg4_strong = {"error": ...}; (b) a rank that hangs in a sub-record -> the watchdog ends the run, rank 0 prints the main
+    line it already holds; (c) without faults, rank 0 alone drives the devices of all ranks ([0, 0] on this box) through the
+    C-ABI's several-device drivers: the single_process_{cfg3,cfg4,cfg5} records."""
+    base = ["--log2n", "16", "--iters", "70", "--nwin", "32", "--rehearse-sub-records"]
+    rec = _run(base)
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    assert rec["cfg4_strong"]["windows_per_gpu"] == [16, 16] and rec["cfg4_strong"]["psd_argmax"] == 33
+    sp = rec["single_process"]
+    assert sp["n_devices"] == 2 and sp["devices"] == [0, 0]
+    assert sp["single_process_cfg3"]["signals"] == 4 and sp["single_process_cfg3"]["iters_min_max"] == [70, 70]
+    assert sp["single_process_cfg4"]["psd_argmax"] == 33 and sp["single_process_cfg4"]["rccl_gather_ranks"] == 0     # (shards share the device: host gather)
+    assert sp["single_process_cfg5"]["channels"] == 4 and sp["single_process_cfg5"]["value"] > 0
+    rec = _run(base + ["--no-single-process"], {"LPVS_BENCH_INJECT": "fail:1"})
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and "error" in rec["cfg4_strong"]
+    rec = _run(base + ["--no-single-process", "--sub-timeout", "25"], {"LPVS_BENCH_INJECT": "hang:1"})
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and "watchdog" in rec["sub_records_note"]
+
+
+@pytest.mark.gpu
+def test_single_process_drivers_through_the_library_rccl_binding(monkeypatch):
+    """One device, LPVS_MULTI_FORCE_RCCL: the gather of lpvs_windows_estimate_multi_f64 goes through the dlopen'ed RCCL (a one-rank
+    communicator) and the record says so; the same coefficients as the plain single-device engine."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import lpvspectral_jl_amd as L
+    monkeypatch.setenv("LPVS_MULTI_FORCE_RCCL", "1")
+    r = bench.single_process_records(L, [0], iters4=70, nwin4=32, log2n4=12, which=("cfg4",))
+    rec = r["single_process_cfg4"]
+    assert "error" not in rec, rec
+    assert rec["rccl_gather_ranks"] == 1 and rec["psd_argmax"] == 33 and rec["iters_min_max"] == [70, 70]
+    monkeypatch.delenv("LPVS_MULTI_FORCE_RCCL")
+    r3 = bench.single_process_records(L, [0], iters3=60, log2n3=15, nf3=64, which=("cfg3",))["single_process_cfg3"]
+    assert "error" not in r3 and r3["signals"] == 2 and r3["iters_min_max"] == [60, 60], r3
 
 
 def _run1(extra):

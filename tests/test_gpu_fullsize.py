@@ -30,12 +30,9 @@ def cfg3_inputs(log2n, Nf=512, seed=0):
 
 
 def test_cfg3_gram_additivity_and_forms(L):
-    """N = 2^18 rows at the full n = 8192: G and b are sums over samples; both Gram forms agree."""
+    """N = 2^18 rows at the full n = 8192: G and b are sums over samples (interleaved halves); both Gram forms agree."""
     y, X, V, w = cfg3_inputs(18)
     N = len(y)
-    # V spans [0,1] in every part only if the basis centres are shared: use the same V range by keeping the
-    # end points in both halves (interleaved split)
-    ev, od = slice(0, N, 2), slice(1, N, 2)
     Vfix = V.clone()
     grams = {}
     for form in ("ap", "krs", "kr"):          # structured (w is an arithmetic progression), symmetric-pair MFMA, plain MFMA
@@ -61,6 +58,23 @@ def test_cfg3_gram_additivity_and_forms(L):
     with L.Problem.lpv(2.0 * y, X, Vfix, w, 8) as p:
         _, b3 = p.get_gram()
     assert np.abs(b3 - 2.0 * bd).max() <= 1e-13 * np.abs(bd).max()
+    # additivity over samples.  The basis centres come from the range of the V a problem is given (src/utilities.jl:24-25), so
+    # both interleaved halves keep BOTH end points: A = even rows + the last row, B = odd rows + the first row; the two rows
+    # counted twice are the two-row problem E.   G(all) + G(E) = G(A) + G(B),  b likewise -- in the default and in the dense form.
+    dev = y.device
+    iA = torch.cat([torch.arange(0, N, 2, device=dev), torch.tensor([N - 1], device=dev)])
+    iB = torch.cat([torch.tensor([0], device=dev), torch.arange(1, N, 2, device=dev)])
+    iE = torch.tensor([0, N - 1], device=dev)
+    for form, (Gall, ball) in (("auto", (Gd, bd)), ("krs", (G, b))):
+        parts = []
+        for idx in (iA, iB, iE):
+            with L.default_options(gram_form=None if form == "auto" else form):
+                with L.Problem.lpv(y[idx].contiguous(), X[idx].contiguous(), Vfix[idx].contiguous(), w, 8) as p:
+                    parts.append(p.get_gram())
+        (GA, bA), (GB, bB), (GE, bE) = parts
+        eg = np.abs(Gall + GE - (GA + GB)).max() / scale
+        eb = np.abs(ball + bE - (bA + bB)).max() / np.abs(ball).max()
+        assert eg <= 1e-12 and eb <= 1e-12, (form, eg, eb)
 
 
 def test_fourier_gram_additivity_cfg2(L):
