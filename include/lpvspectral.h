@@ -74,7 +74,8 @@ int32_t lpvs_release_cached_memory(void);
 
 /* ---- options: how a handle stores the inverse its ADMM mat-vec streams, how it iterates, which Gram form its constructor
  * takes.  Value 0 (LPVS_OPT_DEFAULT) = the library's choice, which an environment variable of the same name may override for
- * experiments (LPVS_M_STORAGE, LPVS_ITERATION, LPVS_GRAM_FORM, LPVS_NT_LOADS, LPVS_NUDFT); an explicit option wins over the
+ * experiments (LPVS_M_STORAGE, LPVS_ITERATION, LPVS_GRAM_FORM, LPVS_NT_LOADS, LPVS_NUDFT, LPVS_WINDOW_CHUNK_MB [0 = uncut],
+ * LPVS_WINDOWS_IN_FLIGHT, LPVS_RESERVE_CUS [0 = none]); an explicit option wins over the
  * environment.  Results do not depend on ITERATION / NT_LOADS / SLOT_SUMS beyond rounding (tests/test_gpu_one_launch.py,
  * tests/test_gpu_nufft.py); M_STORAGE trades bytes per iteration against 1e-10 in the iterates (see the header comment).
  *   lpvs_set_default_option:  thread-local default for handles created and batched-window calls made AFTERWARDS by the calling
@@ -82,7 +83,8 @@ int32_t lpvs_release_cached_memory(void);
  *   lpvs_problem_set_option:  one handle.  ITERATION / NT_LOADS take effect at the next lpvs_admm_run; a CHANGED M_STORAGE
  *                             invalidates the iteration state (the packed copy is rebuilt): lpvs_admm_init must follow, an
  *                             lpvs_admm_run without it returns LPVS_ESTATE;
- *                             GRAM_FORM and SLOT_SUMS are constructor-time choices (LPVS_ESTATE on a handle: set the default). */
+ *                             GRAM_FORM and SLOT_SUMS are constructor-time choices, WINDOW_CHUNK_MB / WINDOWS_IN_FLIGHT / RESERVE_CUS
+ *                             belong to calls without a handle or to the device (LPVS_ESTATE on a handle: set the default). */
 #define LPVS_OPT_DEFAULT 0
 #define LPVS_OPT_M_STORAGE 1  /* LPVS_STORAGE_*  : packed inverse of n >= 2048 handles / window batches */
 #define LPVS_OPT_ITERATION 2  /* LPVS_ITERATION_*: one launch per ADMM iteration (where applicable) or mat-vec + update launches */
@@ -99,8 +101,15 @@ int32_t lpvs_release_cached_memory(void);
 #define LPVS_GRAM_KR 3        /* dense, Khatri-Rao contraction */
 #define LPVS_NT_OFF 1
 #define LPVS_NT_ON 2
+#define LPVS_OPT_WINDOW_CHUNK_MB 6   /* batched-window engine: MB of packed inverses per chunk (a chunk is re-read from the Infinity Cache every
+                                       * iteration); > 0: that many MB, LPVS_WINDOW_UNCUT: every window in one launch per iteration; default:
+                                       * 1.0625 x the device's Infinity Cache as the KFD topology reports it (285 MB on MI355X) */
+#define LPVS_OPT_WINDOWS_IN_FLIGHT 7 /* parts of a chunk solved concurrently on streams of their own: 1 .. 4 (default 2) */
+#define LPVS_OPT_RESERVE_CUS 8       /* CUs the factorisation's trailing updates leave to its pivot chain: > 0, or LPVS_RESERVE_NONE (default 8) */
 #define LPVS_SLOTS_NUFFT 1
 #define LPVS_SLOTS_DIRECT 2
+#define LPVS_WINDOW_UNCUT (-1)
+#define LPVS_RESERVE_NONE (-1)
 int32_t lpvs_set_default_option(int32_t option, int32_t value);
 int32_t lpvs_get_default_option(int32_t option, int32_t *value);   /* the calling thread's explicit default (0 if none) */
 int32_t lpvs_problem_set_option(lpvs_problem *h, int32_t option, int32_t value);

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblpvspectral.so")
+# (LPVS_LIBRARY: measurement tools load an instrumented build of the SAME sources, e.g. liblpvspectral_timeline.so -- never a fallback)
+LIB_PATH = os.environ.get("LPVS_LIBRARY") or os.path.join(_HERE, "liblpvspectral.so")
 
 LPVS_OK = 0
 LPVS_EARGUMENT, LPVS_EASSERT, LPVS_EDOMAIN, LPVS_ENOMEM = -1, -2, -3, -4
@@ -28,7 +29,13 @@ OPTIONS = {
     "gram_form": (3, {"ap": 1, "krs": 2, "kr": 3}),
     "nt_loads": (4, {"off": 1, "on": 2}),
     "slot_sums": (5, {"nufft": 1, "direct": 2}),
+    # integer-valued: window_chunk_mb = MB of packed inverses per chunk of the batched-window engine ("uncut": one chunk),
+    # windows_in_flight = 1 .. 4 parts of a chunk at a time, reserve_cus = CUs left to the factorisation's pivot chain ("none")
+    "window_chunk_mb": (6, {"uncut": -1}),
+    "windows_in_flight": (7, {}),
+    "reserve_cus": (8, {"none": -1}),
 }
+_INT_OPTIONS = {"window_chunk_mb", "windows_in_flight", "reserve_cus"}
 
 
 def option_ids(name, value):
@@ -38,6 +45,8 @@ def option_ids(name, value):
     oid, vals = OPTIONS[name]
     if value is None or value == "default":
         return oid, 0
+    if name in _INT_OPTIONS and not isinstance(value, (str, bool)):
+        return oid, int(value)
     if isinstance(value, bool):
         value = "on" if value else "off"
     if value not in vals:

@@ -191,7 +191,10 @@ def get_default_option(name):
     oid, vals = _lib.OPTIONS[name]
     v = C.c_int32(0)
     check(lib().lpvs_get_default_option(oid, C.byref(v)))
-    return {i: k for k, i in vals.items()}.get(int(v.value))
+    named = {i: k for k, i in vals.items()}
+    if name in _lib._INT_OPTIONS:                                    # integer-valued options: the number itself (None = no explicit default)
+        return named.get(int(v.value), int(v.value) if v.value != 0 else None)
+    return named.get(int(v.value))
 
 
 class default_options:

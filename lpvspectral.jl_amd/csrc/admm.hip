@@ -3059,6 +3059,19 @@ __device__ __forceinline__ void fi_fixed_product(const FixRaw &fr, const double 
 }
 
 
+#ifdef LPVS_TIMELINE
+// Debug build only (make timeline -> liblpvspectral_timeline.so; tools/iter_timeline.py): every workgroup of the single-problem one-launch
+// iteration leaves wall-clock stamps (s_memrealtime, 100 MHz) of its phases, 8 words per workgroup and launch parity:
+//   {g, entry, update done, prologue barrier passed, tile consumed, last atomic issued, XCC_ID, HW_ID}
+__device__ unsigned long long *g_lpvs_tl = nullptr;
+extern "C" int32_t lpvs_debug_set_timeline(unsigned long long *dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lpvs_tl), &dev_buf, sizeof(dev_buf)) == hipSuccess ? LPVS_OK : LPVS_EDEVICE;
+}
+#define LPVS_TL_STAMP(k) do { if (tl_on && threadIdx.x == 0) tl_rec[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LPVS_TL_STAMP(k) do { } while (0)
+#endif
+
 // g: FIRST / MID -- index of the right-hand side this launch multiplies (the update it performs is u_{g-1});  LAST -- g - 1 is the
 // update it performs (it multiplies nothing).  aslot: accumulator this launch adds into (FIRST / MID) resp. would have (LAST).
 // BATCH: blockIdx.y = problem of a batch that each own their matrix (the windows of ls_windowpsd; p.ns = problems, vectors [ns][np],
@@ -3071,6 +3084,15 @@ __global__ void __launch_bounds__(256, 3)
 admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
                        int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev, size_t mp_stride, int /* PA as a run-time value: unused */) {
     constexpr bool prefetch_all = PA;               // (a template parameter: the two cases need different register sets, together they spill)
+#ifdef LPVS_TIMELINE
+    const bool tl_on = MODE == FI_MID && !BATCH && !F32 && g_lpvs_tl != nullptr;
+    unsigned long long *tl_rec = tl_on ? g_lpvs_tl + ((size_t)(g & 1) * (size_t)ntiles + blockIdx.x) * 8 : nullptr;
+    if (tl_on && threadIdx.x == 0) {
+        tl_rec[0] = (unsigned long long)g; tl_rec[1] = __builtin_amdgcn_s_memrealtime();
+        tl_rec[6] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);      // HW_REG_XCC_ID[3:0]
+        tl_rec[7] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID
+    }
+#endif
     __shared__ double sI[TS], sJ[TS], sT[4][TS], sq[2 * TS], red[3][4];
     const int sg = BATCH ? (int)blockIdx.y : 0, nprob = BATCH ? (int)gridDim.y : 1;
     const int64_t voff = (int64_t)sg * p.np;                           // this problem's vectors
@@ -3232,6 +3254,7 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
         }
     }
     if (MODE == FI_LAST) return;
+    LPVS_TL_STAMP(2);
     if (I == J && threadIdx.x < TS) f.acc((aslot + 1) % 3)[voff + e] = 0;   // the accumulator of the next launch
     if (threadIdx.x < TS) sI[i] = rhs_v; else sJ[i] = rhs_v;
     // ---- this launch's quantum (identical in every workgroup)
@@ -3249,6 +3272,7 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     const double quantum = bound_ok ? ldexp(1.0, eb - 62) : __longlong_as_double(0x7ff8000000000000ll), invq = bound_ok ? ldexp(1.0, 62 - eb) : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) f.qbuf[pg * nprob + sg] = quantum;
     __syncthreads();
+    LPVS_TL_STAMP(3);
     // ---- tile product
     const int c = lane & 15, gq = lane >> 4;
     double rj[8], tc[8], v[8];
@@ -3324,6 +3348,7 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
         }
     }
     // ---- row sums (halving butterfly over the 16 column lanes), column sums (four row lanes, then the four waves), added into x
+    LPVS_TL_STAMP(4);
 #pragma unroll
     for (int m = 8, cnt = 4; m >= 2; m >>= 1, cnt >>= 1) {
         const bool up = (c & m) != 0;
@@ -3359,6 +3384,7 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
             atomicAdd(acc_cur + voff + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
         }
     }
+    LPVS_TL_STAMP(5);
 }
 
 // constants and records of the one-launch iteration (after lpvs_admm_init / set_state; base = iterations done so far); p.ns problems

@@ -26,7 +26,7 @@ void set_error(const char *fmt, ...) {
 }
 
 // ---- options -----------------------------------------------------------------------------------------------------------
-static thread_local int g_opt[kOptCount] = {0, 0, 0, 0, 0, 0};
+static thread_local int g_opt[kOptCount] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 static int option_from_env(int option) {
     auto is = [](const char *e, const char *v) { return e != nullptr && std::strcmp(e, v) == 0; };
     switch (option) {
@@ -36,8 +36,35 @@ static int option_from_env(int option) {
     case LPVS_OPT_GRAM_FORM: { const char *e = getenv("LPVS_GRAM_FORM"); return is(e, "ap") ? LPVS_GRAM_AP : (is(e, "krs") || is(e, "panel")) ? LPVS_GRAM_KRS : is(e, "kr") ? LPVS_GRAM_KR : 0; }   // (panel: the Fourier problems' dense form)
     case LPVS_OPT_NT_LOADS: { const char *e = getenv("LPVS_NT_LOADS"); return e == nullptr ? 0 : (e[0] == '1' ? LPVS_NT_ON : LPVS_NT_OFF); }
     case LPVS_OPT_SLOT_SUMS: { const char *e = getenv("LPVS_NUDFT"); return is(e, "direct") ? LPVS_SLOTS_DIRECT : is(e, "nufft") ? LPVS_SLOTS_NUFFT : 0; }
+    case LPVS_OPT_WINDOW_CHUNK_MB: { const char *e = getenv("LPVS_WINDOW_CHUNK_MB"); if (!e) return 0; const double v = atof(e); return v <= 0 ? LPVS_WINDOW_UNCUT : (int)(v < 1 ? 1 : v); }
+    case LPVS_OPT_WINDOWS_IN_FLIGHT: { const char *e = getenv("LPVS_WINDOWS_IN_FLIGHT"); if (!e) return 0; const int v = atoi(e); return v < 1 ? 1 : (v > 4 ? 4 : v); }
+    case LPVS_OPT_RESERVE_CUS: { const char *e = getenv("LPVS_RESERVE_CUS"); if (!e) return 0; const int v = atoi(e); return v <= 0 ? LPVS_RESERVE_NONE : v; }
     }
     return 0;
+}
+// Last-level (Infinity / MALL) cache of the device: the largest level-3 cache the KFD topology lists (kB; every GPU of a node is the
+// same part).  256 MiB -- MI355X -- when the topology cannot be read.
+double infinity_cache_bytes() {
+    static const double bytes = [] {
+        double best = 0;
+        for (int node = 0; node < 64; ++node) {
+            for (int c = 0; c < 512; ++c) {
+                char path[160];
+                snprintf(path, sizeof(path), "/sys/class/kfd/kfd/topology/nodes/%d/caches/%d/properties", node, c);
+                FILE *fp = fopen(path, "r");
+                if (!fp) break;
+                char key[64]; long long val = 0, level = 0, size_kb = 0;
+                while (fscanf(fp, "%63s %lld", key, &val) == 2) {
+                    if (!strcmp(key, "level")) level = val;
+                    else if (!strcmp(key, "size")) size_kb = val;
+                }
+                fclose(fp);
+                if (level == 3 && (double)size_kb * 1024.0 > best) best = (double)size_kb * 1024.0;
+            }
+        }
+        return best >= (double)(16 << 20) ? best : 256.0 * 1048576.0;
+    }();
+    return bytes;
 }
 int option_in_effect(int option, int explicit_value) {
     if (option <= 0 || option >= kOptCount) return 0;
@@ -54,6 +81,9 @@ static bool option_value_ok(int option, int value) {
     case LPVS_OPT_GRAM_FORM: return value >= LPVS_GRAM_AP && value <= LPVS_GRAM_KR;
     case LPVS_OPT_NT_LOADS: return value == LPVS_NT_OFF || value == LPVS_NT_ON;
     case LPVS_OPT_SLOT_SUMS: return value == LPVS_SLOTS_NUFFT || value == LPVS_SLOTS_DIRECT;
+    case LPVS_OPT_WINDOW_CHUNK_MB: return value == LPVS_WINDOW_UNCUT || (value >= 1 && value <= (1 << 20));
+    case LPVS_OPT_WINDOWS_IN_FLIGHT: return value >= 1 && value <= 4;
+    case LPVS_OPT_RESERVE_CUS: return value == LPVS_RESERVE_NONE || (value >= 1 && value <= 128);
     }
     return false;
 }
@@ -534,8 +564,8 @@ int32_t lpvs_get_default_option(int32_t option, int32_t *value) {
 int32_t lpvs_problem_set_option(lpvs_problem *h, int32_t option, int32_t value) {
     if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
     if (option <= 0 || option >= kOptCount || !option_value_ok(option, value)) { set_error("unknown option %d or value %d", option, value); return LPVS_EARGUMENT; }
-    if (option == LPVS_OPT_GRAM_FORM || option == LPVS_OPT_SLOT_SUMS) {
-        set_error("option %d is chosen when a handle is constructed: set it with lpvs_set_default_option before creating the handle", option);
+    if (option == LPVS_OPT_GRAM_FORM || option == LPVS_OPT_SLOT_SUMS || option >= LPVS_OPT_WINDOW_CHUNK_MB) {
+        set_error("option %d is chosen when a handle is constructed (or belongs to calls without a handle): set it with lpvs_set_default_option", option);
         return LPVS_ESTATE;
     }
     if (h->opt[option] != value) {
@@ -1845,13 +1875,17 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
 // the other's stream.  Chunks of 256 / 320 / 448 / 512 windows: 269 / 264 / 288 / 299 ms; three parts: 258 ms.  Small ranges (the
 // shards of an 8-GPU run: 128 windows) gain the same way: 44.3 -> 36.7 ms.  The per-window results do not depend on how a range is
 // cut (tests), and the sink sees them in window order -- buffered per part, replayed in order -- so every accumulation over windows
-// is bit-identical to the uncut call.  LPVS_WINDOW_CHUNK_MB (default 285; 0: one chunk), LPVS_WINDOWS_IN_FLIGHT (default 2).
+// is bit-identical to the uncut call.  LPVS_OPT_WINDOW_CHUNK_MB (default 1.0625 x the Infinity Cache = 285 MB; uncut: one chunk),
+// LPVS_OPT_WINDOWS_IN_FLIGHT (default 2); the environment variables of the same names are the fallback.
 template <class Sink>
 int32_t windows_engine_chunked(const WinJob &a0, Sink sink) {
     const int64_t nwin = a0.win_hi - a0.win_lo;
     const bool sparse = a0.estimator == LPVS_EST_SPARSE || a0.estimator == LPVS_EST_SPARSE_INIT;
-    const double chunk_mb = [] { const char *e = getenv("LPVS_WINDOW_CHUNK_MB"); return e ? atof(e) : 285.0; }();
-    const int in_flight = [] { const char *e = getenv("LPVS_WINDOWS_IN_FLIGHT"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    // (options: the job's captured copy of its caller's defaults when it runs on a worker thread, else this thread's; then the environment)
+    const int o_chunk = option_in_effect(LPVS_OPT_WINDOW_CHUNK_MB, a0.opt_captured ? a0.opt[LPVS_OPT_WINDOW_CHUNK_MB] : 0);
+    const int o_fly = option_in_effect(LPVS_OPT_WINDOWS_IN_FLIGHT, a0.opt_captured ? a0.opt[LPVS_OPT_WINDOWS_IN_FLIGHT] : 0);
+    const double chunk_mb = o_chunk == LPVS_WINDOW_UNCUT ? 0.0 : (o_chunk > 0 ? (double)o_chunk : 1.0625 * infinity_cache_bytes() * 1e-6);   // 285 MB for 256 MiB
+    const int in_flight = o_fly > 0 ? o_fly : 2;
     int64_t zf = 0;
     if (!sparse || nwin < 16 || a0.iters < 64 || a0.freqs == nullptr || a0.Nf < 1 || is_device_ptr(a0.freqs) || lpvs_check_freq_f64(a0.freqs, a0.Nf, &zf) != LPVS_OK ||
         (in_flight == 1 && chunk_mb <= 0))
@@ -1888,8 +1922,9 @@ int32_t windows_engine_chunked(const WinJob &a0, Sink sink) {
         if (parts == 1) run(0);
         else {
             std::vector<std::thread> th;
-            for (int p = 1; p < parts; ++p) th.emplace_back(run, p);
-            run(0);
+            auto guarded = [&](int p) { run_guarded([&] { run(p); }, [&](int32_t rc) { rcs[(size_t)p] = rc; errs[(size_t)p] = lpvs_last_error(); }); };
+            for (int p = 1; p < parts; ++p) th.emplace_back(guarded, p);
+            guarded(0);
             for (auto &q : th) q.join();
         }
         for (int p = 0; p < parts; ++p)

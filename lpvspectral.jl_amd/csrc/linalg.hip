@@ -1130,8 +1130,9 @@ int32_t SweepAux::ensure() {
     // The pair schedule's trailing updates fill every CU with two workgroups of ~208 registers per lane: the one-workgroup pivot
     // inverse (304 registers per lane) then waits for a workgroup to retire, and once resident shares its SIMDs with a stream of f64
     // matrix instructions that its own vector instructions cannot overlap (measured: 235 us instead of 80).  The updates therefore run
-    // on a stream whose CU mask leaves a few CUs (LPVS_RESERVE_CUS, default 8 of 256; 0 = no mask) to the side stream's chains.
-    const int reserve = [] { const char *e = getenv("LPVS_RESERVE_CUS"); return e ? atoi(e) : 8; }();
+    // on a stream whose CU mask leaves a few CUs (LPVS_OPT_RESERVE_CUS, default 8 of 256) to the side stream's chains.
+    const int o_res = option_in_effect(LPVS_OPT_RESERVE_CUS);   // (the creating thread's default, else LPVS_RESERVE_CUS)
+    const int reserve = o_res == LPVS_RESERVE_NONE ? 0 : (o_res > 0 ? o_res : 8);
     int dev = 0, cus = 0;
     if (reserve > 0 && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
         cus > 4 * reserve) {

@@ -1,6 +1,8 @@
 // lpvs_internal.h -- shared declarations of the gfx950 implementation behind include/lpvspectral.h
 #pragma once
 #include <hip/hip_runtime.h>
+#include <exception>
+#include <new>
 #include <stdint.h>
 #include <functional>
 #include <string>
@@ -31,9 +33,19 @@ void set_error(const char *fmt, ...);
 // ---- options (include/lpvspectral.h LPVS_OPT_*; api.hip) ------------------------------------------------------------
 // value in effect: the explicit value (a handle's, or a job's captured copy of its caller's defaults), else the calling thread's
 // default, else what the environment variable of the same name says, else 0 (the library's own choice)
-constexpr int kOptCount = 6;
+constexpr int kOptCount = 9;
 int option_in_effect(int option, int explicit_value = 0);
-void capture_default_options(int *opt /*[kOptCount]*/);   // the calling thread's defaults (for work handed to other threads)
+void capture_default_options(int *opt /*[kOptCount]*/);
+double infinity_cache_bytes();   // the device's last-level (Infinity) cache from the KFD topology, 256 MiB when it cannot be read   // the calling thread's defaults (for work handed to other threads)
+
+// Body of a worker std::thread: an exception leaving it would end the process (std::terminate) -- it becomes a status instead.
+template <class F, class OnFail>
+static inline void run_guarded(F &&f, OnFail &&on_fail) {
+    try { f(); }
+    catch (const std::bad_alloc &) { set_error("out of host memory in a worker thread of the library"); on_fail(LPVS_ENOMEM); }
+    catch (const std::exception &e) { set_error("worker thread of the library: %s", e.what()); on_fail(LPVS_EDEVICE); }
+    catch (...) { set_error("worker thread of the library: unknown exception"); on_fail(LPVS_EDEVICE); }
+}
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -181,7 +181,8 @@ static int32_t windows_estimate_multi(const double *Y, int64_t ns, const double 
     if (ngpus == 1) work(0);
     else {
         std::vector<std::thread> th_;
-        for (int r = 0; r < ngpus; ++r) th_.emplace_back(work, r);
+        for (int r = 0; r < ngpus; ++r)
+            th_.emplace_back([&, r] { run_guarded([&] { work(r); }, [&](int32_t rc) { sh[(size_t)r].rc = rc; sh[(size_t)r].err = lpvs_last_error(); }); });
         for (auto &q : th_) q.join();
     }
     struct Cleanup { std::vector<Shard> &s; ~Cleanup() { for (auto &S : s) if (S.stream) { (void)hipSetDevice(S.device); (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); } } } cleanup{sh};
@@ -317,7 +318,8 @@ int32_t lpvs_lpv_batch_multi_f64(const double *Y, int64_t ns, const double *X, c
         for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, saved[o]);
     } else {
         std::vector<std::thread> th_;
-        for (int r = 0; r < ngpus; ++r) th_.emplace_back(work, r);
+        for (int r = 0; r < ngpus; ++r)
+            th_.emplace_back([&, r] { run_guarded([&] { work(r); }, [&](int32_t rc) { sh[(size_t)r].rc = rc; sh[(size_t)r].err = lpvs_last_error(); }); });
         for (auto &q : th_) q.join();
     }
     for (auto &S : sh) if (S.rc != LPVS_OK) { set_error("device %d (channels [%lld,%lld)): %s", S.device, (long long)S.lo, (long long)S.hi, S.err.c_str()); return S.rc; }
@@ -394,7 +396,10 @@ int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const doubl
     else {
         std::vector<std::thread> th_;
         for (int r = 0; r < ngpus; ++r)
-            for (int k = 0; k < in_flight; ++k) th_.emplace_back(work, r);
+            for (int k = 0; k < in_flight; ++k)
+                th_.emplace_back([&, r] { run_guarded([&] { work(r); }, [&](int32_t rc) {
+                    std::lock_guard<std::mutex> g(err_mu);
+                    if (first_rc == LPVS_OK) { first_rc = rc; first_err = lpvs_last_error(); first_sig = rg[(size_t)r].lo; } }); });
         for (auto &q : th_) q.join();
     }
     for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, saved[o]);
@@ -466,7 +471,10 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
     if (nth == 1) work();
     else {
         std::vector<std::thread> th_;
-        for (int t = 0; t < nth; ++t) th_.emplace_back(work);
+        for (int t = 0; t < nth; ++t)
+            th_.emplace_back([&] { run_guarded(work, [&](int32_t rc) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (first_rc == LPVS_OK) { first_rc = rc; first_err = lpvs_last_error(); first_win = 0; } }); });
         for (auto &q : th_) q.join();
     }
     for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, saved[o]);

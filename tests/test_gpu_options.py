@@ -118,3 +118,43 @@ def test_default_options_reach_constructors_estimators_and_the_window_engine(L, 
     assert not api.windowpsd_last_timing()["one_launch_iteration"]
     S3, _ = L.ls_windowpsd(yw, t, f, storage="f64", ngpus=0, **kww)      # the multi-device driver: options travel to its worker threads
     assert rel(S2, S1) <= 1e-9 and rel(S3, S1) <= 1e-9
+
+
+def test_window_plan_options_replace_the_environment_knobs(L, monkeypatch):
+    """LPVS_OPT_WINDOW_CHUNK_MB / LPVS_OPT_WINDOWS_IN_FLIGHT / LPVS_OPT_RESERVE_CUS as default options (the environment variables of
+    the same names stay as the fallback): integer values, the uncut plan by name, an explicit option wins over the environment, and the
+    engine's results do not depend on the plan, bit for bit."""
+    for v in ("LPVS_WINDOW_CHUNK_MB", "LPVS_WINDOWS_IN_FLIGHT", "LPVS_RESERVE_CUS"):
+        monkeypatch.delenv(v, raising=False)
+    rng = np.random.default_rng(12)
+    n, nwin, Nf = 1 << 10, 83, 96
+    t = np.arange(nwin * n, dtype=np.float64)
+    f = np.arange(1, Nf + 1) / 250.0
+    y = np.sin(2 * np.pi * f[20] * t) + 0.3 * rng.standard_normal(nwin * n)
+    kw = dict(λ=0.3, μ=1e-3, tol=0.0, iters=150)
+    with L.default_options(window_chunk_mb="uncut", windows_in_flight=1):
+        assert L.get_default_option("window_chunk_mb") == "uncut" and L.get_default_option("windows_in_flight") == 1
+        x0, S0, its0 = L.windowpsd_sparse_batched(y, t, f, n, 0, None, **kw)
+    assert L.get_default_option("window_chunk_mb") is None
+    for opts in (dict(window_chunk_mb=3, windows_in_flight=2), dict(window_chunk_mb=5, windows_in_flight=3), dict()):
+        with L.default_options(**opts):
+            x1, S1, its1 = L.windowpsd_sparse_batched(y, t, f, n, 0, None, **kw)
+        assert np.array_equal(x1, x0) and np.array_equal(S1, S0) and np.array_equal(its1, its0), opts
+    monkeypatch.setenv("LPVS_WINDOW_CHUNK_MB", "0"); monkeypatch.setenv("LPVS_WINDOWS_IN_FLIGHT", "1")     # the fallback still works ...
+    x2, S2, _ = L.windowpsd_sparse_batched(y, t, f, n, 0, None, **kw)
+    with L.default_options(window_chunk_mb=3, windows_in_flight=2):                                         # ... and loses against an option
+        x3, S3, _ = L.windowpsd_sparse_batched(y, t, f, n, 0, None, **kw)
+    assert np.array_equal(x2, x0) and np.array_equal(x3, x0)
+    with pytest.raises(ValueError):
+        L.set_default_option("windows_in_flight", 9)
+    # the factorisation's CU reservation: a device-level knob, same inverse either way
+    N = 1 << 16
+    sy, sX, sV, sw = _signal(N, 128, np.random.default_rng(5))
+    Ms = []
+    for r in ("none", 16, None):
+        with L.default_options(reserve_cus=r):
+            with L.Problem.lpv(sy, sX, sV, sw, 8) as p:
+                with pytest.raises(RuntimeError):
+                    p.set_option("reserve_cus", 4)                         # not a handle option
+                Ms.append(p.get_inverse(20.0))
+    assert rel(Ms[1], Ms[0]) <= 1e-12 and rel(Ms[2], Ms[0]) <= 1e-12
