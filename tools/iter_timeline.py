@@ -10,7 +10,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["LPVS_LIBRARY"] = os.path.join(ROOT, "lpvspectral.jl_amd", "liblpvspectral_timeline.so")
+FULL = "--full" in sys.argv                       # all five stamps (perturbs: the stamps in the middle serialise the kernel's overlapped phases)
+sys.argv = [a for a in sys.argv if a != "--full"]
+os.environ["LPVS_LIBRARY"] = os.path.join(ROOT, "lpvspectral.jl_amd", "liblpvspectral_timeline2.so" if FULL else "liblpvspectral_timeline.so")
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
@@ -41,10 +43,16 @@ with L.Problem.lpv(y, X, V, w, Nv, True, False) as p:
     assert setter(None) == 0
     rec = buf.cpu().numpy().reshape(2, ntiles, 8)
 
+nwg = int((rec[0, :, 1] != 0).sum())             # workgroups of a launch (several tiles per workgroup: fewer than tiles)
+assert nwg == int((rec[1, :, 1] != 0).sum()) and (rec[:, :nwg, 1] != 0).all()
+rec = rec[:, :nwg]
 g = rec[:, :, 0]
 assert (g[0] == g[0, 0]).all() and (g[1] == g[1, 0]).all() and abs(int(g[0, 0]) - int(g[1, 0])) == 1, "stamps of mixed launches"
 first, second = (0, 1) if g[0, 0] < g[1, 0] else (1, 0)
 A, B = rec[first].astype(np.int64), rec[second].astype(np.int64)
+print(f"# workgroups per launch: {nwg} ({nblk} diagonal + {nwg - nblk} with {-(-(ntiles - nblk) // max(nwg - nblk, 1))} tiles each)" if nwg != ntiles else f"# workgroups per launch: {nwg} (one tile each)")
+ntiles_all, ntiles = ntiles, nwg
+print(f"# stamps: {'all five (perturbing)' if FULL else 'entry and end only'}")
 print(f"# admm_iter_mixed_kernel<FI_MID>, n = {p.n} ({nblk} row blocks, {ntiles} workgroups), launches g = {int(A[0, 0])} and {int(B[0, 0])}; times in us, clock 100 MHz (10 ns ticks)")
 
 
@@ -61,14 +69,15 @@ for tag, R in (("launch A", A), ("launch B", B)):
     ent, upd, bar, cons, end = (R[:, k] - t0 for k in (1, 2, 3, 4, 5))
     print(f"\n== {tag}: span (first entry -> last workgroup's last atomic) {end.max() * TICK_US:.2f} us")
     describe("entry (after the launch's first entry)", ent)
-    describe("update done - entry (state loads, prox, dual step)", upd - ent)
-    describe("prologue barrier passed - entry", bar - ent)
-    describe("tile consumed - barrier (wait for the tile + product)", cons - bar)
-    describe("last atomic - tile consumed (butterflies, LDS, atomics)", end - cons)
+    if FULL:
+        describe("update done - entry (state loads, prox, dual step)", upd - ent)
+        describe("prologue barrier passed - entry", bar - ent)
+        describe("tile consumed - barrier (wait for the tile + product)", cons - bar)
+        describe("last atomic - tile consumed (butterflies, LDS, atomics)", end - cons)
     describe("workgroup lifetime (entry -> last atomic)", end - ent)
     diag = np.arange(ntiles) < nblk
     describe("  diagonal (float-head, 96 KB) workgroups: lifetime", (end - ent)[diag])
-    describe("  off-diagonal (36-bit, 74 KB) workgroups: lifetime", (end - ent)[~diag])
+    describe("  off-diagonal (36-bit, 74 KB per tile) workgroups: lifetime", (end - ent)[~diag])
     # occupancy over time: workgroups alive per microsecond
     edges = np.arange(0, end.max() + 100, 100)
     alive = [(int(((ent <= e) & (end > e)).sum())) for e in edges]
