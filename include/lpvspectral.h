@@ -405,14 +405,16 @@ int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const doubl
 
 /* ---- ls_windowpsd_lpv                                                                    src/lsfft.jl:267-277
  * S[Nf] = sum over the windows of Windows3(Y, X, V, n, noverlap, rect), in window order, of abs2.(sum(reshape_params(x_i, Nf), dims=2))
- * with x_i = ls_spectral_lpv(y_i, x_i, v_i, w, Nv; lam, coulomb, normalize).x (:239-250: every window its own basis centres, Gram,
- * factorisation and ridge solve on the device; no covariance -- the driver never reads it).  The windows share nothing: `in_flight`
- * (1 .. 8) of them are solved at a time on handles and streams of their own.  n = length(Y) / nw as the caller computes it (:269).
+ * with x_i = ls_spectral_lpv(y_i, x_i, v_i, w, Nv; lam, coulomb, normalize).x (:239-250: every window its own basis centres and Gram).
+ * The windows' Grams are built `in_flight` (1 .. 8) at a time on streams of their own into ONE batch; their factorisations and
+ * refined ridge solves then run for all windows at once (the batch machinery of the window engine).  n = length(Y) / nw as the caller
+ * computes it (:269).  fva_out (HOST, k = window count entries, may be NULL): each window's fraction of variance explained
+ * 1 - var(e)/var(y) (:255) -- the reference warns when it is below 0.9, the bindings do the same.
  * LPVS_ENUMERIC when a window's normal equations are singular to working precision (the reference's QR route is the wrapper's).
  * S_out: HOST array. */
 int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V, int64_t N, const double *w, int64_t Nf, int64_t Nv,
                                int64_t n, int64_t noverlap, double lam, int32_t normalize, int32_t coulomb, int32_t device, int32_t in_flight,
-                               double *S_out);
+                               double *S_out, double *fva_out);
 
 /* ---- ls_windowcsd / ls_cohere on the engine                                              src/lsfft.jl:140-156, :176-193
  * Accumulators over the windows [win_lo, win_hi) in window order (NOT yet normalised: ls_windowcsd returns Syu / k,

@@ -613,11 +613,17 @@ function ls_windowpsd_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVecto
         @assert length(Y) == length(X) == length(V) "y, t and v has to be the same length"
         Yv, Xv, Vv, wv = dense(Float64, Y), dense(Float64, X), dense(Float64, V), dense(Float64, w[:])
         kw = (; kwargs...)
+        kcnt = Ref{Int64}(0)
+        check(@ccall LIB.lpvs_window_count(length(Yv)::Int64, Int64(length(Yv) ÷ nw)::Int64, Int64(noverlap)::Int64, kcnt::Ref{Int64})::Int32)
+        fva = ones(max(kcnt[], 1))
         try
-            GC.@preserve Yv Xv Vv wv S check(@ccall LIB.lpvs_windowpsd_lpv_f64(Yv::Ptr{Float64}, Xv::Ptr{Float64}, Vv::Ptr{Float64}, length(Yv)::Int64,
+            GC.@preserve Yv Xv Vv wv S fva check(@ccall LIB.lpvs_windowpsd_lpv_f64(Yv::Ptr{Float64}, Xv::Ptr{Float64}, Vv::Ptr{Float64}, length(Yv)::Int64,
                 wv::Ptr{Float64}, length(wv)::Int64, Int64(Nv)::Int64, Int64(length(Yv) ÷ nw)::Int64, Int64(noverlap)::Int64, Float64(get(kw, :λ, 1e-8))::Float64,
                 Int32(get(kw, :normalize, true))::Int32, Int32(get(kw, :coulomb, false))::Int32, Int32(get(kw, :device, 0))::Int32,
-                Int32(clamp(in_flight, 1, 8))::Int32, S::Ptr{Float64})::Int32)
+                Int32(clamp(in_flight, 1, 8))::Int32, S::Ptr{Float64}, fva::Ptr{Float64})::Int32)
+            for v in fva[1:kcnt[]]
+                v < 0.9 && @warn("Fraction of variance explained = $(v)")            # src/lsfft.jl:255-256, per window
+            end
             return S
         catch e
             e isa NumericError || rethrow()

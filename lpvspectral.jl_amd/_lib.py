@@ -108,7 +108,7 @@ SIGNATURES = {
     "lpvs_windows_estimate_multi_f64": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
                                                 _P, _I32, _P, _P, _P]),
     "lpvs_lpv_batch_multi_f64": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _F64, _I64, _F64, _F64, _I64, _P, _I32, _P, _P, _P]),
-    "lpvs_windowpsd_lpv_f64": (_I32, [_P, _P, _P, _I64, _P, _I64, _I64, _I64, _I64, _F64, _I32, _I32, _I32, _I32, _P]),
+    "lpvs_windowpsd_lpv_f64": (_I32, [_P, _P, _P, _I64, _P, _I64, _I64, _I64, _I64, _F64, _I32, _I32, _I32, _I32, _P, _P]),
     "lpvs_lpv_signals_multi_f64": (_I32, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _F64, _I64, _F64, _F64, _I64, _P, _I32, _I32, _P, _P, _P]),
     "lpvs_windowcsd_f64": (_I32, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
                                    _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),

@@ -1151,10 +1151,10 @@ def ls_cohere(y, u, t, freqs=None, nw=10, noverlap=-1, estimator=None, batched=T
 
 @_with_options
 def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, in_flight=2, **kwargs):
-    """src/lsfft.jl:267-277.  The windows' regressors share nothing (each has its own samples of X and V), so every window is a
-    device solve of its own (Gram, factorisation, ridge solve with refinement); ``in_flight`` of them run concurrently, each on its
-    own handle and stream (an extension; 1 = one after the other) -- the latency-bound stretches of one solve hide under the other.
-    The sum over windows is taken in window order either way (:274), so the result does not depend on ``in_flight``."""
+    """src/lsfft.jl:267-277.  The windows' regressors share nothing (each has its own samples of X and V): their Grams are built
+    ``in_flight`` at a time (an extension; 1 = one after the other) into one batch, whose factorisations and refined ridge solves
+    then run for all windows at once (``lpvs_windowpsd_lpv_f64``).  The sum over windows is taken in window order (:274), so the
+    result does not depend on ``in_flight``; windows explaining less than 0.9 of their variance warn as the reference does (:255-256)."""
     w = np.ravel(_host(w))
     S = np.zeros(len(w))
     # the library's own driver (lpvs_windowpsd_lpv_f64: the same device solves, the library's worker threads) whenever the call has only
@@ -1163,10 +1163,17 @@ def ls_windowpsd_lpv(Y, X, V, w, Nv, nw=10, noverlap=0, in_flight=2, **kwargs):
         Yh, Xh, Vh = (np.ascontiguousarray(_host(a), dtype=np.float64) for a in (Y, X, V))
         assert len(Yh) == len(Xh) == len(Vh), "y, t and v has to be the same length"   # src/windows.jl:96
         wv = np.ascontiguousarray(w, dtype=np.float64)
+        kcnt = C.c_int64(0)
+        check(lib().lpvs_window_count(len(Yh), len(Yh) // int(nw), int(noverlap), C.byref(kcnt)))
+        fva = np.ones(max(int(kcnt.value), 1))
         try:
             check(lib().lpvs_windowpsd_lpv_f64(out_ptr(Yh), out_ptr(Xh), out_ptr(Vh), len(Yh), out_ptr(wv), len(wv), int(Nv), len(Yh) // int(nw), int(noverlap),
                                                float(kwargs.get("λ", 1e-8)), int(bool(kwargs.get("normalize", True))), int(bool(kwargs.get("coulomb", False))),
-                                               int(kwargs.get("device", 0)), max(1, min(8, int(in_flight))), out_ptr(S)))
+                                               int(kwargs.get("device", 0)), max(1, min(8, int(in_flight))), out_ptr(S), out_ptr(fva)))
+            for v in fva[:int(kcnt.value)]:
+                if v < 0.9:                                            # src/lsfft.jl:255-256, once per window as the reference's loop does
+                    import warnings
+                    warnings.warn(f"Fraction of variance explained = {v}")
             return S
         except _lib.NumericError as e:
             log.info("ls_windowpsd_lpv: %s; per-window path", e)

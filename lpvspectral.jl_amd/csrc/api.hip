@@ -284,12 +284,6 @@ struct EventPair {
 
 // Declared AFTER the temporaries of a scope (so destroyed BEFORE them): on an early error return the stream is drained
 // before the temporaries' blocks go back to the process-wide cache, where another handle's stream could pick them up.
-struct DrainOnExit {
-    hipStream_t s;
-    explicit DrainOnExit(hipStream_t s_) : s(s_) {}
-    ~DrainOnExit() { (void)hipStreamSynchronize(s); }
-};
-
 }  // namespace lpvs
 
 using namespace lpvs;

@@ -38,6 +38,13 @@ int option_in_effect(int option, int explicit_value = 0);
 void capture_default_options(int *opt /*[kOptCount]*/);
 double infinity_cache_bytes();   // the device's last-level (Infinity) cache from the KFD topology, 256 MiB when it cannot be read   // the calling thread's defaults (for work handed to other threads)
 
+// synchronises a stream when the scope is left: DevBufs declared BEFORE it return to the pool only after the stream is idle
+struct DrainOnExit {
+    hipStream_t s;
+    explicit DrainOnExit(hipStream_t s_) : s(s_) {}
+    ~DrainOnExit() { (void)hipStreamSynchronize(s); }
+};
+
 // Body of a worker std::thread: an exception leaving it would end the process (std::terminate) -- it becomes a status instead.
 template <class F, class OnFail>
 static inline void run_guarded(F &&f, OnFail &&on_fail) {

@@ -409,16 +409,23 @@ int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const doubl
 
 // ---- ls_windowpsd_lpv (src/lsfft.jl:267-277) inside the library ------------------------------------------------------------------
 // Windows3(Y, X, V, n, noverlap, rect): every window is a dense LPV estimate of its own (ls_spectral_lpv, :239-250: basis centres from
-// the WINDOW's range of V, Gram, factorisation of G + lam^2 I, ridge solve with refinement) -- the windows share nothing, so they are
-// separate device solves, `in_flight` of them at a time on handles and streams of their own (host threads of the library).
-// S = sum over windows, IN WINDOW ORDER (:274), of abs2.(sum(reshape_params(x, Nf), dims = 2)).  A window whose normal equations are
-// singular to working precision returns LPVS_ENUMERIC (the wrapper then takes the reference's QR route per window on the host).
+// the WINDOW's range of V, its own Gram).  Two phases per chunk of windows (a chunk = what 24 GiB of matrices hold):
+//   1. the windows' Grams G_q = Phi_q' Phi_q and right-hand sides Phi_q' [y_q, 1] by the single-problem builder (structured / NUFFT or
+//      dense MFMA form, whatever its admission rules choose), `in_flight` windows at a time on host threads and streams of their
+//      own, each written into its slot of ONE batch [windows][np][np];
+//   2. the whole chunk through the batch machinery of the window engine: (G_q + lam^2 I)^-1 of all windows by ONE blocked sweep
+//      (spd_inverse_inplace_batch), x_q = M_q b_q refined twice against every window's own Gram (launch_batch_ridge_solve), the
+//      residual test of lpvs_problem_solve_ridge per window.
+// S = sum over windows, IN WINDOW ORDER (:274), of abs2.(sum(reshape_params(x, Nf), dims = 2)).  fva_out (optional, k entries): the
+// window's fraction of variance explained 1 - var(e)/var(y) (:255; the reference warns below 0.9 -- the bindings do) from the second
+// right-hand side Phi'1.  A window whose normal equations are singular to working precision returns LPVS_ENUMERIC (the wrapper then
+// takes the reference's QR route per window on the host).
 int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V, int64_t N, const double *w, int64_t Nf, int64_t Nv,
                                int64_t n, int64_t noverlap, double lam, int32_t normalize, int32_t coulomb, int32_t device, int32_t in_flight,
-                               double *S_out) {
+                               double *S_out, double *fva_out) {
     if (!Y || !X || !V || !w || !S_out || N < 1 || Nf < 1 || Nv < 1 || n < 1) { set_error("NULL argument or empty size"); return LPVS_EARGUMENT; }
     if (in_flight < 1 || in_flight > 8) { set_error("in_flight = %d: 1 .. 8 solves at a time", in_flight); return LPVS_EARGUMENT; }
-    if (is_device_ptr(S_out)) { set_error("lpvs_windowpsd_lpv: S_out is a host array"); return LPVS_EARGUMENT; }
+    if (is_device_ptr(S_out) || (fva_out && is_device_ptr(fva_out))) { set_error("lpvs_windowpsd_lpv: S_out / fva_out are host arrays"); return LPVS_EARGUMENT; }
     int64_t k = 0;
     LPVS_TRY(lpvs_window_count(N, n, noverlap, &k));
     for (int64_t f = 0; f < Nf; ++f) S_out[f] = 0.0;
@@ -426,59 +433,129 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
     std::vector<int64_t> offs((size_t)k);
     int64_t kk = 0;
     LPVS_TRY(lpvs_window_offsets(N, n, noverlap, offs.data(), k, &kk));
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device visible (the gfx950 path has no CPU fallback)"); return LPVS_EDEVICE; }
+    if (device < 0 || device >= count) { set_error("device %d out of range [0,%d)", device, count); return LPVS_EDEVICE; }
     struct DeviceRestore { int dev = -1; DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
                            ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore_device;
-    const int64_t nb = coulomb ? 2 * Nv : Nv, m = Nf * nb;
+    LPVS_HIP(hipSetDevice(device));
+    const int64_t nb = coulomb ? 2 * Nv : Nv, m = Nf * nb, n2 = 2 * m, np = round_up(n2, 128);
+    const int nrhs = 2;                                          // y and the ones vector (sum of the residuals for var(e))
+    // the record on the host: y'y and sum(y) of every window, and the staging of [y_q, 1] for the constructor
+    std::vector<double> Yh_;
+    const double *Yh = Y;
+    if (is_device_ptr(Y)) { Yh_.resize((size_t)N); LPVS_HIP(hipMemcpy(Yh_.data(), Y, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost)); Yh = Yh_.data(); }
+    const size_t mat = sizeof(double) * (size_t)np * (size_t)np;
+    int64_t cw = (int64_t)(((size_t)24 << 30) / (2 * mat + spd_inverse_work_bytes(np)));
+    if (cw < 1) cw = 1;
+    if (cw > k) cw = k;
+    hipStream_t s = nullptr;
+    LPVS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } sguard{s};
+    DevBuf Qb, Mb, work, istat, bb, xv, t1, t2;
+    DrainOnExit drain(s);
+    LPVS_TRY(Qb.alloc(mat * (size_t)cw)); LPVS_TRY(Mb.alloc(mat * (size_t)cw));
+    LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)cw)); LPVS_TRY(istat.alloc(sizeof(int) * (size_t)cw));
+    const size_t vb = sizeof(double) * (size_t)np * (size_t)cw * (size_t)nrhs;
+    LPVS_TRY(bb.alloc(vb)); LPVS_TRY(xv.alloc(vb)); LPVS_TRY(t1.alloc(vb)); LPVS_TRY(t2.alloc(vb));
     std::vector<double> Sw((size_t)k * (size_t)Nf, 0.0);         // per-window contributions, summed in window order afterwards
+    std::vector<double> hx((size_t)np * (size_t)cw * (size_t)nrhs), hq(hx.size()), hb(hx.size());
+    std::vector<int> hist_((size_t)cw);
     int copt[kOptCount];
     capture_default_options(copt);
-    std::atomic<int64_t> next{0};
-    std::mutex err_mu;
-    int32_t first_rc = LPVS_OK; std::string first_err; int64_t first_win = -1;
-    auto work = [&]() {
-        for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, copt[o]);
-        std::vector<double> x, re((size_t)m), im((size_t)m);
-        for (;;) {
-            const int64_t q = next.fetch_add(1);
-            if (q >= k) return;
-            { std::lock_guard<std::mutex> g(err_mu); if (first_rc != LPVS_OK) return; }
-            lpvs_problem *h = nullptr;
-            auto fail = [&](int32_t rc) {
-                std::lock_guard<std::mutex> g(err_mu);
-                if (first_rc == LPVS_OK) { first_rc = rc; first_err = lpvs_last_error(); first_win = q; }
-                if (h) lpvs_problem_destroy(h);
-            };
-            const int64_t o = offs[(size_t)q];
-            int32_t rc = lpvs_problem_create_lpv_f64(Y + o, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
-            if (rc != LPVS_OK) return fail(rc);
-            int64_t nn = 0;
-            if ((rc = lpvs_problem_size(h, &nn)) != LPVS_OK) return fail(rc);
-            x.assign((size_t)nn, 0.0);
-            if ((rc = lpvs_problem_solve_ridge_f64(h, lam * lam, x.data())) != LPVS_OK) return fail(rc);   // real_complex_bs, src/utilities.jl:49-54
-            if ((rc = lpvs_problem_pack_params_f64(h, x.data(), re.data(), im.data())) != LPVS_OK) return fail(rc);
-            lpvs_problem_destroy(h);
-            double *sw = Sw.data() + (size_t)q * (size_t)Nf;
-            for (int64_t f = 0; f < Nf; ++f) {                    // abs2(sum over the basis functions of frequency f), parameter index f + (v-1) Nf
-                double sr = 0.0, si = 0.0;
-                for (int64_t v = 0; v < nb; ++v) { sr += re[(size_t)(f + v * Nf)]; si += im[(size_t)(f + v * Nf)]; }
-                sw[f] = sr * sr + si * si;
-            }
-        }
-    };
     int saved[kOptCount];
     capture_default_options(saved);
-    const int nth = (int)std::min<int64_t>(in_flight, k);
-    if (nth == 1) work();
-    else {
-        std::vector<std::thread> th_;
-        for (int t = 0; t < nth; ++t)
-            th_.emplace_back([&] { run_guarded(work, [&](int32_t rc) {
-                std::lock_guard<std::mutex> g(err_mu);
-                if (first_rc == LPVS_OK) { first_rc = rc; first_err = lpvs_last_error(); first_win = 0; } }); });
-        for (auto &q : th_) q.join();
+    struct RestoreOptions { int *saved; ~RestoreOptions() { for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, saved[o]); } } ropt{saved};
+    for (int64_t c0 = 0; c0 < k; c0 += cw) {
+        const int nbw = (int)std::min<int64_t>(cw, k - c0);
+        // ---- phase 1: the windows' Grams and right-hand sides into their slots
+        std::atomic<int64_t> next{0};
+        std::mutex err_mu;
+        int32_t first_rc = LPVS_OK; std::string first_err; int64_t first_win = -1;
+        auto fail_with = [&](int32_t rc, int64_t q) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (first_rc == LPVS_OK) { first_rc = rc; first_err = lpvs_last_error(); first_win = c0 + q; }
+        };
+        auto work_fn = [&]() {
+            for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, copt[o]);
+            if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); set_error("hipSetDevice failed"); return fail_with(LPVS_EDEVICE, 0); }
+            std::vector<double> y2((size_t)2 * (size_t)n, 1.0);   // [y_q | 1], column-major n x 2
+            for (;;) {
+                const int64_t q = next.fetch_add(1);
+                if (q >= nbw) return;
+                { std::lock_guard<std::mutex> g(err_mu); if (first_rc != LPVS_OK) return; }
+                const int64_t o = offs[(size_t)(c0 + q)];
+                memcpy(y2.data(), Yh + o, sizeof(double) * (size_t)n);
+                lpvs_problem *h = nullptr;
+                int32_t rc = lpvs_problem_create_lpv_multi_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
+                if (rc != LPVS_OK) return fail_with(rc, q);
+                double *G = nullptr, *b = nullptr; int64_t hnp = 0;
+                rc = lpvs_problem_device_gram_f64(h, &G, &b, &hnp);
+                if (rc == LPVS_OK && hnp != np) { set_error("window Gram of padded size %lld, expected %lld", (long long)hnp, (long long)np); rc = LPVS_EDEVICE; }
+                if (rc == LPVS_OK && (hipMemcpy(Qb.as<double>() + (size_t)q * (size_t)np * (size_t)np, G, mat, hipMemcpyDeviceToDevice) != hipSuccess ||
+                                      hipMemcpy(bb.as<double>() + (size_t)q * (size_t)nrhs * (size_t)np, b, sizeof(double) * (size_t)np * (size_t)nrhs, hipMemcpyDeviceToDevice) != hipSuccess)) {
+                    (void)hipGetLastError(); set_error("copy of a window's Gram into the batch failed"); rc = LPVS_EDEVICE;
+                }
+                lpvs_problem_destroy(h);
+                if (rc != LPVS_OK) return fail_with(rc, q);
+            }
+        };
+        const int nth = (int)std::min<int64_t>(in_flight, nbw);
+        if (nth == 1) run_guarded(work_fn, [&](int32_t rc) { fail_with(rc, 0); });
+        else {
+            std::vector<std::thread> th_;
+            for (int t = 0; t < nth; ++t) th_.emplace_back([&] { run_guarded(work_fn, [&](int32_t rc) { fail_with(rc, 0); }); });
+            for (auto &q : th_) q.join();
+        }
+        if (first_rc != LPVS_OK) { set_error("window %lld: %s", (long long)first_win, first_err.c_str()); return first_rc; }
+        LPVS_HIP(hipSetDevice(device));
+        // ---- phase 2: all windows of the chunk at once
+        const double ridge = lam * lam;                          // real_complex_bs(A, Y, lam): [A; lam I] \ [Y; 0], src/utilities.jl:49-54
+        LPVS_HIP(hipMemcpyAsync(Mb.p, Qb.p, mat * (size_t)nbw, hipMemcpyDeviceToDevice, s));
+        LPVS_TRY(launch_add_diag_batch(Mb.as<double>(), np, n2, ridge, nbw, s));
+        LPVS_TRY(spd_inverse_inplace_batch(Mb.as<double>(), np, nbw, work.as<double>(), istat.as<int>(), s));
+        LPVS_HIP(hipMemcpyAsync(hist_.data(), istat.p, sizeof(int) * (size_t)nbw, hipMemcpyDeviceToHost, s));
+        LPVS_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < nbw; ++q)
+            if (hist_[(size_t)q] != 0) { set_error("window %lld: (G + %.3g I) is not positive definite to working precision", (long long)(c0 + q), ridge); return LPVS_ENUMERIC; }
+        const int nprob = nbw * nrhs;
+        LPVS_TRY(launch_batch_ridge_solve(Qb.as<double>(), Mb.as<double>(), np, n2, nprob, nrhs, bb.as<double>(), ridge, 2, xv.as<double>(), t1.as<double>(), t2.as<double>(), s));
+        LPVS_TRY(launch_batch_matvec(Qb.as<double>(), np, nprob, nrhs, xv.as<double>(), t1.as<double>(), s));     // G x of the refined solutions
+        const size_t cnt = (size_t)np * (size_t)nprob;
+        LPVS_HIP(hipMemcpyAsync(hx.data(), xv.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, s));
+        LPVS_HIP(hipMemcpyAsync(hq.data(), t1.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, s));
+        LPVS_HIP(hipMemcpyAsync(hb.data(), bb.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, s));
+        LPVS_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < nbw; ++q) {
+            const double *x = hx.data() + (size_t)q * (size_t)nrhs * (size_t)np, *Gx = hq.data() + (size_t)q * (size_t)nrhs * (size_t)np;
+            const double *b0 = hb.data() + (size_t)q * (size_t)nrhs * (size_t)np, *b1 = b0 + np;
+            double r2 = 0, b2 = 0, xGx = 0, xb0 = 0, xb1 = 0;
+            for (int64_t i = 0; i < n2; ++i) {
+                const double r = b0[i] - (ridge * x[i] + Gx[i]);
+                r2 += r * r; b2 += b0[i] * b0[i]; xGx += x[i] * Gx[i]; xb0 += x[i] * b0[i]; xb1 += x[i] * b1[i];
+            }
+            if (!(r2 <= 1e-18 * b2) && b2 > 0) {     // (as lpvs_problem_solve_ridge: the reference's QR of [A; lam I] still works there -- the wrapper's route)
+                set_error("window %lld: normal equations (G + %.3g I) x = b are too ill-conditioned for the device solve (relative residual %.3g after refinement)",
+                          (long long)(c0 + q), ridge, std::sqrt(r2 / b2));
+                return LPVS_ENUMERIC;
+            }
+            double *sw = Sw.data() + (size_t)(c0 + q) * (size_t)Nf;
+            for (int64_t f = 0; f < Nf; ++f) {                    // abs2(sum over the basis functions of frequency f): param f + (v-1) Nf = x[f 2nb + v] + i x[f 2nb + nb + v]
+                double sr = 0.0, si = 0.0;
+                for (int64_t v = 0; v < nb; ++v) { sr += x[f * 2 * nb + v]; si += x[f * 2 * nb + nb + v]; }
+                sw[f] = sr * sr + si * si;
+            }
+            if (fva_out) {   // e = A x - y: |e|^2 = x'Gx - 2 x'b + y'y, sum(e) = x'(A'1) - sum(y); var with the n - 1 divisor (Statistics.var), src/lsfft.jl:252-255
+                const double *yq = Yh + offs[(size_t)(c0 + q)];
+                double yy = 0, ys = 0;
+                for (int64_t i = 0; i < n; ++i) { yy += yq[i] * yq[i]; ys += yq[i]; }
+                const double e2 = xGx - 2.0 * xb0 + yy, es = xb1 - ys;
+                const double var_e = n > 1 ? (e2 - es * es / (double)n) / (double)(n - 1) : 0.0;
+                const double var_y = n > 1 ? (yy - ys * ys / (double)n) / (double)(n - 1) : 0.0;
+                fva_out[c0 + q] = 1.0 - var_e / var_y;
+            }
+        }
     }
-    for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, saved[o]);
-    if (first_rc != LPVS_OK) { set_error("window %lld: %s", (long long)first_win, first_err.c_str()); return first_rc; }
     for (int64_t q = 0; q < k; ++q)
         for (int64_t f = 0; f < Nf; ++f) S_out[f] += Sw[(size_t)q * (size_t)Nf + (size_t)f];                     // S += ..., window order (:274)
     return LPVS_OK;

@@ -344,7 +344,8 @@ def test_ls_spectral_lpv_top3(L, oracle):
     # its windows two in flight (the default) or one after the other: the same solves, summed in window order; the call above went through
     # the library's own driver (lpvs_windowpsd_lpv_f64), with `covariance=False` spelled out it takes the wrapper's per-window loop
     assert np.array_equal(Sw, L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02, in_flight=1))
-    assert np.array_equal(Sw, L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02, covariance=False))
+    Sww = L.ls_windowpsd_lpv(Y, X, V, w_test, 50, λ=0.02, covariance=False)
+    assert rel(Sw, Sww) <= 1e-9, rel(Sw, Sww)                    # (the batched refinement and the single-handle one sum in different orders)
     So = sum(np.abs(oracle.ls_spectral_lpv(Y[i * 50:(i + 1) * 50], X[i * 50:(i + 1) * 50], V[i * 50:(i + 1) * 50], w_test, 50, lam=0.02).reshape(-1, len(w_test)).sum(axis=0)) ** 2
              for i in range(10))
     assert rel(Sw, So) <= 1e-6
@@ -353,7 +354,8 @@ def test_ls_spectral_lpv_top3(L, oracle):
     S4 = L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, in_flight=2)
     assert np.array_equal(S4, L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, in_flight=1))
     assert np.array_equal(S4, L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, in_flight=5))
-    assert np.array_equal(S4, L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, covariance=False))
+    S4w = L.ls_windowpsd_lpv(Y, X, V, w_test, 4, 4, λ=1e-4, covariance=False)      # the wrapper's per-window loop (single-handle solves)
+    assert rel(S4, S4w) <= 1e-10, rel(S4, S4w)                                      # (batched and single-handle refinement sum in different orders)
     So4 = sum(np.abs(oracle.ls_spectral_lpv(Y[i * 125:(i + 1) * 125], X[i * 125:(i + 1) * 125], V[i * 125:(i + 1) * 125], w_test, 4, lam=1e-4).reshape(-1, len(w_test)).sum(axis=0)) ** 2
               for i in range(4))
     assert rel(S4, So4) <= 1e-6
@@ -366,6 +368,51 @@ def test_ls_spectral_lpv_top3(L, oracle):
     e = Ar @ xr - Y
     Sig = np.var(e, ddof=1) * np.linalg.inv(Ar.T @ Ar + 0.02 * np.eye(Ar.shape[1]))
     assert se.Σ.shape == Sig.shape and np.abs(se.Σ - Sig).max() <= 1e-6 * np.abs(Sig).max()
+
+
+def test_ls_windowpsd_lpv_batch_of_64_windows(L, oracle):
+    """src/lsfft.jl:267-277 through the batch machinery (lpvs_windowpsd_lpv_f64: the windows' Grams into one batch, ONE blocked sweep for
+    all factorisations, batched refined ridge solves): 64 windows of 600 samples, 96 unknowns each, against the oracle's
+    ls_spectral_lpv per window, S summed in window order; the per-window fraction of variance explained against a direct numpy
+    evaluation, and the reference's warning (:255-256) for windows below 0.9."""
+    import ctypes as C
+    import warnings
+    from lpvspectral_jl_amd._lib import lib, out_ptr, check
+    nw, nwin_len, Nv = 64, 600, 4
+    Y, X, V = lpv_signal(nw * nwin_len, 3, xmax=10.0 * nw)                          # (every window spans 10 units of X, as the 500-sample record of the reference's test)
+    w_test = 2 * np.pi * np.arange(2, 26, 2.0)
+    Nf = len(w_test)
+    S = np.zeros(Nf); fva = np.zeros(nw)
+    Yh, Xh, Vh = (np.ascontiguousarray(a, dtype=np.float64) for a in (Y, X, V))
+    check(lib().lpvs_windowpsd_lpv_f64(out_ptr(Yh), out_ptr(Xh), out_ptr(Vh), len(Yh), out_ptr(w_test), Nf, Nv, nwin_len, 0, 0.02, 1, 0, 0, 3, out_ptr(S), out_ptr(fva)))
+    So = np.zeros(Nf); fo = np.zeros(nw)
+    for i in range(nw):
+        sl = slice(i * nwin_len, (i + 1) * nwin_len)
+        xo = oracle.ls_spectral_lpv(Y[sl], X[sl], V[sl], w_test, Nv, lam=0.02)
+        So += np.abs(xo.reshape(-1, Nf).sum(axis=0)) ** 2                        # abs2.(sum(reshape_params(x, Nf), dims = 2)), window order
+        Ar = oracle.lpv_regressor(X[sl], V[sl], w_test, Nv, permuted=False)
+        e = Ar @ np.concatenate([xo.real, xo.imag]) - Y[sl]
+        fo[i] = 1 - np.var(e, ddof=1) / np.var(Y[sl], ddof=1)
+    assert rel(S, So) <= 1e-8, rel(S, So)
+    assert np.abs(fva - fo).max() <= 1e-8, np.abs(fva - fo).max()
+    # the wrapper: same S whatever in_flight, and one warning per window below 0.9
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        Sw = L.ls_windowpsd_lpv(Y, X, V, w_test, Nv, nw, 0, λ=0.02)
+        S1 = L.ls_windowpsd_lpv(Y, X, V, w_test, Nv, nw, 0, λ=0.02, in_flight=1)
+    assert np.array_equal(Sw, S) and np.array_equal(S1, S)
+    nlow = int((fo < 0.9).sum())
+    assert sum("Fraction of variance explained" in str(r.message) for r in rec) == 2 * nlow
+    # overlapping windows, ragged tail dropped (Windows3 / arraysplit)
+    S2 = np.zeros(Nf)
+    k = C.c_int64(0)
+    check(lib().lpvs_window_count(len(Yh), 700, 350, C.byref(k)))
+    check(lib().lpvs_windowpsd_lpv_f64(out_ptr(Yh), out_ptr(Xh), out_ptr(Vh), len(Yh), out_ptr(w_test), Nf, Nv, 700, 350, 0.02, 1, 0, 0, 2, out_ptr(S2), None))
+    So2 = np.zeros(Nf)
+    for i in range(int(k.value)):
+        sl = slice(i * 350, i * 350 + 700)
+        So2 += np.abs(oracle.ls_spectral_lpv(Y[sl], X[sl], V[sl], w_test, Nv, lam=0.02).reshape(-1, Nf).sum(axis=0)) ** 2
+    assert int(k.value) == (len(Yh) - 700) // 350 + 1 and rel(S2, So2) <= 1e-8
 
 
 # ------------------------------------------------------------------ batched windows (cfg4 engine)
