@@ -1898,7 +1898,7 @@ int32_t windows_engine_chunked(const WinJob &a0, Sink sink) {
     const double chunk_mb = o_chunk == LPVS_WINDOW_UNCUT ? 0.0 : (o_chunk > 0 ? (double)o_chunk : 1.0625 * infinity_cache_bytes() * 1e-6);   // 285 MB for 256 MiB
     const int in_flight = o_fly > 0 ? o_fly : 2;
     int64_t zf = 0;
-    if (!sparse || nwin < 16 || a0.iters < 64 || a0.freqs == nullptr || a0.Nf < 1 || is_device_ptr(a0.freqs) || lpvs_check_freq_f64(a0.freqs, a0.Nf, &zf) != LPVS_OK ||
+    if (!sparse || nwin < 16 || a0.iters < 64 || a0.freqs == nullptr || a0.Nf < 1 || lpvs_check_freq_f64(a0.freqs, a0.Nf, &zf) != LPVS_OK ||
         (in_flight == 1 && chunk_mb <= 0))
         return windows_engine(a0, sink);              // (argument errors are reported by the engine itself)
     const int64_t nreg = zf ? 2 * a0.Nf - 1 : 2 * a0.Nf, np = round_up(nreg, 128), nblk = np / 128;
@@ -1910,6 +1910,7 @@ int32_t windows_engine_chunked(const WinJob &a0, Sink sink) {
     chunk = ceil_div(nwin, nchunks);                  // even chunks
     WinJob a = a0;
     if (!a.opt_captured) { capture_default_options(a.opt); a.opt_captured = true; }   // (the parts run on other threads)
+    a.f32_grid = a0.f32_grid || g_f32_admission;      // ... and so does the float-grid admission of the _f32 entry points (a thread-local switch)
     struct Rec { int64_t w, sg, its; std::vector<double> re, im; };
     double tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t Nf = a.Nf;

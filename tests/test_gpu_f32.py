@@ -192,6 +192,28 @@ def test_f32_remaining_entry_points(L):
     assert Syy.dtype == np.float32 and np.array_equal(xy, xs[0]) and np.array_equal(xu, xs[1])
 
 
+def test_f32_window_calls_take_the_chunked_plan(L):
+    """the single-device _f32 window entry points widen freqs into a device buffer, which used to keep them off
+    the engine's chunked plan (cache-sized chunks, parts in flight), and the float-grid admission -- a thread-local switch -- did not
+    travel to the parts' worker threads.  40 windows, float grid: the default plan, small chunks with three parts in flight and the
+    uncut plan agree bit for bit, and the structured Gram is taken on the worker threads too."""
+    from lpvspectral_jl_amd import api
+    rng = np.random.default_rng(61)
+    n, nwin, Nf = 1 << 10, 40, 64
+    t = np.arange(n * nwin, dtype=np.float32)
+    f = (np.arange(Nf) / 128.0).astype(np.float32)          # a float grid: admitted as the progression it was rounded from
+    y = (np.sin(2 * np.pi * f[9].astype(np.float64) * t.astype(np.float64)) + 0.3 * rng.standard_normal(n * nwin)).astype(np.float32)
+    eng = dict(estimator=1, lam=0.0, prox=(1, 0.3, 0), μ=1e-3, tol=0.0, iters=100, sign=-1)
+    out = {}
+    for name, opts in (("uncut", dict(window_chunk_mb="uncut", windows_in_flight=1)), ("default", dict()), ("small", dict(window_chunk_mb=1, windows_in_flight=3))):
+        with L.default_options(**opts):
+            x, its = L.windows_estimate([y], t, f, n, 0, None, eng)
+        tm = api.windowpsd_last_timing()
+        assert x.dtype == np.complex64 and tm["gram_form"] in ("ap", "ap-nufft"), (name, tm)
+        out[name] = x
+    assert np.array_equal(out["default"], out["uncut"]) and np.array_equal(out["small"], out["uncut"])
+
+
 def test_f32_record_with_f64_time_stamps_keeps_t_exact(L):
     """Eltype promotion as Julia does it (src/lsfft.jl:121 -> src/lasso.jl:111 -> src/lsfft.jl:26: the regressor is evaluated in the
     eltype of t and freqs): a Float32 record with Float64 time stamps above 2^24 is a Float64 problem -- identical to the widened
