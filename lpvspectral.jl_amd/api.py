@@ -483,6 +483,10 @@ class Problem:
         np_ = -(-self.n // 128) * 128
         one_launch = bool(int(k.value) & 16)
         k = C.c_int32(int(k.value) & 15)
+        if one_launch and int(k.value) == 0:                               # small problems (np < 2048): full matrix, one launch per iteration
+            return dict(kernel="admm_small_iter_kernel", one_launch_iteration=True,
+                        storage="full symmetric f64; every workgroup redoes the update (prox, dual step, norm) and multiplies its four rows",
+                        bytes_formula="8 B x np^2 (np = %d)" % np_)
         if one_launch and int(k.value) == 2:                               # _f32 handles: single-precision copy of the inverse
             return dict(kernel="admm_iter_mixed_kernel", one_launch_iteration=True,
                         storage="tile-packed lower triangle, f32 (4 B); tile partials added into x by 64-bit fixed-point atomics, prox / dual "

@@ -343,6 +343,7 @@ struct lpvs_problem {
     bool M_valid = false; double M_shift = 0;
     bool Mp_valid = false;   // Mp is the packed copy of the CURRENT M (cleared whenever M is recomputed or G changes)
     int64_t Mp_fixed_diag = 0;   // ... of which on the diagonal (type 2)
+    DevBuf sm_ctl;               // control words of the one-launch iteration of small problems (AdmmParams::sm_ctl)
     DevBuf fi_tiles;             // tile lists of the several-tiles-per-workgroup iteration (AdmmParams::fi_tiles)
     int fi_nsingle = 0, fi_nmulti = 0;
     int Mp_mode = 0;         // storage of Mp: kMpF64 / kMpF32 / kMpSplit / kMpMixed (see make_params)
@@ -399,6 +400,7 @@ int32_t alloc_state(lpvs_problem *h) {
     LPVS_TRY(h->x.alloc(v)); LPVS_TRY(h->z.alloc(v)); LPVS_TRY(h->u.alloc(v)); LPVS_TRY(h->rhs.alloc(v));
     LPVS_TRY(h->bs.alloc(v)); LPVS_TRY(h->scratch.alloc(2 * v));
     LPVS_TRY(h->status.alloc(sizeof(AdmmStatus) * (size_t)h->ns)); LPVS_TRY(h->istat.alloc(sizeof(int)));
+    if (h->np < kSymmetricMinNp) { LPVS_TRY(h->sm_ctl.alloc(sizeof(int) * 4 * (size_t)h->ns)); LPVS_HIP(hipMemsetAsync(h->sm_ctl.p, 0, h->sm_ctl.bytes, h->stream)); }
     LPVS_TRY(h->part.alloc(sizeof(double) * symv_part_doubles(h->np, h->ns)));
     LPVS_HIP(hipMemsetAsync(h->x.p, 0, v, h->stream));
     LPVS_HIP(hipMemsetAsync(h->status.p, 0, sizeof(AdmmStatus) * (size_t)h->ns, h->stream));
@@ -451,6 +453,7 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.fi_prefetch_all = sym && h->Mp_mode == kMpMixed && h->Mp_fixed_tiles == (int64_t)(symv_packed_doubles(h->np) / (128 * 128)) ? 1 : 0;
     if (sym && h->Mp_mode == kMpMixed && h->ns == 1 && h->fi_tiles.p && h->fi_nmulti > 0) { p.fi_tiles = h->fi_tiles.as<int>(); p.fi_nsingle = h->fi_nsingle; p.fi_nmulti = h->fi_nmulti; }
     p.opt_iteration = h->opt[LPVS_OPT_ITERATION]; p.opt_nt_loads = h->opt[LPVS_OPT_NT_LOADS];
+    p.sm_ctl = !sym && h->sm_ctl.p ? h->sm_ctl.as<int>() : nullptr;
     return p;
 }
 
@@ -1272,7 +1275,9 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
         if (fi_applicable(p) && h->fi_sync != p.fi_base) LPVS_TRY(launch_fi_setup(p, p.fi_base, false, s));   // state set from outside, or the last chunk took the other path
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
         int64_t todo = max_iters;
-        constexpr int64_t kGraphIters = 50;
+        // (the one-launch iteration of small problems pays two extra launches per chunk: longer chunks)
+        const int64_t kGraphIters = small_iter_applicable(p) ? 250 : 50;
+        if (h->admm_graph && h->admm_graph_iters != kGraphIters) h->drop_graph();
         if (h->np < kSymmetricMinNp && todo >= 2 * kGraphIters) {
             // two launches of a few microseconds per iteration: host launch cost dominates, so replay a captured
             // chunk.  Iterations past convergence are no-ops (device flag), and exactly max_iters are enqueued.
@@ -1320,7 +1325,7 @@ int32_t lpvs_admm_matvec_kind(lpvs_problem *h, int32_t *kind) {
     if (!h || !kind) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited) { set_error("lpvs_admm_matvec_kind before lpvs_admm_init"); return LPVS_ESTATE; }
     *kind = h->np >= kSymmetricMinNp ? h->Mp_mode : kMpNone;
-    if (fi_applicable(make_params(h))) *kind |= 16;   // one launch per iteration (with the prox currently set)
+    if (fi_applicable(make_params(h)) || small_iter_applicable(make_params(h))) *kind |= 16;   // one launch per iteration (with the prox currently set)
     return LPVS_OK;
 }
 

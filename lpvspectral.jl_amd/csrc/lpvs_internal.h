@@ -241,7 +241,12 @@ struct AdmmParams {
     const int *fi_tiles = nullptr;
     int fi_nsingle = 0, fi_nmulti = 0;
     int opt_iteration = 0, opt_nt_loads = 0;   // LPVS_OPT_ITERATION / LPVS_OPT_NT_LOADS of the handle (0: thread default / environment)
+    // one launch per iteration of the full-matrix path (np < kSymmetricMinNp; admm_small_iter_kernel): 4 ints per signal --
+    // {converged before launch parity 0, parity 1, launch of the chunk that converged (-1: none), unused}; nullptr = two launches.
+    // The alternate x / u buffers of that scheme are the two halves of `scratch`.
+    int *sm_ctl = nullptr;
 };
+bool small_iter_applicable(const AdmmParams &p);
 size_t fi_doubles(int64_t np, int64_t nprob = 1);
 bool fi_applicable(const AdmmParams &p);
 int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s);
