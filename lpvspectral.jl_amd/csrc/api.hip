@@ -1278,7 +1278,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
         // (the one-launch iteration of small problems pays two extra launches per chunk: longer chunks)
         const int64_t kGraphIters = small_iter_applicable(p) ? 250 : 50;
         if (h->admm_graph && h->admm_graph_iters != kGraphIters) h->drop_graph();
-        if (h->np < kSymmetricMinNp && todo >= 2 * kGraphIters) {
+        if (h->np < kSymmetricMinNp && todo >= 2 * kGraphIters && getenv("LPVS_NO_GRAPH") == nullptr) {
             // two launches of a few microseconds per iteration: host launch cost dominates, so replay a captured
             // chunk.  Iterations past convergence are no-ops (device flag), and exactly max_iters are enqueued.
             if (!h->admm_graph) {

@@ -480,6 +480,11 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
             for (int o = 1; o < kOptCount; ++o) (void)lpvs_set_default_option(o, copt[o]);
             if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); set_error("hipSetDevice failed"); return fail_with(LPVS_EDEVICE, 0); }
             std::vector<double> y2((size_t)2 * (size_t)n, 1.0);   // [y_q | 1], column-major n x 2
+            // (a stream of this thread's own for the copies into the batch: a plain hipMemcpy between device buffers may return before it
+            // has run, and the handle's blocks go back to the pool right after it)
+            hipStream_t cs = nullptr;
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); set_error("stream creation failed"); return fail_with(LPVS_EDEVICE, 0); }
+            struct CsGuard { hipStream_t s; ~CsGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } csg{cs};
             for (;;) {
                 const int64_t q = next.fetch_add(1);
                 if (q >= nbw) return;
@@ -492,8 +497,9 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
                 double *G = nullptr, *b = nullptr; int64_t hnp = 0;
                 rc = lpvs_problem_device_gram_f64(h, &G, &b, &hnp);
                 if (rc == LPVS_OK && hnp != np) { set_error("window Gram of padded size %lld, expected %lld", (long long)hnp, (long long)np); rc = LPVS_EDEVICE; }
-                if (rc == LPVS_OK && (hipMemcpy(Qb.as<double>() + (size_t)q * (size_t)np * (size_t)np, G, mat, hipMemcpyDeviceToDevice) != hipSuccess ||
-                                      hipMemcpy(bb.as<double>() + (size_t)q * (size_t)nrhs * (size_t)np, b, sizeof(double) * (size_t)np * (size_t)nrhs, hipMemcpyDeviceToDevice) != hipSuccess)) {
+                if (rc == LPVS_OK && (hipMemcpyAsync(Qb.as<double>() + (size_t)q * (size_t)np * (size_t)np, G, mat, hipMemcpyDeviceToDevice, cs) != hipSuccess ||
+                                      hipMemcpyAsync(bb.as<double>() + (size_t)q * (size_t)nrhs * (size_t)np, b, sizeof(double) * (size_t)np * (size_t)nrhs, hipMemcpyDeviceToDevice, cs) != hipSuccess ||
+                                      hipStreamSynchronize(cs) != hipSuccess)) {
                     (void)hipGetLastError(); set_error("copy of a window's Gram into the batch failed"); rc = LPVS_EDEVICE;
                 }
                 lpvs_problem_destroy(h);

@@ -85,7 +85,8 @@ def test_cfg2_fullsize_admm_vs_oracle(L, oracle, equidistant):
 
 
 # ------------------------------------------------------------------ cfg3
-CFG3_PAIR_BOUND = 1e-8       # rel-L2(z) between any two of the cfg3 solves below: 3x the largest value measured (0.7e-9 .. 3.1e-9 over two builds)
+CFG3_PAIR_BOUND = 1e-8       # rel-L2(z) between any two of the cfg3 solves below: 3x the largest value measured (0.7e-9 .. 3.1e-9 over two builds);
+                             # against the ORACLE the benchmarked path measures 1.9e-9 at 2000 iterations (tests/test_gpu_judged_size.py, round 4)
 def test_cfg3_fullsize_structured_vs_dense_end_to_end(L):
     """The benchmarked path (structured Gram -> factorisation -> 2000 iterations at N = 2^20) against the same solve on the
     dense f64-MFMA Gram (LPVS_GRAM_FORM=krs), as an experiment that separates WHAT makes two solves of this size differ:
@@ -103,8 +104,10 @@ def test_cfg3_fullsize_structured_vs_dense_end_to_end(L):
     (2) dense-exact vs dense-rounded: ONE kernel chain, the phases perturbed by <= ulp(w*x)/2 = 3.7e-10 rad: what the reference's
         fl(w*x) costs -- also at the floor: the two effects are not separable at N = 2^20, and both are an order of magnitude inside
         the reference's own solver tolerance.
-    Identical supports throughout.  SURVEY 8(d)'s 1e-9 is met with margin where an oracle can run (3e-11 at n = 2048,
-    test_gpu_oracle_on_bench_kernels.py); at the judged size every pair is held to CFG3_PAIR_BOUND = 3x the largest value measured."""
+    Identical supports throughout.  SURVEY 8(d)'s 1e-9 is met with margin at oracle sizes (3e-11 at n = 2048,
+    test_gpu_oracle_on_bench_kernels.py) and, against the oracle at THIS size, up to ~500 iterations (4.7e-10 at 200, 9.4e-10 at
+    500); at 2000 iterations the oracle itself is 1.9e-9 away (round 4: tests/test_gpu_judged_size.py), i.e. the floor of (0) is a
+    property of the iteration, not of a device kernel chain.  Every pair here is held to CFG3_PAIR_BOUND = 3x the largest value measured."""
     import bench
     y, X, V, w = bench.synth_signal(1 << 20, 512, 0, torch.device("cuda"))
     out = {}
