@@ -703,7 +703,9 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                  "added into x by 64-bit fixed-point atomics)") if one_launch else
                 "symv_tile_mixed_batch_kernel (6-byte float-head tiles on the diagonal, 36-bit fixed-point tiles elsewhere)")
         roof = {"bound": "hbm", "kernel": kern + ": one tile-packed (Q + I/mu)^-1 per window, all windows of the shard per launch",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": None,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved),
+                **dict(zip(("traffic_of_one_part_launch", "traffic_source"), pmc_traffic("admm_iter_mixed_kernel<1", "cfg4") if (one_launch and nwin == CFG4["nwin"]) else (None, None))),
+                "traffic": None,
                 "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "windows_per_launch": nmv, "launches_per_step": iters,
                 "matvec_only_launch_us": mv_only_us,
                 "note": ("launch_us = the time one ADMM iteration of ALL the shard's windows takes = HIP events around the ADMM loops of the last timed "
@@ -711,7 +713,9 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                          "in flight on two streams, one launch per iteration and half: a chunk's inverses are re-read from the 256 MiB Infinity Cache "
                          "iteration after iteration, which is why `achieved` may exceed the HBM stream rate (LPVS_WINDOW_CHUNK_MB=0 "
                          "LPVS_WINDOWS_IN_FLIGHT=1: every window in one launch per iteration, HBM-bound: 126 us = 6.06 TB/s); "
-                         "matvec_only_launch_us = 200 back-to-back launches of the two-launch scheme's stand-alone batch mat-vec over ALL the shard's windows in one launch (uncut: HBM-bound)") if one_launch else
+                         "matvec_only_launch_us = 200 back-to-back launches of the two-launch scheme's stand-alone batch mat-vec over ALL the shard's windows in one launch (uncut: HBM-bound); "
+                         "`traffic` is null on purpose: an iteration of the shard is SEVERAL launches under the chunked plan (one per chunk half), whose fabric bytes "
+                         "the PMC summary reports per launch (traffic_of_one_part_launch, ~171 windows each) -- mostly served by the Infinity Cache, not HBM") if one_launch else
                         "HIP events around 200 back-to-back launches of the batch mat-vec on the library's stream (rank 0's shard)"}
     out = {
         "metric": "windows/sec, ls_windowpsd estimator=ls_sparse_spectral (NormL1), %d windows x N=2^%d, Nf=%d, %d ADMM iters per window"
@@ -982,7 +986,13 @@ def run_cfg2(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         mv_us, mv_bytes = p.time_matvec(500)
         info = p.matvec_info()
     it_us = phase["admm_ms"] * 1e3 / iters
+    one_launch = bool(info.get("one_launch_iteration"))
+    mv_only_us = mv_us
+    if one_launch:
+        mv_us = it_us                                                  # the iteration IS one launch of admm_small_iter_kernel (measured over the timed steps)
     achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
+    traffic2, traffic2_src = pmc_traffic("admm_small_iter_kernel<1" if one_launch else "symv_kernel", "cfg2")
+    npad = -(-2 * Nf // 128) * 128
     out = {"metric": "signals/sec, ls_sparse_spectral NormL1(%g) N=2^%d Nf=%d (%d ADMM iters; iters/sec in admm_iters_per_sec)" % (CFG2["lam"], CFG2["log2n"], Nf, iters),
            "value": world * steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -992,9 +1002,17 @@ def run_cfg2(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
            "admm_iters_per_sec": iters / (phase["admm_ms"] * 1e-3), "phase_ms": phase, "final_nxz": nxz,
            "peaks_1based": sorted((np.argsort(-np.abs(params))[:5] + 1).tolist()),
            "roofline": {"bound": "hbm", "kernel": info["kernel"] + " (full symmetric (G + I/mu)^-1, n = 1024: 8.4 MB, Infinity-Cache resident)",
-                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": None,
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": traffic2, "traffic_source": traffic2_src,
                         "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "launches_per_step": iters, "iteration_us": it_us,
-                        "note": "launch-latency bound, not bandwidth bound: an iteration is two dependent launches of a few microseconds (mat-vec + prox / "
+                        "matvec_only_launch_us": mv_only_us,
+                        "redundant_state_bytes_per_launch": float(npad // 4) * 3 * 8 * npad if one_launch else 0.0,
+                        "note": ("launch-latency bound, not bandwidth bound: the iteration is ONE launch of np / 4 workgroups (admm_small_iter_kernel: every workgroup redoes "
+                                 "the update from x, u, b -- 24 KB each, 6.3 MB per launch besides the 8.4 MB of M -- and multiplies its four rows), replayed as hipGraph chunks "
+                                 "of 250 iterations; launch_us = iteration_us = HIP events around the ADMM loop / iterations; matvec_only_launch_us = the two-launch scheme's "
+                                 "stand-alone mat-vec, 500 back-to-back launches.  The floor is the dependent-kernel boundary (1.4-1.8 us measured between two launches of "
+                                 "the cfg3 iteration, profiles/r04_iteration_timeline.txt) plus one fabric round trip for state written by other XCDs, not the bytes.")
+                                if one_launch else
+                                "launch-latency bound, not bandwidth bound: an iteration is two dependent launches of a few microseconds (mat-vec + prox / "
                                 "dual update), replayed as hipGraph chunks of 50 iterations; iteration_us = HIP events around the ADMM loop / iterations; "
                                 "launch_us = the mat-vec alone, 500 back-to-back launches.  The floor is the dependent-kernel boundary "
                                 "(MI355X_MICROARCH.md: 1.2-1.9 us each), not the 8.4 MB the kernel reads."}}
@@ -1042,8 +1060,18 @@ def run_cfg5(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         p.admm_init(None, μ=CFG5["mu"], tol=0.0)
         mv_us, mv_bytes = p.time_matvec(30)
         info = p.matvec_info()
-    achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
     n = 2 * Nf * Nv
+    # the launch also WRITES its tile partials: one record per run of tiles for the row sums, one per tile for the
+    # column sums, 128 rows x `signals_per_pass` doubles each -- algorithmic bytes of the kernel as built, counted from this round on
+    nblk5 = n // 128
+    ntiles5 = nblk5 * (nblk5 + 1) // 2
+    spp = info.get("signals_per_pass", 16)
+    nruns = min(ntiles5, (ntiles5 + 7) // 8 + nblk5)
+    partial_bytes = float(ntiles5 + nruns) * 128 * spp * 8
+    tile_bytes = mv_bytes
+    mv_bytes = tile_bytes + partial_bytes
+    achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
+    traffic5, traffic5_src = pmc_traffic("symv_tile_mfma_ws_kernel", "cfg5") if args.log2n == CFG5["log2n"] else (None, None)
     out = {"metric": "signals/sec, multichannel ls_sparse_spectral_lpv IndBallL0(%d) N=2^%d Nf=%d Nv=%d, %d channels per GPU (%d ADMM iters)"
                      % (CFG5["r"], args.log2n, Nf, Nv, ns, iters),
            "value": world * ns * steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -1056,12 +1084,13 @@ def run_cfg5(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
            "factorisation": {"flops": float(n) ** 3, "ms": phase["factor_ms"], "achieved_TFLOPs": float(n) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12,
                              "frac_of_f64_mfma_peak": float(n) ** 3 / (phase["factor_ms"] * 1e-3) * 1e-12 / F64_MFMA_PEAK_TFLOPS},
            "roofline": {"bound": "hbm", "kernel": info["kernel"] + " (tile product of the packed (G + I/mu)^-1 with all channels on %s)" % info.get("mfma", "the matrix cores"),
-                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": None,
-                        "algorithmic_bytes_per_launch": mv_bytes, "launch_us": mv_us, "launches_per_step": iters,
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved), "traffic": traffic5, "traffic_source": traffic5_src,
+                        "algorithmic_bytes_per_launch": mv_bytes, "tile_bytes_per_launch": tile_bytes, "partial_bytes_written_per_launch": partial_bytes,
+                        "achieved_on_tile_bytes_only": tile_bytes / (mv_us * 1e-6) * 1e-9, "launch_us": mv_us, "launches_per_step": iters,
                         "share_of_step": iters * mv_us * 1e-3 / (elapsed / steps * 1e3),
                         "mfma_flops_per_launch": 4.0 * float(n) * float(n + 128) / 2 * info.get("signals_per_pass", 16) * 2 / 2,
-                        "note": "algorithmic bytes = %s (+ the tile partials the launch writes: one record per run of tiles for the row sums, one per tile "
-                                "for the column sums: 34 + 270 MB at n = 32768, not counted); HIP events around 30 back-to-back launches on the library's stream; "
+                        "note": "algorithmic bytes = %s + the tile partials the launch writes (one record per run of tiles for the row sums, one per tile "
+                                "for the column sums: ~34 + 270 MB at n = 32768); HIP events around 30 back-to-back launches on the library's stream; "
                                 "the same launch also issues n(n+128)/2 x %d signal columns x 2 products of f64 MFMA work; launch time varies by ~10 %% with the "
                                 "box and with where the 3.2 GB buffer landed (DESIGN.md 4.5.1)" % (info["bytes_formula"], info.get("signals_per_pass", 16))}}
     if world == 1 and not args.no_cpu_baseline:
@@ -1075,8 +1104,8 @@ def source_sha16(rel="lpvspectral.jl_amd/csrc/admm.hip"):
         return hashlib.sha256(fh.read()).hexdigest()[:16]
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the mat-vec kernel from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
+def pmc_traffic(kernel_prefix, workload="cfg3"):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of `workload`
     (PMC passes cannot run inside the timed bench).  tools/pmc_summary.py stamps a summary with the sha256 of the kernel source
     it was collected from; a summary whose stamp is missing or differs from the present csrc/admm.hip is NOT quoted (a stale
     figure is worse than none)."""
@@ -1089,13 +1118,13 @@ def pmc_traffic(kernel_prefix):
             continue
         meta = next((r for r in rows if r.get("kernel") == "__meta__"), None)
         rel = os.path.relpath(path, ROOT)
-        if not meta or meta.get("admm_hip_sha16") != now:
+        if not meta or meta.get("admm_hip_sha16") != now or meta.get("workload", "cfg3") != workload:
             continue
         for r in rows:
             if r.get("kernel", "").startswith(kernel_prefix):
                 return (r["fetch_corrected_bytes_per_launch"] + r["write_bytes_per_launch"],
                         f"{rel} (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, bytes per launch; collected from csrc/admm.hip sha256 {now})")
-    return None, "no PMC summary under profiles/ was collected from the present csrc/admm.hip (sha256 %s): not quoted" % now
+    return None, "no PMC summary of %s under profiles/ was collected from the present csrc/admm.hip (sha256 %s): not quoted" % (workload, now)
 
 
 if __name__ == "__main__":
