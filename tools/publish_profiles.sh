@@ -8,5 +8,7 @@ for w in cfg3 cfg4 cfg2 cfg5 cfg3_f32; do [ -s $P/bench_$w.json ] && cp $P/bench
 [ -s $P/k3_kernel_stats.csv ] && cp $P/k3_kernel_stats.csv profiles/${R}_bench_cfg3_kernel_stats.csv
 for k in 4 5 2; do [ -s $P/k${k}_kernel_stats.csv ] && cp $P/k${k}_kernel_stats.csv profiles/${R}_cfg${k}_kernel_stats.csv; done
 [ -s $P/pmc/pmc_summary.json ] && cp $P/pmc/pmc_summary.json profiles/${R}_pmc_traffic.json
+for w in cfg2 cfg4 cfg5; do [ -s $P/pmc_$w/pmc_summary.json ] && cp $P/pmc_$w/pmc_summary.json profiles/${R}_pmc_traffic_$w.json; done
+[ -s $P/iteration_timeline.txt ] && cp $P/iteration_timeline.txt profiles/${R}_iteration_timeline.txt
 [ -s $P/pmc_factor/factor_mfma_summary.json ] && cp $P/pmc_factor/factor_mfma_summary.json profiles/${R}_factor_mfma_pmc.json
 ls -la profiles | grep "${R}_"
