@@ -3084,7 +3084,7 @@ extern "C" int32_t lpvs_debug_set_timeline(unsigned long long *dev_buf) {
 template <int MODE, int NK, bool BATCH, bool NT, bool PA, bool F32>
 __device__ __forceinline__ void
 fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
-                 int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev, size_t mp_stride, int tile_ij = -1 /* (I << 16) | J of a workgroup past the diagonal ones, or -1: from blockIdx.x */) {
+                 int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev, size_t mp_stride) {
     constexpr bool prefetch_all = PA;               // (a template parameter: the two cases need different register sets, together they spill)
 #ifdef LPVS_TIMELINE
     const bool tl_on = MODE == FI_MID && !BATCH && !F32 && g_lpvs_tl != nullptr;
@@ -3107,7 +3107,6 @@ fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, cons
     // would be the slowest one.
     int I, J;
     if (MODE == FI_LAST || (int)blockIdx.x < nblk) { I = J = blockIdx.x; }
-    else if (tile_ij >= 0) { I = tile_ij >> 16; J = tile_ij & 0xffff; }
     else {
         const int k = (int)blockIdx.x - nblk;                           // k-th tile below the diagonal: k = I (I - 1) / 2 + J, J < I
         I = (int)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);
@@ -3397,232 +3396,6 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     fi_one_tile_body<MODE, NK, BATCH, NT, PA, F32>(p, Mp, types, ntiles, nblk, g, aslot, uslot, commit_prev, mp_stride);
 }
 
-// ---- several tiles per workgroup (single problems whose off-diagonal tiles are all in the fixed format: cfg3) -----------------------
-// profiles/r04_iteration_timeline.txt: with one tile per workgroup the launch streams at ~7.3 TB/s while every slot is taken and loses
-// ~5 us at its ends -- nothing retires for the first 5 us (768 workgroups share the fabric, each behind its own prologue), and the last
-// workgroups only REQUEST their tiles when a slot frees at ~20 us, then run their whole chain (state -> prox -> barrier -> tile ->
-// butterflies -> atomics, 5 us) on an emptying machine.  Here the nblk diagonal workgroups keep the one-tile path (they own the row
-// blocks' state; float-head tiles) and the off-diagonal tiles are dealt T consecutive ones to a workgroup, every workgroup resident
-// from the start of the launch: a lane's tile registers are refilled row group by row group with the NEXT tile's bytes as soon as the
-// current tile's have been consumed, the next tile's state is requested before the current product starts, and the end of the launch
-// is one product + reduction after the last byte.  All loads stay unconditional and in program order (counted waits); tiles past the
-// end of the list are read through size-0 descriptors and skipped.
-template <int MODE, int NK, int T>
-__device__ __forceinline__ void
-fi_multi_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, int nblk, long long g, int aslot, int uslot, int commit_prev) {
-    typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
-    __shared__ double sI[TS], sJ[TS], sT[4][TS], sq[2 * TS];
-    const FiBufs f = fi_views(p.fi, p.np, nblk, 1);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gq = lane >> 4, c = lane & 15;
-    const int k0 = ((int)blockIdx.x - p.fi_nsingle) * T;
-    int Iq[T], Jq[T];
-    bool vq[T];
-#pragma unroll
-    for (int q = 0; q < T; ++q) {
-        vq[q] = k0 + q < p.fi_nmulti;
-        const int ij = p.fi_tiles[p.fi_nsingle + (vq[q] ? k0 + q : p.fi_nmulti - 1)];   // (uniform: scalar loads)
-        Iq[q] = ij >> 16; Jq[q] = ij & 0xffff;
-    }
-    const int conv_flag = __builtin_nontemporal_load(&p.status->converged);
-    const int i = threadIdx.x & (TS - 1);
-    const int pg = (int)(g & 1), pg1 = pg ^ 1;
-    // state of this thread's element of tile 0 (threads < 128: row block I, the others: J), then the launch's records, then tile 0
-    long long accp[2] = {0, 0};
-    double xbv[2] = {0, 0}, uv[2] = {0, 0}, rmem[2] = {0, 0};
-    const long long *acc_prev = f.acc((aslot + 2) % 3);
-    const double *usrc = uslot ? f.ualt : p.u;
-    auto state_load = [&](int q, int s_) {
-        const int64_t e = (int64_t)(threadIdx.x < TS ? Iq[q] : Jq[q]) * TS + i;
-        if (MODE == FI_FIRST) rmem[s_] = p.rhs[e];
-        else { accp[s_] = acc_prev[e]; xbv[s_] = p.xb[e]; uv[s_] = usrc[e]; }
-    };
-    state_load(0, 0);
-    const double qprev = MODE == FI_FIRST ? 0.0 : f.qbuf[pg1];
-    double bnv[NK];
-    double2 recv[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int b = lane + 64 * k < nblk ? lane + 64 * k : nblk - 1;
-        bnv[k] = MODE != FI_FIRST ? f.bn[pg * nblk + b] : 0.0;
-        recv[k] = f.rec[pg * nblk + b];
-    }
-    const double Rrow = p.fi_R, xbmax = p.fi_xbmax;
-    __builtin_amdgcn_sched_barrier(0);
-    FixRaw fr;
-    const int off_head = ((wave * 32 + gq) * TS + 4 * c) * 4;
-    const int off_nq = (int)kFixHeadBytes + (wave * 64 + lane) * 32, off_st = (int)(kFixHeadBytes + kFixNibBytes) + (wave * 4 + gq) * 32;
-    auto tile_rsrc = [&](int q) {
-        const unsigned char *tile = Mp + (size_t)(Iq[q] * (Iq[q] + 1) / 2 + Jq[q]) * kSplitTileBytes;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tile), 0, vq[q] ? (int)kMixedFixedTileBytes : 0, 0x00020000);
-    };
-    {
-        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(0);
-        fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 0, 0));
-        fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 16, 0));
-        fr.st[0] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 0, 0));
-        fr.st[1] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 16, 0));
-#pragma unroll
-        for (int rg = 0; rg < 8; ++rg) {
-            fr.ha[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4), 0));
-            fr.hb[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_head, rg * (4 * TS * 4) + 256, 0));
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    double mR = 0, mU = 0;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) { mR = fmax(mR, recv[k].x); mU = fmax(mU, recv[k].y); }
-    if (conv_flag) return;
-    if (MODE != FI_FIRST && commit_prev && p.tol > 0.0) {             // the decision every workgroup takes alike (block 0 keeps the status)
-        double part = 0.0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) part += lane + 64 * k < nblk ? bnv[k] : 0.0;
-        if (sqrt(wave_sum(part)) < p.tol) return;
-    }
-    // ---- this launch's quantum (identical in every workgroup: see fi_one_tile_body)
-    mR = wave_max_nonneg(mR); mU = wave_max_nonneg(mU);
-    double B = Rrow * ((xbmax + Rrow * mR + mU) / p.mu) * 1.000001;
-    const bool bound_ok = B < 0x1p1000;
-    if (!(B > 0x1p-900)) B = 0x1p-900;
-    int eb = 0;
-    (void)frexp(bound_ok ? B : 1.0, &eb);
-    const double invq = bound_ok ? ldexp(1.0, 62 - eb) : 0.0;
-    unsigned long long *acc_cur = reinterpret_cast<unsigned long long *>(f.acc(aslot));
-#pragma unroll
-    for (int q = 0; q < T; ++q) {
-        const int s_ = q & 1;
-        // ---- right-hand-side values of this tile's two row blocks: the update u_{g-1} recomputed from the state (the diagonal workgroups own it)
-        double rhs_v;
-        {
-            const int64_t e = (int64_t)(threadIdx.x < TS ? Iq[q] : Jq[q]) * TS + i;
-            const bool ok = e < p.n;
-            if (MODE == FI_FIRST) rhs_v = rmem[s_];
-            else {
-                const double xi = ok ? xbv[s_] + (double)accp[s_] * qprev : 0.0;
-                const double ui = ok ? uv[s_] : 0.0;
-                const double v = xi + ui;
-                double zi = 0.0;
-                if (p.prox_kind == LPVS_PROX_L1) {
-                    const double gl = p.mu * p.prox_param;
-                    zi = v + (v <= -gl ? gl : (v >= gl ? -gl : -v));
-                } else if (p.prox_kind == LPVS_PROX_L0) {
-                    zi = fabs(v) > sqrt(2.0 * p.mu * p.prox_param) ? v : 0.0;
-                } else {
-                    const int gl = (int)p.group_len;
-                    sq[threadIdx.x] = v * v;
-                    __syncthreads();
-                    const double *grp = sq + (threadIdx.x & TS) + (i / gl) * gl;
-                    double s2 = 0;
-                    for (int k = 0; k < gl; ++k) s2 += grp[k];
-                    double scale = 1.0 - p.prox_param * p.mu / sqrt(s2);
-                    if (!(scale > 0)) scale = 0.0;
-                    zi = scale * v;
-                }
-                if (!ok) zi = 0.0;
-                const double d = xi - zi, un = ui + d;
-                rhs_v = ok ? (zi - un) / p.mu : 0.0;
-            }
-        }
-        if (threadIdx.x < TS) sI[i] = rhs_v; else sJ[i] = rhs_v;
-        if (q + 1 < T) state_load(q + 1, s_ ^ 1);                      // the next tile's state: requested before its bytes, in flight during this product
-        __syncthreads();
-        // ---- product, the lane's registers refilled with the next tile's bytes row group by row group
-        double rj[8], tc[8], v[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { rj[k] = sJ[4 * c + k]; rj[4 + k] = sJ[64 + 4 * c + k]; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tc[k] = 0.0;
-        const float stv[8] = {fr.st[0].x, fr.st[0].y, fr.st[0].z, fr.st[0].w, fr.st[1].x, fr.st[1].y, fr.st[1].z, fr.st[1].w};
-        const unsigned int nw[8] = {fr.nq[0].x, fr.nq[0].y, fr.nq[0].z, fr.nq[0].w, fr.nq[1].x, fr.nq[1].y, fr.nq[1].z, fr.nq[1].w};
-        const __amdgpu_buffer_rsrc_t rsn = tile_rsrc(q + 1 < T ? q + 1 : q);
-        double ri = (double)stv[0] * sI[wave * 32 + gq];
-#pragma unroll
-        for (int rg = 0; rg < 8; ++rg) {
-            const double step = (double)stv[rg];
-            const double ri_next = rg + 1 < 8 ? (double)stv[rg + 1] * sI[wave * 32 + 4 * (rg + 1) + gq] : 0.0;
-            const int hh[8] = {fr.ha[rg].x, fr.ha[rg].y, fr.ha[rg].z, fr.ha[rg].w, fr.hb[rg].x, fr.hb[rg].y, fr.hb[rg].z, fr.hb[rg].w};
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                const double m0 = fix_decode((unsigned int)hh[k], (nw[rg] >> (4 * k)) & 15u);
-                const double m1 = fix_decode((unsigned int)hh[k + 1], (nw[rg] >> (4 * k + 4)) & 15u);
-                tc[k] = opaque(fma(m0, ri, tc[k]));
-                tc[k + 1] = opaque(fma(m1, ri, tc[k + 1]));
-                a0 = fma(m0, rj[k], a0);
-                a1 = fma(m1, rj[k + 1], a1);
-            }
-            v[rg] = step * (a0 + a1);
-            ri = ri_next;
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 1 < T) {
-                fr.ha[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rsn, off_head, rg * (4 * TS * 4), 0));
-                fr.hb[rg] = __builtin_bit_cast(int4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rsn, off_head, rg * (4 * TS * 4) + 256, 0));
-                if (rg == 3) {   // the next tile's nibbles and steps, once half of this tile's are dead (requested up front they cost 8 registers: spills)
-                    fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rsn, off_nq, 0, 0));
-                    fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rsn, off_nq, 16, 0));
-                    fr.st[0] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rsn, off_st, 0, 0));
-                    fr.st[1] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rsn, off_st, 16, 0));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // ---- row sums / column sums into x (as fi_one_tile_body; a tile below the diagonal)
-#pragma unroll
-        for (int m = 8, cnt = 4; m >= 2; m >>= 1, cnt >>= 1) {
-            const bool up = (c & m) != 0;
-#pragma unroll
-            for (int k = 0; k < cnt; ++k) {
-                const double lo_ = opaque(v[k]), hi_ = opaque(v[k + cnt]);
-                v[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
-            }
-        }
-        v[0] += __shfl_xor(v[0], 1, 64);
-        if ((c & 1) == 0 && vq[q]) {
-            const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
-            const int row = wave * 32 + 4 * rg + gq;
-            atomicAdd(acc_cur + (int64_t)Iq[q] * TS + row, (unsigned long long)__double2ll_rn(v[0] * invq));
-        }
-#pragma unroll
-        for (int m = 32, cnt = 4; m >= 16; m >>= 1, cnt >>= 1) {
-            const bool up = (lane & m) != 0;
-#pragma unroll
-            for (int k = 0; k < cnt; ++k) {
-                const double lo_ = opaque(tc[k]), hi_ = opaque(tc[k + cnt]);
-                tc[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
-            }
-        }
-        const int col = ((lane & 32) ? 64 : 0) + 4 * c + ((lane & 16) ? 2 : 0);
-        sT[wave][col] = tc[0]; sT[wave][col + 1] = tc[1];
-        __syncthreads();
-        if (threadIdx.x < TS && vq[q]) {
-            const double r2 = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
-            atomicAdd(acc_cur + (int64_t)Jq[q] * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
-        }
-    }
-}
-
-template <int MODE, int NK, int T>
-__global__ void __launch_bounds__(256, 3)
-admm_iter_mixed_mt_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
-                          int uslot, int commit_prev, size_t mp_stride, int) {
-    if ((int)blockIdx.x < p.fi_nsingle) {            // (uniform) one tile each: the diagonal workgroups, owners of the row blocks' state, and float-head tiles below it
-        fi_one_tile_body<MODE, NK, false, false, false, false>(p, Mp, types, ntiles, nblk, g, aslot, uslot, commit_prev, mp_stride,
-                                                               (int)blockIdx.x < nblk ? -1 : p.fi_tiles[blockIdx.x]);
-        return;
-    }
-#ifdef LPVS_TIMELINE
-    const bool tl_on = MODE == FI_MID && g_lpvs_tl != nullptr;
-    unsigned long long *tl_rec = tl_on ? g_lpvs_tl + ((size_t)(g & 1) * (size_t)ntiles + blockIdx.x) * 8 : nullptr;
-    if (tl_on && threadIdx.x == 0) {
-        tl_rec[0] = (unsigned long long)g; tl_rec[1] = __builtin_amdgcn_s_memrealtime();
-        tl_rec[6] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
-        tl_rec[7] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
-    }
-#endif
-    fi_multi_tile_body<MODE, NK, T>(p, Mp, nblk, g, aslot, uslot, commit_prev);
-    LPVS_TL_STAMP(5);
-}
-
 // constants and records of the one-launch iteration (after lpvs_admm_init / set_state; base = iterations done so far); p.ns problems
 int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s) {
     const int nblk = (int)(p.np / TS), nprob = p.ns;
@@ -3690,12 +3463,6 @@ static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa, bo
     if (nt) return pa ? fi_kernel_mode<6, false, true, true>(mode) : fi_kernel_mode<6, false, true, false>(mode);
     return pa ? fi_kernel_mode<6, false, false, true>(mode) : fi_kernel_mode<6, false, false, false>(mode);
 }
-template <int NK, int T>
-static FiKernel fi_kernel_mt_mode(int mode) { return mode == FI_FIRST ? admm_iter_mixed_mt_kernel<FI_FIRST, NK, T> : admm_iter_mixed_mt_kernel<FI_MID, NK, T>; }
-static FiKernel fi_kernel_mt(int mode, bool small, int T) {
-    if (small) return T == 2 ? fi_kernel_mt_mode<1, 2>(mode) : T == 3 ? fi_kernel_mt_mode<1, 3>(mode) : fi_kernel_mt_mode<1, 4>(mode);
-    return T == 2 ? fi_kernel_mt_mode<6, 2>(mode) : T == 3 ? fi_kernel_mt_mode<6, 3>(mode) : fi_kernel_mt_mode<6, 4>(mode);
-}
 static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, size_t mp_stride, bool prefetch_all, hipStream_t s) {
     const int nblk = (int)(p.np / TS), nprob = batch ? p.ns : 1;
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
@@ -3708,28 +3475,8 @@ static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, s
     // (single problems: the bytes the launch really reads -- the fixed-point tiles are shorter than their slots; only the kernel for more than 64 row blocks has the variant)
     const size_t stream_bytes = batch ? (size_t)ntiles * kSplitTileBytes * (size_t)nprob : (size_t)ntiles * kMixedFixedTileBytes;
     const bool nt = (batch || !small) && !p.mp_f32 && (nto ? nto == LPVS_NT_ON : stream_bytes > ((size_t)240 << 20));
-    // several tiles per workgroup (admm_iter_mixed_mt_kernel): single problems whose tiles below the diagonal are all in the fixed
-    // format and whose diagonal tiles are not (cfg3).  T = tiles per workgroup such that every workgroup of the launch is resident
-    // from its start (three per CU); LPVS_FI_TILES=1 keeps the one-tile launch (A/B measurements, tests), 2..4 force T.
-    int mt = 0;
-    if (!batch && !p.mp_f32 && !prefetch_all && p.fi_tiles != nullptr && p.fi_nmulti > 0) {
-        static const int cus = [] { int d = 0, c = 0; return (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && c > 0) ? c : 256; }();
-        const int slots = 3 * cus - p.fi_nsingle;
-        const char *e = getenv("LPVS_FI_TILES");
-        // Measured at cfg3 (tools/fi_tiles_ab.sh, profiles/r04_iteration_timeline_*.txt): T = 1 (the plain launch) 27.4 us, T = 2 29.0, T = 3 31.7,
-        // T = 4 32.2 -- a statically dealt workgroup cannot make up for the fabric's uneven service (lifetimes of equal workgroups spread
-        // 21 .. 30 us) the way the dispatcher's hand-out of one-tile workgroups does.  Off unless asked for.
-        mt = e ? atoi(e) : 0;
-        (void)slots;
-        if (mt > 4) mt = 4;
-        if (mt < 2) mt = 0;                           // (one tile per workgroup: the plain launch)
-    }
-    const unsigned mt_grid = mt ? (unsigned)(p.fi_nsingle + (p.fi_nmulti + mt - 1) / mt) : 0;
-    if (getenv("LPVS_TRACE")) fprintf(stderr, "[lpvs] one-launch iteration: %d row blocks, %u tiles (%d + %d), tiles per workgroup %d (grid %u), %lld iterations\n", nblk, ntiles, p.fi_nsingle, p.fi_nmulti, mt ? mt : 1, mt ? mt_grid : ntiles, (long long)iters);
     auto launch = [&](int mode, unsigned grid, long long g, int aslot, int uslot, int commit_prev) {
-        FiKernel k = fi_kernel(mode, small, batch, nt, prefetch_all, p.mp_f32 != 0);
-        if (mt && mode != FI_LAST) { k = fi_kernel_mt(mode, small, mt); grid = mt_grid; }
-        hipLaunchKernelGGL(k, dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
+        hipLaunchKernelGGL(fi_kernel(mode, small, batch, nt, prefetch_all, p.mp_f32 != 0), dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
                            commit_prev, mp_stride, prefetch_all ? 1 : 0);
     };
     launch(FI_FIRST, ntiles, base, 0, 0, 0);

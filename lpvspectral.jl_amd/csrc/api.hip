@@ -344,8 +344,6 @@ struct lpvs_problem {
     bool Mp_valid = false;   // Mp is the packed copy of the CURRENT M (cleared whenever M is recomputed or G changes)
     int64_t Mp_fixed_diag = 0;   // ... of which on the diagonal (type 2)
     DevBuf sm_ctl;               // control words of the one-launch iteration of small problems (AdmmParams::sm_ctl)
-    DevBuf fi_tiles;             // tile lists of the several-tiles-per-workgroup iteration (AdmmParams::fi_tiles)
-    int fi_nsingle = 0, fi_nmulti = 0;
     int Mp_mode = 0;         // storage of Mp: kMpF64 / kMpF32 / kMpSplit / kMpMixed (see make_params)
     double Mp_stream_bytes = 0;   // bytes of Mp one mat-vec launch reads (mixed storage: depends on the tile formats chosen)
     int64_t Mp_fixed_tiles = 0;
@@ -451,7 +449,6 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.fi = sym && h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && h->fi.p ? h->fi.as<double>() : nullptr;
     p.fi_R = h->fi_R; p.fi_xbmax = h->fi_xbmax;
     p.fi_prefetch_all = sym && h->Mp_mode == kMpMixed && h->Mp_fixed_tiles == (int64_t)(symv_packed_doubles(h->np) / (128 * 128)) ? 1 : 0;
-    if (sym && h->Mp_mode == kMpMixed && h->ns == 1 && h->fi_tiles.p && h->fi_nmulti > 0) { p.fi_tiles = h->fi_tiles.as<int>(); p.fi_nsingle = h->fi_nsingle; p.fi_nmulti = h->fi_nmulti; }
     p.opt_iteration = h->opt[LPVS_OPT_ITERATION]; p.opt_nt_loads = h->opt[LPVS_OPT_NT_LOADS];
     p.sm_ctl = !sym && h->sm_ctl.p ? h->sm_ctl.as<int>() : nullptr;
     return p;
@@ -1170,7 +1167,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         const size_t need = elt * symv_packed_doubles(h->np) + (mode == kMpMixed ? ((ntiles + 255) / 256) * 256 + 256 : 0);   // + tile types + max|M|
         if (!h->Mp.p || h->Mp.bytes < need) LPVS_TRY(h->Mp.alloc(need));
         h->Mp_stream_bytes = (double)elt * (double)symv_packed_doubles(h->np);
-        h->Mp_fixed_tiles = 0; h->Mp_fixed_diag = 0; h->fi_nsingle = h->fi_nmulti = 0;
+        h->Mp_fixed_tiles = 0; h->Mp_fixed_diag = 0;
         if (mode == kMpF32) LPVS_TRY(launch_pack_tiles_f32(h->M.as<double>(), h->np, h->Mp.as<float>(), s));
         else if (mode == kMpSplit) LPVS_TRY(launch_pack_tiles_split(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), s));
         else if (mode == kMpMixed) {
@@ -1183,18 +1180,6 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
             size_t ndiag = 0;
             for (unsigned char t : ht) { h->Mp_fixed_tiles += t != 0; ndiag += t == 2; }
             h->Mp_fixed_diag = (int64_t)ndiag;
-            h->fi_nsingle = h->fi_nmulti = 0;
-            if (h->ns == 1) {   // tile lists of the several-tiles-per-workgroup iteration: diagonal tiles, float-head tiles below it | fixed-format tiles below it
-                const int nb_ = (int)(h->np / 128);
-                std::vector<int> single, multi;
-                for (int b = 0; b < nb_; ++b) single.push_back((b << 16) | b);
-                for (int I = 1; I < nb_; ++I)
-                    for (int J = 0; J < I; ++J) (ht[(size_t)(I * (I + 1) / 2 + J)] == 1 ? multi : single).push_back((I << 16) | J);
-                h->fi_nsingle = (int)single.size(); h->fi_nmulti = (int)multi.size();
-                single.insert(single.end(), multi.begin(), multi.end());
-                LPVS_TRY(h->fi_tiles.alloc(sizeof(int) * single.size()));
-                LPVS_TRY(copy_to_device(h->fi_tiles.p, single.data(), sizeof(int) * single.size(), s));
-            }
             h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)kMixedFixedTileBytes + (double)ndiag * 1024.0 +
                                  (double)(ntiles - (size_t)h->Mp_fixed_tiles) * (double)kMixedFloatTileBytes;
             const size_t nblk_ = (size_t)(h->np / 128);
@@ -1203,7 +1188,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
                 // not a diagonally dominant inverse: the mixed kernel (three workgroups per CU, float-head tiles in two halves) would
                 // only lose against the plain 6-byte kernel -- store every tile in the float-head format
                 LPVS_TRY(launch_pack_tiles_split(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), s));
-                h->Mp_fixed_tiles = 0; h->Mp_fixed_diag = 0; h->fi_nsingle = h->fi_nmulti = 0;
+                h->Mp_fixed_tiles = 0; h->Mp_fixed_diag = 0;
                 h->Mp_stream_bytes = 6.0 * (double)symv_packed_doubles(h->np);
                 h->Mp_valid = true; h->Mp_mode = kMpSplit; h->Mp_demoted = true; just_demoted = true;
             }

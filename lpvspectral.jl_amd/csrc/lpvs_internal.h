@@ -235,11 +235,6 @@ struct AdmmParams {
     long long fi_base = 0;
     double fi_R = 0, fi_xbmax = 0;   // largest absolute row sum of M (x 1) and max|xb|: host copies of fi's constants (single problems)
     int fi_prefetch_all = 0;         // every tile is in the fixed format: diagonal tiles are requested up front too
-    // several tiles per workgroup (single problems, admm_iter_mixed_mt_kernel): tiles as (I << 16) | J -- first fi_nsingle tiles that keep a
-    // workgroup of their own (every diagonal tile, in order, then the float-head tiles below the diagonal), then fi_nmulti fixed-format
-    // tiles below the diagonal in row-major order
-    const int *fi_tiles = nullptr;
-    int fi_nsingle = 0, fi_nmulti = 0;
     int opt_iteration = 0, opt_nt_loads = 0;   // LPVS_OPT_ITERATION / LPVS_OPT_NT_LOADS of the handle (0: thread default / environment)
     // one launch per iteration of the full-matrix path (np < kSymmetricMinNp; admm_small_iter_kernel): 4 ints per signal --
     // {converged before launch parity 0, parity 1, launch of the chunk that converged (-1: none), unused}; nullptr = two launches.

@@ -50,7 +50,7 @@ g = rec[:, :, 0]
 assert (g[0] == g[0, 0]).all() and (g[1] == g[1, 0]).all() and abs(int(g[0, 0]) - int(g[1, 0])) == 1, "stamps of mixed launches"
 first, second = (0, 1) if g[0, 0] < g[1, 0] else (1, 0)
 A, B = rec[first].astype(np.int64), rec[second].astype(np.int64)
-print(f"# workgroups per launch: {nwg} ({nblk} diagonal + {nwg - nblk} with {-(-(ntiles - nblk) // max(nwg - nblk, 1))} tiles each)" if nwg != ntiles else f"# workgroups per launch: {nwg} (one tile each)")
+print(f"# workgroups per launch: {nwg}" + (" (one tile each)" if nwg == ntiles else ""))
 ntiles_all, ntiles = ntiles, nwg
 print(f"# stamps: {'all five (perturbing)' if FULL else 'entry and end only'}")
 print(f"# admm_iter_mixed_kernel<FI_MID>, n = {p.n} ({nblk} row blocks, {ntiles} workgroups), launches g = {int(A[0, 0])} and {int(B[0, 0])}; times in us, clock 100 MHz (10 ns ticks)")
