@@ -414,7 +414,7 @@ admm_prox_kernel(AdmmParams p) {
             for (int k = 0; k < EPT; ++k) {
                 const int64_t e = threadIdx.x + 1024 * k;
                 const bool ok = e < cnt;
-                xv[k] = ok ? X[c0 + e] : 0.0; uv[k] = ok ? U[c0 + e] : 0.0; bv[k] = ok ? B[c0 + e] : 0.0;
+                xv[k] = ok ? X[c0 + e] : 0.0; uv[k] = ok ? U[c0 + e] : 0.0; bv[k] = ok && !offset_form ? B[c0 + e] : 0.0;   // (offset form: the right-hand side carries no b)
             }
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
@@ -447,7 +447,7 @@ admm_prox_kernel(AdmmParams p) {
             for (int k = 0; k < EPT; ++k) {
                 const int64_t i = c0 + threadIdx.x + 1024 * k;
                 const bool ok = i < n;
-                xv[k] = ok ? X[i] : 0.0; uv[k] = ok ? U[i] : 0.0; bv[k] = ok ? B[i] : 0.0;
+                xv[k] = ok ? X[i] : 0.0; uv[k] = ok ? U[i] : 0.0; bv[k] = ok && !offset_form ? B[i] : 0.0;   // (offset form: the right-hand side carries no b)
             }
             if (kind == LPVS_PROX_L1 || kind == LPVS_PROX_L0 || ball_r <= 0 || ball_r >= n) {
 #pragma unroll
