@@ -111,10 +111,14 @@ end
 #   iteration = :one (default where applicable: one launch per ADMM iteration) | :two
 #   gram_form = :ap | :krs | :kr,  nt_loads = :on | :off,  slot_sums = :nufft | :direct        (`nothing` = the library's choice)
 # Estimators take them as keywords (`ls_sparse_spectral_lpv(...; storage=:f64)`); results do not depend on them beyond rounding.
-const OPT_ID = (storage=Int32(1), iteration=Int32(2), gram_form=Int32(3), nt_loads=Int32(4), slot_sums=Int32(5))
+#   window_chunk_mb = MB of packed inverses per chunk of the batched-window engine | :uncut;  windows_in_flight = 1 .. 4 parts of a chunk;
+#   reserve_cus = CUs the factorisation leaves to its pivot chain | :none                     (integers; defaults only, not handle options)
+const OPT_ID = (storage=Int32(1), iteration=Int32(2), gram_form=Int32(3), nt_loads=Int32(4), slot_sums=Int32(5),
+                window_chunk_mb=Int32(6), windows_in_flight=Int32(7), reserve_cus=Int32(8))
 const OPT_VALUES = (storage=(mixed=1, split=2, f64=3), iteration=(one=1, two=2), gram_form=(ap=1, krs=2, kr=3),
-                    nt_loads=(off=1, on=2), slot_sums=(nufft=1, direct=2))
-optvalue(name::Symbol, v) = v === nothing ? Int32(0) : Int32(getfield(getfield(OPT_VALUES, name), Symbol(v)))
+                    nt_loads=(off=1, on=2), slot_sums=(nufft=1, direct=2), window_chunk_mb=(uncut=-1,), windows_in_flight=NamedTuple(),
+                    reserve_cus=(none=-1,))
+optvalue(name::Symbol, v) = v === nothing ? Int32(0) : v isa Integer ? Int32(v) : Int32(getfield(getfield(OPT_VALUES, name), Symbol(v)))
 function set_default_option(name::Symbol, v=nothing)       # thread-local: handles created / window batches run afterwards
     oid, vid = getfield(OPT_ID, name), optvalue(name, v)
     check(@ccall LIB.lpvs_set_default_option(oid::Int32, vid::Int32)::Int32)
@@ -122,7 +126,10 @@ end
 function get_default_option(name::Symbol)
     oid = getfield(OPT_ID, name); r = Ref{Int32}(0)
     check(@ccall LIB.lpvs_get_default_option(oid::Int32, r::Ref{Int32})::Int32)
-    r[] == 0 ? nothing : keys(getfield(OPT_VALUES, name))[r[]]
+    r[] == 0 && return nothing
+    vals = getfield(OPT_VALUES, name)
+    for k in keys(vals); getfield(vals, k) == r[] && return k; end
+    Int(r[])                                              # integer-valued options: the number itself
 end
 const OPTION_KEYS = keys(OPT_ID)
 # run f() with the given option keywords as thread defaults, restore the previous defaults afterwards; returns the
