@@ -484,7 +484,7 @@ def main():
                 if hostgrp is not None:
                     dist.barrier(group=hostgrp)
                 if rank == 0:
-                    devs = [r % ndev for r in range(world)] if args.share_gpu else list(range(world))   # the devices this run's ranks own, no others
+                    devs = [r % ndev for r in range(world)] if args.share_gpu else list(range(min(world, ndev)))   # the devices this run's ranks own, no others
                     ref = state["out"].pop("_params_rank0", None)
                     kw = dict(reference_params=ref if full_size else None)
                     if not full_size:                                   # rehearsals (tests): sizes follow the diagnostic flags
