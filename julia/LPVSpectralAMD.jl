@@ -612,7 +612,7 @@ end
 # `julia -t N`) run concurrently, each on its own handle and stream -- statically scheduled, so a solve stays on the thread whose
 # thread-local option defaults and error string it uses (defaults set with `set_default_option` on the calling thread do not reach the
 # others: pass options as keywords).  The sum is taken in window order either way (src/lsfft.jl:274).
-function ls_windowpsd_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer, nw::Int=10, noverlap=0; in_flight::Int=2, kwargs...)
+function ls_windowpsd_lpv(Y::AbstractVector, X::AbstractVector, V::AbstractVector, w, Nv::Integer, nw::Int=10, noverlap=0; in_flight::Int=4, kwargs...)
     S = zeros(length(w))                                                             # src/lsfft.jl:267-277
     # the library's own driver (the same device solves on the library's worker threads: no `julia -t` needed) whenever the call has only
     # what it takes; a singular window (NumericError) sends the call down the per-window path below, which has the host-QR route
