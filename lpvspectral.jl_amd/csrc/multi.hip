@@ -445,6 +445,7 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
     std::vector<double> Yh_;
     const double *Yh = Y;
     if (is_device_ptr(Y)) { Yh_.resize((size_t)N); LPVS_HIP(hipMemcpy(Yh_.data(), Y, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost)); Yh = Yh_.data(); }
+    const bool xv_host = !is_device_ptr(X) && !is_device_ptr(V);
     const size_t mat = sizeof(double) * (size_t)np * (size_t)np;
     int64_t cw = (int64_t)(((size_t)24 << 30) / (2 * mat + spd_inverse_work_bytes(np)));
     if (cw < 1) cw = 1;
@@ -492,7 +493,20 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
                 const int64_t o = offs[(size_t)(c0 + q)];
                 memcpy(y2.data(), Yh + o, sizeof(double) * (size_t)n);
                 lpvs_problem *h = nullptr;
-                int32_t rc = lpvs_problem_create_lpv_multi_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
+                int32_t rc;
+                if (xv_host) {   // the window's ranges on the host: two device reductions and their synchronisations less per window
+                    double r4[4] = {V[o], V[o], 0.0, 0.0};
+                    for (int64_t i = 0; i < n; ++i) {
+                        const double v = V[o + i], x = X[o + i], av = v < 0 ? -v : v, ax = x < 0 ? -x : x;
+                        if (v < r4[0]) r4[0] = v;
+                        if (v > r4[1]) r4[1] = v;
+                        if (av > r4[2]) r4[2] = av;
+                        if (ax > r4[3]) r4[3] = ax;
+                    }
+                    const bool finite = r4[0] <= r4[1] && r4[2] < 0x1p1000 && r4[3] < 0x1p1000;   // (NaN / Inf: let the device path report them as it always did)
+                    rc = finite ? lpvs_problem_create_lpv_rows_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, r4, device, &h)
+                                : lpvs_problem_create_lpv_multi_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
+                } else rc = lpvs_problem_create_lpv_multi_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
                 if (rc != LPVS_OK) return fail_with(rc, q);
                 double *G = nullptr, *b = nullptr; int64_t hnp = 0;
                 rc = lpvs_problem_device_gram_f64(h, &G, &b, &hnp);
