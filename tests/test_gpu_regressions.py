@@ -107,3 +107,24 @@ def test_resume_from_saved_state_continues_bit_for_bit(L):
         xr, zr, ur = q.admm_get()
     assert (it, conv) == (it_full, conv_full) and nxz == nxz_full
     assert np.array_equal(zr, zf) and np.array_equal(xr, xf) and np.array_equal(ur, uf)
+
+
+def test_device_inputs_of_the_signals_driver_are_validated(L):
+    """lpv_signals_multi passed data_ptr() of device tensors straight to the _f64 entry point -- a float32
+    tensor was read as doubles (twice its allocation).  Now: TypeError for a non-float64 device tensor, ValueError for tensors on
+    different devices / of the wrong rank; float64 device inputs are used in place and give the host-input result."""
+    import torch
+    rng = np.random.default_rng(3)
+    N, Nf, Nv, nsig = 4000, 12, 4, 2
+    X = np.sort(rng.random((N, nsig)) * 10, axis=0); V = np.tile(np.linspace(0, 1, N)[:, None], (1, nsig))
+    w = 2 * np.pi * np.arange(1, Nf + 1)
+    Y = np.cos(w[3] * X) * (1 + V) + 0.05 * rng.standard_normal((N, nsig))
+    col = lambda a, dt: torch.tensor(np.ascontiguousarray(a.T), dtype=dt, device="cuda").T      # column-major N x nsig on the device
+    kw = dict(λ=3.0, μ=0.05, tol=0.0, iters=80, devices=[0], in_flight=2)
+    Ph, ih = L.lpv_signals_multi(Y, X, V, w, Nv, **kw)
+    Pd, idv = L.lpv_signals_multi(col(Y, torch.float64), col(X, torch.float64), col(V, torch.float64), w, Nv, **kw)
+    assert np.array_equal(Ph, Pd) and np.array_equal(ih, idv)
+    with pytest.raises(TypeError):
+        L.lpv_signals_multi(col(Y, torch.float32), col(X, torch.float32), col(V, torch.float32), w, Nv, **kw)
+    with pytest.raises(ValueError):
+        L.lpv_signals_multi(col(Y, torch.float64)[:, 0], col(X, torch.float64)[:, 0], col(V, torch.float64)[:, 0], w, Nv, **kw)
