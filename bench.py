@@ -623,7 +623,7 @@ def single_process_records(L, devices, iters3=ADMM_ITERS, log2n3=LOG2N, nf3=NF, 
         tm = L.windowpsd_last_timing()
         S = L.sharding.reduce_psd_in_order(x[0])
         return {"entry_point": "lpvs_windows_estimate_multi_f64", "value": nwin4 / e, "unit": "windows/s", "windows": nwin4, "ms_per_call": e * 1e3,
-                "collective": "the library's own RCCL all-gather (librccl.so.1 by dlopen), %d-rank communicator" % tm["rccl_gather_ranks"] if tm["rccl_gather_ranks"] else "none (one device)",
+                "collective": "the library's own RCCL all-gather (librccl.so.1 by dlopen), %d-rank communicator" % tm["rccl_gather_ranks"] if tm["rccl_gather_ranks"] else ("none (one device)" if len(set(devices)) == len(devices) and nd == 1 else "none (shards share a device: the shard images are taken from the host staging)"),
                 "rccl_gather_ranks": tm["rccl_gather_ranks"], "psd_argmax": int(np.argmax(S)), "iters_min_max": [int(its.min()), int(its.max())]}
 
     def rec5():
