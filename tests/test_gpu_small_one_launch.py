@@ -147,3 +147,42 @@ def test_small_one_launch_multi_signal_and_resume(L, oracle):
         assert it == 200
         for a_, b_ in zip(p.admm_get(), ref):
             assert np.array_equal(a_, b_)
+
+
+def _spd_problem(n, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((3 * n // 2, n)) / np.sqrt(n)
+    k = min(9, n)
+    xs = np.zeros(n); xs[rng.choice(n, k, replace=False)] = rng.standard_normal(k) * 3
+    y = A @ xs + 0.01 * rng.standard_normal(A.shape[0])
+    return A.T @ A, A.T @ y
+
+
+@pytest.mark.parametrize("n", [5, 100, 128, 129, 640, 1000, 1025, 1100, 1900, 2047])
+def test_small_one_launch_edge_sizes(L, oracle, n):
+    """Sizes around the kernel's boundaries: one row block (np = 128), exactly a block, one past it, the largest size of the
+    np <= 1024 instances and the first of the others, the largest padded size below the tile-packed path (np = 1920), and n = 2047
+    (np = 2048: the tile-packed path takes over -- the same result from a different kernel).  Explicit-Gram problems, L1 and a group
+    prox whose groups do not align with anything, tol > 0 (every workgroup forms the norm) and tol = 0 (only workgroup 0 does)."""
+    G, b = _spd_problem(n, 100 + n)
+    glen = next(g for g in (7, 5, 4, 3, 1) if n % g == 0)
+    lam = float(np.quantile(np.abs(b), 0.5))
+    gb = np.linalg.norm(b.reshape(-1, glen), axis=1)
+    for prox, oprox in ((L.NormL1(lam), oracle.NormL1(lam)),
+                        (L.SlicedSeparableSum.frequency_groups(float(np.quantile(gb, 0.5)), n // glen, glen), oracle.GroupL2(float(np.quantile(gb, 0.5)), glen))):
+        for tol in (0.0, 1e-6):
+            with L.Problem.gram(G, b) as p:
+                p.set_prox(prox)
+                p.admm_init(None, μ=0.05, tol=tol)
+                info = p.matvec_info()
+                it, nxz, conv = p.admm_run(400)
+                x, z, u = p.admm_get()
+            assert (info["kernel"] == "admm_small_iter_kernel") == (n <= 1920), (n, info)
+            ro = oracle.admm_gram(G, b, oprox, iters=400, tol=tol, mu=0.05, history=True)
+            k = ro["iters"]
+            unambiguous = tol == 0.0 or k == 400 or min(abs(ro["nxz"][k - 1] - tol), abs(ro["nxz"][k - 2] - tol) if k >= 2 else 1.0) > 1e-6 * tol
+            if unambiguous:
+                assert it == k, (n, tol, it, k)
+                for a, q in ((x, "x"), (z, "z"), (u, "u")):
+                    assert rel(a, ro[q]) <= 1e-9, (n, tol, q, rel(a, ro[q]))
+                assert np.array_equal(z != 0, ro["z"] != 0), (n, tol)
