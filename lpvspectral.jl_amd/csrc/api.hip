@@ -996,7 +996,10 @@ int32_t lpvs_problem_create_fourier_f64(const double *y, const double *t, int64_
             LPVS_HIP(hipEventRecord(h->ev[0].a, s));
             LPVS_TRY(sd.upload(sl, s));
             LPVS_HIP(hipEventRecord(h->ev[0].b, s));
-            LPVS_TRY(part.alloc(nudft_partial_bytes(N, sl.nsl, 1)));
+            // (BOTH launches below share `part`: the right-hand side's has a third of the slots but -- fewer slot groups, so smaller chunks --
+            // up to four times the chunks.  Sized for the Gram launch alone it overflowed for N / rows-per-chunk in [171, 256), e.g.
+            // N = 118727 or 204800: found as a GPU fault in test_fourier_gram_additivity_cfg2 when the minimum chunk went from 512 to 64.)
+            LPVS_TRY(part.alloc(std::max(nudft_partial_bytes(N, sl.nsl, 1), nudft_partial_bytes(N, sl.nf8, 1))));
             LPVS_TRY(tab.alloc(sizeof(double) * (size_t)sl.nsl * 4));
             LPVS_TRY(tabb.alloc(sizeof(double) * (size_t)sl.nf8 * 4));
             const double *Wd = W ? dW.p : nullptr;               // A' diag(W) A and A' (W .* y), src/lasso.jl:119-120

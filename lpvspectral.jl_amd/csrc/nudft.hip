@@ -354,11 +354,13 @@ void launch_accumulate(unsigned nchunks, hipStream_t s, const double *x, const d
 
 }  // namespace
 
-// samples per workgroup: 8192, fewer for short signals so that (slot groups) x (chunks) still fills the chip
+// samples per workgroup: 8192, fewer for short signals so that (slot groups) x (chunks) still fills the chip -- down to 64: a
+// workgroup walks its samples one after the other (~0.19 us each), so the short records of ls_windowpsd_lpv's windows (600 samples:
+// two chunks of 512 took 95 us per launch, three launches per window) are latency, not work
 int64_t nudft_rows_per_chunk(int64_t N, int64_t nslots) {
     const int64_t groups = ceil_div(nslots, 128);
     int64_t rpc = 8192;
-    while (rpc > 512 && groups * ceil_div(N, rpc) < 2048) rpc >>= 1;
+    while (rpc > 64 && groups * ceil_div(N, rpc) < 2048) rpc >>= 1;
     return rpc;
 }
 size_t nudft_chunks(int64_t N, int64_t nslots) { return (size_t)ceil_div(N, nudft_rows_per_chunk(N, nslots)); }

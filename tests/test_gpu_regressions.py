@@ -128,3 +128,35 @@ def test_device_inputs_of_the_signals_driver_are_validated(L):
         L.lpv_signals_multi(col(Y, torch.float32), col(X, torch.float32), col(V, torch.float32), w, Nv, **kw)
     with pytest.raises(ValueError):
         L.lpv_signals_multi(col(Y, torch.float64)[:, 0], col(X, torch.float64)[:, 0], col(V, torch.float64)[:, 0], w, Nv, **kw)
+
+
+@pytest.mark.parametrize("N,Nf", [(409600, 128), (118727, 512), (204800, 512)])
+def test_fourier_rhs_partials_fit_their_buffer(L, N, Nf):
+    """Round 4: the structured Fourier constructor sized the chunk-partial buffer its two non-uniform-DFT launches share for the Gram
+    launch alone; the right-hand side's launch has a third of the slots but, with fewer slot groups, up to four times the chunks
+    (N / rows-per-chunk in [171, 256) for Nf = 512; [683, 1024) for Nf = 128): it wrote past the buffer -- a GPU fault once the
+    minimum chunk went from 512 to 64 samples, silent corruption of a neighbouring block before.  b against a host evaluation,
+    G against the dense panel form."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(N)
+    t = torch.sort(torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * N).values
+    fh = np.arange(1, Nf + 1) / (2.0 * Nf)
+    f = torch.tensor(fh, dtype=torch.float64, device="cuda")
+    y = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
+    with L.Problem.fourier(y, t, f) as p:
+        assert p.timing()["gram_form"] in ("ap", "ap-nufft")
+        G, b = p.get_gram()
+    th, yh = t.cpu().numpy(), y.cpu().numpy()
+    bo = np.empty(2 * Nf)
+    for k in range(Nf):                                               # A[n,k] = cos(2 pi f_k t_n)/sqrt(2 Nf), A[n,k+Nf] = -sin(...)/sqrt(2 Nf)   src/lsfft.jl:34-41
+        ph = 2 * np.pi * fh[k] * th
+        bo[k] = np.cos(ph) @ yh; bo[Nf + k] = -(np.sin(ph) @ yh)
+    bo /= np.sqrt(2.0 * Nf)
+    # (the host phases 2 pi f t are rounded products -- up to 2^-53 |phase| rad per sample, which the structured form does not commit)
+    tol = 1e-11 * max(np.abs(bo).max(), np.sqrt(N / (2.0 * Nf))) + 5e-16 * (2 * np.pi * fh[-1] * th[-1]) * np.linalg.norm(yh) / np.sqrt(2.0 * Nf)
+    assert np.abs(b - bo).max() <= tol, (np.abs(b - bo).max(), tol)
+    with L.default_options(gram_form="krs"):
+        with L.Problem.fourier(y, t, f) as p:
+            assert p.timing()["gram_form"] not in ("ap", "ap-nufft")
+            Gd, bd = p.get_gram()
+    assert np.abs(G - Gd).max() <= 1e-11 * np.abs(Gd).max() + tol and np.abs(b - bd).max() <= tol
