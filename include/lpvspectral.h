@@ -101,9 +101,10 @@ int32_t lpvs_release_cached_memory(void);
 #define LPVS_GRAM_KR 3        /* dense, Khatri-Rao contraction */
 #define LPVS_NT_OFF 1
 #define LPVS_NT_ON 2
-#define LPVS_OPT_WINDOW_CHUNK_MB 6   /* batched-window engine: MB of packed inverses per chunk (a chunk is re-read from the Infinity Cache every
-                                       * iteration); > 0: that many MB, LPVS_WINDOW_UNCUT: every window in one launch per iteration; default:
-                                       * 1.0625 x the device's Infinity Cache as the KFD topology reports it (285 MB on MI355X) */
+#define LPVS_OPT_WINDOW_CHUNK_MB 6   /* batched-window engine: MB (10^6 bytes) of packed inverses per chunk (a chunk is re-read from the Infinity
+                                       * Cache every iteration); > 0: that many MB, LPVS_WINDOW_UNCUT: every window in one launch per iteration;
+                                       * default: 1.0625 x the Infinity Cache of the GPU nodes of the KFD topology (256 MiB on MI355X = 268.4 MB
+                                       * -> 285 MB) */
 #define LPVS_OPT_WINDOWS_IN_FLIGHT 7 /* parts of a chunk solved concurrently on streams of their own: 1 .. 4 (default 2) */
 #define LPVS_OPT_RESERVE_CUS 8       /* CUs the factorisation's trailing updates leave to its pivot chain: > 0, or LPVS_RESERVE_NONE (default 8) */
 #define LPVS_SLOTS_NUFFT 1
@@ -409,7 +410,10 @@ int32_t lpvs_lpv_signals_multi_f64(const double *Y, const double *X, const doubl
  * The windows' Grams are built `in_flight` (1 .. 8) at a time on streams of their own into ONE batch; their factorisations and
  * refined ridge solves then run for all windows at once (the batch machinery of the window engine).  n = length(Y) / nw as the caller
  * computes it (:269).  fva_out (HOST, k = window count entries, may be NULL): each window's fraction of variance explained
- * 1 - var(e)/var(y) (:255) -- the reference warns when it is below 0.9, the bindings do the same.
+ * 1 - var(e)/var(y) (:255) -- the reference warns when it is below 0.9, the bindings do the same.  It is formed from the Gram
+ * (x'Gx - 2x'b + y'y), i.e. from separately rounded sums: good to ~1e-8 of var(y), enough for the 0.9 threshold and no more; a constant
+ * window (var(y) = 0) reports -Inf, so that it warns.  The windows are solved in chunks sized from the device's free memory; a window's
+ * coefficients depend on the chunking to rounding only.
  * LPVS_ENUMERIC when a window's normal equations are singular to working precision (the reference's QR route is the wrapper's).
  * S_out: HOST array. */
 int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V, int64_t N, const double *w, int64_t Nf, int64_t Nv,

@@ -42,12 +42,21 @@ static int option_from_env(int option) {
     }
     return 0;
 }
-// Last-level (Infinity / MALL) cache of the device: the largest level-3 cache the KFD topology lists (kB; every GPU of a node is the
-// same part).  256 MiB -- MI355X -- when the topology cannot be read.
+// Last-level (Infinity / MALL) cache of the device, in BYTES: the largest level-3 cache the KFD topology lists for a GPU node (a node
+// whose properties say simd_count > 0 -- CPU nodes list their L3 the same way and must not set the window chunk plan; every GPU of a
+// node is the same part).  256 MiB -- MI355X -- when the topology cannot be read.
 double infinity_cache_bytes() {
     static const double bytes = [] {
         double best = 0;
         for (int node = 0; node < 64; ++node) {
+            char npath[160];
+            snprintf(npath, sizeof(npath), "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
+            FILE *np_ = fopen(npath, "r");
+            if (!np_) continue;
+            char nkey[64]; long long nval = 0, simd = 0;
+            while (fscanf(np_, "%63s %lld", nkey, &nval) == 2) if (!strcmp(nkey, "simd_count")) simd = nval;
+            fclose(np_);
+            if (simd <= 0) continue;                              // a CPU node
             for (int c = 0; c < 512; ++c) {
                 char path[160];
                 snprintf(path, sizeof(path), "/sys/class/kfd/kfd/topology/nodes/%d/caches/%d/properties", node, c);
@@ -131,6 +140,12 @@ struct Pool {
 };
 Pool &pool() { static Pool p; return p; }
 }  // namespace
+
+size_t pool_cached_bytes(int dev) {
+    if (dev < 0 || dev >= 16) return 0;
+    std::lock_guard<std::mutex> lk(pool().m);
+    return pool().cached[dev];
+}
 
 int32_t DevBuf::alloc(size_t nbytes) {
     release();
@@ -1213,7 +1228,12 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     h->offset_form = h->np >= kSymmetricMinNp && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
     if (h->offset_form) {
         if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
-        LPVS_TRY(launch_symv(h->M.as<double>(), h->np, h->bs.as<double>(), h->xb.as<double>(), s, (int)h->ns));   // every signal's M b
+        // every signal's M b, refined against the Gram the handle still holds (launch_offset_vector_refined says why); rhs and
+        // scratch are free until launch_admm_init below writes the state
+        int steps = 2;
+        if (const char *e = getenv("LPVS_XB_REFINE")) steps = atoi(e) < 0 ? 0 : atoi(e);
+        LPVS_TRY(launch_offset_vector_refined(h->G.as<double>(), h->M.as<double>(), h->np, h->n, (int)h->ns, h->bs.as<double>(), h->M_shift, steps,
+                                              h->xb.as<double>(), h->rhs.as<double>(), h->scratch.as<double>(), s));
     }
     if (h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && !h->fi.p) LPVS_TRY(h->fi.alloc(sizeof(double) * fi_doubles(h->np)));
     const AdmmParams p = make_params(h);

@@ -71,6 +71,7 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
+size_t pool_cached_bytes(int dev);   // bytes of freed blocks the caching allocator holds for a device (handed out again before hipMalloc is asked)
 bool is_device_ptr(const void *p);
 int device_of_ptr(const void *p);   // owning device, -1 for host memory
 // dst device <- src (host or device); dst (host or device) <- src device
@@ -309,6 +310,8 @@ int32_t launch_rect_matvec(const double *A, int64_t rows, int64_t cols, int64_t 
 int32_t launch_fourier_dual_panel(const double *t, int64_t N, const double *f, int64_t Nf, int zerofreq, double *D, int64_t ldn,
                                   int64_t nrows, hipStream_t s);
 // x = M b refined against H = G + ridge I:  x += M (b - H x), `steps` times (t1, t2: np doubles of scratch)
+int32_t launch_offset_vector_refined(const double *G, const double *M, int64_t np, int64_t n, int ns, const double *b, double shift, int steps,
+                                     double *xb, double *t1, double *t2, hipStream_t s);
 int32_t launch_ridge_solve_refined(const double *G, const double *M, int64_t np, int64_t n, const double *b, double ridge, int steps,
                                    double *x, double *t1, double *t2, hipStream_t s);
 // x = Minv * rhs_in (one GEMV; ridge solves)

@@ -447,7 +447,16 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
     if (is_device_ptr(Y)) { Yh_.resize((size_t)N); LPVS_HIP(hipMemcpy(Yh_.data(), Y, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost)); Yh = Yh_.data(); }
     const bool xv_host = !is_device_ptr(X) && !is_device_ptr(V);
     const size_t mat = sizeof(double) * (size_t)np * (size_t)np;
-    int64_t cw = (int64_t)(((size_t)24 << 30) / (2 * mat + spd_inverse_work_bytes(np)));
+    // windows per chunk: Qb + Mb + work + the eight [np][2] vectors of a window within HALF of what the device has free now (the rest
+    // is for the in_flight handles building the Grams, each with its own G / state, and for whoever shares the device), 24 GiB at most;
+    // halved again below if the allocation still fails.  A window's result depends on the chunking only to rounding: the batch
+    // inverse takes the 64-wide sweep for two windows or more and the two-level schedule for a lone one.
+    const size_t per_window = 2 * mat + spd_inverse_work_bytes(np) + 8 * sizeof(double) * (size_t)np * 2 + sizeof(int);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)48 << 30; }
+    free_b += pool_cached_bytes(device);                           // blocks this library holds in its cache are free for this call
+    size_t budget = free_b / 2 < ((size_t)24 << 30) ? free_b / 2 : ((size_t)24 << 30);
+    int64_t cw = (int64_t)(budget / per_window);
     if (cw < 1) cw = 1;
     if (cw > k) cw = k;
     hipStream_t s = nullptr;
@@ -455,10 +464,19 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } sguard{s};
     DevBuf Qb, Mb, work, istat, bb, xv, t1, t2;
     DrainOnExit drain(s);
-    LPVS_TRY(Qb.alloc(mat * (size_t)cw)); LPVS_TRY(Mb.alloc(mat * (size_t)cw));
-    LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)cw)); LPVS_TRY(istat.alloc(sizeof(int) * (size_t)cw));
-    const size_t vb = sizeof(double) * (size_t)np * (size_t)cw * (size_t)nrhs;
-    LPVS_TRY(bb.alloc(vb)); LPVS_TRY(xv.alloc(vb)); LPVS_TRY(t1.alloc(vb)); LPVS_TRY(t2.alloc(vb));
+    for (;;) {                                                     // (out of memory with this chunk size: release, halve, try again)
+        const size_t vb_ = sizeof(double) * (size_t)np * (size_t)cw * (size_t)nrhs;
+        const int32_t rc = [&]() -> int32_t {
+            LPVS_TRY(Qb.alloc(mat * (size_t)cw)); LPVS_TRY(Mb.alloc(mat * (size_t)cw));
+            LPVS_TRY(work.alloc(spd_inverse_work_bytes(np) * (size_t)cw)); LPVS_TRY(istat.alloc(sizeof(int) * (size_t)cw));
+            LPVS_TRY(bb.alloc(vb_)); LPVS_TRY(xv.alloc(vb_)); LPVS_TRY(t1.alloc(vb_)); LPVS_TRY(t2.alloc(vb_));
+            return LPVS_OK;
+        }();
+        if (rc == LPVS_OK) break;
+        if (rc != LPVS_ENOMEM || cw == 1) return rc;
+        Qb.release(); Mb.release(); work.release(); istat.release(); bb.release(); xv.release(); t1.release(); t2.release();
+        cw = (cw + 1) / 2;
+    }
     std::vector<double> Sw((size_t)k * (size_t)Nf, 0.0);         // per-window contributions, summed in window order afterwards
     std::vector<double> hx((size_t)np * (size_t)cw * (size_t)nrhs), hq(hx.size()), hb(hx.size());
     std::vector<int> hist_((size_t)cw);
@@ -496,14 +514,16 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
                 int32_t rc;
                 if (xv_host) {   // the window's ranges on the host: two device reductions and their synchronisations less per window
                     double r4[4] = {V[o], V[o], 0.0, 0.0};
+                    bool bad = false;                              // a NaN fails every comparison below, wherever it sits: track it explicitly
                     for (int64_t i = 0; i < n; ++i) {
                         const double v = V[o + i], x = X[o + i], av = v < 0 ? -v : v, ax = x < 0 ? -x : x;
+                        bad |= !(av < 0x1p1000) || !(ax < 0x1p1000);
                         if (v < r4[0]) r4[0] = v;
                         if (v > r4[1]) r4[1] = v;
                         if (av > r4[2]) r4[2] = av;
                         if (ax > r4[3]) r4[3] = ax;
                     }
-                    const bool finite = r4[0] <= r4[1] && r4[2] < 0x1p1000 && r4[3] < 0x1p1000;   // (NaN / Inf: let the device path report them as it always did)
+                    const bool finite = !bad && r4[0] <= r4[1];   // (NaN / Inf anywhere in the window: the device path's own range pass reports them as it always did)
                     rc = finite ? lpvs_problem_create_lpv_rows_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, r4, device, &h)
                                 : lpvs_problem_create_lpv_multi_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
                 } else rc = lpvs_problem_create_lpv_multi_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
@@ -570,9 +590,13 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
                 double yy = 0, ys = 0;
                 for (int64_t i = 0; i < n; ++i) { yy += yq[i] * yq[i]; ys += yq[i]; }
                 const double e2 = xGx - 2.0 * xb0 + yy, es = xb1 - ys;
-                const double var_e = n > 1 ? (e2 - es * es / (double)n) / (double)(n - 1) : 0.0;
+                // (formed from separately rounded sums: good to ~1e-8 of var(y), which is all the 0.9 warning threshold of src/lsfft.jl:255 needs --
+                // the header says so; a tiny negative var(e) from the cancellation is clamped, and a constant window (var(y) = 0), for which
+                // the reference's 1 - var(e)/var(y) is -Inf or NaN, reports -Inf so that the bindings warn)
+                double var_e = n > 1 ? (e2 - es * es / (double)n) / (double)(n - 1) : 0.0;
                 const double var_y = n > 1 ? (yy - ys * ys / (double)n) / (double)(n - 1) : 0.0;
-                fva_out[c0 + q] = 1.0 - var_e / var_y;
+                if (var_e < 0) var_e = 0;
+                fva_out[c0 + q] = var_y > 0 ? 1.0 - var_e / var_y : -HUGE_VAL;
             }
         }
     }

@@ -234,6 +234,30 @@ def admm_gram(G, b, proxg, x0=None, iters=10000, tol=1e-5, mu=0.05, history=Fals
     return dict(x=x, z=z, u=u, iters=int(it), nxz=hist[:it] if history else None)
 
 
+_LIB_LD = None
+
+
+def admm_gram_ld(G, b, proxg, snaps, x0=None, mu=0.05, verbose=False):
+    """lpvs_oracle_ld.c: admm_gram carried in x87 extended precision (64-bit mantissa) -- the adjudicator between two f64
+    paths.  Returns {iteration count: (x, z, u)} for the ascending counts in `snaps` (tol = 0: no stopping test)."""
+    global _LIB_LD
+    if _LIB_LD is None:
+        _LIB_LD = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblpvs_oracle_ld.so"))
+        _LIB_LD.lpvo_admm_gram_ld.restype = C.c_int64
+        assert _LIB_LD.lpvo_ld_mantissa_bits() == 64, "long double is not the x87 extended format on this host"
+    G = np.asfortranarray(G, dtype=np.float64)
+    b = _f64(b)
+    n = len(b)
+    snaps = np.ascontiguousarray(sorted(int(s) for s in snaps), dtype=np.int64)
+    xs, zs, us = (np.zeros((len(snaps), n)) for _ in range(3))
+    x0a = _f64(x0) if x0 is not None else None
+    it = _LIB_LD.lpvo_admm_gram_ld(_p(G), C.c_int64(n), _p(b), _p(x0a) if x0a is not None else None, C.c_int(proxg.kind),
+                                   C.c_double(proxg.param), C.c_int64(proxg.glen), C.c_double(mu), _p(snaps), C.c_int64(len(snaps)),
+                                   _p(xs), _p(zs), _p(us), C.c_int(1 if verbose else 0))
+    assert it == snaps[-1], it
+    return {int(s): (xs[k], zs[k], us[k]) for k, s in enumerate(snaps)}
+
+
 def gram(A, y=None, W=None):
     A = np.asfortranarray(A, dtype=np.float64)
     m, n = A.shape

@@ -50,6 +50,18 @@ def test_bench_sub_records_cannot_cost_the_main_line():
     assert sp["single_process_cfg3"]["signals"] == 4 and sp["single_process_cfg3"]["iters_min_max"] == [70, 70]
     assert sp["single_process_cfg4"]["psd_argmax"] == 33 and sp["single_process_cfg4"]["rccl_gather_ranks"] == 0     # (shards share the device: host gather)
     assert sp["single_process_cfg5"]["channels"] == 4 and sp["single_process_cfg5"]["value"] > 0
+    # round 5: BASELINE's other configurations and the row-sharded Gram ride on the same line, and everything a reader
+    # of the driver's record needs is repeated as SCALARS of config / roofline (its parser drops nested records and unknown top-level keys)
+    assert rec["cfg2"]["value"] > 0 and rec["cfg2"]["n_gpus"] == 2 and rec["cfg2"]["roofline"]["kernel"].startswith("admm_small_iter_kernel")
+    assert rec["cfg5"]["value"] > 0 and rec["cfg5"]["roofline"]["kernel"].startswith("symv_tile_mfma_ws_kernel")
+    rs = rec["cfg3_row_sharded"]
+    assert rs["value"] > 0 and rs["iters"] == 70 and rs["scaling"] == "strong" and rs["allreduce_ms_rank0"] > 0
+    cfg = rec["config"]
+    for k in ("admm_iters_per_sec", "phase_factor_ms", "phase_admm_ms", "cfg2_signals_per_s", "cfg2_launch_us", "cfg2_roofline_frac", "cfg4_windows_per_s",
+              "cfg5_signals_per_s", "cfg5_roofline_frac", "rowsharded_signals_per_s", "one_process_cfg3_signals_per_s", "one_process_cfg4_windows_per_s"):
+        assert isinstance(cfg[k], float) and cfg[k] > 0, k
+    assert cfg["collective_ranks"] == 2 and rec["roofline"]["factorisation_frac_of_f64_mfma_peak"] > 0
+    assert all(len(k) <= 40 for k in list(cfg) + list(rec["roofline"]))
     rec = _run(base + ["--no-single-process"], {"LPVS_BENCH_INJECT": "fail:1"})
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and "error" in rec["cfg4_strong"]
     rec = _run(base + ["--no-single-process", "--sub-timeout", "25"], {"LPVS_BENCH_INJECT": "hang:1"})

@@ -2,37 +2,146 @@
 """cfg3 at the judged size, the bench's own iteration count: admm_iter_mixed_kernel against the CPU oracle's Gram-form ADMM (Cholesky
 x-update) on the Gram read back from the device, at several iteration counts.  (The test-suite holds 200 iterations to 1e-9:
 tests/test_gpu_judged_size.py; this prints how the difference grows up to the bench's 2000.)  ~4 CPU-minutes on two threads.
-usage: cfg3_vs_oracle.py [iteration counts ...]"""
-import os, sys, time
+
+--longdouble adds the ADJUDICATOR: oracle/lpvs_oracle_ld.c, the same algorithm carried in x87 extended precision (64-bit
+mantissa) on the same G, b -- device-vs-LD and oracle-vs-LD say which f64 side carries the difference (~6 more CPU-minutes on
+two threads).  Its iterates (doubles) and a fingerprint of the G they belong to are written to --save (an .npz the test-suite
+holds the device to: tests/golden/cfg3_extended_precision_iterates.npz).
+--refine A,B,...  runs the device leg once per value of LPVS_XB_REFINE (rounds of refinement of the offset vector xb = M b).
+--reuse-ld FILE  takes the extended-precision iterates from FILE instead (they are deterministic: valid when the sha256 of G, b matches).
+--variants       more device legs at the last count (round-2 factorisation schedule, two-launch iteration) and the COSINES between the
+                 error vectors (device legs, oracle) against the extended-precision iterate: one dominant sensitive mode shows as |cos| ~ 1.
+--perturb        the f64 oracle once more on G (1 + d), b (1 + d), |d| <= 2^-52 elementwise (symmetric): what a one-ulp uncertainty of
+                 the INPUTS does to the iterate -- the conditioning of the problem itself, whatever computes it.
+usage: cfg3_vs_oracle.py [--longdouble | --reuse-ld FILE] [--save FILE] [--refine 0,2] [--variants] [--perturb] [--no-f64-oracle] [iteration counts ...]"""
+import argparse, os, sys, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import lpvspectral_jl_amd as L
 from oracle import oracle as o
 import bench
-counts = [int(a) for a in sys.argv[1:]] or [200, 500, 1000, 2000]
+ap = argparse.ArgumentParser()
+ap.add_argument("--longdouble", action="store_true")
+ap.add_argument("--save", default=None)
+ap.add_argument("--refine", default=None)
+ap.add_argument("--no-f64-oracle", action="store_true")
+ap.add_argument("--reuse-ld", default=None)
+ap.add_argument("--variants", action="store_true")
+ap.add_argument("--perturb", action="store_true")
+ap.add_argument("counts", nargs="*", type=int)
+a = ap.parse_args()
+counts = a.counts or [200, 500, 1000, 2000]
+refines = [None] if a.refine is None else [int(r) for r in a.refine.split(",")]
 y, X, V, w = bench.synth_signal(1 << 20, 512, 0, torch.device("cuda"))
-dev = {}
+rel = lambda p, q: np.linalg.norm(p - q) / np.linalg.norm(q)
+
+
+def device_leg(p, storage=None):
+    if storage:
+        p.set_option("storage", storage)
+    p.admm_init(None, μ=0.05, tol=0.0)
+    out, done = {}, 0
+    for c in counts:
+        p.admm_run(c - done); done = c
+        out[c] = p.admm_get()
+    return out
+
+
+dev, dev64, variants = {}, {}, {}
 with L.Problem.lpv(y, X, V, w, 8) as p:
     G, b = p.get_gram()
     p.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, 512, 16))
-    p.admm_init(None, μ=0.05, tol=0.0)
-    assert p.matvec_info()["kernel"] == "admm_iter_mixed_kernel"
-    done = 0
-    for c in counts:
-        p.admm_run(c - done); done = c
-        dev[c] = p.admm_get()
-    # the same with the inverse streamed as doubles
-    p.set_option("storage", "f64")
-    p.admm_init(None, μ=0.05, tol=0.0)
-    done = 0
-    dev64 = {}
-    for c in counts:
-        p.admm_run(c - done); done = c
-        dev64[c] = p.admm_get()
-rel = lambda a, b_: np.linalg.norm(a - b_) / np.linalg.norm(b_)
+    for r in refines:
+        if r is not None:
+            os.environ["LPVS_XB_REFINE"] = str(r)
+        dev[r] = device_leg(p)
+        assert p.matvec_info()["kernel"] == "admm_iter_mixed_kernel"
+    for r in refines:                       # the same with the inverse streamed as doubles
+        if r is not None:
+            os.environ["LPVS_XB_REFINE"] = str(r)
+        dev64[r] = device_leg(p, "f64")
+    if a.variants:                          # other evaluation orders of the same mathematics, at the last count
+        c = counts[-1]
+        saved = list(counts); counts[:] = [c]
+        os.environ.pop("LPVS_XB_REFINE", None)
+        p.set_option("storage", "mixed")
+        p.set_option("iteration", "two")
+        variants["two-launch iteration"] = device_leg(p)[c]
+        p.set_option("iteration", "one")
+        counts[:] = saved
+if a.variants:
+    c = counts[-1]
+    os.environ["LPVS_FACTOR_SCHEME"] = "steps"
+    with L.Problem.lpv(y, X, V, w, 8) as p2:
+        p2.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, 512, 16))
+        p2.admm_init(None, μ=0.05, tol=0.0)
+        p2.admm_run(c)
+        variants["round-2 factorisation schedule"] = p2.admm_get()
+    del os.environ["LPVS_FACTOR_SCHEME"]
+fp = hashlib.sha256(np.ascontiguousarray(G).tobytes() + np.ascontiguousarray(b).tobytes()).hexdigest()
+print(f"G, b sha256 {fp}  n = {len(b)}  threads {o.num_threads()}", flush=True)
 t0 = time.time()
-for c in counts:            # (the oracle restarts for every count: its factorisation dominates, ~40 s each on two threads)
-    ro = o.admm_gram(G, b, o.GroupL2(5.0, 16), iters=c, tol=0.0, mu=0.05)
-    x, z, u = dev[c]; x8, z8, u8 = dev64[c]
-    print(f"{c:5d} iterations: mixed storage vs oracle  x {rel(x, ro['x']):.2e} z {rel(z, ro['z']):.2e} u {rel(u, ro['u']):.2e} same support {np.array_equal(z != 0, ro['z'] != 0)} | "
-          f"8-byte storage vs oracle z {rel(z8, ro['z']):.2e} | mixed vs 8-byte z {rel(z, z8):.2e}   nnz {np.count_nonzero(ro['z'])}   [{time.time() - t0:.0f} s]", flush=True)
+ldz = None
+if a.reuse_ld:
+    d = np.load(a.reuse_ld)
+    assert str(d["sha256"]) == fp, "the saved extended-precision iterates belong to another G, b: %s" % d["sha256"]
+    have = {int(c): k for k, c in enumerate(d["counts"])}
+    ldz = {c: (d["x"][have[c]], d["z"][have[c]], d["u"][have[c]]) for c in counts}
+    print("extended-precision iterates taken from %s (same G, b)" % a.reuse_ld, flush=True)
+    for c in counts:
+        for r in refines:
+            print(f"{c:5d} iterations, xb refinement rounds {r}: device (mixed) vs LD  z {rel(dev[r][c][1], ldz[c][1]):.2e} | device (8-byte) vs LD z {rel(dev64[r][c][1], ldz[c][1]):.2e}", flush=True)
+elif a.longdouble:
+    ldz = o.admm_gram_ld(G, b, o.GroupL2(5.0, 16), counts, mu=0.05, verbose=True)
+    print(f"extended-precision leg: {time.time() - t0:.0f} s", flush=True)
+    if a.save:
+        np.savez_compressed(a.save, counts=np.array(counts), sha256=np.array(fp), x=np.stack([ldz[c][0] for c in counts]),
+                            z=np.stack([ldz[c][1] for c in counts]), u=np.stack([ldz[c][2] for c in counts]))
+    for c in counts:
+        for r in refines:
+            print(f"{c:5d} iterations, xb refinement rounds {r}: device (mixed) vs LD  z {rel(dev[r][c][1], ldz[c][1]):.2e} x {rel(dev[r][c][0], ldz[c][0]):.2e} "
+                  f"u {rel(dev[r][c][2], ldz[c][2]):.2e} | device (8-byte) vs LD z {rel(dev64[r][c][1], ldz[c][1]):.2e}", flush=True)
+if not a.no_f64_oracle:
+    t0 = time.time()
+    for c in counts:            # (the oracle restarts for every count: its factorisation dominates, ~40 s each on two threads)
+        ro = o.admm_gram(G, b, o.GroupL2(5.0, 16), iters=c, tol=0.0, mu=0.05)
+        for r in refines:
+            x, z, u = dev[r][c]; x8, z8, u8 = dev64[r][c]
+            print(f"{c:5d} iterations, xb refinement rounds {r}: mixed storage vs oracle  x {rel(x, ro['x']):.2e} z {rel(z, ro['z']):.2e} u {rel(u, ro['u']):.2e} "
+                  f"same support {np.array_equal(z != 0, ro['z'] != 0)} | 8-byte storage vs oracle z {rel(z8, ro['z']):.2e} | mixed vs 8-byte z {rel(z, z8):.2e}   "
+                  f"nnz {np.count_nonzero(ro['z'])}   [{time.time() - t0:.0f} s]", flush=True)
+        if ldz is not None:
+            print(f"{c:5d} iterations: f64 oracle vs LD  z {rel(ro['z'], ldz[c][1]):.2e} x {rel(ro['x'], ldz[c][0]):.2e} u {rel(ro['u'], ldz[c][2]):.2e}", flush=True)
+
+if a.variants or a.perturb:
+    c = counts[-1]
+    legs = {}
+    for r in refines:
+        legs[f"device, mixed storage, xb refinement {r}"] = dev[r][c][1]
+        legs[f"device, 8-byte storage ({r})"] = dev64[r][c][1]
+    for k, v in variants.items():
+        legs["device, " + k] = v[1]
+    if not a.no_f64_oracle:
+        legs["f64 oracle (Cholesky)"] = ro["z"]
+    if a.perturb:
+        rng = np.random.default_rng(5)
+        D = np.tril(rng.uniform(-2.0 ** -52, 2.0 ** -52, G.shape)); D = D + np.tril(D, -1).T
+        Gp, bp = G * (1 + D), b * (1 + rng.uniform(-2.0 ** -52, 2.0 ** -52, b.shape))
+        t0 = time.time()
+        rp = o.admm_gram(Gp, bp, o.GroupL2(5.0, 16), iters=c, tol=0.0, mu=0.05)
+        legs["f64 oracle on inputs perturbed by <= one ulp"] = rp["z"]
+        print(f"perturbed-input oracle leg: {time.time() - t0:.0f} s", flush=True)
+        if not a.no_f64_oracle:
+            print(f"{c:5d} iterations: f64 oracle vs f64 oracle on one-ulp-perturbed G, b: z {rel(rp['z'], ro['z']):.2e}", flush=True)
+    names = list(legs)
+    base = ldz[c][1] if ldz is not None else legs[names[-1]]
+    E = np.stack([legs[k] - base for k in names]) / np.linalg.norm(base)
+    print(f"error vectors at {c} iterations against {'the extended-precision iterate' if ldz is not None else names[-1]}: norms and cosines", flush=True)
+    nr = np.linalg.norm(E, axis=1)
+    for i, k in enumerate(names):
+        cs = " ".join("%+.2f" % (E[i] @ E[j] / max(nr[i] * nr[j], 1e-300)) for j in range(len(names)))
+        print(f"  [{i}] {nr[i]:.2e}  {cs}   {k}", flush=True)
+    sv = np.linalg.svd(E, compute_uv=False)
+    print("  singular values of the stacked error vectors / largest: " + " ".join("%.3f" % (x / sv[0]) for x in sv), flush=True)
+    if a.save:
+        np.savez_compressed(a.save.replace(".npz", "") + "_legs.npz", names=np.array(names), z=np.stack([legs[k] for k in names]), base=base)
