@@ -226,6 +226,15 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
  * iterations they represent; lpvs_admm_run then continues exactly as the uninterrupted run would (the x-update of
  * src/lasso.jl:150-151 only needs z and u).  Arrays are n (x ns) in the solver's own order, as lpvs_admm_get_f64 returns. */
 int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *z, const double *u, int64_t iters_done);
+/* Handles of n >= 2048 run the x-update in its offset form, x = xb + M (z - u)/mu, and re-form the offset vector after the iterations
+ * 1, 2, 4, 8, ... so that the systematic error of the explicit inverse leaves the iteration (xb_eff = xb - E (x_k - xb), E = M H - I with
+ * both products accumulated in twice the mantissa).  That vector is part of the iteration's state between two
+ * scheduled iterations: a checkpoint that is to continue BIT FOR BIT saves it with lpvs_admm_get_offset_f64 next to x, z, u and
+ * installs it with lpvs_admm_set_offset_f64 after lpvs_admm_set_state_f64 (which, without it, re-forms the vector from the x it is
+ * given -- the same to second order, ~1e-24 relative).  Always doubles (also for handles made by the _f32 constructors), n (x ns).
+ * LPVS_ESTATE when the handle has no offset vector (n < 2048, or before lpvs_admm_init). */
+int32_t lpvs_admm_get_offset_f64(lpvs_problem *h, double *xb_out);
+int32_t lpvs_admm_set_offset_f64(lpvs_problem *h, const double *xb);
 /* per-signal state of a multi-signal handle (lpvs_admm_run reports the slowest signal / the largest ||x-z||) */
 int32_t lpvs_admm_status(lpvs_problem *h, int64_t signal, int64_t *iters_done, double *nxz, int32_t *converged);
 /* iterates in the solver's own (regressor-column) order; any pointer may be NULL */

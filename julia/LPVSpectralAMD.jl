@@ -249,10 +249,22 @@ function iterates(p::Problem)
     p.ns == 1 ? (vec(x), vec(z), vec(u)) : (x, z, u)
 end
 # resume (SURVEY.md section 5): install iterates saved by `iterates` into a freshly initialised handle
-function set_state!(p::Problem, x, z, u, iters_done::Integer)
+function set_state!(p::Problem, x, z, u, iters_done::Integer; offset=nothing)
     xv, zv, uv = dense(Float64, x), dense(Float64, z), dense(Float64, u)
     GC.@preserve xv zv uv check(@ccall LIB.lpvs_admm_set_state_f64(p.h::Ptr{Cvoid}, xv::Ptr{Float64}, zv::Ptr{Float64}, uv::Ptr{Float64},
         Int64(iters_done)::Int64)::Int32)
+    if offset !== nothing          # the offset vector saved with the iterates (`offset_vector`): the run continues bit for bit
+        ov = dense(Float64, offset)
+        GC.@preserve ov check(@ccall LIB.lpvs_admm_set_offset_f64(p.h::Ptr{Cvoid}, ov::Ptr{Float64})::Int32)
+    end
+end
+# the x-update's offset vector currently in effect (handles of n >= 2048; `nothing` otherwise): part of a checkpoint next to `iterates`
+function offset_vector(p::Problem)
+    xb = zeros(p.n, p.ns)
+    rc = GC.@preserve xb @ccall LIB.lpvs_admm_get_offset_f64(p.h::Ptr{Cvoid}, xb::Ptr{Float64})::Int32
+    rc == LPVS_ESTATE && return nothing
+    check(rc)
+    p.ns == 1 ? vec(xb) : xb
 end
 
 # ---- ADMM driver: src/lasso.jl:136-171 with the iterations on the GPU ---------------------------

@@ -456,12 +456,27 @@ class Problem:
         check(lib().lpvs_admm_run(self._h, int(max_iters), C.byref(it), C.byref(nxz), C.byref(conv)))
         return int(it.value), float(nxz.value), bool(conv.value)
 
-    def admm_set_state(self, x, z, u, iters=0):
-        """Resume: install iterates saved by :meth:`admm_get` (after :meth:`admm_init` with the same parameters)."""
+    def admm_set_state(self, x, z, u, iters=0, offset=None):
+        """Resume: install iterates saved by :meth:`admm_get` (after :meth:`admm_init` with the same parameters).  ``offset`` = the vector
+        :meth:`admm_get_offset` returned with them (handles of n >= 2048): with it the run continues bit for bit, without it the library
+        re-forms the vector from ``x`` (the same to second order)."""
         arrs = [np.asfortranarray(np.asarray(a, dtype=np.float32 if self.f32 else np.float64)) for a in (x, z, u)]
         assert all(a.size == self.n * self.ns for a in arrs), "x, z, u have the wrong length"
         fn = lib().lpvs_admm_set_state_f32 if self.f32 else lib().lpvs_admm_set_state_f64
         check(fn(self._h, out_ptr(arrs[0]), out_ptr(arrs[1]), out_ptr(arrs[2]), int(iters)))
+        if offset is not None:
+            off = np.asfortranarray(np.asarray(offset, dtype=np.float64))
+            assert off.size == self.n * self.ns, "offset has the wrong length"
+            check(lib().lpvs_admm_set_offset_f64(self._h, out_ptr(off)))
+
+    def admm_get_offset(self):
+        """The offset vector of the x-update currently in effect (doubles), or ``None`` for handles without one (n < 2048)."""
+        xb = np.zeros(self.n if self.ns == 1 else (self.n, self.ns), order="F")
+        rc = lib().lpvs_admm_get_offset_f64(self._h, out_ptr(xb))
+        if rc == _lib.LPVS_ESTATE:
+            return None
+        check(rc)
+        return xb
 
     def admm_get(self):
         shape = self.n if self.ns == 1 else (self.n, self.ns)

@@ -12,6 +12,10 @@
 #include "lpvs_internal.h"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -1460,7 +1464,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int WS_NS = 16;                            // signal columns of the LDS images = the MFMA's N
 constexpr size_t symv_ws_lds() { return sizeof(double) * 2 * ((size_t)MT_ROWS * MT_RS + (size_t)MT_ROWS * WS_NS + (size_t)TS * WS_NS); }
 
-struct StreamVisit { int t, pass, I, J, k, end; };  // one (tile, signal pass): four 32-row stages; RUNS: of segment k = [.., end)
+struct StreamVisit { int t, pass, I, J, k, end, u; };  // one (tile, signal pass): four 32-row stages; RUNS: of segment k = [.., end); PANEL: of unit u = row I of panel k, columns .. end
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_f64(double v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
@@ -1486,11 +1490,23 @@ __device__ __forceinline__ void store_f64(double v, __amdgpu_buffer_rsrc_t rsrc,
 // every stage, through buffer descriptors of size zero for the format the tile does not have (those loads are dropped: no load under a
 // branch); a fixed-point element decodes in four vector instructions (bit-field extract, two integer instructions that assemble
 // 2^52 + q, one FMA with the row's step).
-template <bool SPLIT, bool Q4, bool RUNS, bool FIX>
+// PANEL (with RUNS and Q4; round 5): the triangle is walked in COLUMN PANELS of kPanelC tile columns, a panel from its diagonal down, row by
+// row -- unit (k, I) = the tiles (I, kC .. min(kC + C - 1, I)) of row I in panel k, unit index u = k nblk - C k (k - 1) / 2 + I - k C.  A
+// workgroup walks a contiguous range of units [u0, u1) (the host cuts the unit list into gridDim.x ranges of equal tile counts: panel_plan).
+//   P1 (row sums): one record per unit, id u -- the run logic of RUNS with the unit as the run;
+//   P2 (column sums): the C column blocks of the panel keep their sums in registers of the two P2 waves across
+//   ALL rows a workgroup walks in the panel, and are written out once per (workgroup, panel) as records f C + c, f = the running
+//   flush index (ptab gives the workgroup's first; the flushes of panel k are the contiguous range [F0[k], F0[k+1]), which is
+//   how the consumers find them).  At n = 32768: 8 224 P1 records + ~320 x 4 P2 records per signal instead of 4 370 + 32 640 -- the
+//   270 MB of per-tile column sums of a launch (and their re-read by the reduction) become 10 MB.
+constexpr int kPanelC = 4;
+constexpr size_t kPanelLds = 0;                                       // (the column sums live in registers)
+template <bool SPLIT, bool Q4, bool RUNS, bool FIX, bool PANEL = false>
 __global__ void __launch_bounds__(512, 1)
 symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
                          double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status, int nseg,
-                         const unsigned char *__restrict__ types /* FIX: per-tile formats */) {
+                         const unsigned char *__restrict__ types /* FIX: per-tile formats */, const int *__restrict__ ptab = nullptr /* PANEL: panel_plan's table */) {
+    static_assert(!PANEL || (RUNS && Q4), "the panel walk keeps P1 runs and needs the 8-signal LDS images (room for the column sums)");
     if (status != nullptr) {
         bool all = true;
         for (int q = 0; q < ns; ++q) all = all && status[q].converged;
@@ -1517,10 +1533,20 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
     const int tend = ntiles;
     auto seg_begin = [&](int k) -> int { return (int)(((unsigned long long)(unsigned)k * (unsigned)ntiles) / (unsigned)nseg); };
     if ((int)blockIdx.x >= (RUNS ? nseg : ntiles)) return;
+    const int nblk = (int)(np / TS);
+    int pu1 = 0, pf0 = 0;                            // PANEL: end of this workgroup's unit range, its first flush index
     auto next = [&](StreamVisit v) -> StreamVisit {  // scalar only; t >= ntiles after the workgroup's last visit
         if (++v.pass == npass) {
             v.pass = 0;
-            if constexpr (RUNS) {
+            if constexpr (PANEL) {
+                if (++v.J <= v.end) ++v.t;
+                else if (++v.u < pu1) {              // the next unit: the next row of the panel, or the first row of the next panel
+                    if (++v.I == nblk) { ++v.k; v.I = v.k * kPanelC; }
+                    v.J = v.k * kPanelC;
+                    v.end = v.J + kPanelC - 1 < v.I ? v.J + kPanelC - 1 : v.I;
+                    v.t = v.I * (v.I + 1) / 2 + v.J;
+                } else v.t = ntiles;
+            } else if constexpr (RUNS) {
                 if (++v.t < v.end) {
                     if (++v.J > v.I) { v.J = 0; ++v.I; }
                 } else if ((v.k += G) < nseg) {      // the workgroup's next segment
@@ -1537,10 +1563,20 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
         return v;
     };
     auto s0_of = [&](const StreamVisit &v) -> int { const int s0 = v.pass * NS; return s0 < s0max ? s0 : s0max; };
-    StreamVisit cv{RUNS ? seg_begin(blockIdx.x) : (int)blockIdx.x, 0, 0, 0, (int)blockIdx.x, RUNS ? seg_begin(blockIdx.x + 1) : 0};   // the visit being multiplied
-    cv.t = __builtin_amdgcn_readfirstlane(cv.t); cv.end = __builtin_amdgcn_readfirstlane(cv.end);
-    tile_index(cv.t, cv.I, cv.J);
-    cv.I = __builtin_amdgcn_readfirstlane(cv.I); cv.J = __builtin_amdgcn_readfirstlane(cv.J);
+    StreamVisit cv{RUNS ? seg_begin(blockIdx.x) : (int)blockIdx.x, 0, 0, 0, (int)blockIdx.x, RUNS ? seg_begin(blockIdx.x + 1) : 0, 0};   // the visit being multiplied
+    if constexpr (PANEL) {
+        const int *row = ptab + 5 * blockIdx.x;      // {u0, u1, k0, I0, f0}: scalar loads
+        cv.u = __builtin_amdgcn_readfirstlane(row[0]); pu1 = __builtin_amdgcn_readfirstlane(row[1]);
+        cv.k = __builtin_amdgcn_readfirstlane(row[2]); cv.I = __builtin_amdgcn_readfirstlane(row[3]); pf0 = __builtin_amdgcn_readfirstlane(row[4]);
+        if (cv.u >= pu1) return;                     // (more workgroups than units: uniform)
+        cv.J = cv.k * kPanelC;
+        cv.end = cv.J + kPanelC - 1 < cv.I ? cv.J + kPanelC - 1 : cv.I;
+        cv.t = cv.I * (cv.I + 1) / 2 + cv.J;
+    } else {
+        cv.t = __builtin_amdgcn_readfirstlane(cv.t); cv.end = __builtin_amdgcn_readfirstlane(cv.end);
+        tile_index(cv.t, cv.I, cv.J);
+        cv.I = __builtin_amdgcn_readfirstlane(cv.I); cv.J = __builtin_amdgcn_readfirstlane(cv.J);
+    }
     int tp = 0;                                      // parity of the visit count
 
     if (wave >= 4) {
@@ -1789,9 +1825,9 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             step(integral_constant<int, 3>{}, tp ^ 1);
             const StreamVisit nv = next(cv);
             if constexpr (RUNS) {
-                fresh = nv.t >= tend || nv.I != cv.I || nv.k != cv.k;   // the run ends with this tile: record I + k
+                fresh = PANEL ? (nv.t >= tend || nv.u != cv.u) : (nv.t >= tend || nv.I != cv.I || nv.k != cv.k);   // the run ends with this tile: record I + k (PANEL: the unit's, u)
                 if (fresh) {
-                    const int rec = cv.I + cv.k;
+                    const int rec = PANEL ? cv.u : cv.I + cv.k;
 #pragma unroll
                     for (int Q = 0; Q < NQ; ++Q) store1(run0[Q], run1[Q4 ? 0 : Q], (rec * TS + MT_ROWS * ((Q + q0) & (NQ - 1))) * 8);
                 }
@@ -1840,7 +1876,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             load(integral_constant<int, 3>{}, par, 1); __builtin_amdgcn_sched_barrier(0); mul(0, false); __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                         // the next step is staged; this step's images are free
             load(integral_constant<int, 0>{}, par ^ 1, 0); __builtin_amdgcn_sched_barrier(0); mul(1, false); __builtin_amdgcn_sched_barrier(0);
-            if constexpr (Q == NQ - 1) {             // P2 of the tile is complete: D row = s = lk + 4*reg, col = li
+            if constexpr (Q == NQ - 1 && !PANEL) {   // P2 of the tile is complete: D row = s = lk + 4*reg, col = li
                 if (cv.I != cv.J) {
                     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part2_all + (int64_t)s0_of(cv) * ntiles * TS, 0, part_records, 0x00020000);
 #pragma unroll
@@ -1855,13 +1891,52 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
                 }
             }
         };
+        // PANEL: the panel's column sums stay in REGISTERS (one set of four f64x2 per column block: the workgroup's 512 threads own the
+        // CU, the P2 waves have a hundred registers to spare); the slot c = J - k C is wave-uniform, so picking the set is a scalar branch.
+        // (A first version kept them in LDS: the read-modify-write after every tile sat on the P2 waves' way to the next barrier and cost
+        // the launch 38 us of its 611.)
+        f64x2 col[kPanelC][4];
+        int nflush = 0;
+        if constexpr (PANEL) {
+#pragma unroll
+            for (int c = 0; c < kPanelC; ++c)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) col[c][u] = (f64x2){0.0, 0.0};
+        }
 #pragma unroll 1
         for (;;) {
             step(integral_constant<int, 0>{});
             step(integral_constant<int, 1>{});
             step(integral_constant<int, 2>{});
             step(integral_constant<int, 3>{});
-            cv = next(cv);
+            const StreamVisit nv = next(cv);
+            if constexpr (PANEL) {
+                if (cv.I != cv.J) {                  // (a diagonal tile's transposed product is its own P1)
+                    const int c = cv.J - cv.k * kPanelC;
+#pragma unroll
+                    for (int cc = 0; cc < kPanelC; ++cc)
+                        if (c == cc) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) col[cc][u] += acc4[u];
+                        }
+                }
+                if (nv.t >= tend || nv.k != cv.k) {  // the workgroup leaves the panel: one record per column block, id (f0 + nflush) C + c
+                    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part2_all, 0, part_records, 0x00020000);
+#pragma unroll
+                    for (int c = 0; c < kPanelC; ++c) {
+                        const int rec = (pf0 + nflush) * kPanelC + c;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+                                store_f64(col[c][u][k], pr, (k ? hi_valid : lo_valid) ? s_lane + 128 * u : (int)0x80000000u, (int)(((int64_t)4 * k * ntiles + rec) * TS * 8));
+                            col[c][u] = (f64x2){0.0, 0.0};
+                        }
+                    }
+                    ++nflush;
+                }
+            }
+            cv = nv;
             if (cv.t >= tend) break;
         }
     }
@@ -1933,6 +2008,20 @@ symv_tile_batch_kernel(const double *__restrict__ Mp_all, int64_t mp_stride, con
 // The part1 records of row block I: the tiles (I, 0..I) -- or, when the multi-signal kernel wrote one record per RUN (runs_G = its
 // number of segments), the records I + k for the segments k = [k ntiles / nseg, (k+1) ntiles / nseg) that meet the row.
 struct Part1Range { int first, count; };
+// PANEL layout of the multi-signal kernel's partials (runs_G = -C, ptab = panel_plan's table; F0 behind the 5 G workgroup rows, whose count
+// sits in F0[-1]): row block I's contributions are its P1 records u(k, I), k = 0 .. I / C, then the P2 records (F0[kI] .. F0[kI + 1]) C + I - kI C.
+struct PanelList { int n1, nent, f0, c, C, nblk; };
+__device__ __forceinline__ PanelList panel_list(int I, int nblk, int runs_G, const int *__restrict__ ptab) {
+    const int C = -runs_G, kI = I / C;
+    const int *F0 = ptab + 1 + 5 * ptab[0];
+    const int f0 = F0[kI], f1 = F0[kI + 1];
+    return {kI + 1, kI + 1 + f1 - f0, f0, I - kI * C, C, nblk};
+}
+__device__ __forceinline__ unsigned panel_entry(const PanelList &l, int I, int e, unsigned p2off) {   // element offset of entry e's 128 values from part1
+    return e < l.n1 ? (unsigned)(e * l.nblk - l.C * (e * (e - 1) / 2) + I - e * l.C) * TS
+                    : p2off + (unsigned)((l.f0 + e - l.n1) * l.C + l.c) * TS;
+}
+
 __device__ __forceinline__ Part1Range part1_range(int I, int ntiles, int runs_G) {
     const int t0 = I * (I + 1) / 2;
     if (runs_G == 0) return {t0, I + 1};
@@ -2017,16 +2106,20 @@ symv_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ 
 // then combined in fixed order.
 __global__ void __launch_bounds__(1024)
 symv_reduce_runs_kernel(const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk, int ntiles, int64_t np,
-                        double *__restrict__ x, const AdmmStatus *status, const double *__restrict__ xb, int runs_G) {
+                        double *__restrict__ x, const AdmmStatus *status, const double *__restrict__ xb, int runs_G, const int *__restrict__ ptab) {
     const int sg = blockIdx.y, I = blockIdx.x;
     if (status != nullptr && status[sg].converged) return;
     __shared__ double sh[7 * TS];
     const double *part1 = part1_all + (int64_t)sg * ntiles * TS, *part2 = part2_all + (int64_t)sg * ntiles * TS;
     const int i = threadIdx.x & 127, g = threadIdx.x >> 7;
-    const Part1Range r1 = part1_range(I, ntiles, runs_G);
-    const int nent = r1.count + nblk - 1 - I, eshift = I + 1 - r1.count;
+    const bool panel = runs_G < 0;
+    const Part1Range r1 = part1_range(I, ntiles, panel ? 0 : runs_G);
+    const PanelList pl = panel ? panel_list(I, nblk, runs_G, ptab) : PanelList{0, 0, 0, 0, 1, nblk};
+    const int nent = panel ? pl.nent : r1.count + nblk - 1 - I, eshift = I + 1 - r1.count;
     const int per = (nent + 7) / 8, e0 = g * per, e1 = e0 + per < nent ? e0 + per : nent;
+    const unsigned p2off = (unsigned)(part2 - part1);
     auto at = [&](int e) -> const double * {
+        if (panel) return part1 + panel_entry(pl, I, e, p2off) + i;
         const int K = e + eshift;
         return e < r1.count ? part1 + ((int64_t)r1.first + e) * TS + i : part2 + ((int64_t)K * (K + 1) / 2 + I) * TS + i;
     };
@@ -2163,7 +2256,7 @@ __device__ __forceinline__ double pending_norm(const double *__restrict__ bn, in
 
 __global__ void __launch_bounds__(512)
 admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, const double *__restrict__ part2_all, int nblk,
-                          int ntiles, double *__restrict__ blocknorm_all, int parity, int commit_prev, int runs_G) {
+                          int ntiles, double *__restrict__ blocknorm_all, int parity, int commit_prev, int runs_G, const int *__restrict__ ptab) {
     const int sg = blockIdx.y;
     AdmmStatus *status = p.status + sg;
     __shared__ double sh[3 * TS], sq[TS], gs[TS], slot;
@@ -2181,14 +2274,17 @@ admm_fused_update2_kernel(AdmmParams p, const double *__restrict__ part1_all, co
     const double u_raw = p.u[gi], b_raw = (offset_form ? p.xb : p.b)[gi];
     const int gq = threadIdx.x >> 7;
     // the row block's contributions as one list: its part1 records (tiles (I, 0..I), or the runs of the multi-signal kernel), then part2 of tiles (K > I, I)
-    const Part1Range r1 = part1_range(I, ntiles, runs_G);
-    const int nent = r1.count + nblk - 1 - I, eshift = I + 1 - r1.count;      // (runs_G == 0: nent = nblk, eshift = 0)
+    const bool panel = runs_G < 0;                                            // (the multi-signal kernel's panel walk: uniform)
+    const Part1Range r1 = part1_range(I, ntiles, panel ? 0 : runs_G);
+    const PanelList pl = panel ? panel_list(I, nblk, runs_G, ptab) : PanelList{0, 0, 0, 0, 1, nblk};
+    const int nent = panel ? pl.nent : r1.count + nblk - 1 - I, eshift = I + 1 - r1.count;      // (runs_G == 0: nent = nblk, eshift = 0)
     const int per = (nent + 3) / 4, e0 = gq * per, e1 = e0 + per < nent ? e0 + per : nent;
     // (32-bit element offsets from part1: both partial arrays live in one buffer, part2 behind part1; the 64-bit form of this
     // address arithmetic was 300 instructions ahead of the first load)
     const unsigned p2off = (unsigned)(part2 - part1);
     const unsigned rowoff = (unsigned)r1.first * TS + i;
     auto at = [&](int e) -> const double * {
+        if (panel) return part1 + panel_entry(pl, I, e, p2off) + i;
         const int K = e + eshift;
         return part1 + (e < r1.count ? rowoff + (unsigned)e * TS : p2off + ((unsigned)(K * (K + 1) / 2 + I)) * TS + i);
     };
@@ -2727,13 +2823,73 @@ static unsigned stream_grid(unsigned ntiles) {
 }
 static int stream_runs(const AdmmParams &p);
 
-template <bool SPLIT, bool Q4, bool RUNS, bool FIX>
+// The panel walk's plan (symv_tile_mfma_ws_kernel<.., PANEL>): the unit list (row I of panel k; kPanelC tile columns per panel) cut into G
+// ranges of equal tile counts.  Device table (ints), cached per (device, nblk, G):  [0] = G;  then G rows {u0, u1, k0, I0, f0};  then
+// F0[npanel + 1], the first flush index of every panel (a workgroup flushes the panel's column sums once per panel it walks in).
+struct PanelPlan { const int *dev = nullptr; int G = 0, nflush = 0; };
+static PanelPlan panel_plan(int nblk, int G) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, PanelPlan> cache;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_tuple(device, nblk, G);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    constexpr int C = kPanelC;
+    const int npanel = (nblk + C - 1) / C;
+    const long long ntiles = (long long)nblk * (nblk + 1) / 2;
+    struct Unit { int k, I, cnt; };
+    std::vector<Unit> units;
+    for (int k = 0; k < npanel; ++k)
+        for (int I = k * C; I < nblk; ++I) units.push_back({k, I, std::min({C, I - k * C + 1, nblk - k * C})});
+    std::vector<int> tab(1 + 5 * (size_t)G + (size_t)npanel + 1, 0);
+    tab[0] = G;
+    std::vector<int> flushes_of_panel((size_t)npanel, 0);
+    size_t u = 0;
+    long long done = 0;
+    int f = 0;
+    for (int g = 0; g < G; ++g) {
+        const long long want = ntiles * (g + 1) / G;            // cumulative tiles after workgroup g (the last one takes the rest)
+        const size_t u0 = u;
+        while (u < units.size() && (g == G - 1 || done + units[u].cnt / 2 < want)) { done += units[u].cnt; ++u; }
+        int *row = tab.data() + 1 + 5 * (size_t)g;
+        row[0] = (int)u0; row[1] = (int)u; row[4] = f;
+        if (u > u0) {
+            row[2] = units[u0].k; row[3] = units[u0].I;
+            for (size_t q = u0; q < u; ++q)
+                if (q == u0 || units[q].k != units[q - 1].k) { ++flushes_of_panel[(size_t)units[q].k]; ++f; }
+        }
+    }
+    // flush order = (workgroup, panel), and a workgroup's panels follow the previous workgroup's: panel k's flushes are consecutive
+    int *F0 = tab.data() + 1 + 5 * (size_t)G;
+    for (int k = 0; k < npanel; ++k) F0[k + 1] = F0[k] + flushes_of_panel[(size_t)k];
+    PanelPlan pl;
+    int *dev = nullptr;
+    if (hipMalloc(&dev, tab.size() * sizeof(int)) != hipSuccess || hipMemcpy(dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        return pl;                                              // (not cached: the caller falls back to the run walk)
+    }
+    pl.dev = dev; pl.G = G; pl.nflush = f;
+    cache[key] = pl;
+    return pl;
+}
+static bool stream_panel(const AdmmParams &p);
+
+template <bool SPLIT, bool Q4, bool RUNS, bool FIX, bool PANEL = false>
 static void launch_mfma_stream(const AdmmParams &p, unsigned ntiles, double *part1, double *part2, const AdmmStatus *status, hipStream_t s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS, FIX>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)symv_ws_lds());   // per device; cheap
+    const size_t lds = symv_ws_lds() + (PANEL ? kPanelLds : 0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS, FIX, PANEL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);   // per device; cheap
+    if constexpr (PANEL) {
+        const PanelPlan pl = panel_plan((int)(p.np / TS), (int)stream_cus());
+        hipLaunchKernelGGL((symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS, FIX, PANEL>), dim3((unsigned)pl.G), dim3(512), lds, s,
+                           reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status, pl.G, FIX ? p.mp_types : nullptr, pl.dev + 1);
+        return;
+    }
     const int nseg = RUNS ? stream_runs(p) : 0;
-    hipLaunchKernelGGL((symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS, FIX>), dim3(RUNS ? std::min(stream_cus(), (unsigned)nseg) : stream_grid(ntiles)), dim3(512), symv_ws_lds(), s,
-                       reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status, nseg, FIX ? p.mp_types : nullptr);
+    hipLaunchKernelGGL((symv_tile_mfma_ws_kernel<SPLIT, Q4, RUNS, FIX, PANEL>), dim3(RUNS ? std::min(stream_cus(), (unsigned)nseg) : stream_grid(ntiles)), dim3(512), lds, s,
+                       reinterpret_cast<const unsigned char *>(p.Mp), p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status, nseg, FIX ? p.mp_types : nullptr, nullptr);
 }
 
 // multi-signal handles: stream (default: persistent, register-staged MFMA kernel), dma (LDS-DMA staged MFMA kernel, 8-byte
@@ -2763,6 +2919,16 @@ static int stream_runs(const AdmmParams &p) {
     const unsigned rounds = (ntiles + cus * L - 1) / (cus * L), nseg = cus * rounds;
     return nseg + (unsigned)nblk <= ntiles ? (int)nseg : 0;
 }
+// The panel walk (round 5) where the run walk applies and the four-block MFMA form does (up to 8 signals: its LDS images leave room for the
+// panel's column sums); LPVS_MULTI_WALK=runs keeps round 3's segments.  The consumers get runs_G = -kPanelC and the plan's table.
+static bool stream_panel(const AdmmParams &p) {
+    const bool off = [] { const char *e = getenv("LPVS_MULTI_WALK"); return e && std::string(e) == "runs"; }();   // (read per call: tests switch it)
+    const bool q4_off = [] { const char *e = getenv("LPVS_MULTI_MFMA"); return e && std::string(e) == "16"; }();
+    if (off || q4_off || stream_runs(p) == 0 || p.ns > 8 || !p.mp_split) return false;
+    return panel_plan((int)(p.np / TS), (int)stream_cus()).dev != nullptr;
+}
+static int stream_layout(const AdmmParams &p) { return stream_panel(p) ? -kPanelC : stream_runs(p); }
+static const int *stream_table(const AdmmParams &p) { return stream_panel(p) ? panel_plan((int)(p.np / TS), (int)stream_cus()).dev : nullptr; }
 
 // the mat-vec of one iteration on the packed symmetric form (tile partials -> part1 / part2)
 static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hipStream_t s) {
@@ -2775,6 +2941,11 @@ static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hip
         // up to 8 signals: the 4x4x4 four-block MFMA (no padded columns); LPVS_MULTI_MFMA=16 keeps the 16-column instruction
         const bool q4_off = [] { const char *e = getenv("LPVS_MULTI_MFMA"); return e && std::string(e) == "16"; }();
         const bool q4 = p.ns <= 8 && !q4_off, runs = stream_runs(p) != 0;
+        if (stream_panel(p)) {                       // (6-byte / mixed tiles, up to 8 signals, a triangle large enough for runs)
+            if (p.mp_types != nullptr) launch_mfma_stream<true, true, true, true, true>(p, ntiles, part1, part2, status, s);
+            else launch_mfma_stream<true, true, true, false, true>(p, ntiles, part1, part2, status, s);
+            return;
+        }
         auto go = [&](auto split, auto q4c, auto runsc) {
             if constexpr (decltype(split)::value) {
                 if (p.mp_types != nullptr) { launch_mfma_stream<true, decltype(q4c)::value, decltype(runsc)::value, true>(p, ntiles, part1, part2, status, s); return; }
@@ -2815,10 +2986,10 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
     launch_sym_matvec(p, p.status, s);
     if (fused_ok(p)) {
-        hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0, stream_runs(p));
+        hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0, stream_layout(p), stream_table(p));
     } else {
-        if (const int runs = stream_runs(p))
-            hipLaunchKernelGGL(symv_reduce_runs_kernel, dim3((unsigned)nblk, ns), dim3(1024), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, runs);
+        if (const int runs = stream_layout(p))
+            hipLaunchKernelGGL(symv_reduce_runs_kernel, dim3((unsigned)nblk, ns), dim3(1024), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, runs, stream_table(p));
         else
             hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, 0);
         hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
@@ -2896,30 +3067,127 @@ int32_t launch_symv(const double *M, int64_t np, const double *rhs, double *x, h
     return LPVS_OK;
 }
 
-// r[sg][i] = b[sg][i] - (Hx[sg][i] ... with H = G + shift I) on the first n entries of every signal, 0 on the pad
-__global__ void __launch_bounds__(256)
-shifted_residual_kernel(const double *__restrict__ b, const double *__restrict__ Gx, const double *__restrict__ x, double shift, int64_t n,
-                        int64_t np, int64_t total, double *__restrict__ r) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < total) r[i] = (i % np) < n ? b[i] - fma(shift, x[i], Gx[i]) : 0.0;
+// ---- accurate accumulation for the two places that need it: the offset vector's residual and the x-update's correction ---------
+// Accumulation as accurate as if carried with twice the mantissa and rounded once (Ogita, Rump, Oishi: Dot2): error-free products
+// (fma), error-free sums (Knuth's two-sum), the error terms added up in a second double.  -ffp-contract=off (Makefile) and the _rn
+// intrinsics keep the compiler from fusing or reassociating any of it.
+struct dot2_t { double s, c; };
+__device__ __forceinline__ void dot2_add(dot2_t &a, double p, double e) {      // a += p + e, p the leading term
+    const double s = __dadd_rn(a.s, p), bb = __dadd_rn(s, -a.s);
+    const double err = __dadd_rn(__dadd_rn(a.s, -__dadd_rn(s, -bb)), __dadd_rn(p, -bb));
+    a.s = s;
+    a.c = __dadd_rn(a.c, __dadd_rn(e, err));
+}
+__device__ __forceinline__ void dot2_fma(dot2_t &a, double x, double y) {      // a += x * y
+    const double p = __dmul_rn(x, y);
+    dot2_add(a, p, __fma_rn(x, y, -p));
 }
 
-// xb = M b for every signal, then `steps` rounds  xb += M (b - (G + shift I) xb)  against the Gram the inverse was taken of.
-// The offset form of the x-update (x = xb + M~ (z-u)/mu) carries xb through every iteration unchanged: the forward error of
-// the explicit inverse in xb (|M H - I| ~ 2e-13 at n = 8192, on a vector that lies in H's strong directions) is a constant
-// perturbation of the iteration's fixed point, which the iterates approach as they converge; refined, what is left of the
-// inverse's error multiplies x - xb only.  t1, t2: [ns][np] scratch.
+// r[sg][i] = bsign b[sg][i] - sum_j A[i][j] x[sg][j] - shift x[sg][i] in that arithmetic, rounded once; 0 on the pad (b may be NULL: 0).
+// One wave per row (lane covers columns lane + 64 t), four rows per workgroup; the row is read ONCE for up to 8 signals (blockIdx.y =
+// group of 8 signals): the matrix of a multi-signal handle is 8 GiB.
+constexpr int kDdSignals = 8;
+__global__ void __launch_bounds__(256)
+shifted_residual_dd_kernel(const double *__restrict__ A, int64_t np, int64_t n, int ns, const double *__restrict__ b_all, double bsign,
+                           const double *__restrict__ x_all, double shift, double *__restrict__ r_all) {
+    const int sg0 = blockIdx.y * kDdSignals, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nsg = ns - sg0 < kDdSignals ? ns - sg0 : kDdSignals;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= np) return;
+    const double *a = A + row * np;
+    dot2_t acc[kDdSignals];
+#pragma unroll
+    for (int q = 0; q < kDdSignals; ++q) acc[q] = {0.0, 0.0};
+    if (row < n)
+        for (int64_t j = lane; j < np; j += 64) {
+            const double m = -a[j];
+#pragma unroll
+            for (int q = 0; q < kDdSignals; ++q)
+                if (q < nsg) dot2_fma(acc[q], m, x_all[(int64_t)(sg0 + q) * np + j]);
+        }
+#pragma unroll
+    for (int q = 0; q < kDdSignals; ++q) {
+        if (q >= nsg) break;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double os = __shfl_xor(acc[q].s, o, 64), oc = __shfl_xor(acc[q].c, o, 64);
+            dot2_add(acc[q], os, oc);
+        }
+        if (lane == 0) {
+            double r = 0.0;
+            if (row < n) {
+                const int64_t gi = (int64_t)(sg0 + q) * np + row;
+                dot2_fma(acc[q], -shift, x_all[gi]);
+                if (b_all != nullptr) dot2_add(acc[q], bsign * b_all[gi], 0.0);
+                r = __dadd_rn(acc[q].s, acc[q].c);
+            }
+            r_all[(int64_t)(sg0 + q) * np + row] = r;
+        }
+    }
+}
+static void launch_residual_dd(const double *A, int64_t np, int64_t n, int ns, const double *b, double bsign, const double *x, double shift, double *r,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(shifted_residual_dd_kernel, dim3((unsigned)ceil_div(np, 4), (unsigned)ceil_div(ns, kDdSignals)), dim3(256), 0, s, A, np, n, ns, b, bsign, x, shift, r);
+}
+
+// ---- the offset vector xb = (G + shift I)^-1 b of the x-update's offset form: xb = M b, then `steps` rounds  xb += M (b - (G + shift I) xb)
+// with the residual accumulated as above -- the forward error of the explicit inverse (|M H - I| ~ 2e-13 at n = 8192) leaves xb, whatever
+// it multiplies in the iteration.  G, b are the problem's data, exact as given.  t1, t2: [ns][np] scratch.
 int32_t launch_offset_vector_refined(const double *G, const double *M, int64_t np, int64_t n, int ns, const double *b, double shift, int steps,
                                      double *xb, double *t1, double *t2, hipStream_t s) {
     launch_symv_raw(M, np, b, xb, nullptr, ns, s);
     const int64_t total = np * (int64_t)ns;
     const unsigned nb = (unsigned)ceil_div(total, 256);
     for (int k = 0; k < steps; ++k) {
-        launch_symv_raw(G, np, xb, t1, nullptr, ns, s);                                                          // t1 = G xb
-        hipLaunchKernelGGL(shifted_residual_kernel, dim3(nb), dim3(256), 0, s, b, t1, xb, shift, n, np, total, t2);   // t2 = b - H xb
+        launch_residual_dd(G, np, n, ns, b, 1.0, xb, shift, t2, s);                                              // t2 = b - H xb
         launch_symv_raw(M, np, t2, t1, nullptr, ns, s);                                                          // t1 = M r
         hipLaunchKernelGGL(vec_add_kernel, dim3(nb), dim3(256), 0, s, xb, t1, total);
     }
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
+// ---- the x-update's systematic error, removed (round 5).
+// The iteration applies M~ = (I + E) H^-1 -- the explicit inverse with its forward error, |E| = |M H - I| ~ 2e-13 elementwise at cfg3,
+// and the 2^-40 rounding of the packed copy on top -- instead of H^-1:  x_{k+1} = xb + M~ v_k = H^-1 (b + v_k) + E w_{k+1},  w = M~ v.
+// E w is the SAME vector iteration after iteration once the iterates move slowly, i.e. a constant forcing of the map, and at cfg3 the
+// map's slowest mode amplifies it ~10^3 times on the way to the fixed point: every f64 evaluation of the iteration -- this library's
+// with any storage of M and either launch scheme, and a CPU restatement's Cholesky solves alike -- sits 0.3 .. 1.3e-9 from the
+// extended-precision iterates after 2000 iterations, all along one direction (profiles/r05_cfg3_error_directions.txt), where one
+// ulp of INPUT uncertainty moves the answer by 1e-10.
+// The cure is one step of iterative refinement -- per CORRECTION, not per iteration: with v the right-hand side the next x-update is
+// about to multiply,   w = M~ v,   r = v - H w  (accumulated in twice the mantissa: formed in doubles it would drown in its own
+// rounding, eps cond(H)),   d = M~ r,   and the offset vector becomes  xb_eff = xb + d  = xb - E w.  Between corrections the error
+// is E (w_k - w), second order; the fixed point of the corrected map is the exact one whatever M~ is (it only preconditions), so the
+// packed copy's rounding is corrected along with the inverse's.  Both M~ products go through the handle's own packed mat-vec.
+// t: 3 x [ns][np] scratch.
+__global__ void __launch_bounds__(256)
+vec_sum_kernel(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = a[i] + b[i];
+}
+// out = M~ rhs through the packed tiles (the handle's stand-alone mat-vec + the gather of its partials), no offset, no status
+static void launch_packed_apply(const AdmmParams &p, const double *rhs, double *out, hipStream_t s) {
+    AdmmParams q = p;
+    q.rhs = const_cast<double *>(rhs);
+    launch_sym_matvec(q, nullptr, s);
+    const int nblk = (int)(p.np / TS);
+    const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2), ns = (unsigned)p.ns;
+    double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
+    if (const int runs = stream_layout(p))
+        hipLaunchKernelGGL(symv_reduce_runs_kernel, dim3((unsigned)nblk, ns), dim3(1024), 0, s, part1, part2, nblk, (int)ntiles, p.np, out, nullptr, nullptr, runs, stream_table(p));
+    else
+        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, out, nullptr, nullptr, 0);
+}
+int32_t launch_xupdate_correction(const AdmmParams &p, const double *G, double shift, const double *xb0, double *xb_eff, double *t, hipStream_t s) {
+    if (p.part == nullptr || p.Mp == nullptr) { set_error("the x-update correction needs the packed inverse"); return LPVS_ESTATE; }
+    const int64_t total = p.np * (int64_t)p.ns;
+    const unsigned nb = (unsigned)ceil_div(total, 256);
+    double *w = t, *r = t + total, *d = t + 2 * total;
+    launch_packed_apply(p, p.rhs, w, s);                                             // w = M~ v
+    launch_residual_dd(G, p.np, p.n, p.ns, p.rhs, 1.0, w, shift, r, s);              // r = v - H w
+    launch_packed_apply(p, r, d, s);                                                 // d = M~ r
+    hipLaunchKernelGGL(vec_sum_kernel, dim3(nb), dim3(256), 0, s, xb0, (const double *)d, xb_eff, total);   // xb_eff = xb + d
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }

@@ -364,6 +364,17 @@ struct lpvs_problem {
     int64_t Mp_fixed_tiles = 0;
     bool Mp_demoted = false;      // mixed storage was asked for, but fewer than half of the tiles qualified: stored as split
     DevBuf xb; bool offset_form = false;   // xb = M * (signed b), computed at admm_init from the full-precision M (AdmmParams::xb)
+    // the x-update's systematic error removed (admm.hip, launch_xupdate_correction): xb0 = the refined offset vector, xb = xb0 - E (x_k - xb0)
+    // re-formed after the iterations k = 1, 2, 4, 8, ... (k_enq = iterations enqueued since lpvs_admm_init / lpvs_admm_set_state)
+    DevBuf xb0, corr; int xcorr_base = 0, xcorr_every = 0; long long k_enq = 0;
+    // the schedule: after the iterations base^j (xcorr_base >= 2), or after iteration 16 and every xcorr_every-th one; 0 0 = no correction
+    long long next_correction(long long k) const {
+        if (xcorr_every > 0) { if (k < 16 && xcorr_every > 16) return 16; return (k / xcorr_every + 1) * (long long)xcorr_every; }
+        long long q = 1;
+        while (q <= k) q *= xcorr_base;
+        return q;
+    }
+    bool xcorr() const { return xcorr_base >= 2 || xcorr_every > 0; }
     DevBuf fi; long long fi_sync = -1; double fi_R = 0, fi_xbmax = 0;      // one-launch iteration (AdmmParams::fi): its records are those of iteration fi_sync
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
@@ -1225,16 +1236,33 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     if (linear_sign < 0) for (auto &q : hb) q = -q;
     LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
     // reduced-precision copies of M (split, f32) are only ever applied to (z-u)/mu: x = xb + M~ (z-u)/mu, xb = M b in full precision
-    h->offset_form = h->np >= kSymmetricMinNp && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
+    // (round 5: the 8-byte storage too -- the offset vector is refined against a double-double residual, which the in-loop product M (b + v) cannot be)
+    h->offset_form = h->np >= kSymmetricMinNp && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
     if (h->offset_form) {
         if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
-        // every signal's M b, refined against the Gram the handle still holds (launch_offset_vector_refined says why); rhs and
-        // scratch are free until launch_admm_init below writes the state
+        // every signal's M b, refined against the Gram the handle still holds with a double-double residual (admm.hip,
+        // launch_offset_vector_refined, says why); rhs and scratch are free until launch_admm_init below writes the state.
+        // LPVS_XB_REFINE = rounds (A/B measurements: 0 = the plain product of rounds 1-4)
         int steps = 2;
         if (const char *e = getenv("LPVS_XB_REFINE")) steps = atoi(e) < 0 ? 0 : atoi(e);
         LPVS_TRY(launch_offset_vector_refined(h->G.as<double>(), h->M.as<double>(), h->np, h->n, (int)h->ns, h->bs.as<double>(), h->M_shift, steps,
                                               h->xb.as<double>(), h->rhs.as<double>(), h->scratch.as<double>(), s));
-    }
+        // LPVS_XUPDATE_CORRECTION = base of the correction schedule (2: after iterations 1, 2, 4, ...; default), 0 = none (A/B measurements)
+        // Handles with several right-hand sides run without it unless asked: a correction is two products over the f64 matrices per signal
+        // in ~50 flops per element (15 ms for the 8 channels of n = 32768, eleven times in 2000 iterations: +11 %), where one signal at
+        // n = 8192 pays 0.2 ms.
+        h->xcorr_base = 0; h->xcorr_every = h->ns == 1 ? 512 : 0;   // after iteration 16 and every 512th: four corrections in 2000 iterations (DESIGN.md section 6 has the table)
+        if (const char *e = getenv("LPVS_XUPDATE_CORRECTION")) {   // "0": none; "B": after iterations B^j; "eN": after iteration 16 and every N-th
+            if (e[0] == 'e') { h->xcorr_base = 0; h->xcorr_every = atoi(e + 1) > 0 ? atoi(e + 1) : 0; }
+            else { h->xcorr_every = 0; h->xcorr_base = atoi(e) < 2 ? 0 : atoi(e); }
+        }
+        if (h->xcorr()) {
+            if (!h->xb0.p) LPVS_TRY(h->xb0.alloc(v));
+            if (!h->corr.p) LPVS_TRY(h->corr.alloc(3 * v));
+            LPVS_HIP(hipMemcpyAsync(h->xb0.p, h->xb.p, v, hipMemcpyDeviceToDevice, s));
+        }
+    } else { h->xcorr_base = 0; h->xcorr_every = 0; }
+    h->k_enq = 0;
     if (h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && !h->fi.p) LPVS_TRY(h->fi.alloc(sizeof(double) * fi_doubles(h->np)));
     const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_init(p, s));
@@ -1243,7 +1271,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         LPVS_TRY(launch_fi_setup(p, 0, true, s));
         double hc[2] = {0, 0};
         LPVS_TRY(fi_read_consts(p, hc, s));              // (synchronises)
-        h->fi_R = hc[0]; h->fi_xbmax = hc[1]; h->fi_sync = 0;
+        h->fi_R = hc[0]; h->fi_xbmax = hc[1] * (1.0 + 0x1p-20); h->fi_sync = 0;   // (max|xb| bounds the corrected offset vector too: it moves by ~1e-12 of it)
     }
     LPVS_HIP(hipStreamSynchronize(s));
     h->inited = true;
@@ -1262,6 +1290,9 @@ int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *
     const AdmmParams p = make_params(h);
     LPVS_TRY(launch_admm_restate(p, iters_done, s));
     h->fi_sync = -1;                                  // (the next run rebuilds the one-launch iteration's records from the new state)
+    h->k_enq = iters_done;
+    if (h->xcorr() && iters_done > 0)                 // re-entry: the correction of the state handed in (an uninterrupted run holds the one of its last scheduled iteration: same to second order)
+        LPVS_TRY(launch_xupdate_correction(make_params(h), h->G.as<double>(), h->M_shift, h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
     LPVS_HIP(hipStreamSynchronize(s));
     return LPVS_OK;
 }
@@ -1307,7 +1338,29 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
             }
             while (todo >= h->admm_graph_iters) { LPVS_HIP(hipGraphLaunch(h->admm_graph, s)); todo -= h->admm_graph_iters; }
         }
-        if (todo > 0) LPVS_TRY(launch_admm_iterations(p, todo, s));
+        while (todo > 0) {
+            // the correction schedule cuts the run at the iterations base^j, whatever chunks the caller asks for: the iterates do not depend on the chunking
+            int64_t step = todo;
+            long long next_corr = 0;
+            if (h->xcorr()) {
+                next_corr = h->next_correction(h->k_enq);
+                if (next_corr - h->k_enq < step) step = next_corr - h->k_enq;
+            }
+            LPVS_TRY(launch_admm_iterations(p, step, s));
+            todo -= step; h->k_enq += step;
+            if (h->xcorr() && h->k_enq == next_corr) {
+                LPVS_TRY(launch_xupdate_correction(p, h->G.as<double>(), h->M_shift, h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
+                if (todo > 0 && !(h->tol > 0)) p.fi_base += step;   // (no stopping test can fire: the device committed exactly `step` more)
+                else if (todo > 0) {   // the next sub-chunk starts from the iteration count the device committed (a stopping test may have fired)
+                    LPVS_HIP(hipMemcpyAsync(st.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
+                    LPVS_HIP(hipStreamSynchronize(s));
+                    bool alls = true;
+                    for (auto &q : st) alls = alls && q.converged;
+                    if (alls) break;
+                    p.fi_base = st[0].iters;
+                }
+            }
+        }
         LPVS_HIP(hipEventRecord(h->ev[0].b, s));
     }
     LPVS_HIP(hipMemcpyAsync(st.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
@@ -1373,6 +1426,19 @@ int32_t lpvs_admm_status(lpvs_problem *h, int64_t signal, int64_t *iters_done, d
     if (nxz) *nxz = st.nxz;
     if (converged) *converged = st.converged;
     return LPVS_OK;
+}
+
+int32_t lpvs_admm_get_offset_f64(lpvs_problem *h, double *xb_out) {
+    if (!h || !xb_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (!h->inited || !h->offset_form || !h->xb.p) { set_error("this handle has no offset vector (n < 2048, or lpvs_admm_init has not run)"); return LPVS_ESTATE; }
+    LPVS_HIP(hipSetDevice(h->device));
+    return copy_state_out(h, h->xb.p, xb_out);
+}
+int32_t lpvs_admm_set_offset_f64(lpvs_problem *h, const double *xb) {
+    if (!h || !xb) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (!h->inited || !h->offset_form || !h->xb.p) { set_error("this handle has no offset vector (n < 2048, or lpvs_admm_init has not run)"); return LPVS_ESTATE; }
+    LPVS_HIP(hipSetDevice(h->device));
+    return copy_state_in(h, h->xb.p, xb);
 }
 
 int32_t lpvs_admm_get_f64(lpvs_problem *h, double *x_out, double *z_out, double *u_out) {

@@ -243,6 +243,9 @@ struct AdmmParams {
     int *sm_ctl = nullptr;
 };
 bool small_iter_applicable(const AdmmParams &p);
+// one step of iterative refinement for the right-hand side the next x-update multiplies (p.rhs), its residual in twice-the-mantissa
+// accumulation against H = G + shift I; xb_eff = xb0 + M~ (v - H M~ v).  t: 3 x [ns][np] scratch (admm.hip says why)
+int32_t launch_xupdate_correction(const AdmmParams &p, const double *G, double shift, const double *xb0, double *xb_eff, double *t, hipStream_t s);
 size_t fi_doubles(int64_t np, int64_t nprob = 1);
 bool fi_applicable(const AdmmParams &p);
 int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s);

@@ -247,7 +247,8 @@ def test_cfg5_fullshape_eight_channels_invariants(L, oracle):
         Gblk = Gd.index_select(0, ct).index_select(1, ct).cpu().numpy()
         phase = 4.5e-16 * float(wh.max() * Xh.max())
         eg = np.abs(Gblk - Go).max() / np.abs(Go).max()
-        eb = max(np.abs(B[cols, q] - Bo[:, q]).max() / np.abs(Bo[:, q]).max() for q in range(ns))
+        # (of the channel's largest right-hand-side entry over ALL rows, as for cfg3: the five groups need not hold a channel's own frequencies)
+        eb = max(np.abs(B[cols, q] - Bo[:, q]).max() / np.abs(B[:, q]).max() for q in range(ns))
         print(f"cfg5 N=2^20 n=32768 default ({p.timing()['gram_form']}) form vs oracle columns: G block {eg:.2e}, B rows {eb:.2e}; phase-rounding bound {phase:.2e}")
         assert p.timing()["gram_form"] == "ap-nufft"
         assert eg <= min(1e-12 + phase, 5e-12) and eb <= min(1e-12 + phase, 5e-12), (eg, eb, phase)

@@ -35,15 +35,15 @@ def _run(L, problem, prox, chunks, monkeypatch, mode, tol=0.0, state=None):
     with L.Problem.lpv(y, X, V, w, Nv) as p:
         p.set_prox(prox)
         p.admm_init(None, μ=0.05, tol=tol)
-        if state is not None:
-            p.admm_set_state(*state)
+        if state is not None:                            # (x, z, u, iterations, offset vector of the x-update)
+            p.admm_set_state(state[0], state[1], state[2], state[3], offset=state[4] if len(state) > 4 else None)
         info = p.matvec_info()
         assert info["kernel"] == ("symv_tile_mixed_kernel" if mode == "two" else "admm_iter_mixed_kernel"), info
         for c in chunks:
             it, nxz, conv = p.admm_run(c)
             if conv:
                 break
-        return (it, nxz, conv) + p.admm_get()
+        return (it, nxz, conv) + p.admm_get() + (p.admm_get_offset(),)
 
 
 @pytest.mark.parametrize("kind", ["group", "l1", "l0"])
@@ -52,7 +52,7 @@ def test_one_launch_iteration_equals_two_launch_iteration(L, problem, kind, monk
     a = _run(L, problem, prox, [300], monkeypatch, "two")
     b = _run(L, problem, prox, [300], monkeypatch, "one")
     assert a[0] == b[0] == 300
-    for va, vb in zip(a[3:], b[3:]):                     # x, z, u
+    for va, vb in zip(a[3:6], b[3:6]):                     # x, z, u
         assert np.abs(va - vb).max() <= 1e-12 * max(np.abs(va).max(), 1.0), np.abs(va - vb).max()
     assert np.array_equal(a[4] != 0, b[4] != 0)          # same support
     assert abs(a[1] - b[1]) <= 1e-10 * a[1]
@@ -64,7 +64,7 @@ def test_one_launch_iteration_does_not_depend_on_chunking(L, problem, monkeypatc
     for chunks in ([80, 80, 80], [1, 1, 2, 3, 233], [239, 1], [7] * 34 + [2]):
         r = _run(L, problem, prox, chunks, monkeypatch, "one")
         assert r[0] == ref[0] == 240 and r[1] == ref[1]
-        for a, b in zip(r[3:], ref[3:]):
+        for a, b in zip(r[3:6], ref[3:6]):
             assert np.array_equal(a, b)
 
 
@@ -78,7 +78,7 @@ def test_one_launch_iteration_stops_where_the_two_launch_one_does(L, problem, mo
         for chunks in ([4000], [a[0] - 1, 50], [a[0], 50], [a[0] + 1, 50], [13] * 400):
             b = _run(L, problem, prox, chunks, monkeypatch, "one", tol=tol)
             assert b[2] and b[0] == a[0], (tol, chunks, a[0], b[0])
-            for va, vb in zip(a[3:], b[3:]):
+            for va, vb in zip(a[3:6], b[3:6]):
                 assert np.abs(va - vb).max() <= 1e-12 * max(np.abs(va).max(), 1.0)
 
 
@@ -86,9 +86,10 @@ def test_one_launch_iteration_resumes_from_a_saved_state(L, problem, monkeypatch
     prox = _proxes(L, problem[1], problem[2])["group"]
     full = _run(L, problem, prox, [200], monkeypatch, "one")
     half = _run(L, problem, prox, [120], monkeypatch, "one")
-    rest = _run(L, problem, prox, [80], monkeypatch, "one", state=(half[3], half[4], half[5], 120))
+    # (x, z, u and the x-update's offset vector, re-formed after iteration 16 and every 512th: part of the state in between)
+    rest = _run(L, problem, prox, [80], monkeypatch, "one", state=(half[3], half[4], half[5], 120, half[6]))
     assert rest[0] == 200
-    for a, b in zip(rest[3:], full[3:]):
+    for a, b in zip(rest[3:6], full[3:6]):
         assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1.0)
 
 

@@ -87,8 +87,10 @@ def test_ridge_solves_on_ill_conditioned_lpv_bases(L, oracle):
 
 
 def test_resume_from_saved_state_continues_bit_for_bit(L):
-    """SURVEY section 5 (checkpoint / resume): x, z, u and the iteration count read back from one handle and installed into
-    a fresh one continue the run bit for bit, including the stopping iteration."""
+    """SURVEY section 5 (checkpoint / resume): x, z, u, the x-update's offset vector (round 5: it is re-formed after the iterations
+    1, 2, 4, ... and so part of the state between two of them -- iteration 60 sits between 32 and 64) and the iteration count read
+    back from one handle and installed into a fresh one continue the run bit for bit, including the stopping iteration.  Without the
+    offset vector the library re-forms it from the x it is given: the same run to second order (1e-10 here), same stopping iteration."""
     n, mu = 2304, 0.05
     G, b = _spd_problem(n, 9)
     with L.Problem.gram(G, b) as p:
@@ -96,17 +98,29 @@ def test_resume_from_saved_state_continues_bit_for_bit(L):
         p.admm_init(None, μ=mu, tol=1e-7)
         p.admm_run(60)
         x1, z1, u1 = p.admm_get()
+        off1 = p.admm_get_offset()
         it_full, nxz_full, conv_full = p.admm_run(5000)
         xf, zf, uf = p.admm_get()
-    assert conv_full and it_full > 60
+    assert conv_full and it_full > 60 and off1 is not None and off1.shape == (n,)
+    with L.Problem.gram(G, b) as q:
+        q.set_prox(L.NormL1(0.3))
+        q.admm_init(None, μ=mu, tol=1e-7)
+        q.admm_set_state(x1, z1, u1, iters=60, offset=off1)
+        it, nxz, conv = q.admm_run(5000)
+        xr, zr, ur = q.admm_get()
+    assert (it, conv) == (it_full, conv_full) and nxz == nxz_full
+    assert np.array_equal(zr, zf) and np.array_equal(xr, xf) and np.array_equal(ur, uf)
     with L.Problem.gram(G, b) as q:
         q.set_prox(L.NormL1(0.3))
         q.admm_init(None, μ=mu, tol=1e-7)
         q.admm_set_state(x1, z1, u1, iters=60)
         it, nxz, conv = q.admm_run(5000)
         xr, zr, ur = q.admm_get()
-    assert (it, conv) == (it_full, conv_full) and nxz == nxz_full
-    assert np.array_equal(zr, zf) and np.array_equal(xr, xf) and np.array_equal(ur, uf)
+    assert (it, conv) == (it_full, conv_full) and abs(nxz - nxz_full) <= 1e-8 * nxz_full
+    assert np.linalg.norm(zr - zf) <= 1e-10 * np.linalg.norm(zf) and np.array_equal(zr != 0, zf != 0)
+    with L.Problem.gram(G[:512, :512].copy(), b[:512].copy()) as q:           # (n < 2048: the plain x-update, no offset vector)
+        q.set_prox(L.NormL1(0.3)); q.admm_init(None, μ=mu, tol=1e-7)
+        assert q.admm_get_offset() is None
 
 
 def test_device_inputs_of_the_signals_driver_are_validated(L):

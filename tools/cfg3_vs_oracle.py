@@ -28,10 +28,23 @@ ap.add_argument("--no-f64-oracle", action="store_true")
 ap.add_argument("--reuse-ld", default=None)
 ap.add_argument("--variants", action="store_true")
 ap.add_argument("--perturb", action="store_true")
+ap.add_argument("--xcorr", default=None, help="bases of the x-update correction schedule to run the device legs with (LPVS_XUPDATE_CORRECTION: 0 = none, 2, 4, ...)")
 ap.add_argument("counts", nargs="*", type=int)
 a = ap.parse_args()
 counts = a.counts or [200, 500, 1000, 2000]
 refines = [None] if a.refine is None else [int(r) for r in a.refine.split(",")]
+if a.xcorr is not None:                       # legs = (refinement rounds, correction base) pairs, written "r/x"
+    refines = ["%s/%s" % (r if r is not None else 2, x) for r in refines for x in a.xcorr.split(",")]
+
+
+def set_leg(r):
+    if r is None:
+        return
+    if isinstance(r, str):
+        rr, xx = r.split("/")
+        os.environ["LPVS_XB_REFINE"] = rr; os.environ["LPVS_XUPDATE_CORRECTION"] = xx
+    else:
+        os.environ["LPVS_XB_REFINE"] = str(r)
 y, X, V, w = bench.synth_signal(1 << 20, 512, 0, torch.device("cuda"))
 rel = lambda p, q: np.linalg.norm(p - q) / np.linalg.norm(q)
 
@@ -52,18 +65,16 @@ with L.Problem.lpv(y, X, V, w, 8) as p:
     G, b = p.get_gram()
     p.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, 512, 16))
     for r in refines:
-        if r is not None:
-            os.environ["LPVS_XB_REFINE"] = str(r)
+        set_leg(r)
         dev[r] = device_leg(p)
         assert p.matvec_info()["kernel"] == "admm_iter_mixed_kernel"
     for r in refines:                       # the same with the inverse streamed as doubles
-        if r is not None:
-            os.environ["LPVS_XB_REFINE"] = str(r)
+        set_leg(r)
         dev64[r] = device_leg(p, "f64")
     if a.variants:                          # other evaluation orders of the same mathematics, at the last count
         c = counts[-1]
         saved = list(counts); counts[:] = [c]
-        os.environ.pop("LPVS_XB_REFINE", None)
+        os.environ.pop("LPVS_XB_REFINE", None); os.environ.pop("LPVS_XUPDATE_CORRECTION", None)
         p.set_option("storage", "mixed")
         p.set_option("iteration", "two")
         variants["two-launch iteration"] = device_leg(p)[c]
@@ -101,10 +112,12 @@ elif a.longdouble:
         for r in refines:
             print(f"{c:5d} iterations, xb refinement rounds {r}: device (mixed) vs LD  z {rel(dev[r][c][1], ldz[c][1]):.2e} x {rel(dev[r][c][0], ldz[c][0]):.2e} "
                   f"u {rel(dev[r][c][2], ldz[c][2]):.2e} | device (8-byte) vs LD z {rel(dev64[r][c][1], ldz[c][1]):.2e}", flush=True)
+orc = {}
 if not a.no_f64_oracle:
     t0 = time.time()
     for c in counts:            # (the oracle restarts for every count: its factorisation dominates, ~40 s each on two threads)
         ro = o.admm_gram(G, b, o.GroupL2(5.0, 16), iters=c, tol=0.0, mu=0.05)
+        orc[c] = (ro["x"].copy(), ro["z"].copy(), ro["u"].copy())
         for r in refines:
             x, z, u = dev[r][c]; x8, z8, u8 = dev64[r][c]
             print(f"{c:5d} iterations, xb refinement rounds {r}: mixed storage vs oracle  x {rel(x, ro['x']):.2e} z {rel(z, ro['z']):.2e} u {rel(u, ro['u']):.2e} "
@@ -112,6 +125,14 @@ if not a.no_f64_oracle:
                   f"nnz {np.count_nonzero(ro['z'])}   [{time.time() - t0:.0f} s]", flush=True)
         if ldz is not None:
             print(f"{c:5d} iterations: f64 oracle vs LD  z {rel(ro['z'], ldz[c][1]):.2e} x {rel(ro['x'], ldz[c][0]):.2e} u {rel(ro['u'], ldz[c][2]):.2e}", flush=True)
+
+if a.save and ldz is not None and orc and not a.longdouble:
+    # the fixture of tests/test_gpu_judged_size.py: the extended-precision iterates and the f64 oracle's (both deterministic functions of G, b)
+    np.savez_compressed(a.save, counts=np.array(counts), sha256=np.array(fp), x=np.stack([ldz[c][0] for c in counts]),
+                        z=np.stack([ldz[c][1] for c in counts]), u=np.stack([ldz[c][2] for c in counts]),
+                        oracle_x=np.stack([orc[c][0] for c in counts]), oracle_z=np.stack([orc[c][1] for c in counts]),
+                        oracle_u=np.stack([orc[c][2] for c in counts]), oracle_threads=np.array(o.num_threads()))
+    print("fixture written: " + a.save, flush=True)
 
 if a.variants or a.perturb:
     c = counts[-1]
@@ -144,4 +165,4 @@ if a.variants or a.perturb:
     sv = np.linalg.svd(E, compute_uv=False)
     print("  singular values of the stacked error vectors / largest: " + " ".join("%.3f" % (x / sv[0]) for x in sv), flush=True)
     if a.save:
-        np.savez_compressed(a.save.replace(".npz", "") + "_legs.npz", names=np.array(names), z=np.stack([legs[k] for k in names]), base=base)
+        np.savez_compressed((a.save if a.save.endswith("_legs.npz") else a.save.replace(".npz", "") + "_legs.npz"), names=np.array(names), z=np.stack([legs[k] for k in names]), base=base)
