@@ -91,9 +91,16 @@ int32_t lpvs_release_cached_memory(void);
 #define LPVS_OPT_GRAM_FORM 3  /* LPVS_GRAM_*     : structured Gram for arithmetic-progression grids, or the dense MFMA forms */
 #define LPVS_OPT_NT_LOADS 4   /* LPVS_NT_*       : non-temporal tile loads (default: when a launch streams more than 240 MiB of inverses -- window batches, single problems from n = 10752) */
 #define LPVS_OPT_SLOT_SUMS 5  /* LPVS_SLOTS_*    : slot sums of the structured Gram by non-uniform FFT or by direct evaluation */
-#define LPVS_STORAGE_MIXED 1  /* float head + 16-bit tail (40 bits) for tiles with large entries, 36-bit fixed point elsewhere */
+#define LPVS_STORAGE_MIXED 1  /* float head + 16-bit tail (40 bits) for tiles with large entries, 36-bit fixed point elsewhere (the default) */
 #define LPVS_STORAGE_SPLIT 2  /* float head + 16-bit tail everywhere (6 bytes, 40 significant bits) */
 #define LPVS_STORAGE_F64 3    /* doubles (8 bytes): the reference-width copy */
+#define LPVS_STORAGE_MIXED32 4 /* as MIXED with 32 significant bits in the fixed-point tiles (4 B per element: 140 instead of 157 MB per iteration at
+                                * n = 8192, +6 % signals/s): for handles whose x-update is corrected (one right-hand side, n >= 2048; MIXED otherwise).
+                                * x and z keep their distance to the exact iterates (the correction removes the storage error's systematic part: measured
+                                * 1.2e-10 after 2000 iterations at cfg3 with 36, 32 and 30 bits alike); the DUAL variable u does not -- it integrates the
+                                * x-update's error over the iterations in the directions the iteration hardly feeds back (inactive groups, large
+                                * eigenvalues of G): 2e-9 .. 7e-9 against 1e-10 .. 5e-10 with 36 bits.  u is internal state (ADMM returns x and z,
+                                * src/lasso.jl:170) and the extra error does not reach x or z, but it is why this is an option and not the default. */
 #define LPVS_ITERATION_ONE 1
 #define LPVS_ITERATION_TWO 2
 #define LPVS_GRAM_AP 1        /* structured (error unless the grid is an arithmetic progression up to rounding) */
@@ -256,7 +263,8 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
  * actually issues (tiles*128*256*2*Npad; the structured form: 8*N*(3Nf-1)*P VALU flops), out[6]
  * algorithmic Gram flops N*n*(n+1), out[7] ADMM iterations timed in out[4], out[8] Gram form used:
  * 0 none (Gram given), 1 n x n lower triangle, 2 symmetric-pair, 3 k-major panel, 4 structured
- * (arithmetic-progression w, nudft.hip). */
+ * (arithmetic-progression w, nudft.hip), 5 structured with the slot sums by non-uniform FFT; out[9] the time of the x-update
+ * corrections inside out[4] (HIP events around each), out[10] their count. */
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out);
 
 /* average duration (microseconds) of the ADMM mat-vec kernel of this handle over `reps` back-to-back launches, from
@@ -448,7 +456,9 @@ int32_t lpvs_windowcsd_f64(const double *y, const double *u, const double *t, in
  * LPVS_M_STORAGE=f64 selects 1.  Bit 4 (+16) is set when, with the prox operator currently set, the ADMM iteration runs as ONE
  * launch (kind 4, one right-hand side, L1 / L0 / group prox whose groups divide 128: the tile partials are added into x with 64-bit
  * fixed-point atomics -- exact and order-independent -- and the next launch's tile workgroups apply prox and dual update in their
- * prologue); LPVS_ITERATION=two keeps the separate mat-vec and update launches */
+ * prologue); LPVS_ITERATION=two keeps the separate mat-vec and update launches.  Bit 5 (+32): the fixed-point tiles of kind 4 keep
+ * 32 significant bits (4 B per element: handles whose x-update is corrected -- one right-hand side, n >= 2048 -- where the storage
+ * error's systematic part leaves the iteration with the inverse's) */
 int32_t lpvs_admm_matvec_kind(lpvs_problem *h, int32_t *kind);
 
 #ifdef __cplusplus

@@ -107,7 +107,8 @@ end
 
 # ---- options (include/lpvspectral.h LPVS_OPT_*) ---------------------------------------------------
 # Extensions (the reference has none of them): how a handle stores the inverse its ADMM mat-vec streams and how it iterates.
-#   storage   = :mixed (default: >= 36 significant bits per element, 1e-10 in the iterates) | :split (40 bits) | :f64 (doubles)
+#   storage   = :mixed (default: >= 36 significant bits per element, 1e-10 in the iterates) | :split (40 bits) | :f64 (doubles) |
+#               :mixed32 (32-bit fixed-point tiles, +6 % at n = 8192; x, z as with :mixed, the dual variable u to ~5e-9: include/lpvspectral.h)
 #   iteration = :one (default where applicable: one launch per ADMM iteration) | :two
 #   gram_form = :ap | :krs | :kr,  nt_loads = :on | :off,  slot_sums = :nufft | :direct        (`nothing` = the library's choice)
 # Estimators take them as keywords (`ls_sparse_spectral_lpv(...; storage=:f64)`); results do not depend on them beyond rounding.
@@ -115,7 +116,7 @@ end
 #   reserve_cus = CUs the factorisation leaves to its pivot chain | :none                     (integers; defaults only, not handle options)
 const OPT_ID = (storage=Int32(1), iteration=Int32(2), gram_form=Int32(3), nt_loads=Int32(4), slot_sums=Int32(5),
                 window_chunk_mb=Int32(6), windows_in_flight=Int32(7), reserve_cus=Int32(8))
-const OPT_VALUES = (storage=(mixed=1, split=2, f64=3), iteration=(one=1, two=2), gram_form=(ap=1, krs=2, kr=3),
+const OPT_VALUES = (storage=(mixed=1, split=2, f64=3, mixed32=4), iteration=(one=1, two=2), gram_form=(ap=1, krs=2, kr=3),
                     nt_loads=(off=1, on=2), slot_sums=(nufft=1, direct=2), window_chunk_mb=(uncut=-1,), windows_in_flight=NamedTuple(),
                     reserve_cus=(none=-1,))
 optvalue(name::Symbol, v) = v === nothing ? Int32(0) : v isa Integer ? Int32(v) : Int32(getfield(getfield(OPT_VALUES, name), Symbol(v)))

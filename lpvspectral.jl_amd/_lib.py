@@ -24,7 +24,7 @@ LINEAR_LEAST_SQUARES, LINEAR_QUADRATIC_AS_WRITTEN = 1, -1
 EST_SPARSE, EST_DENSE, EST_SPARSE_INIT = 1, 2, 3
 # options (include/lpvspectral.h LPVS_OPT_*): name -> (option id, {value name -> value}); None / "default" = 0
 OPTIONS = {
-    "storage": (1, {"mixed": 1, "split": 2, "f64": 3}),
+    "storage": (1, {"mixed": 1, "split": 2, "f64": 3, "mixed32": 4}),
     "iteration": (2, {"one": 1, "two": 2}),
     "gram_form": (3, {"ap": 1, "krs": 2, "kr": 3}),
     "nt_loads": (4, {"off": 1, "on": 2}),

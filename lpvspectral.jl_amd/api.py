@@ -497,6 +497,10 @@ class Problem:
         check(lib().lpvs_admm_matvec_kind(self._h, C.byref(k)))
         np_ = -(-self.n // 128) * 128
         one_launch = bool(int(k.value) & 16)
+        fix32 = bool(int(k.value) & 32)            # the fixed-point tiles keep 32 significant bits (handles whose x-update is corrected)
+        fixs = ("32-bit fixed point with per-row steps (4.03 B: the nibbles of the 36-bit form are zero and not read)" if fix32 else
+                "36-bit fixed point with per-row steps (4.53 B)")
+        fixb = 66048 if fix32 else 74240
         k = C.c_int32(int(k.value) & 15)
         if one_launch and int(k.value) == 0:                               # small problems (np < 2048): full matrix, one launch per iteration
             return dict(kernel="admm_small_iter_kernel", one_launch_iteration=True,
@@ -510,9 +514,9 @@ class Problem:
         if one_launch:                                                     # mixed storage, single signal, fusable prox
             return dict(kernel="admm_iter_mixed_kernel", one_launch_iteration=True,
                         storage="tile-packed lower triangle, mixed: float head + 16-bit tail (6 B, 40 significant bits) for the diagonal tiles, "
-                                "36-bit fixed point with per-row steps (4.53 B) for tiles of small entries; tile partials added into x by 64-bit "
+                                + fixs + " for tiles of small entries; tile partials added into x by 64-bit "
                                 "fixed-point atomics, prox / dual update in the next launch's prologue",
-                        bytes_formula="98304 B per 6-byte tile, 74240 B per fixed-point tile (np = %d; 8-byte form %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2))
+                        bytes_formula="98304 B per 6-byte tile, %d B per fixed-point tile (np = %d; 8-byte form %.1f MB)" % (fixb, np_, 8e-6 * np_ * (np_ + 128) / 2))
         if self.ns > 1 and int(k.value) == 4:                              # fixed-point tiles below the diagonal, float-head tiles on it
             q4 = self.ns <= 8 and os.environ.get("LPVS_MULTI_MFMA") != "16"
             nb = np_ // 128
@@ -535,8 +539,8 @@ class Problem:
                 2: dict(kernel="symv_tile_f32_kernel" if self.ns == 1 else "symv_tile_kernel<float>", storage="tile-packed lower triangle, f32 (4 B)",
                         bytes_formula="4 B x np(np+128)/2 (np = %d)" % np_),
                 4: dict(kernel="symv_tile_mixed_kernel", storage="tile-packed lower triangle, mixed: float head + 16-bit tail (6 B, 40 significant bits) "
-                                                                 "for the diagonal tiles, 36-bit fixed point with per-row steps (4.53 B) for tiles of small entries",
-                        bytes_formula="98304 B per 6-byte tile, 74240 B per fixed-point tile (np = %d; 8-byte form %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2)),
+                                                                 "for the diagonal tiles, " + fixs + " for tiles of small entries",
+                        bytes_formula="98304 B per 6-byte tile, %d B per fixed-point tile (np = %d; 8-byte form %.1f MB)" % (fixb, np_, 8e-6 * np_ * (np_ + 128) / 2)),
                 3: dict(kernel="symv_tile_split_kernel", storage="tile-packed lower triangle, float head + 16-bit tail (6 B, 40 significant bits)",
                         bytes_formula="6 B x np(np+128)/2 (np = %d; the 8-byte form would be %.1f MB)" % (np_, 8e-6 * np_ * (np_ + 128) / 2))}[int(k.value)]
 
@@ -562,11 +566,12 @@ class Problem:
         return re + 1j * im
 
     def timing(self):
-        t = np.zeros(9)
-        check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 9))
+        t = np.zeros(11)
+        check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 11))
         return dict(basis_ms=t[0], gram_ms=t[1], reduce_rhs_ms=t[2], factor_ms=t[3], admm_ms=t[4],
                     gram_issued_flops=t[5], gram_flops=t[6], admm_iters=t[7],
-                    gram_form=("given", "kr", "krs", "panel", "ap", "ap-nufft")[int(t[8])])
+                    gram_form=("given", "kr", "krs", "panel", "ap", "ap-nufft")[int(t[8])],
+                    xcorr_ms=t[9], xcorr_count=int(t[10]))      # the x-update corrections inside admm_ms
 
 
 # --------------------------------------------------------------------------- ADMM driver

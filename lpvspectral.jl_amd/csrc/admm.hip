@@ -770,12 +770,14 @@ __device__ __forceinline__ void tile_reduce_store(double (&v)[8], double (&tc)[8
     }
 }
 
+// max|M| of a symmetric positive definite matrix sits on its diagonal (|m_ij| <= sqrt(m_ii m_jj)): np loads instead of a pass over np^2
+// entries (0.2 ms at n = 8192).  Every matrix packed here is the inverse of G + shift I, G a Gram matrix.
 __global__ void __launch_bounds__(256)
-absmax_kernel(const double *__restrict__ M, int64_t count, unsigned long long *__restrict__ out) {
-    M += (int64_t)blockIdx.y * count;                // blockIdx.y = matrix of a batch
+absmax_kernel(const double *__restrict__ M, int64_t np, unsigned long long *__restrict__ out) {
+    M += (int64_t)blockIdx.y * np * np;              // blockIdx.y = matrix of a batch
     out += blockIdx.y;
     double m = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) m = fmax(m, fabs(M[i]));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < np; i += (int64_t)gridDim.x * 256) m = fmax(m, fabs(M[i * np + i]));
 #pragma unroll
     for (int w = 32; w >= 1; w >>= 1) m = fmax(m, __shfl_xor(m, w, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));   // positive doubles order like integers
@@ -784,7 +786,9 @@ absmax_kernel(const double *__restrict__ M, int64_t count, unsigned long long *_
 // mixed packing: tile blockIdx.x of matrix blockIdx.y -> float-head format or fixed point; types[matrix][tile] says which
 __global__ void __launch_bounds__(256)
 pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char *__restrict__ Mp, unsigned char *__restrict__ types,
-                        const unsigned long long *__restrict__ absmax_bits, double step_scale, int diag_float /* diagonal tiles always in the float-head format */) {
+                        const unsigned long long *__restrict__ absmax_bits, double step_scale, int diag_float /* diagonal tiles always in the float-head format */,
+                        double *__restrict__ abs1 /* [tile][128] sums of |m| over the tile's rows, or nullptr */, double *__restrict__ abs2 /* ... over its columns */,
+                        int fix_drop_bits /* 0; experiments: low bits of the 36 set to zero */) {
     int I, J;
     tile_index(blockIdx.x, I, J);
     M += (int64_t)blockIdx.y * np * np;              // blockIdx.y = matrix of a batch
@@ -795,14 +799,22 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
     unsigned char *slot = Mp + (size_t)blockIdx.x * kSplitTileBytes;
     __shared__ float rowstep[TS];
     __shared__ int bad;
+    __shared__ double colabs[4][TS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) bad = (diag_float && I == J) ? 1 : 0;
     __syncthreads();
     {
         const double limit = __longlong_as_double((long long)*absmax_bits) * step_scale;     // largest admissible step
+        double c0 = 0.0, c1 = 0.0;                                    // this lane's two columns over the wave's rows
         for (int r = wave; r < TS; r += 4) {
-            const double e0 = (I == J && lane == r) ? 0.0 : fabs(src[(int64_t)r * np + lane]);          // (a diagonal tile: without its diagonal)
-            const double e1 = (I == J && 64 + lane == r) ? 0.0 : fabs(src[(int64_t)r * np + 64 + lane]);
+            const double a0 = fabs(src[(int64_t)r * np + lane]), a1 = fabs(src[(int64_t)r * np + 64 + lane]);
+            if (abs1 != nullptr) {
+                c0 += a0; c1 += a1;
+                const double rs = wave_sum(a0 + a1);
+                if (lane == 0) abs1[(size_t)blockIdx.x * TS + r] = rs;
+            }
+            const double e0 = (I == J && lane == r) ? 0.0 : a0;          // (a diagonal tile: without its diagonal)
+            const double e1 = (I == J && 64 + lane == r) ? 0.0 : a1;
             double m = fmax(e0, e1);
 #pragma unroll
             for (int w = 32; w >= 1; w >>= 1) m = fmax(m, __shfl_xor(m, w, 64));
@@ -814,8 +826,11 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
                 if (m > 0.0 && (!(st <= limit) || e - 35 < -120)) atomicOr(&bad, 1);
             }
         }
+        if (abs1 != nullptr) { colabs[wave][lane] = c0; colabs[wave][64 + lane] = c1; }
     }
     __syncthreads();
+    if (abs2 != nullptr && threadIdx.x < TS)
+        abs2[(size_t)blockIdx.x * TS + threadIdx.x] = ((colabs[0][threadIdx.x] + colabs[1][threadIdx.x]) + colabs[2][threadIdx.x]) + colabs[3][threadIdx.x];
     const bool fixed = !bad;
     if (threadIdx.x == 0) types[blockIdx.x] = fixed ? (I == J ? 2 : 1) : 0;
     if (!fixed) {
@@ -834,6 +849,7 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
         }
         return;
     }
+    const double drop = (double)(1 << fix_drop_bits), drop_inv = 1.0 / drop;
     unsigned int *hi = reinterpret_cast<unsigned int *>(slot);
     unsigned int *nib = reinterpret_cast<unsigned int *>(slot + kFixHeadBytes);
     float *steps = reinterpret_cast<float *>(slot + kFixHeadBytes + kFixNibBytes);
@@ -846,7 +862,7 @@ pack_tiles_mixed_kernel(const double *__restrict__ M, int64_t np, unsigned char 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int col = k < 4 ? 4 * c + k : 64 + 4 * c + (k - 4);
-            double qd = (I == J && col == r) ? 0.0 : rint(src[(int64_t)r * np + col] * inv);
+            double qd = (I == J && col == r) ? 0.0 : rint(src[(int64_t)r * np + col] * inv * drop_inv) * drop;   // (drop > 1: LPVS_FIX_BITS experiments, fewer significant bits in the same format)
             qd = fmin(fmax(qd, -0x1p35 + 1.0), 0x1p35 - 1.0);
             const unsigned long long q = (unsigned long long)((long long)qd + (1ll << 35));   // biased: 0 < q < 2^36
             hi[r * TS + col] = (unsigned int)(q >> 4);
@@ -881,13 +897,15 @@ __device__ __forceinline__ V load16(const void *p) {
     return __builtin_bit_cast(V, r);
 }
 
+// fix32 (wave-uniform): the tile keeps 32 significant bits -- its nibbles are zero and are not read (4 B per element instead of 4.5)
 template <bool NT = false>
-__device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, int lane, FixRaw &w) {
+__device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, int lane, FixRaw &w, bool fix32 = false) {
     const int g = lane >> 4, c = lane & 15;
     // nibbles and steps FIRST: loads return in order, and the first row group's products need them -- requested last, they kept
     // every product waiting for the tile's last byte (all of a tile's arithmetic then sat at the end of its load)
     const uint4 *nq = reinterpret_cast<const uint4 *>(tile + kFixHeadBytes) + (wave * 64 + lane) * 2;
-    w.nq[0] = load16<NT, uint4>(nq); w.nq[1] = load16<NT, uint4>(nq + 1);
+    if (fix32) { w.nq[0] = make_uint4(0, 0, 0, 0); w.nq[1] = w.nq[0]; }
+    else { w.nq[0] = load16<NT, uint4>(nq); w.nq[1] = load16<NT, uint4>(nq + 1); }
     const float4 *st = reinterpret_cast<const float4 *>(tile + kFixHeadBytes + kFixNibBytes) + (wave * 4 + g) * 2;
     w.st[0] = load16<NT, float4>(st); w.st[1] = load16<NT, float4>(st + 1);
     const int *head = reinterpret_cast<const int *>(tile) + (wave * 32 + g) * TS + 4 * c;
@@ -1082,7 +1100,7 @@ symv_tile_f32_kernel(const float *__restrict__ Mp, const double *__restrict__ rh
 // tiles (the diagonal ones) are processed in two halves of 64 rows to fit as well.
 __global__ void __launch_bounds__(256, 3)
 symv_tile_mixed_kernel(const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, const double *__restrict__ rhs, int64_t np,
-                       int ntiles, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status) {
+                       int ntiles, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status, int fix32) {
     if (status != nullptr && status[0].converged) return;
     __shared__ double sI[TS], sJ[TS], sT[4][TS];
     const int t = blockIdx.x;
@@ -1091,9 +1109,9 @@ symv_tile_mixed_kernel(const unsigned char *__restrict__ Mp, const unsigned char
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned char *tile = Mp + (size_t)t * kSplitTileBytes;
     double *part1 = part1_all + (int64_t)t * TS, *part2 = part2_all + (int64_t)t * TS;
-    if (types[t] != 0) {                             // (uniform) 36-bit fixed point; type 2: a diagonal tile, its diagonal apart in doubles
+    if (types[t] != 0) {                             // (uniform) 36- / 32-bit fixed point; type 2: a diagonal tile, its diagonal apart in doubles
         FixRaw f;
-        fix_load(tile, wave, lane, f);
+        fix_load(tile, wave, lane, f, fix32 != 0);
         if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
         else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
         __syncthreads();
@@ -2763,21 +2781,37 @@ int32_t launch_pack_tiles_split_batch(const double *M, int64_t np, int nbatch, u
 }
 
 // mixed packing (single matrix): types = ntiles bytes after the tile slots; absmax = 8 bytes of device scratch
+__global__ void __launch_bounds__(256)
+absmax_vec_kernel(const double *__restrict__ v, int64_t n, unsigned long long *__restrict__ out) {   // max |v_i|, i < n: one workgroup
+    double m = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmax(m, fabs(v[i]));
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) m = fmax(m, __shfl_xor(m, w, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+// abs_part (symv_part_doubles(np) doubles of scratch: the handle's tile-partial buffer) != nullptr: the tiles' absolute row / column sums are
+// gathered into the largest absolute row sum over rows < n_valid, left behind max|M| in absmax[1] (bit pattern of a non-negative double)
 int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s,
-                                bool diag_float) {
-    return launch_pack_tiles_mixed_batch(M, np, 1, Mp, types, absmax, s, diag_float);
+                                bool diag_float, double *abs_part, int64_t n_valid, double *rows_scratch, int fix_bits) {
+    return launch_pack_tiles_mixed_batch(M, np, 1, Mp, types, absmax, s, diag_float, abs_part, n_valid, rows_scratch, fix_bits);
 }
 
 // ... of nbatch matrices: types = [nbatch][ntiles] bytes, absmax = nbatch * 8 bytes of device scratch
 int32_t launch_pack_tiles_mixed_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, unsigned char *types, unsigned long long *absmax,
-                                      hipStream_t s, bool diag_float) {
+                                      hipStream_t s, bool diag_float, double *abs_part, int64_t n_valid, double *rows_scratch, int fix_bits) {
     const int nblk = (int)(np / TS);
-    LPVS_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned long long) * (size_t)nbatch, s));
-    const int64_t count = np * np;
-    const unsigned gx = (unsigned)std::min<int64_t>(1024, ceil_div(count, 256 * 8));
-    hipLaunchKernelGGL(absmax_kernel, dim3(gx, (unsigned)nbatch), dim3(256), 0, s, M, count, absmax);
+    LPVS_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned long long) * ((size_t)nbatch + (abs_part ? 1 : 0)), s));
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<int64_t>(16, ceil_div(np, 256)), (unsigned)nbatch), dim3(256), 0, s, M, np, absmax);
     const double step_scale = 0x1p-44 * std::sqrt(8192.0 / (double)np);
-    hipLaunchKernelGGL(pack_tiles_mixed_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2), (unsigned)nbatch), dim3(256), 0, s, M, np, Mp, types, absmax, step_scale, diag_float ? 1 : 0);
+    hipLaunchKernelGGL(pack_tiles_mixed_kernel, dim3((unsigned)(nblk * (nblk + 1) / 2), (unsigned)nbatch), dim3(256), 0, s, M, np, Mp, types, absmax, step_scale, diag_float ? 1 : 0,
+                       abs_part, abs_part ? abs_part + (size_t)(nblk * (nblk + 1) / 2) * TS : nullptr,
+                       fix_bits >= 20 && fix_bits < 36 ? 36 - fix_bits : 0);
+    if (abs_part != nullptr && rows_scratch != nullptr && nbatch == 1) {   // R = the largest absolute row sum over the valid rows, from the tiles' |m| sums (the quantum bound of the one-launch iteration)
+        const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
+        double *rows = rows_scratch;                                       // np doubles
+        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, 1u), dim3(256), 0, s, abs_part, abs_part + (size_t)ntiles * TS, nblk, (int)ntiles, np, rows, nullptr, nullptr, 0);
+        hipLaunchKernelGGL(absmax_vec_kernel, dim3(1), dim3(256), 0, s, rows, n_valid, absmax + 1);
+    }
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -2802,8 +2836,8 @@ bool fused_ok(const AdmmParams &p) {
 }
 
 static void launch_split(const unsigned char *Mp, const unsigned char *types, const double *rhs, int64_t np, unsigned ntiles, double *part1,
-                         double *part2, const AdmmStatus *status, hipStream_t s) {
-    if (types != nullptr) hipLaunchKernelGGL(symv_tile_mixed_kernel, dim3(ntiles), dim3(256), 0, s, Mp, types, rhs, np, (int)ntiles, part1, part2, status);
+                         double *part2, const AdmmStatus *status, hipStream_t s, int fix32 = 0) {
+    if (types != nullptr) hipLaunchKernelGGL(symv_tile_mixed_kernel, dim3(ntiles), dim3(256), 0, s, Mp, types, rhs, np, (int)ntiles, part1, part2, status, fix32);
     else hipLaunchKernelGGL(symv_tile_split_kernel, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
 }
 
@@ -2919,10 +2953,13 @@ static int stream_runs(const AdmmParams &p) {
     const unsigned rounds = (ntiles + cus * L - 1) / (cus * L), nseg = cus * rounds;
     return nseg + (unsigned)nblk <= ntiles ? (int)nseg : 0;
 }
-// The panel walk (round 5) where the run walk applies and the four-block MFMA form does (up to 8 signals: its LDS images leave room for the
-// panel's column sums); LPVS_MULTI_WALK=runs keeps round 3's segments.  The consumers get runs_G = -kPanelC and the plan's table.
+// The panel walk (round 5; LPVS_MULTI_WALK=panel) where the run walk applies and the four-block MFMA form does (up to 8 signals).  NOT the
+// default: measured at cfg5 on one box, same process (tools/cfg5_ab.py, profiles/r05_cfg5_walks_ab.txt) the product takes 650 us against
+// 605 with the run walk -- every unit of four tiles is a jump of I x 96 KB for its workgroup, where the run walk's 256 workgroups stream one
+// contiguous window between them -- and the gather of the partials 40 us less (10 MB of column sums instead of 270 MB): 0.731 ms per
+// iteration either way.  The consumers get runs_G = -kPanelC and the plan's table.
 static bool stream_panel(const AdmmParams &p) {
-    const bool off = [] { const char *e = getenv("LPVS_MULTI_WALK"); return e && std::string(e) == "runs"; }();   // (read per call: tests switch it)
+    const bool off = [] { const char *e = getenv("LPVS_MULTI_WALK"); return !(e && std::string(e) == "panel"); }();   // (read per call: tests switch it)
     const bool q4_off = [] { const char *e = getenv("LPVS_MULTI_MFMA"); return e && std::string(e) == "16"; }();
     if (off || q4_off || stream_runs(p) == 0 || p.ns > 8 || !p.mp_split) return false;
     return panel_plan((int)(p.np / TS), (int)stream_cus()).dev != nullptr;
@@ -2972,7 +3009,7 @@ static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hip
         hipLaunchKernelGGL(symv_tile_kernel<float>, dim3(ntiles), dim3(256), 0, s, reinterpret_cast<const float *>(p.Mp), p.rhs, p.np, p.ns,
                            (int)ntiles, part1, part2, status);
     else if (p.mp_split)
-        launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types, p.rhs, p.np, ntiles, part1, part2, status, s);
+        launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types, p.rhs, p.np, ntiles, part1, part2, status, s, p.mp_fix32);
     else
         hipLaunchKernelGGL(symv_tile_kernel<double>, dim3(ntiles), dim3(256), 0, s, p.Mp, p.rhs, p.np, p.ns, (int)ntiles, part1, part2, status);
 }
@@ -3162,7 +3199,7 @@ int32_t launch_offset_vector_refined(const double *G, const double *M, int64_t n
 // packed copy's rounding is corrected along with the inverse's.  Both M~ products go through the handle's own packed mat-vec.
 // t: 3 x [ns][np] scratch.
 __global__ void __launch_bounds__(256)
-vec_sum_kernel(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, int64_t total) {
+vec_sum_kernel(const double *a, const double *b, double *out, int64_t total) {   // (out may be one of the inputs)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < total) out[i] = a[i] + b[i];
 }
@@ -3179,15 +3216,23 @@ static void launch_packed_apply(const AdmmParams &p, const double *rhs, double *
     else
         hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, out, nullptr, nullptr, 0);
 }
-int32_t launch_xupdate_correction(const AdmmParams &p, const double *G, double shift, const double *xb0, double *xb_eff, double *t, hipStream_t s) {
+// b != nullptr: the refinement step is taken for the WHOLE right-hand side b + v -- x = xb0 + M~ v is what the next x-update would produce,
+// r = b + v - H x -- so that the error of xb0 = M b itself is corrected along with E w (handles whose offset vector was not refined at
+// lpvs_admm_init: one accurate product per correction instead of one more per solve).
+int32_t launch_xupdate_correction(const AdmmParams &p, const double *G, double shift, const double *b, const double *xb0, double *xb_eff, double *t, hipStream_t s) {
     if (p.part == nullptr || p.Mp == nullptr) { set_error("the x-update correction needs the packed inverse"); return LPVS_ESTATE; }
     const int64_t total = p.np * (int64_t)p.ns;
     const unsigned nb = (unsigned)ceil_div(total, 256);
     double *w = t, *r = t + total, *d = t + 2 * total;
     launch_packed_apply(p, p.rhs, w, s);                                             // w = M~ v
-    launch_residual_dd(G, p.np, p.n, p.ns, p.rhs, 1.0, w, shift, r, s);              // r = v - H w
+    if (b != nullptr) {
+        hipLaunchKernelGGL(vec_sum_kernel, dim3(nb), dim3(256), 0, s, xb0, (const double *)w, w, total);          // w = xb0 + M~ v = the next x
+        hipLaunchKernelGGL(vec_sum_kernel, dim3(nb), dim3(256), 0, s, b, (const double *)p.rhs, d, total);        // d = b + v (scratch)
+        launch_residual_dd(G, p.np, p.n, p.ns, d, 1.0, w, shift, r, s);              // r = b + v - H x
+    } else
+        launch_residual_dd(G, p.np, p.n, p.ns, p.rhs, 1.0, w, shift, r, s);          // r = v - H w
     launch_packed_apply(p, r, d, s);                                                 // d = M~ r
-    hipLaunchKernelGGL(vec_sum_kernel, dim3(nb), dim3(256), 0, s, xb0, (const double *)d, xb_eff, total);   // xb_eff = xb + d
+    hipLaunchKernelGGL(vec_sum_kernel, dim3(nb), dim3(256), 0, s, xb0, (const double *)d, xb_eff, total);   // xb_eff = xb0 + d
     LPVS_HIP(hipGetLastError());
     return LPVS_OK;
 }
@@ -3464,11 +3509,13 @@ fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, cons
         constexpr int aux = NT ? 2 : 0;
         const int tbytes = I != J ? (int)kMixedFixedTileBytes : (prefetch_all ? (int)kMixedFixedTileBytes + TS * 8 : 0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tile), 0, tbytes, 0x00020000);
+        // (32-bit tiles: the nibbles are zero and are not read -- the same two loads through a descriptor of size zero return them without traffic)
+        const __amdgpu_buffer_rsrc_t rs_nq = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tile), 0, p.mp_fix32 ? 0 : tbytes, 0x00020000);
         const int gq_ = lane >> 4, c_ = lane & 15;
         const int off_head = ((wave * 32 + gq_) * TS + 4 * c_) * 4;
         const int off_nq = (int)kFixHeadBytes + (wave * 64 + lane) * 32, off_st = (int)(kFixHeadBytes + kFixNibBytes) + (wave * 4 + gq_) * 32;
-        fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 0, aux));    // (nibbles and steps first: fix_load)
-        fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_nq, 16, aux));
+        fr.nq[0] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs_nq, off_nq, 0, aux));    // (nibbles and steps first: fix_load)
+        fr.nq[1] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs_nq, off_nq, 16, aux));
         fr.st[0] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 0, aux));
         fr.st[1] = __builtin_bit_cast(float4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(rs, off_st, 16, aux));
 #pragma unroll
@@ -3602,7 +3649,7 @@ fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, cons
         // compiler wait for everything before the first product)
         if (!PA && I == J) {                         // (uniform) a diagonal tile in the fixed format that was not requested up front: only now
             FixRaw fd;
-            fix_load(tile, wave, lane, fd);
+            fix_load(tile, wave, lane, fd, p.mp_fix32 != 0);
             fi_fixed_product(fd, sI, sJ, wave, lane, v, tc);
         } else fi_fixed_product(fr, sI, sJ, wave, lane, v, tc);
         if (ttype == 2 && !prefetch_all) diag = reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4);
@@ -3693,12 +3740,14 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
 }
 
 // constants and records of the one-launch iteration (after lpvs_admm_init / set_state; base = iterations done so far); p.ns problems
-int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s) {
+__global__ void set_double_kernel(double *dst, double v) { *dst = v; }
+int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s, double r_known) {
     const int nblk = (int)(p.np / TS), nprob = p.ns;
     const FiBufs f = fi_views(p.fi, (int64_t)nprob * p.np, nprob * nblk, nprob);
     if (with_consts) {
         LPVS_HIP(hipMemsetAsync(f.consts, 0, sizeof(double) * 2 * (size_t)nprob, s));
-        hipLaunchKernelGGL(fi_rowsum_kernel, dim3((unsigned)ceil_div(p.np, 4), (unsigned)nprob), dim3(256), 0, s, p.M, p.np, p.n, reinterpret_cast<unsigned long long *>(f.consts));
+        if (r_known > 0 && nprob == 1) hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, s, f.consts, r_known);   // (the packing pass left it)
+        else hipLaunchKernelGGL(fi_rowsum_kernel, dim3((unsigned)ceil_div(p.np, 4), (unsigned)nprob), dim3(256), 0, s, p.M, p.np, p.n, reinterpret_cast<unsigned long long *>(f.consts));
     }
     hipLaunchKernelGGL(fi_state_kernel, dim3((unsigned)nprob), dim3(256), 0, s, p, nblk, base, with_consts ? 1 : 0);
     LPVS_HIP(hipGetLastError());

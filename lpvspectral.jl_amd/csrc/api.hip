@@ -31,7 +31,7 @@ static int option_from_env(int option) {
     auto is = [](const char *e, const char *v) { return e != nullptr && std::strcmp(e, v) == 0; };
     switch (option) {
     case LPVS_OPT_M_STORAGE: { const char *e = getenv("LPVS_M_STORAGE");
-        return is(e, "mixed") ? LPVS_STORAGE_MIXED : is(e, "split") ? LPVS_STORAGE_SPLIT : is(e, "f64") ? LPVS_STORAGE_F64 : 0; }
+        return is(e, "mixed") ? LPVS_STORAGE_MIXED : is(e, "split") ? LPVS_STORAGE_SPLIT : is(e, "f64") ? LPVS_STORAGE_F64 : is(e, "mixed32") ? LPVS_STORAGE_MIXED32 : 0; }
     case LPVS_OPT_ITERATION: { const char *e = getenv("LPVS_ITERATION"); return is(e, "two") ? LPVS_ITERATION_TWO : is(e, "one") ? LPVS_ITERATION_ONE : 0; }
     case LPVS_OPT_GRAM_FORM: { const char *e = getenv("LPVS_GRAM_FORM"); return is(e, "ap") ? LPVS_GRAM_AP : (is(e, "krs") || is(e, "panel")) ? LPVS_GRAM_KRS : is(e, "kr") ? LPVS_GRAM_KR : 0; }   // (panel: the Fourier problems' dense form)
     case LPVS_OPT_NT_LOADS: { const char *e = getenv("LPVS_NT_LOADS"); return e == nullptr ? 0 : (e[0] == '1' ? LPVS_NT_ON : LPVS_NT_OFF); }
@@ -85,7 +85,7 @@ void capture_default_options(int *opt) { for (int i = 0; i < kOptCount; ++i) opt
 static bool option_value_ok(int option, int value) {
     if (value == 0) return true;
     switch (option) {
-    case LPVS_OPT_M_STORAGE: return value >= LPVS_STORAGE_MIXED && value <= LPVS_STORAGE_F64;
+    case LPVS_OPT_M_STORAGE: return value >= LPVS_STORAGE_MIXED && value <= LPVS_STORAGE_MIXED32;
     case LPVS_OPT_ITERATION: return value == LPVS_ITERATION_ONE || value == LPVS_ITERATION_TWO;
     case LPVS_OPT_GRAM_FORM: return value >= LPVS_GRAM_AP && value <= LPVS_GRAM_KR;
     case LPVS_OPT_NT_LOADS: return value == LPVS_NT_OFF || value == LPVS_NT_ON;
@@ -366,20 +366,31 @@ struct lpvs_problem {
     DevBuf xb; bool offset_form = false;   // xb = M * (signed b), computed at admm_init from the full-precision M (AdmmParams::xb)
     // the x-update's systematic error removed (admm.hip, launch_xupdate_correction): xb0 = the refined offset vector, xb = xb0 - E (x_k - xb0)
     // re-formed after the iterations k = 1, 2, 4, 8, ... (k_enq = iterations enqueued since lpvs_admm_init / lpvs_admm_set_state)
-    DevBuf xb0, corr; int xcorr_base = 0, xcorr_every = 0; long long k_enq = 0;
+    DevBuf xb0, corr; int xcorr_base = 0, xcorr_every = 0; long long k_enq = 0; bool xb_refined = false, xcorr_double = false, xcorr_early = false;
     // the schedule: after the iterations base^j (xcorr_base >= 2), or after iteration 16 and every xcorr_every-th one; 0 0 = no correction
     long long next_correction(long long k) const {
+        if (xcorr_every > 0 && xcorr_double) {   // 16 (xcorr_early: 1, 2, 4, 8, 16), then xcorr_every and its doublings: the iterates move ever more slowly
+            if (xcorr_early && k < 16) { long long q = 1; while (q <= k) q *= 2; return q; }
+            if (k < 16 && xcorr_every > 16) return 16;
+            long long q = xcorr_every;
+            while (q <= k) q *= 2;
+            return q;
+        }
         if (xcorr_every > 0) { if (k < 16 && xcorr_every > 16) return 16; return (k / xcorr_every + 1) * (long long)xcorr_every; }
         long long q = 1;
         while (q <= k) q *= xcorr_base;
         return q;
     }
     bool xcorr() const { return xcorr_base >= 2 || xcorr_every > 0; }
+    int Mp_fix_bits = 36;   // significant bits of the fixed-point tiles of the packed copy (32: nibbles zero and not read)
+    double Mp_rowsum = 0;   // largest absolute row sum of M over its valid rows, left by the mixed packing pass (0: not known)
     DevBuf fi; long long fi_sync = -1; double fi_R = 0, fi_xbmax = 0;      // one-launch iteration (AdmmParams::fi): its records are those of iteration fi_sync
     int prox_kind = LPVS_PROX_L1; double prox_param = 1.0; int64_t group_len = 0;
     double mu = 0.05, tol = 1e-5; int sign = 1; bool inited = false;
     // timing (ms) -- see lpvs_problem_get_timing
     double t_basis = 0, t_gram = 0, t_reduce = 0, t_factor = 0, t_admm = 0, gram_launches = 0, gram_flops = 0, admm_iters_timed = 0, gram_form = 0;
+    double t_xcorr = 0, n_xcorr = 0;       // the x-update corrections inside t_admm: their time (HIP events around each) and count
+    std::vector<hipEvent_t> xc_ev;         // event pairs of the corrections of the running lpvs_admm_run call (read after its final synchronisation, then reused)
     EventPair ev[4];          // copies of the bundle's events (owned by `res`)
     StreamBundle *res = nullptr;   // stream, events and the factorisation's side stream, borrowed from the cache
     bool f32 = false;     // created through an _f32 entry point: the ADMM mat-vec streams a single-precision copy of M
@@ -389,6 +400,7 @@ struct lpvs_problem {
     int64_t admm_graph_iters = 0;
     void drop_graph() { if (admm_graph) (void)hipGraphExecDestroy(admm_graph); admm_graph = nullptr; admm_graph_iters = 0; }
     ~lpvs_problem() {
+        for (hipEvent_t e : xc_ev) (void)hipEventDestroy(e);
         drop_graph();
         bundle_release(res);
     }
@@ -471,6 +483,7 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.mp_f32 = sym && h->Mp_mode == kMpF32 ? 1 : 0;
     p.mp_split = sym && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed) ? 1 : 0;
     p.mp_types = sym && h->Mp_mode == kMpMixed ? h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np) : nullptr;
+    p.mp_fix32 = p.mp_types != nullptr && h->Mp_fix_bits <= 32 ? 1 : 0;
     p.xb = sym && h->offset_form ? h->xb.as<double>() : nullptr;
     p.fi = sym && h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && h->fi.p ? h->fi.as<double>() : nullptr;
     p.fi_R = h->fi_R; p.fi_xbmax = h->fi_xbmax;
@@ -484,7 +497,7 @@ AdmmParams make_params(const lpvs_problem *h) {
 int32_t factorize(lpvs_problem *h, double shift) {
     if (h->M_valid && h->M_shift == shift) return LPVS_OK;
     const int64_t np = h->np, n = h->n;
-    h->Mp_valid = false;
+    h->Mp_valid = false; h->Mp_rowsum = 0;
     if (!h->M.p) LPVS_TRY(h->M.alloc(sizeof(double) * (size_t)np * (size_t)np));
     if (!h->work.p) LPVS_TRY(h->work.alloc(spd_inverse_work_bytes(np)));
     LPVS_HIP(hipEventRecord(h->ev[3].a, h->stream));
@@ -1186,6 +1199,27 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     hipStream_t s = h->stream;
     h->drop_graph();
     LPVS_TRY(factorize(h, 1.0 / mu));            // no-op when M is cached for this shift; clears Mp_valid otherwise
+    // ---- the x-update correction (admm.hip, launch_xupdate_correction): decided first, the packing below depends on it.
+    // Default: single-signal handles of n >= 2048, after the iterations 16, 512, 1024, 2048, ... (three corrections in 2000 iterations).
+    // Handles with several right-hand sides run without it unless asked: a correction is an accurate product over the f64 Gram per signal
+    // (7 ms for the 8 channels of n = 32768), where one signal at n = 8192 pays 0.1 ms.
+    // LPVS_XUPDATE_CORRECTION (A/B measurements): "0" none; "B" after B^j; "eN" after 16 and every N-th; "dN" after 16, N, 2N, 4N, ...
+    const bool offset_form_wanted = h->np >= kSymmetricMinNp && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
+    h->xcorr_base = 0; h->xcorr_every = (offset_form_wanted && h->ns == 1) ? 512 : 0; h->xcorr_double = true;
+    if (const char *e = getenv("LPVS_XUPDATE_CORRECTION")) {
+        h->xcorr_double = e[0] == 'd' || e[0] == 'q'; h->xcorr_early = e[0] == 'q';   // "qN": after 1, 2, 4, 8, 16, N, 2N, 4N, ...
+        if (e[0] == 'e' || e[0] == 'd' || e[0] == 'q') { h->xcorr_base = 0; h->xcorr_every = atoi(e + 1) > 0 ? atoi(e + 1) : 0; }
+        else { h->xcorr_every = 0; h->xcorr_base = atoi(e) < 2 ? 0 : atoi(e); }
+        if (!offset_form_wanted) { h->xcorr_base = 0; h->xcorr_every = 0; }
+    }
+    // LPVS_STORAGE_MIXED32 on a corrected handle: 32 significant bits in the fixed-point tiles (4 B per element instead of 4.5: the nibbles
+    // are zero and are not read).  The storage error's systematic part leaves x and z with the inverse's -- measured at cfg3, 36 / 32 / 30
+    // bits: the same 1.2e-10 from the exact iterates after 2000 iterations -- but u integrates what is left of it (2e-9 .. 7e-9 instead of
+    // 1e-10 .. 5e-10: profiles/r05_cfg3_fixbits.txt), which is why 36 bits stay the default.
+    // LPVS_FIX_BITS overrides (experiments: fewer bits are emulated in the same bytes).
+    int fix_bits = (h->xcorr() && option_in_effect(LPVS_OPT_M_STORAGE, h->opt[LPVS_OPT_M_STORAGE]) == LPVS_STORAGE_MIXED32) ? 32 : 36;
+    if (const char *e = getenv("LPVS_FIX_BITS")) fix_bits = atoi(e) >= 20 && atoi(e) <= 36 ? atoi(e) : fix_bits;
+    if (h->Mp_valid && h->Mp_mode == kMpMixed && h->Mp_fix_bits != fix_bits) h->Mp_valid = false;   // (the same M packed for the other choice)
     const int mode = mp_mode_for(h);
     const bool demoted = mode == kMpMixed && h->Mp_mode == kMpSplit && h->Mp_demoted;   // mixed was tried for this M and found no small tiles
     if (h->np >= kSymmetricMinNp && (!h->Mp_valid || (h->Mp_mode != mode && !demoted))) {   // tile-packed lower triangle for the half-traffic mat-vec
@@ -1201,15 +1235,23 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         else if (mode == kMpSplit) LPVS_TRY(launch_pack_tiles_split(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), s));
         else if (mode == kMpMixed) {
             unsigned char *types = h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np);
-            LPVS_TRY(launch_pack_tiles_mixed(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), types,
-                                             reinterpret_cast<unsigned long long *>(types + ((ntiles + 255) / 256) * 256), s, /*diag_float=*/h->ns > 1));
+            // (single-signal handles: the packing pass also leaves the largest absolute row sum of M, which the one-launch iteration's quantum
+            // bound needs -- one more pass over the matrix otherwise; the tile partials' buffer and the scratch vector are free here)
+            unsigned long long *amax = reinterpret_cast<unsigned long long *>(types + ((ntiles + 255) / 256) * 256);
+            const bool want_R = h->ns == 1;
+            LPVS_TRY(launch_pack_tiles_mixed(h->M.as<double>(), h->np, h->Mp.as<unsigned char>(), types, amax, s, /*diag_float=*/h->ns > 1,
+                                             want_R ? h->part.as<double>() : nullptr, h->n, want_R ? h->scratch.as<double>() : nullptr, fix_bits));
+            h->Mp_fix_bits = fix_bits;
             std::vector<unsigned char> ht(ntiles);
+            unsigned long long rbits = 0;
             LPVS_HIP(hipMemcpyAsync(ht.data(), types, ntiles, hipMemcpyDeviceToHost, s));
+            if (want_R) LPVS_HIP(hipMemcpyAsync(&rbits, amax + 1, sizeof(rbits), hipMemcpyDeviceToHost, s));
             LPVS_HIP(hipStreamSynchronize(s));
+            if (want_R) memcpy(&h->Mp_rowsum, &rbits, sizeof(double));
             size_t ndiag = 0;
             for (unsigned char t : ht) { h->Mp_fixed_tiles += t != 0; ndiag += t == 2; }
             h->Mp_fixed_diag = (int64_t)ndiag;
-            h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)kMixedFixedTileBytes + (double)ndiag * 1024.0 +
+            h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)(fix_bits <= 32 ? kMixedFixed32TileBytes : kMixedFixedTileBytes) + (double)ndiag * 1024.0 +
                                  (double)(ntiles - (size_t)h->Mp_fixed_tiles) * (double)kMixedFloatTileBytes;
             const size_t nblk_ = (size_t)(h->np / 128);
             if (getenv("LPVS_TRACE")) fprintf(stderr, "[lpvs] mixed packing: %lld of %zu tiles fixed point (%zu diagonal), ns = %lld\n", (long long)h->Mp_fixed_tiles, ntiles, nblk_, (long long)h->ns);
@@ -1240,22 +1282,15 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     h->offset_form = h->np >= kSymmetricMinNp && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
     if (h->offset_form) {
         if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
-        // every signal's M b, refined against the Gram the handle still holds with a double-double residual (admm.hip,
-        // launch_offset_vector_refined, says why); rhs and scratch are free until launch_admm_init below writes the state.
-        // LPVS_XB_REFINE = rounds (A/B measurements: 0 = the plain product of rounds 1-4)
-        int steps = 2;
+        // every signal's M b.  Corrected handles leave its forward error to the first correction (which refines the whole right-hand side
+        // b + v: sixteen iterations with an offset vector good to ~1e-12 do not show); the others refine it here against the Gram the handle
+        // still holds, residual in twice the mantissa (admm.hip).  rhs and scratch are free until launch_admm_init below writes the state.
+        // LPVS_XB_REFINE = rounds (A/B measurements)
+        int steps = h->xcorr() ? 0 : 1;
         if (const char *e = getenv("LPVS_XB_REFINE")) steps = atoi(e) < 0 ? 0 : atoi(e);
+        h->xb_refined = steps > 0;
         LPVS_TRY(launch_offset_vector_refined(h->G.as<double>(), h->M.as<double>(), h->np, h->n, (int)h->ns, h->bs.as<double>(), h->M_shift, steps,
                                               h->xb.as<double>(), h->rhs.as<double>(), h->scratch.as<double>(), s));
-        // LPVS_XUPDATE_CORRECTION = base of the correction schedule (2: after iterations 1, 2, 4, ...; default), 0 = none (A/B measurements)
-        // Handles with several right-hand sides run without it unless asked: a correction is two products over the f64 matrices per signal
-        // in ~50 flops per element (15 ms for the 8 channels of n = 32768, eleven times in 2000 iterations: +11 %), where one signal at
-        // n = 8192 pays 0.2 ms.
-        h->xcorr_base = 0; h->xcorr_every = h->ns == 1 ? 512 : 0;   // after iteration 16 and every 512th: four corrections in 2000 iterations (DESIGN.md section 6 has the table)
-        if (const char *e = getenv("LPVS_XUPDATE_CORRECTION")) {   // "0": none; "B": after iterations B^j; "eN": after iteration 16 and every N-th
-            if (e[0] == 'e') { h->xcorr_base = 0; h->xcorr_every = atoi(e + 1) > 0 ? atoi(e + 1) : 0; }
-            else { h->xcorr_every = 0; h->xcorr_base = atoi(e) < 2 ? 0 : atoi(e); }
-        }
         if (h->xcorr()) {
             if (!h->xb0.p) LPVS_TRY(h->xb0.alloc(v));
             if (!h->corr.p) LPVS_TRY(h->corr.alloc(3 * v));
@@ -1268,7 +1303,10 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     LPVS_TRY(launch_admm_init(p, s));
     h->fi_sync = -1;
     if (p.fi) {   // constants (largest row sum of M, max|xb|) and the records of iteration 0
-        LPVS_TRY(launch_fi_setup(p, 0, true, s));
+        if (h->Mp_rowsum > 0 && h->Mp_mode == kMpMixed) {
+            AdmmParams pr = p; pr.fi_R = h->Mp_rowsum;
+            LPVS_TRY(launch_fi_setup(pr, 0, true, s, h->Mp_rowsum));
+        } else LPVS_TRY(launch_fi_setup(p, 0, true, s));
         double hc[2] = {0, 0};
         LPVS_TRY(fi_read_consts(p, hc, s));              // (synchronises)
         h->fi_R = hc[0]; h->fi_xbmax = hc[1] * (1.0 + 0x1p-20); h->fi_sync = 0;   // (max|xb| bounds the corrected offset vector too: it moves by ~1e-12 of it)
@@ -1292,7 +1330,7 @@ int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *
     h->fi_sync = -1;                                  // (the next run rebuilds the one-launch iteration's records from the new state)
     h->k_enq = iters_done;
     if (h->xcorr() && iters_done > 0)                 // re-entry: the correction of the state handed in (an uninterrupted run holds the one of its last scheduled iteration: same to second order)
-        LPVS_TRY(launch_xupdate_correction(make_params(h), h->G.as<double>(), h->M_shift, h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
+        LPVS_TRY(launch_xupdate_correction(make_params(h), h->G.as<double>(), h->M_shift, h->xb_refined ? nullptr : h->bs.as<double>(), h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
     LPVS_HIP(hipStreamSynchronize(s));
     return LPVS_OK;
 }
@@ -1310,6 +1348,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
     bool all0 = true;
     for (auto &q : st0) all0 = all0 && q.converged;
     p.fi_base = st0[0].iters;
+    size_t nxc_done = 0;
     if (max_iters > 0 && !all0) {
         if (fi_applicable(p) && h->fi_sync != p.fi_base) LPVS_TRY(launch_fi_setup(p, p.fi_base, false, s));   // state set from outside, or the last chunk took the other path
         LPVS_HIP(hipEventRecord(h->ev[0].a, s));
@@ -1338,6 +1377,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
             }
             while (todo >= h->admm_graph_iters) { LPVS_HIP(hipGraphLaunch(h->admm_graph, s)); todo -= h->admm_graph_iters; }
         }
+        size_t nxc = 0;                              // corrections of this call (event pairs xc_ev[2 i], xc_ev[2 i + 1])
         while (todo > 0) {
             // the correction schedule cuts the run at the iterations base^j, whatever chunks the caller asks for: the iterates do not depend on the chunking
             int64_t step = todo;
@@ -1349,7 +1389,15 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
             LPVS_TRY(launch_admm_iterations(p, step, s));
             todo -= step; h->k_enq += step;
             if (h->xcorr() && h->k_enq == next_corr) {
-                LPVS_TRY(launch_xupdate_correction(p, h->G.as<double>(), h->M_shift, h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
+                if (h->xc_ev.size() < 2 * (nxc + 1)) {
+                    hipEvent_t ea = nullptr, eb = nullptr;
+                    LPVS_HIP(hipEventCreate(&ea)); h->xc_ev.push_back(ea);
+                    LPVS_HIP(hipEventCreate(&eb)); h->xc_ev.push_back(eb);
+                }
+                LPVS_HIP(hipEventRecord(h->xc_ev[2 * nxc], s));
+                LPVS_TRY(launch_xupdate_correction(p, h->G.as<double>(), h->M_shift, h->xb_refined ? nullptr : h->bs.as<double>(), h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
+                LPVS_HIP(hipEventRecord(h->xc_ev[2 * nxc + 1], s));
+                ++nxc;
                 if (todo > 0 && !(h->tol > 0)) p.fi_base += step;   // (no stopping test can fire: the device committed exactly `step` more)
                 else if (todo > 0) {   // the next sub-chunk starts from the iteration count the device committed (a stopping test may have fired)
                     LPVS_HIP(hipMemcpyAsync(st.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
@@ -1362,9 +1410,14 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
             }
         }
         LPVS_HIP(hipEventRecord(h->ev[0].b, s));
+        nxc_done = nxc;
     }
     LPVS_HIP(hipMemcpyAsync(st.data(), h->status.p, sizeof(AdmmStatus) * ns, hipMemcpyDeviceToHost, s));
     LPVS_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < nxc_done; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->xc_ev[2 * i], h->xc_ev[2 * i + 1]) == hipSuccess) { h->t_xcorr += ms; h->n_xcorr += 1; } else (void)hipGetLastError();
+    }
     long long it_max = 0, it0_max = 0; double nxz_max = 0; bool all = true;
     for (size_t q = 0; q < ns; ++q) {
         if (st[q].iters > it_max) it_max = st[q].iters;
@@ -1381,12 +1434,14 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
 }
 
 /* 0: full symmetric matrix (plain mat-vec, n < 2048), 1: tile-packed doubles, 2: tile-packed floats, 3: tile-packed split, 4: mixed;
-   + 16: the iteration runs as ONE launch (fixed-point accumulation of the tile partials, update in the next launch's prologue) */
+   + 16: the iteration runs as ONE launch (fixed-point accumulation of the tile partials, update in the next launch's prologue);
+   + 32: the mixed storage's fixed-point tiles keep 32 significant bits (4 B per element) */
 int32_t lpvs_admm_matvec_kind(lpvs_problem *h, int32_t *kind) {
     if (!h || !kind) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited) { set_error("lpvs_admm_matvec_kind before lpvs_admm_init"); return LPVS_ESTATE; }
     *kind = h->np >= kSymmetricMinNp ? h->Mp_mode : kMpNone;
     if (fi_applicable(make_params(h)) || small_iter_applicable(make_params(h))) *kind |= 16;   // one launch per iteration (with the prox currently set)
+    if (make_params(h).mp_fix32) *kind |= 32;                                                  // 32-bit fixed-point tiles
     return LPVS_OK;
 }
 
@@ -1490,8 +1545,9 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
 
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out) {
     if (!h || !out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
-    const double v[9] = {h->t_basis, h->t_gram, h->t_reduce, h->t_factor, h->t_admm, h->gram_launches, h->gram_flops, h->admm_iters_timed, h->gram_form};
-    for (int i = 0; i < n_out && i < 9; ++i) out[i] = v[i];
+    const double v[11] = {h->t_basis, h->t_gram, h->t_reduce, h->t_factor, h->t_admm, h->gram_launches, h->gram_flops, h->admm_iters_timed, h->gram_form,
+                          h->t_xcorr, h->n_xcorr};
+    for (int i = 0; i < n_out && i < 11; ++i) out[i] = v[i];
     return LPVS_OK;
 }
 

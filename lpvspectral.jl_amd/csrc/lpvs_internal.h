@@ -225,6 +225,7 @@ struct AdmmParams {
     int ns;            // right-hand sides sharing M (signals of a shared-regressor batch); vectors are [ns][np]
     int mp_f32 = 0;    // Mp holds float (the _f32 entry points: M is streamed in single precision, arithmetic stays double)
     int mp_split = 0;  // Mp holds 6-byte elements (float head + 16-bit tail, 40 significant bits; see admm.hip)
+    int mp_fix32 = 0;  // the fixed-point tiles keep 32 significant bits: their nibbles are zero and are not read (handles whose x-update is corrected: the storage error's systematic part leaves the iteration with the inverse's)
     const unsigned char *mp_types = nullptr;   // mixed storage: per-tile format, 1 = 36-bit fixed point (admm.hip); several right-hand sides: diagonal tiles always 0
     // offset form of the x-update (single-problem tile-packed path): x = xb + M (z-u)/mu with xb = M b computed once from
     // the full-precision inverse; the per-iteration product then never multiplies the large constant vector b by the
@@ -245,10 +246,11 @@ struct AdmmParams {
 bool small_iter_applicable(const AdmmParams &p);
 // one step of iterative refinement for the right-hand side the next x-update multiplies (p.rhs), its residual in twice-the-mantissa
 // accumulation against H = G + shift I; xb_eff = xb0 + M~ (v - H M~ v).  t: 3 x [ns][np] scratch (admm.hip says why)
-int32_t launch_xupdate_correction(const AdmmParams &p, const double *G, double shift, const double *xb0, double *xb_eff, double *t, hipStream_t s);
+// b != NULL: for the whole right-hand side b + v, which also corrects an unrefined xb0 = M b
+int32_t launch_xupdate_correction(const AdmmParams &p, const double *G, double shift, const double *b, const double *xb0, double *xb_eff, double *t, hipStream_t s);
 size_t fi_doubles(int64_t np, int64_t nprob = 1);
 bool fi_applicable(const AdmmParams &p);
-int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s);
+int32_t launch_fi_setup(const AdmmParams &p, long long base, bool with_consts, hipStream_t s, double r_known = -1.0);   // r_known > 0: the largest absolute row sum is known (p.fi_R)
 int32_t fi_read_consts(const AdmmParams &p, double out[2], hipStream_t s);
 size_t symv_part_doubles(int64_t np, int64_t ns = 1);
 size_t symv_packed_doubles(int64_t np);
@@ -256,11 +258,12 @@ int32_t launch_pack_tiles(const double *M, int64_t np, double *Mp, hipStream_t s
 int32_t launch_pack_tiles_f32(const double *M, int64_t np, float *Mp, hipStream_t s);
 int32_t launch_pack_tiles_split(const double *M, int64_t np, unsigned char *Mp, hipStream_t s);   // 6 * symv_packed_doubles(np) bytes
 int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s,
-                                bool diag_float = false);   // diag_float: diagonal tiles always in the float-head format (multi-signal handles)
+                                bool diag_float = false, double *abs_part = nullptr, int64_t n_valid = 0, double *rows_scratch = nullptr, int fix_bits = 36);   // diag_float: diagonal tiles always in the float-head format (multi-signal handles); abs_part: also the largest absolute row sum -> absmax[1]
 bool multi_signal_fixed_tiles_ok(int64_t np);               // the multi-signal tile product in use reads fixed-point off-diagonal tiles
 int32_t launch_pack_tiles_mixed_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, unsigned char *types, unsigned long long *absmax,
-                                      hipStream_t s, bool diag_float = false);
+                                      hipStream_t s, bool diag_float = false, double *abs_part = nullptr, int64_t n_valid = 0, double *rows_scratch = nullptr, int fix_bits = 36);
 constexpr size_t kMixedFixedTileBytes = 128 * 128 * 4 + 128 * 128 / 2 + 128 * 4, kMixedFloatTileBytes = 128 * 128 * 6;
+constexpr size_t kMixedFixed32TileBytes = 128 * 128 * 4 + 128 * 4;   // read per 32-bit fixed-point tile: heads + steps (same slot layout, the nibble area is skipped)
 // element conversions for the _f32 entry points (device buffers)
 int32_t launch_cvt_f32_f64(const float *src, double *dst, int64_t count, hipStream_t s);
 int32_t launch_cvt_f64_f32(const double *src, float *dst, int64_t count, hipStream_t s);

@@ -88,8 +88,11 @@ def test_cfg2_fullsize_admm_vs_oracle(L, oracle, equidistant):
 
 
 # ------------------------------------------------------------------ cfg3
-CFG3_PAIR_BOUND = 1e-8       # rel-L2(z) between any two of the cfg3 solves below: 3x the largest value measured (0.7e-9 .. 3.1e-9 over two builds);
-                             # against the ORACLE the benchmarked path measures 1.9e-9 at 2000 iterations (tests/test_gpu_judged_size.py, round 4)
+CFG3_FLOOR_BOUND = 3e-10    # the SAME Gram through two factorisation schedules (different roundings of M): measured 0.8e-10 / 1.1e-10 (round 4, before
+                             # the x-update correction: 1.1 .. 1.5e-9)
+CFG3_PAIR_BOUND = 5e-9       # two solves on DIFFERENT Grams (structured / dense, exact / rounded phases: max|dG| = 5e-14 max|G|, a few hundred ulps of
+                             # its large entries): measured 1.6 .. 2.7e-9 -- the conditioning of the problem (ONE ulp of input uncertainty moves the
+                             # iterate by 1.0e-10: profiles/r05_cfg3_error_directions.txt), not an evaluation error
 def test_cfg3_fullsize_structured_vs_dense_end_to_end(L):
     """The benchmarked path (structured Gram -> factorisation -> 2000 iterations at N = 2^20) against the same solve on the
     dense f64-MFMA Gram (LPVS_GRAM_FORM=krs), as an experiment that separates WHAT makes two solves of this size differ:
@@ -100,17 +103,18 @@ def test_cfg3_fullsize_structured_vs_dense_end_to_end(L):
       ... and `structured` / `dense-exact` once more with the round-2 factorisation schedule (LPVS_FACTOR_SCHEME=steps): the SAME Gram
       bit for bit (both Gram paths are deterministic), the same algorithm, only the order in which the inverse's sums are rounded.
 
-    (0) NOISE FLOOR: the same Gram through two summation orders of the factorisation.  |M H - I| is 2e-13 either way, and 2000
-        iterations of the (not yet converged) ADMM map carry that difference to ~1e-9 in z.  No comparison between two f64
-        implementations at this size can be expected below it -- the reference's own x-update stops at sqrt(eps) = 1.5e-8.
-    (1) structured vs dense-exact: the same mathematical problem through entirely different kernel chains -- at the floor.
+    (0) SAME INPUTS, two evaluation orders: the same Gram through two summation orders of the factorisation.  |M H - I| is 2e-13 either
+        way; rounds 3 and 4 measured 1.1 .. 1.5e-9 between the two after 2000 iterations and called it a floor.  It was the explicit
+        inverse's systematic error E w, a constant forcing of the not-yet-converged map; with the x-update
+        correction the two schedules agree to 1e-10 (CFG3_FLOOR_BOUND).
+    (1) structured vs dense-exact: the same mathematical problem through entirely different kernel chains, whose Grams differ by
+        max|dG| = 5e-14 max|G| -- DIFFERENT INPUTS to the iteration, a few hundred ulps of G's large entries apart.
     (2) dense-exact vs dense-rounded: ONE kernel chain, the phases perturbed by <= ulp(w*x)/2 = 3.7e-10 rad: what the reference's
-        fl(w*x) costs -- also at the floor: the two effects are not separable at N = 2^20, and both are an order of magnitude inside
-        the reference's own solver tolerance.
-    Identical supports throughout.  SURVEY 8(d)'s 1e-9 is met with margin at oracle sizes (3e-11 at n = 2048,
-    test_gpu_oracle_on_bench_kernels.py) and, against the oracle at THIS size, up to ~500 iterations (4.7e-10 at 200, 9.4e-10 at
-    500); at 2000 iterations the oracle itself is 1.9e-9 away (round 4: tests/test_gpu_judged_size.py), i.e. the floor of (0) is a
-    property of the iteration, not of a device kernel chain.  Every pair here is held to CFG3_PAIR_BOUND = 3x the largest value measured."""
+        fl(w*x) costs.
+    (1) and (2) measure 1.6 .. 2.7e-9: the conditioning of the problem -- one ulp of uncertainty in G, b moves the 2000th iterate by
+    1.0e-10 (tools/cfg3_vs_oracle.py --perturb) -- and no evaluation can be closer to another than their inputs allow: CFG3_PAIR_BOUND.
+    Identical supports throughout.  Against the ORACLE on the device's own Gram the benchmarked path is within 1e-9 at every count
+    (tests/test_gpu_judged_size.py)."""
     import bench
     y, X, V, w = bench.synth_signal(1 << 20, 512, 0, torch.device("cuda"))
     out = {}
@@ -147,10 +151,11 @@ def test_cfg3_fullsize_structured_vs_dense_end_to_end(L):
           f"structured vs dense-exact {r_se:.3e} (max|dG|/max|G| = {gdiff:.1e}) | dense-exact vs dense-rounded {r_er:.3e} | "
           f"structured vs dense-rounded {r_sr:.3e}; active groups {int(groups(z['structured']).sum())}, "
           f"phase bound 2^-53*max|w x| = {2.0 ** -53 * float(w.max() * X.max()):.2e} rad")
-    for name, r in (("floor/structured", floor_s), ("floor/dense", floor_e), ("structured vs dense-exact", r_se), ("exact vs rounded", r_er),
-                    ("structured vs rounded", r_sr)):
+    for name, r in (("floor/structured", floor_s), ("floor/dense", floor_e)):
+        assert r <= CFG3_FLOOR_BOUND, (name, r)
+    for name, r in (("structured vs dense-exact", r_se), ("exact vs rounded", r_er), ("structured vs rounded", r_sr)):
         assert r <= CFG3_PAIR_BOUND, (name, r)
-    assert max(floor_s, floor_e) > 1e-11                                           # (the floor is real: the two schedules do round differently)
+    assert max(floor_s, floor_e) > 1e-12                                           # (the floor is real: the two schedules do round differently)
     assert {40, 204, 409} <= set(np.nonzero(groups(z["structured"]))[0])          # the three true frequencies are active
 
 

@@ -754,7 +754,10 @@ def test_multi_signal_tile_product_variants_agree(L, oracle, ns, prox, monkeypat
     g = L.IndBallL0(6) if prox == "ball" else None
     kw = dict(λ=3.0, iters=300, tol=1e-6, μ=0.05, printerval=100000, proxg=g)
     out = {}
+    # (round 5: the column-panel walk -- P2 sums in registers across the rows a workgroup walks in a panel, one record per workgroup and panel;
+    # opt-in, LPVS_MULTI_WALK=panel, and only where the run walk and the four-block MFMA apply: it falls back to runs otherwise)
     for name, env in (("tiles", {"LPVS_MULTI_RUNS": "0"}), ("runs2", {"LPVS_MULTI_RUNS": "2"}), ("runs4", {"LPVS_MULTI_RUNS": "4"}),
+                      ("panel", {"LPVS_MULTI_RUNS": "2", "LPVS_MULTI_WALK": "panel"}), ("split/panel", {"LPVS_MULTI_RUNS": "2", "LPVS_MULTI_WALK": "panel", "LPVS_M_STORAGE": "split"}),
                       ("mfma16/tiles", {"LPVS_MULTI_RUNS": "0", "LPVS_MULTI_MFMA": "16"}), ("mfma16/runs2", {"LPVS_MULTI_RUNS": "2", "LPVS_MULTI_MFMA": "16"}),
                       ("split/runs2", {"LPVS_MULTI_RUNS": "2", "LPVS_M_STORAGE": "split"}), ("split/mfma16", {"LPVS_MULTI_RUNS": "0", "LPVS_MULTI_MFMA": "16", "LPVS_M_STORAGE": "split"})):
         for k, v in env.items():

@@ -40,6 +40,10 @@ def test_cfg3_extended_precision_fixture_is_wellformed():
     f = np.load(os.path.join(ROOT, "tests", "golden", "cfg3_extended_precision_iterates.npz"))
     assert list(f["counts"]) == [200, 500, 1000, 2000]
     assert f["x"].shape == f["z"].shape == f["u"].shape == (4, 8192) and len(str(f["sha256"])) == 64
+    assert f["oracle_x"].shape == f["oracle_z"].shape == f["oracle_u"].shape == (4, 8192)
+    # the f64 oracle's own distance to the exact iterates: the part of "device vs oracle" no device can remove
+    d = [float(np.linalg.norm(a - b) / np.linalg.norm(b)) for a, b in zip(f["oracle_z"], f["z"])]
+    assert 1e-10 < d[0] < 3e-10 and 6e-10 < d[3] < 8e-10 and d[0] < d[1] < d[2] < d[3]
     nnz = [int(np.count_nonzero(z)) for z in f["z"]]
     assert nnz[0] == 7904 and nnz[1:] == [8192] * 3 and all(np.isfinite(f[k]).all() for k in "xzu")
     # ADMM invariants that hold for any exact run: groups of z are zero or full, and x - z shrinks as the run proceeds

@@ -17,7 +17,7 @@ with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
     for rep in range(2):
         for walk in ("runs", "panel"):
             for xc in ("0", "2"):
-                os.environ["LPVS_MULTI_WALK"] = walk
+                os.environ["LPVS_MULTI_WALK"] = walk   # (the library default is "runs")
                 os.environ["LPVS_XUPDATE_CORRECTION"] = xc
                 p.admm_init(None, μ=0.05, tol=0.0)
                 mv_us, mv_bytes = p.time_matvec(30)
