@@ -17,7 +17,7 @@ if [ "$PART" = bench ]; then
   timeout -k 10 300 python bench.py --dtype f32 --no-cpu-baseline --no-general-path --no-cfg4-strong --no-single-process > gpurun_out/prof/bench_cfg3_f32.json 2> gpurun_out/prof/bench_cfg3_f32.err
 elif [ "$PART" = stats ]; then
   cd /tmp && export TMPDIR=/tmp
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k3" -o bench -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-general-path --no-alt-storage --no-cfg4-strong --no-concurrent --no-single-process > "$R/gpurun_out/prof/k3.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k3" -o bench -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-general-path --no-alt-storage --no-cfg4-strong --no-baseline-configs --no-concurrent --no-single-process > "$R/gpurun_out/prof/k3.log" 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k4" -o bench -- python3 "$R/bench.py" --workload cfg4 --steps 1 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof/k4.log" 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k5" -o bench -- python3 "$R/bench.py" --workload cfg5 --steps 1 --warmup 0 --iters 500 --no-cpu-baseline > "$R/gpurun_out/prof/k5.log" 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof/k2" -o bench -- python3 "$R/bench.py" --workload cfg2 --steps 2 --warmup 1 --no-cpu-baseline --no-concurrent > "$R/gpurun_out/prof/k2.log" 2>&1
