@@ -114,6 +114,12 @@ int32_t lpvs_release_cached_memory(void);
                                        * -> 285 MB) */
 #define LPVS_OPT_WINDOWS_IN_FLIGHT 7 /* parts of a chunk solved concurrently on streams of their own: 1 .. 4 (default 2) */
 #define LPVS_OPT_RESERVE_CUS 8       /* CUs the factorisation's trailing updates leave to its pivot chain: > 0, or LPVS_RESERVE_NONE (default 8) */
+#define LPVS_OPT_XUPDATE_CORRECTION 9 /* LPVS_XCORR_*: re-form the x-update's offset vector after the iterations 16, 512, 1024, 2048, ... by one step of iterative
+                                       * refinement, residual accumulated in twice the mantissa (handles of n >= 2048).  Default: ON for handles with
+                                       * one right-hand side, OFF for several (a correction costs an accurate product over the f64 Gram per signal).  Per handle
+                                       * (before lpvs_admm_init) or as a thread default. */
+#define LPVS_XCORR_ON 1
+#define LPVS_XCORR_OFF 2
 #define LPVS_SLOTS_NUFFT 1
 #define LPVS_SLOTS_DIRECT 2
 #define LPVS_WINDOW_UNCUT (-1)

@@ -115,10 +115,10 @@ end
 #   window_chunk_mb = MB of packed inverses per chunk of the batched-window engine | :uncut;  windows_in_flight = 1 .. 4 parts of a chunk;
 #   reserve_cus = CUs the factorisation leaves to its pivot chain | :none                     (integers; defaults only, not handle options)
 const OPT_ID = (storage=Int32(1), iteration=Int32(2), gram_form=Int32(3), nt_loads=Int32(4), slot_sums=Int32(5),
-                window_chunk_mb=Int32(6), windows_in_flight=Int32(7), reserve_cus=Int32(8))
+                window_chunk_mb=Int32(6), windows_in_flight=Int32(7), reserve_cus=Int32(8), xupdate_correction=Int32(9))
 const OPT_VALUES = (storage=(mixed=1, split=2, f64=3, mixed32=4), iteration=(one=1, two=2), gram_form=(ap=1, krs=2, kr=3),
                     nt_loads=(off=1, on=2), slot_sums=(nufft=1, direct=2), window_chunk_mb=(uncut=-1,), windows_in_flight=NamedTuple(),
-                    reserve_cus=(none=-1,))
+                    reserve_cus=(none=-1,), xupdate_correction=(on=1, off=2))
 optvalue(name::Symbol, v) = v === nothing ? Int32(0) : v isa Integer ? Int32(v) : Int32(getfield(getfield(OPT_VALUES, name), Symbol(v)))
 function set_default_option(name::Symbol, v=nothing)       # thread-local: handles created / window batches run afterwards
     oid, vid = getfield(OPT_ID, name), optvalue(name, v)

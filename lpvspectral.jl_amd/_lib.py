@@ -34,6 +34,8 @@ OPTIONS = {
     "window_chunk_mb": (6, {"uncut": -1}),
     "windows_in_flight": (7, {}),
     "reserve_cus": (8, {"none": -1}),
+    # the x-update correction (handles of n >= 2048; default: on for one right-hand side, off for several)
+    "xupdate_correction": (9, {"on": 1, "off": 2}),
 }
 _INT_OPTIONS = {"window_chunk_mb", "windows_in_flight", "reserve_cus"}
 

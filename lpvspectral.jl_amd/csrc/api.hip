@@ -26,7 +26,7 @@ void set_error(const char *fmt, ...) {
 }
 
 // ---- options -----------------------------------------------------------------------------------------------------------
-static thread_local int g_opt[kOptCount] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+static thread_local int g_opt[kOptCount] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static int option_from_env(int option) {
     auto is = [](const char *e, const char *v) { return e != nullptr && std::strcmp(e, v) == 0; };
     switch (option) {
@@ -39,6 +39,7 @@ static int option_from_env(int option) {
     case LPVS_OPT_WINDOW_CHUNK_MB: { const char *e = getenv("LPVS_WINDOW_CHUNK_MB"); if (!e) return 0; const double v = atof(e); return v <= 0 ? LPVS_WINDOW_UNCUT : (int)(v < 1 ? 1 : v); }
     case LPVS_OPT_WINDOWS_IN_FLIGHT: { const char *e = getenv("LPVS_WINDOWS_IN_FLIGHT"); if (!e) return 0; const int v = atoi(e); return v < 1 ? 1 : (v > 4 ? 4 : v); }
     case LPVS_OPT_RESERVE_CUS: { const char *e = getenv("LPVS_RESERVE_CUS"); if (!e) return 0; const int v = atoi(e); return v <= 0 ? LPVS_RESERVE_NONE : v; }
+    case LPVS_OPT_XUPDATE_CORRECTION: { const char *e = getenv("LPVS_XUPDATE_CORRECTION"); if (!e) return 0; return (e[0] == '0' && e[1] == 0) ? LPVS_XCORR_OFF : LPVS_XCORR_ON; }   // ("0": off; any schedule: on)
     }
     return 0;
 }
@@ -93,6 +94,7 @@ static bool option_value_ok(int option, int value) {
     case LPVS_OPT_WINDOW_CHUNK_MB: return value == LPVS_WINDOW_UNCUT || (value >= 1 && value <= (1 << 20));
     case LPVS_OPT_WINDOWS_IN_FLIGHT: return value >= 1 && value <= 4;
     case LPVS_OPT_RESERVE_CUS: return value == LPVS_RESERVE_NONE || (value >= 1 && value <= 128);
+    case LPVS_OPT_XUPDATE_CORRECTION: return value == LPVS_XCORR_ON || value == LPVS_XCORR_OFF;
     }
     return false;
 }
@@ -394,7 +396,7 @@ struct lpvs_problem {
     EventPair ev[4];          // copies of the bundle's events (owned by `res`)
     StreamBundle *res = nullptr;   // stream, events and the factorisation's side stream, borrowed from the cache
     bool f32 = false;     // created through an _f32 entry point: the ADMM mat-vec streams a single-precision copy of M
-    int opt[kOptCount] = {0, 0, 0, 0, 0, 0};   // LPVS_OPT_*: explicit values of this handle (the creating thread's defaults at creation, then set_option)
+    int opt[kOptCount] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // LPVS_OPT_*: explicit values of this handle (the creating thread's defaults at creation, then set_option)
     // launch-bound regime (small n): a chunk of ADMM iterations captured once into a hipGraph and replayed
     hipGraphExec_t admm_graph = nullptr;
     int64_t admm_graph_iters = 0;
@@ -601,13 +603,13 @@ int32_t lpvs_get_default_option(int32_t option, int32_t *value) {
 int32_t lpvs_problem_set_option(lpvs_problem *h, int32_t option, int32_t value) {
     if (!h) { set_error("NULL handle"); return LPVS_EARGUMENT; }
     if (option <= 0 || option >= kOptCount || !option_value_ok(option, value)) { set_error("unknown option %d or value %d", option, value); return LPVS_EARGUMENT; }
-    if (option == LPVS_OPT_GRAM_FORM || option == LPVS_OPT_SLOT_SUMS || option >= LPVS_OPT_WINDOW_CHUNK_MB) {
+    if (option == LPVS_OPT_GRAM_FORM || option == LPVS_OPT_SLOT_SUMS || (option >= LPVS_OPT_WINDOW_CHUNK_MB && option != LPVS_OPT_XUPDATE_CORRECTION)) {
         set_error("option %d is chosen when a handle is constructed (or belongs to calls without a handle): set it with lpvs_set_default_option", option);
         return LPVS_ESTATE;
     }
     if (h->opt[option] != value) {
         h->opt[option] = value;
-        if (option == LPVS_OPT_M_STORAGE) h->inited = false;   // the packed copy is rebuilt by the next lpvs_admm_init
+        if (option == LPVS_OPT_M_STORAGE || option == LPVS_OPT_XUPDATE_CORRECTION) h->inited = false;   // the packed copy / the schedule are set up by the next lpvs_admm_init
         h->drop_graph();
     }
     return LPVS_OK;
@@ -1205,8 +1207,12 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     // (7 ms for the 8 channels of n = 32768), where one signal at n = 8192 pays 0.1 ms.
     // LPVS_XUPDATE_CORRECTION (A/B measurements): "0" none; "B" after B^j; "eN" after 16 and every N-th; "dN" after 16, N, 2N, 4N, ...
     const bool offset_form_wanted = h->np >= kSymmetricMinNp && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
-    h->xcorr_base = 0; h->xcorr_every = (offset_form_wanted && h->ns == 1) ? 512 : 0; h->xcorr_double = true;
-    if (const char *e = getenv("LPVS_XUPDATE_CORRECTION")) {
+    const int xc_opt = option_in_effect(LPVS_OPT_XUPDATE_CORRECTION, h->opt[LPVS_OPT_XUPDATE_CORRECTION]);   // explicit, thread default, or environment ("0" = off)
+    const bool xc_on = offset_form_wanted && (xc_opt == LPVS_XCORR_ON || (xc_opt == 0 && h->ns == 1));
+    h->xcorr_base = 0; h->xcorr_every = xc_on ? 512 : 0; h->xcorr_double = true;
+    const char *xc_env = xc_on ? getenv("LPVS_XUPDATE_CORRECTION") : nullptr;
+    if (xc_env != nullptr && xc_env[0] == '0' && xc_env[1] == 0) xc_env = nullptr;   // ("0" only says off, and only as the option's last fallback)
+    if (const char *e = xc_env) {                                                    // schedule experiments: "B", "eN", "dN", "qN"
         h->xcorr_double = e[0] == 'd' || e[0] == 'q'; h->xcorr_early = e[0] == 'q';   // "qN": after 1, 2, 4, 8, 16, N, 2N, 4N, ...
         if (e[0] == 'e' || e[0] == 'd' || e[0] == 'q') { h->xcorr_base = 0; h->xcorr_every = atoi(e + 1) > 0 ? atoi(e + 1) : 0; }
         else { h->xcorr_every = 0; h->xcorr_base = atoi(e) < 2 ? 0 : atoi(e); }

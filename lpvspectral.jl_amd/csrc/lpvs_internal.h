@@ -33,7 +33,7 @@ void set_error(const char *fmt, ...);
 // ---- options (include/lpvspectral.h LPVS_OPT_*; api.hip) ------------------------------------------------------------
 // value in effect: the explicit value (a handle's, or a job's captured copy of its caller's defaults), else the calling thread's
 // default, else what the environment variable of the same name says, else 0 (the library's own choice)
-constexpr int kOptCount = 9;
+constexpr int kOptCount = 10;
 int option_in_effect(int option, int explicit_value = 0);
 void capture_default_options(int *opt /*[kOptCount]*/);
 double infinity_cache_bytes();   // the device's last-level (Infinity) cache from the KFD topology, 256 MiB when it cannot be read   // the calling thread's defaults (for work handed to other threads)
@@ -333,7 +333,7 @@ struct WinJob {
     int64_t win_lo, win_hi; int device;
     double t_absmax = -1.0;                       // max|t| over the WHOLE record when (t, L) is only a span of it (< 0: compute)
     bool f32_grid = false;                        // the frequency grid was widened from floats: snap it to the progression it was rounded from
-    int opt[kOptCount] = {0, 0, 0, 0, 0, 0};      // the caller's default options (captured on ITS thread: multi.hip runs the job on workers)
+    int opt[kOptCount] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // the caller's default options (captured on ITS thread: multi.hip runs the job on workers)
     bool opt_captured = false;
 };
 // sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations): window order, signals innermost

@@ -523,9 +523,11 @@ int32_t lpvs_windowpsd_lpv_f64(const double *Y, const double *X, const double *V
                         if (av > r4[2]) r4[2] = av;
                         if (ax > r4[3]) r4[3] = ax;
                     }
-                    const bool finite = !bad && r4[0] <= r4[1];   // (NaN / Inf anywhere in the window: the device path's own range pass reports them as it always did)
-                    rc = finite ? lpvs_problem_create_lpv_rows_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, r4, device, &h)
-                                : lpvs_problem_create_lpv_multi_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
+                    if (bad || !(r4[0] <= r4[1])) {               // a NaN / Inf anywhere in the window: say so, instead of a "not positive definite" after a Gram build and a batch inverse
+                        set_error("X or V holds a NaN or an Inf (samples %lld .. %lld)", (long long)o, (long long)(o + n - 1));
+                        return fail_with(LPVS_EARGUMENT, q);
+                    }
+                    rc = lpvs_problem_create_lpv_rows_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, r4, device, &h);
                 } else rc = lpvs_problem_create_lpv_multi_f64(y2.data(), nrhs, X + o, V + o, n, w, Nf, Nv, normalize, coulomb, device, &h);
                 if (rc != LPVS_OK) return fail_with(rc, q);
                 double *G = nullptr, *b = nullptr; int64_t hnp = 0;

@@ -174,3 +174,18 @@ def test_fourier_rhs_partials_fit_their_buffer(L, N, Nf):
             assert p.timing()["gram_form"] not in ("ap", "ap-nufft")
             Gd, bd = p.get_gram()
     assert np.abs(G - Gd).max() <= 1e-11 * np.abs(Gd).max() + tol and np.abs(b - bd).max() <= tol
+
+
+def test_windowpsd_lpv_names_a_nan_in_its_inputs(L):
+    """the host range pass of lpvs_windowpsd_lpv_f64 saw a NaN only in a window's first sample; anywhere else it ran a Gram
+    build and a batch inverse into "not positive definite".  Now the window and its sample range are named (ValueError)."""
+    rng = np.random.default_rng(2)
+    N, Nf, Nv, nw = 6000, 6, 4, 6
+    X = np.sort(rng.random(N) * 12); V = np.linspace(0, 1, N); w = 2 * np.pi * np.arange(1, Nf + 1)
+    Y = np.cos(w[2] * X) + 0.1 * rng.standard_normal(N)
+    S0 = L.ls_windowpsd_lpv(Y, X, V, w, Nv, nw=nw, λ=0.02)
+    assert np.isfinite(S0).all() and int(np.argmax(S0)) == 2
+    for arr, pos in ((V, 2500), (X, 4321)):
+        bad = arr.copy(); bad[pos] = np.nan
+        with pytest.raises(ValueError, match=r"window %d: X or V holds a NaN" % (pos // (N // nw))):
+            L.ls_windowpsd_lpv(Y, bad if arr is X else X, bad if arr is V else V, w, Nv, nw=nw, λ=0.02)

@@ -28,34 +28,26 @@ def midsize():
     return y, X, V, w
 
 
-def _solve(L, data, chunks, env=None, state=None):
+def _solve(L, data, chunks, correction=None):
     y, X, V, w = data
-    old = os.environ.get("LPVS_XUPDATE_CORRECTION")
-    if env is not None:
-        os.environ["LPVS_XUPDATE_CORRECTION"] = env
-    try:
-        with L.Problem.lpv(y, X, V, w, 8) as p:
-            G, b = p.get_gram()
-            p.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, 128, 16))
-            p.admm_init(None, μ=0.05, tol=0.0)
-            out = []
-            for c in chunks:
-                p.admm_run(c)
-                out.append(p.admm_get() + (p.admm_get_offset(),))
-            tm = p.timing()
-        return G, b, out, tm
-    finally:
-        if env is not None:
-            if old is None:
-                del os.environ["LPVS_XUPDATE_CORRECTION"]
-            else:
-                os.environ["LPVS_XUPDATE_CORRECTION"] = old
+    with L.Problem.lpv(y, X, V, w, 8) as p:
+        G, b = p.get_gram()
+        if correction is not None:
+            p.set_option("xupdate_correction", correction)      # lpvs_problem_set_option(h, LPVS_OPT_XUPDATE_CORRECTION, ...)
+        p.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, 128, 16))
+        p.admm_init(None, μ=0.05, tol=0.0)
+        out = []
+        for c in chunks:
+            p.admm_run(c)
+            out.append(p.admm_get() + (p.admm_get_offset(),))
+        tm = p.timing()
+    return G, b, out, tm
 
 
 def test_correction_brings_the_iterates_to_the_exact_ones(L, oracle, midsize):
     ctypes.CDLL("libgomp.so.1").omp_set_num_threads(min(8, os.cpu_count() or 1))     # (the oracle's row-block loops do not scale to a 128-thread team)
     G, b, corr, tm = _solve(L, midsize, [375, 375])
-    _, _, plain, tm0 = _solve(L, midsize, [375, 375], env="0")
+    _, _, plain, tm0 = _solve(L, midsize, [375, 375], correction="off")
     assert tm["xcorr_count"] == 2 and tm0["xcorr_count"] == 0 and 0 < tm["xcorr_ms"] < 0.2 * tm["admm_ms"]      # after iterations 16 and 512
     ld = oracle.admm_gram_ld(G, b, oracle.GroupL2(5.0, 16), [375, 750], mu=0.05)
     ro = oracle.admm_gram(G, b, oracle.GroupL2(5.0, 16), iters=750, tol=0.0, mu=0.05)
@@ -83,3 +75,24 @@ def test_correction_schedule_is_absolute_and_the_offset_is_state(L, midsize):
     assert not np.array_equal(off[3], off[4])                             # ... re-formed after iteration 512 ...
     assert np.array_equal(off[4], off[5]) and np.array_equal(off[5], whole[0][3])
     assert 0 < rel(off[5], off[0]) < 1e-9                                 # (it moves by ~1e-12 of itself)
+
+
+def test_correction_is_an_option_of_the_interface(L, midsize):
+    """LPVS_OPT_XUPDATE_CORRECTION: default on for one right-hand side and off for several; explicit values win; thread defaults reach the
+    constructor-created handle."""
+    y, X, V, w = midsize
+    Y2 = torch.stack([y, 0.5 * y], dim=1).contiguous()
+    prox = L.SlicedSeparableSum.frequency_groups(5.0, 128, 16)
+    def count(make, opt=None):
+        with make() as p:
+            if opt:
+                p.set_option("xupdate_correction", opt)
+            p.set_prox(prox); p.admm_init(None, μ=0.05, tol=0.0); p.admm_run(40)
+            return p.timing()["xcorr_count"], p.admm_get()[1]
+    one = lambda: L.Problem.lpv(y, X, V, w, 8)
+    two = lambda: L.Problem.lpv_multi(Y2, X, V, w, 8)
+    c1, z1 = count(one); c0, z0 = count(one, "off"); m0, zm0 = count(two); m1, zm1 = count(two, "on")
+    assert (c1, c0, m0, m1) == (1, 0, 0, 1)                                # after iteration 16
+    assert rel(zm1[:, 0], z1) <= 1e-11 and rel(zm0[:, 0], z0) <= 1e-11     # the multi-signal handle's first channel is the single-signal solve, either way
+    with L.default_options(xupdate_correction="off"):
+        assert count(one)[0] == 0
