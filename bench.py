@@ -148,9 +148,9 @@ def flatten_for_the_driver(o):
     a8 = cfg.get("whole_step_with_8_byte_storage") or {}
     if "signals_per_s_per_gpu" in a8:
         put(cfg, "signals_per_s_with_8_byte_M", a8["signals_per_s_per_gpu"])
-    a32 = cfg.get("whole_step_with_32_bit_tiles") or {}
-    if "signals_per_s_per_gpu" in a32:
-        put(cfg, "signals_per_s_with_32_bit_tiles_option", a32["signals_per_s_per_gpu"])
+    a36 = cfg.get("whole_step_with_36_bit_reads") or {}
+    if "signals_per_s_per_gpu" in a36:
+        put(cfg, "signals_per_s_with_36_bit_reads", a36["signals_per_s_per_gpu"])
     m8 = roof.get("same_matvec_with_8_byte_storage") or {}
     if "frac_of_hbm_peak" in m8:
         put(roof, "matvec_8_byte_frac", m8["frac_of_hbm_peak"]); put(roof, "matvec_8_byte_launch_us", m8["launch_us"])
@@ -982,6 +982,7 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
 
     phase = {k: float(np.mean([t[k] for t in tms])) for k in ("basis_ms", "gram_ms", "reduce_rhs_ms", "factor_ms", "admm_ms", "xcorr_ms")}
     n_xcorr = int(tms[0].get("xcorr_count", 0))
+    n_nib = int(tms[0].get("nibble_refreshes", 0))
     form = tms[0]["gram_form"]
     # ---- the same signals with TWO solves in flight per GPU (two host threads, each handle its own stream): the matrix-core-bound
     # factorisation of one solve runs under the HBM-bound iterations of the other.  Reported beside the judged line (whose `value`,
@@ -1021,6 +1022,8 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         p.admm_init(None, μ=MU, tol=0.0)
         mv_us, mv_bytes = p.time_matvec(300)
         mv_info = p.matvec_info()
+        nib_us = p.timing()["nibble_refresh_us"]           # one refresh of the stale nibble product, stand-alone (0: the handle runs none)
+    phase["nibble_refresh_ms"] = n_nib * nib_us * 1e-3     # (count of the timed steps' solves x that duration: inside admm_ms)
     # the same mat-vec with the inverse stored in doubles (LPVS_M_STORAGE=f64) and in uniform 6-byte elements (=split), for the
     # record: not on the timed path
     def _alt(st):
@@ -1048,26 +1051,27 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
             ms8 = (time.perf_counter() - t1) / 3 * 1e3
             return {"ms_per_step": ms8, "signals_per_s_per_gpu": 1e3 / ms8, "steps": 3}
     alt_step = guarded(_alt_step, "whole_step_with_8_byte_storage") if (alt is not None and "error" not in alt and not rowsh) else None
-    # ... and with 32-bit fixed-point tiles (storage = "mixed32": x and z as with the default, the dual variable to ~5e-9 -- an option, not the judged line)
-    def _alt32_step():
-        with L.default_options(storage="mixed32"):
+    # ... and with every iteration reading all 36 bits of the fixed-point tiles (storage = "mixed" by name: no stale nibble product -- round 4's reads)
+    def _alt36_step():
+        with L.default_options(storage="mixed"):
             run()
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(3):
                 run()
             torch.cuda.synchronize(dev)
-            ms32 = (time.perf_counter() - t1) / 3 * 1e3
-            return {"ms_per_step": ms32, "signals_per_s_per_gpu": 1e3 / ms32, "steps": 3}
-    alt32_step = guarded(_alt32_step, "whole_step_with_32_bit_tiles") if (alt is not None and "error" not in alt and not rowsh) else None
+            ms36 = (time.perf_counter() - t1) / 3 * 1e3
+            return {"ms_per_step": ms36, "signals_per_s_per_gpu": 1e3 / ms36, "steps": 3}
+    alt36_step = guarded(_alt36_step, "whole_step_with_36_bit_reads") if (alt is not None and "error" not in alt and not rowsh and n_nib > 0) else None
     mv_only_us = mv_us
     if mv_info.get("one_launch_iteration"):
         # the iteration IS one launch of this kernel (update in its prologue, fixed-point accumulation at its end): its duration inside
         # the timed region = HIP events around the ADMM loop of every timed step / launches (the loop holds nothing else but the first
         # launch without an update and one update-only launch per 2000); mv_only_us = the same kernel without its update, back to back
         # ... minus the x-update corrections (three in 2000 iterations: two packed products and one accurate Gram product each), which are
-        # other kernels: their time is phase_xcorr_ms
-        mv_us = (phase["admm_ms"] - phase["xcorr_ms"]) * 1e3 / iters
+        # other kernels: their time is phase_xcorr_ms; likewise the refreshes of the stale nibble product (three small kernels every 32
+        # iterations: phase_nibble_refresh_ms = their count x one refresh timed stand-alone)
+        mv_us = (phase["admm_ms"] - phase["xcorr_ms"] - phase["nibble_refresh_ms"]) * 1e3 / iters
     mv_share = iters * mv_us * 1e-3 / (elapsed / steps * 1e3)
     # (the one-launch kernel's instance that carries the update: <1, ...>; <0, ...> is a chunk's first launch, <2, ...> its last update)
     # (the PMC summary is collected from the f64 bench: the _f32 handles run another instance of the kernel on other bytes)
@@ -1103,9 +1107,9 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                    "signals_per_step_per_gpu": 1.0 / world if rowsh else 1, "gram_form": form,
                    "gram": ("structured, slot sums by a non-uniform FFT (nufft.hip); MFMA path not taken" if form == "ap-nufft" else
                             "structured (VALU f64, nudft.hip); MFMA path not taken" if form == "ap" else "dense f64 MFMA (%s)" % form),
-                   "matvec_storage": mv_info["storage"], "xupdate_corrections_per_solve": n_xcorr,
+                   "matvec_storage": mv_info["storage"], "xupdate_corrections_per_solve": n_xcorr, "nibble_refreshes_per_solve": n_nib, "nibble_refresh_us": nib_us,
                    "xupdate_correction": "after iterations 16, 512, 1024, ...: one step of iterative refinement of the x-update's offset vector, residual in twice the mantissa (DESIGN 6.1)",
-                   "whole_step_with_8_byte_storage": alt_step, "whole_step_with_32_bit_tiles": alt32_step, "concurrent_solves_per_gpu": args.streams, "two_solves_in_flight": two_in_flight,
+                   "whole_step_with_8_byte_storage": alt_step, "whole_step_with_36_bit_reads": alt36_step, "concurrent_solves_per_gpu": args.streams, "two_solves_in_flight": two_in_flight,
                    "sharding": "sample rows of one signal over the ranks, one all-reduce of the Gram (SURVEY 8(e)(2))" if rowsh else "independent signals",
                    "final_gather": "none" if (world == 1 or rowsh) else ("rccl" if args.backend == "nccl" else args.backend) + " all_gather"},
         "admm_iters_per_sec": iters / (phase["admm_ms"] * 1e-3),
@@ -1124,7 +1128,7 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                      "matvec_only_launch_us": mv_only_us,
                      "note": ("algorithmic bytes = %s (+ 0.2 MB of state vectors); M is read once per iteration; ONE launch per iteration: the kernel "
                               "rebuilds its right-hand-side blocks (prox + dual update) in the prologue and adds its partial sums into x with 64-bit "
-                              "fixed-point atomics; launch_us = (HIP events around the ADMM loops of the timed steps - the x-update corrections inside them, timed by events of their own) / launches (the two-launch scheme, "
+                              "fixed-point atomics; launch_us = (HIP events around the ADMM loops of the timed steps - the x-update corrections inside them, timed by events of their own, - the refreshes of the stale nibble product, count x one timed stand-alone) / launches (the two-launch scheme, "
                               "LPVS_ITERATION=two: mat-vec 24.7-25.7 us + update 5.3 us = 31.6 us per iteration); matvec_only_launch_us = that "
                               "scheme's stand-alone mat-vec kernel (the same product, no update), 300 back-to-back launches" % mv_info["bytes_formula"])
                              if mv_info.get("one_launch_iteration") else

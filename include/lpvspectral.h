@@ -91,16 +91,16 @@ int32_t lpvs_release_cached_memory(void);
 #define LPVS_OPT_GRAM_FORM 3  /* LPVS_GRAM_*     : structured Gram for arithmetic-progression grids, or the dense MFMA forms */
 #define LPVS_OPT_NT_LOADS 4   /* LPVS_NT_*       : non-temporal tile loads (default: when a launch streams more than 240 MiB of inverses -- window batches, single problems from n = 10752) */
 #define LPVS_OPT_SLOT_SUMS 5  /* LPVS_SLOTS_*    : slot sums of the structured Gram by non-uniform FFT or by direct evaluation */
-#define LPVS_STORAGE_MIXED 1  /* float head + 16-bit tail (40 bits) for tiles with large entries, 36-bit fixed point elsewhere (the default) */
+#define LPVS_STORAGE_MIXED 1  /* float head + 16-bit tail (40 bits) for tiles with large entries, 36-bit fixed point elsewhere, all 36 bits read by every iteration */
 #define LPVS_STORAGE_SPLIT 2  /* float head + 16-bit tail everywhere (6 bytes, 40 significant bits) */
 #define LPVS_STORAGE_F64 3    /* doubles (8 bytes): the reference-width copy */
-#define LPVS_STORAGE_MIXED32 4 /* as MIXED with 32 significant bits in the fixed-point tiles (4 B per element: 140 instead of 157 MB per iteration at
-                                * n = 8192, +6 % signals/s): for handles whose x-update is corrected (one right-hand side, n >= 2048; MIXED otherwise).
-                                * x and z keep their distance to the exact iterates (the correction removes the storage error's systematic part: measured
-                                * 1.2e-10 after 2000 iterations at cfg3 with 36, 32 and 30 bits alike); the DUAL variable u does not -- it integrates the
-                                * x-update's error over the iterations in the directions the iteration hardly feeds back (inactive groups, large
-                                * eigenvalues of G): 2e-9 .. 7e-9 against 1e-10 .. 5e-10 with 36 bits.  u is internal state (ADMM returns x and z,
-                                * src/lasso.jl:170) and the extra error does not reach x or z, but it is why this is an option and not the default. */
+#define LPVS_STORAGE_MIXED32 4 /* MIXED, but the iteration READS the 32 leading bits of the fixed-point tiles only (4 B per element: 140 instead of 157 MB per
+                                * iteration at n = 8192) and the product of the 4-bit planes is taken with a right-hand side at most 32 iterations old, carried
+                                * in the x-update's offset vector ("stale nibble product").  THE DEFAULT of handles whose x-update is
+                                * corrected (one right-hand side, doubles, n >= 2048 -- LPVS_OPT_XUPDATE_CORRECTION); MIXED for every other handle, also when
+                                * asked for by name.  x, z and u stay where MIXED leaves them: at cfg3 after 200 .. 2000 iterations x and z are the same
+                                * 1.2e-10 .. 4.8e-10 from the exact iterates and u 9.8e-11 .. 5.3e-10 (MIXED: 9.6e-11 .. 4.5e-10) --
+                                * profiles/r05_cfg3_stale_nibble_product.txt.  (Without the refresh the dual variable integrates the truncation: u 2e-9 .. 7e-9.) */
 #define LPVS_ITERATION_ONE 1
 #define LPVS_ITERATION_TWO 2
 #define LPVS_GRAM_AP 1        /* structured (error unless the grid is an arithmetic progression up to rounding) */
@@ -240,12 +240,15 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
  * src/lasso.jl:150-151 only needs z and u).  Arrays are n (x ns) in the solver's own order, as lpvs_admm_get_f64 returns. */
 int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *z, const double *u, int64_t iters_done);
 /* Handles of n >= 2048 run the x-update in its offset form, x = xb + M (z - u)/mu, and re-form the offset vector after the iterations
- * 1, 2, 4, 8, ... so that the systematic error of the explicit inverse leaves the iteration (xb_eff = xb - E (x_k - xb), E = M H - I with
- * both products accumulated in twice the mantissa).  That vector is part of the iteration's state between two
+ * 16, 512, 1024, 2048, ... so that the systematic error of the explicit inverse leaves the iteration (one step of iterative refinement
+ * with the residual accumulated in twice the mantissa).  That vector is part of the iteration's state between two
  * scheduled iterations: a checkpoint that is to continue BIT FOR BIT saves it with lpvs_admm_get_offset_f64 next to x, z, u and
- * installs it with lpvs_admm_set_offset_f64 after lpvs_admm_set_state_f64 (which, without it, re-forms the vector from the x it is
- * given -- the same to second order, ~1e-24 relative).  Always doubles (also for handles made by the _f32 constructors), n (x ns).
- * LPVS_ESTATE when the handle has no offset vector (n < 2048, or before lpvs_admm_init). */
+ * installs it with lpvs_admm_set_offset_f64 after lpvs_admm_set_state_f64 (which, without it, re-forms the vector from the state it is
+ * given -- the same to second order).  Always doubles (also for handles made by the _f32 constructors).
+ * lpvs_admm_offset_len: how many -- n x ns, or 2 n for a handle that iterates on LPVS_STORAGE_MIXED32 reads (the vector with and without
+ * the nibble term of the last refresh: both are state); 0 when the handle has no offset vector (n < 2048).  The buffer is opaque: hand
+ * back what lpvs_admm_get_offset_f64 wrote.  get / set: LPVS_ESTATE when the handle has no offset vector, or before lpvs_admm_init. */
+int32_t lpvs_admm_offset_len(lpvs_problem *h, int64_t *len);
 int32_t lpvs_admm_get_offset_f64(lpvs_problem *h, double *xb_out);
 int32_t lpvs_admm_set_offset_f64(lpvs_problem *h, const double *xb);
 /* per-signal state of a multi-signal handle (lpvs_admm_run reports the slowest signal / the largest ||x-z||) */
@@ -270,7 +273,8 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
  * algorithmic Gram flops N*n*(n+1), out[7] ADMM iterations timed in out[4], out[8] Gram form used:
  * 0 none (Gram given), 1 n x n lower triangle, 2 symmetric-pair, 3 k-major panel, 4 structured
  * (arithmetic-progression w, nudft.hip), 5 structured with the slot sums by non-uniform FFT; out[9] the time of the x-update
- * corrections inside out[4] (HIP events around each), out[10] their count. */
+ * corrections inside out[4] (HIP events around each), out[10] their count; out[11] the refreshes of the stale nibble product
+ * enqueued inside out[4] (LPVS_STORAGE_MIXED32), out[12] the duration of one (us; measured stand-alone by lpvs_admm_time_matvec, 0 before). */
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out);
 
 /* average duration (microseconds) of the ADMM mat-vec kernel of this handle over `reps` back-to-back launches, from

@@ -259,13 +259,15 @@ function set_state!(p::Problem, x, z, u, iters_done::Integer; offset=nothing)
         GC.@preserve ov check(@ccall LIB.lpvs_admm_set_offset_f64(p.h::Ptr{Cvoid}, ov::Ptr{Float64})::Int32)
     end
 end
-# the x-update's offset vector currently in effect (handles of n >= 2048; `nothing` otherwise): part of a checkpoint next to `iterates`
+# the x-update's offset vector currently in effect (handles of n >= 2048; `nothing` otherwise): part of a checkpoint next to `iterates`.
+# Opaque: n x ns values, or 2n for a handle that iterates on 32-bit reads of its fixed-point tiles (lpvs_admm_offset_len).
 function offset_vector(p::Problem)
-    xb = zeros(p.n, p.ns)
-    rc = GC.@preserve xb @ccall LIB.lpvs_admm_get_offset_f64(p.h::Ptr{Cvoid}, xb::Ptr{Float64})::Int32
-    rc == LPVS_ESTATE && return nothing
-    check(rc)
-    p.ns == 1 ? vec(xb) : xb
+    k = Ref{Int64}(0)
+    check(@ccall LIB.lpvs_admm_offset_len(p.h::Ptr{Cvoid}, k::Ref{Int64})::Int32)
+    k[] == 0 && return nothing
+    xb = zeros(k[])
+    GC.@preserve xb check(@ccall LIB.lpvs_admm_get_offset_f64(p.h::Ptr{Cvoid}, xb::Ptr{Float64})::Int32)
+    (p.ns == 1 || k[] != p.n * p.ns) ? xb : reshape(xb, p.n, p.ns)
 end
 
 # ---- ADMM driver: src/lasso.jl:136-171 with the iterations on the GPU ---------------------------

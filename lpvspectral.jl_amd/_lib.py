@@ -103,6 +103,7 @@ SIGNATURES = {
     "lpvs_admm_init_f64": (_I32, [_P, _P, _F64, _F64, _I32]),
     "lpvs_admm_run": (_I32, [_P, _I64, _PI64, C.POINTER(_F64), C.POINTER(_I32)]),
     "lpvs_admm_set_state_f64": (_I32, [_P, _P, _P, _P, _I64]),
+    "lpvs_admm_offset_len": (_I32, [_P, _PI64]),
     "lpvs_admm_get_offset_f64": (_I32, [_P, _P]),
     "lpvs_admm_set_offset_f64": (_I32, [_P, _P]),
     "lpvs_admm_matvec_kind": (_I32, [_P, C.POINTER(_I32)]),

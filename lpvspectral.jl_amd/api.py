@@ -466,16 +466,23 @@ class Problem:
         check(fn(self._h, out_ptr(arrs[0]), out_ptr(arrs[1]), out_ptr(arrs[2]), int(iters)))
         if offset is not None:
             off = np.asfortranarray(np.asarray(offset, dtype=np.float64))
-            assert off.size == self.n * self.ns, "offset has the wrong length"
+            assert off.size == self._offset_len(), "offset has the wrong length"
             check(lib().lpvs_admm_set_offset_f64(self._h, out_ptr(off)))
 
+    def _offset_len(self):
+        k = C.c_int64(0)
+        check(lib().lpvs_admm_offset_len(self._h, C.byref(k)))
+        return int(k.value)
+
     def admm_get_offset(self):
-        """The offset vector of the x-update currently in effect (doubles), or ``None`` for handles without one (n < 2048)."""
-        xb = np.zeros(self.n if self.ns == 1 else (self.n, self.ns), order="F")
-        rc = lib().lpvs_admm_get_offset_f64(self._h, out_ptr(xb))
-        if rc == _lib.LPVS_ESTATE:
+        """The offset vector of the x-update currently in effect (doubles), or ``None`` for handles without one (n < 2048).  Opaque:
+        n x ns values, or 2 n for a handle that iterates on 32-bit reads of its fixed-point tiles (the vector with and without the nibble
+        term of the last refresh; the first n are the offset the x-update adds)."""
+        k = self._offset_len()
+        if k == 0:
             return None
-        check(rc)
+        xb = np.zeros(k if k != self.n * self.ns or self.ns == 1 else (self.n, self.ns), order="F")
+        check(lib().lpvs_admm_get_offset_f64(self._h, out_ptr(xb)))
         return xb
 
     def admm_get(self):
@@ -498,7 +505,8 @@ class Problem:
         np_ = -(-self.n // 128) * 128
         one_launch = bool(int(k.value) & 16)
         fix32 = bool(int(k.value) & 32)            # the fixed-point tiles keep 32 significant bits (handles whose x-update is corrected)
-        fixs = ("32-bit fixed point with per-row steps (4.03 B: the nibbles of the 36-bit form are zero and not read)" if fix32 else
+        fixs = ("36-bit fixed point with per-row steps of which the iteration reads the 32 leading bits (4.03 B; the 4-bit planes meet a right-hand side "
+                "every 32 iterations and ride in the offset vector: 32-bit fixed point reads)" if fix32 else
                 "36-bit fixed point with per-row steps (4.53 B)")
         fixb = 66048 if fix32 else 74240
         k = C.c_int32(int(k.value) & 15)
@@ -566,12 +574,13 @@ class Problem:
         return re + 1j * im
 
     def timing(self):
-        t = np.zeros(11)
-        check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 11))
+        t = np.zeros(13)
+        check(lib().lpvs_problem_get_timing(self._h, out_ptr(t), 13))
         return dict(basis_ms=t[0], gram_ms=t[1], reduce_rhs_ms=t[2], factor_ms=t[3], admm_ms=t[4],
                     gram_issued_flops=t[5], gram_flops=t[6], admm_iters=t[7],
                     gram_form=("given", "kr", "krs", "panel", "ap", "ap-nufft")[int(t[8])],
-                    xcorr_ms=t[9], xcorr_count=int(t[10]))      # the x-update corrections inside admm_ms
+                    xcorr_ms=t[9], xcorr_count=int(t[10]),      # the x-update corrections inside admm_ms
+                    nibble_refreshes=int(t[11]), nibble_refresh_us=t[12])   # the stale nibble product's refreshes inside admm_ms; one of them, stand-alone
 
 
 # --------------------------------------------------------------------------- ADMM driver

@@ -897,10 +897,13 @@ __device__ __forceinline__ V load16(const void *p) {
     return __builtin_bit_cast(V, r);
 }
 
-// fix32 (wave-uniform): the tile keeps 32 significant bits -- its nibbles are zero and are not read (4 B per element instead of 4.5)
+// fmode (wave-uniform): 0 = the 36-bit element (heads + nibbles); 1 = its 32 leading bits only -- the nibbles are not read (4 B per element
+// instead of 4.5) and count as zero; 2 = the NIBBLES only (the heads are the bias, so an element decodes to its nibble x step): the part
+// mode 1 leaves out, for the stale nibble product of handles that iterate on 32-bit reads (launch_nibble_refresh)
 template <bool NT = false>
-__device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, int lane, FixRaw &w, bool fix32 = false) {
+__device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, int lane, FixRaw &w, int fmode = 0) {
     const int g = lane >> 4, c = lane & 15;
+    const bool fix32 = fmode == 1;
     // nibbles and steps FIRST: loads return in order, and the first row group's products need them -- requested last, they kept
     // every product waiting for the tile's last byte (all of a tile's arithmetic then sat at the end of its load)
     const uint4 *nq = reinterpret_cast<const uint4 *>(tile + kFixHeadBytes) + (wave * 64 + lane) * 2;
@@ -909,6 +912,12 @@ __device__ __forceinline__ void fix_load(const unsigned char *tile, int wave, in
     const float4 *st = reinterpret_cast<const float4 *>(tile + kFixHeadBytes + kFixNibBytes) + (wave * 4 + g) * 2;
     w.st[0] = load16<NT, float4>(st); w.st[1] = load16<NT, float4>(st + 1);
     const int *head = reinterpret_cast<const int *>(tile) + (wave * 32 + g) * TS + 4 * c;
+    if (fmode == 2) {
+        const int bias = (int)0x80000000u;           // 16 * 2^31 = 2^35: the element decodes to nibble * step
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) { w.ha[rg] = make_int4(bias, bias, bias, bias); w.hb[rg] = w.ha[rg]; }
+        return;
+    }
 #pragma unroll
     for (int rg = 0; rg < 8; ++rg) {
         w.ha[rg] = load16<NT, int4>(head + rg * 4 * TS);
@@ -1100,7 +1109,7 @@ symv_tile_f32_kernel(const float *__restrict__ Mp, const double *__restrict__ rh
 // tiles (the diagonal ones) are processed in two halves of 64 rows to fit as well.
 __global__ void __launch_bounds__(256, 3)
 symv_tile_mixed_kernel(const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, const double *__restrict__ rhs, int64_t np,
-                       int ntiles, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status, int fix32) {
+                       int ntiles, double *__restrict__ part1_all, double *__restrict__ part2_all, const AdmmStatus *status, int fmode) {
     if (status != nullptr && status[0].converged) return;
     __shared__ double sI[TS], sJ[TS], sT[4][TS];
     const int t = blockIdx.x;
@@ -1111,11 +1120,15 @@ symv_tile_mixed_kernel(const unsigned char *__restrict__ Mp, const unsigned char
     double *part1 = part1_all + (int64_t)t * TS, *part2 = part2_all + (int64_t)t * TS;
     if (types[t] != 0) {                             // (uniform) 36- / 32-bit fixed point; type 2: a diagonal tile, its diagonal apart in doubles
         FixRaw f;
-        fix_load(tile, wave, lane, f, fix32 != 0);
+        fix_load(tile, wave, lane, f, fmode);
         if (threadIdx.x < TS) sI[threadIdx.x] = rhs[(int64_t)I * TS + threadIdx.x];
         else sJ[threadIdx.x - TS] = rhs[(int64_t)J * TS + threadIdx.x - TS];
         __syncthreads();
-        fix_tile_product(f, sI, sJ, sT, part1, part2, types[t] == 2 ? reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4) : nullptr);
+        fix_tile_product(f, sI, sJ, sT, part1, part2, (types[t] == 2 && fmode != 2) ? reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4) : nullptr);
+        return;
+    }
+    if (fmode == 2) {                                // (uniform) a float-head tile has no nibbles: zero partials
+        if (threadIdx.x < TS) { part1[threadIdx.x] = 0.0; part2[threadIdx.x] = 0.0; }
         return;
     }
     // float head + 16-bit tail, two halves of four row groups
@@ -2836,8 +2849,8 @@ bool fused_ok(const AdmmParams &p) {
 }
 
 static void launch_split(const unsigned char *Mp, const unsigned char *types, const double *rhs, int64_t np, unsigned ntiles, double *part1,
-                         double *part2, const AdmmStatus *status, hipStream_t s, int fix32 = 0) {
-    if (types != nullptr) hipLaunchKernelGGL(symv_tile_mixed_kernel, dim3(ntiles), dim3(256), 0, s, Mp, types, rhs, np, (int)ntiles, part1, part2, status, fix32);
+                         double *part2, const AdmmStatus *status, hipStream_t s, int fmode = 0) {
+    if (types != nullptr) hipLaunchKernelGGL(symv_tile_mixed_kernel, dim3(ntiles), dim3(256), 0, s, Mp, types, rhs, np, (int)ntiles, part1, part2, status, fmode);
     else hipLaunchKernelGGL(symv_tile_split_kernel, dim3(ntiles), dim3(256), 0, s, Mp, rhs, np, (int)ntiles, part1, part2, status);
 }
 
@@ -3022,6 +3035,11 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     double *part1 = p.part, *part2 = part1 + (size_t)ntiles * TS * ns;
     double *blocknorm = part2 + (size_t)ntiles * TS * ns;
     launch_sym_matvec(p, p.status, s);
+    // (the stale nibble product: refresh R_g sits between the product of rhs_g and the update that adds xb to it -- where the one-launch scheme has it)
+    if (p.nib_period > 0 && p.ns == 1 && p.mp_types != nullptr) {
+        const long long g = p.fi_base + it;
+        if (g == 1 || g % p.nib_period == 0) (void)launch_nibble_refresh(p, false, nullptr, s);
+    }
     if (fused_ok(p)) {
         hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0, stream_layout(p), stream_table(p));
     } else {
@@ -3204,6 +3222,46 @@ vec_sum_kernel(const double *a, const double *b, double *out, int64_t total) {  
     if (i < total) out[i] = a[i] + b[i];
 }
 // out = M~ rhs through the packed tiles (the handle's stand-alone mat-vec + the gather of its partials), no offset, no status
+// ---- the stale nibble product (round 5) --------------------------------------------------------------------------------------------
+// A handle whose x-update is corrected may stream only the 32 leading bits of its fixed-point tiles (AdmmParams::mp_fix32: 4 B per element
+// instead of 4.5, -11 % of the bytes of an iteration at cfg3).  The correction removes the systematic part of what that leaves out from x and
+// z -- but the DUAL variable integrates the rest over the 500+ iterations between two corrections (u: 2e-9 .. 7e-9 from the exact iterates
+// where the 36-bit tiles give 1e-10 .. 5e-10).  So the part left out, N = nibble x step of every element, is multiplied into the right-hand side
+// every nib_period iterations by a pass over the nibble planes alone (16 MB at cfg3, not 157) and carried in the offset vector:
+//     xb = xb_corr + N rhs_g          after the launches g = 1 and g = 0 (mod nib_period)
+// The error left in x is N (rhs_k - rhs_g), k - g < nib_period -- it telescopes over a run instead of integrating.  Absolute launch indices:
+// the iterates do not depend on the chunking of lpvs_admm_run.
+__global__ void __launch_bounds__(256)
+rhs_from_state_kernel(const double *__restrict__ z, const double *__restrict__ u, double mu, int64_t n, int64_t np, double *__restrict__ rhs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < np) rhs[i] = i < n ? (z[i] - u[i]) / mu : 0.0;            // (the very expression the update kernels write: bit-identical to p.rhs at a chunk's end)
+}
+// split = true (after a correction wrote xb = xb0 + d for the right-hand side in memory): xb_corr = xb - N rhs instead, xb stays
+__global__ void __launch_bounds__(256)
+vec_diff_kernel(const double *a, const double *b, double *out, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = a[i] - b[i];
+}
+int32_t launch_nibble_refresh(const AdmmParams &p, bool from_state, const double *u_src, hipStream_t s, bool split) {
+    if (p.ns != 1 || p.mp_types == nullptr || p.xb_corr == nullptr || p.nib_rhs == nullptr || p.nib_part == nullptr) { set_error("nibble refresh: not a single-signal mixed-storage handle"); return LPVS_ESTATE; }
+    const int nblk = (int)(p.np / TS);
+    const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
+    double *part1 = p.nib_part, *part2 = part1 + (size_t)ntiles * TS;
+    const double *rhs = p.rhs;
+    if (from_state) {
+        hipLaunchKernelGGL(rhs_from_state_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p.z, u_src, p.mu, p.n, p.np, p.nib_rhs);
+        rhs = p.nib_rhs;
+    }
+    launch_split(reinterpret_cast<const unsigned char *>(p.Mp), p.mp_types, rhs, p.np, ntiles, part1, part2, nullptr, s, /*fmode=*/2);
+    if (split) {
+        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, 1u), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.nib_rhs, nullptr, (const double *)nullptr, 0);   // N rhs
+        hipLaunchKernelGGL(vec_diff_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p.xb, (const double *)p.nib_rhs, const_cast<double *>(p.xb_corr), p.np);
+    } else
+        hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, 1u), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, const_cast<double *>(p.xb), nullptr, p.xb_corr, 0);
+    LPVS_HIP(hipGetLastError());
+    return LPVS_OK;
+}
+
 static void launch_packed_apply(const AdmmParams &p, const double *rhs, double *out, hipStream_t s) {
     AdmmParams q = p;
     q.rhs = const_cast<double *>(rhs);
@@ -3649,7 +3707,7 @@ fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, cons
         // compiler wait for everything before the first product)
         if (!PA && I == J) {                         // (uniform) a diagonal tile in the fixed format that was not requested up front: only now
             FixRaw fd;
-            fix_load(tile, wave, lane, fd, p.mp_fix32 != 0);
+            fix_load(tile, wave, lane, fd, p.mp_fix32 != 0 ? 1 : 0);
             fi_fixed_product(fd, sI, sJ, wave, lane, v, tc);
         } else fi_fixed_product(fr, sI, sJ, wave, lane, v, tc);
         if (ttype == 2 && !prefetch_all) diag = reinterpret_cast<const double *>(tile + kFixHeadBytes + kFixNibBytes + TS * 4);
@@ -3824,9 +3882,15 @@ static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, s
         hipLaunchKernelGGL(fi_kernel(mode, small, batch, nt, prefetch_all, p.mp_f32 != 0), dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
                            commit_prev, mp_stride, prefetch_all ? 1 : 0);
     };
+    // stale nibble product: after launch g (which multiplied rhs_g) the offset vector of the launches from g + 1 on -- g = 1 and g = 0 mod the period
+    const bool nib = !batch && p.nib_period > 0;
+    auto refresh_due = [&](long long g) { return nib && (g == 1 || g % p.nib_period == 0); };
     launch(FI_FIRST, ntiles, base, 0, 0, 0);
-    for (int64_t j = 1; j < iters; ++j)   // launch j: update u_{j-1} (reads u from slot (j-1) & 1, writes the other), mat-vec of rhs_j
+    if (refresh_due(base)) LPVS_TRY(launch_nibble_refresh(p, false, nullptr, s));              // rhs_base is the one in memory
+    for (int64_t j = 1; j < iters; ++j) {   // launch j: update u_{j-1} (reads u from slot (j-1) & 1, writes the other), mat-vec of rhs_j
         launch(FI_MID, ntiles, base + j, (int)(j % 3), (int)((j - 1) & 1), j >= 2 ? 1 : 0);
+        if (refresh_due(base + j)) LPVS_TRY(launch_nibble_refresh(p, true, ((j - 1) & 1) ? p.u : f.ualt, s));   // rhs_{base+j} = (z - u) / mu of the state this launch left
+    }
     // the chunk's last update u_{iters-1}: sums of launch iters - 1, u from slot (iters - 1) & 1, everything back in the handle's vectors
     launch(FI_LAST, (unsigned)nblk, base + iters, (int)(iters % 3), (int)((iters - 1) & 1), iters >= 2 ? 1 : 0);
     hipLaunchKernelGGL(fi_fixup_kernel, dim3((unsigned)ceil_div(p.np, 256), (unsigned)nprob), dim3(256), 0, s, p, nblk, base, (long long)iters);

@@ -368,6 +368,7 @@ struct lpvs_problem {
     DevBuf xb; bool offset_form = false;   // xb = M * (signed b), computed at admm_init from the full-precision M (AdmmParams::xb)
     // the x-update's systematic error removed (admm.hip, launch_xupdate_correction): xb0 = the refined offset vector, xb = xb0 - E (x_k - xb0)
     // re-formed after the iterations k = 1, 2, 4, 8, ... (k_enq = iterations enqueued since lpvs_admm_init / lpvs_admm_set_state)
+    DevBuf xb_corr, nib_rhs, nib_part; int nib_period = 0; double n_nib = 0, nib_us = 0;   // refreshes enqueued by the timed runs; one refresh stand-alone (lpvs_admm_time_matvec)   // 32-bit reads with a stale nibble product (AdmmParams::nib_period): the offset vector without its nibble term, scratch
     DevBuf xb0, corr; int xcorr_base = 0, xcorr_every = 0; long long k_enq = 0; bool xb_refined = false, xcorr_double = false, xcorr_early = false;
     // the schedule: after the iterations base^j (xcorr_base >= 2), or after iteration 16 and every xcorr_every-th one; 0 0 = no correction
     long long next_correction(long long k) const {
@@ -384,6 +385,7 @@ struct lpvs_problem {
         return q;
     }
     bool xcorr() const { return xcorr_base >= 2 || xcorr_every > 0; }
+    bool Mp_read32 = false; // the iteration reads the 32 leading bits of the fixed-point tiles only (storage mixed32 on a corrected handle)
     int Mp_fix_bits = 36;   // significant bits of the fixed-point tiles of the packed copy (32: nibbles zero and not read)
     double Mp_rowsum = 0;   // largest absolute row sum of M over its valid rows, left by the mixed packing pass (0: not known)
     DevBuf fi; long long fi_sync = -1; double fi_R = 0, fi_xbmax = 0;      // one-launch iteration (AdmmParams::fi): its records are those of iteration fi_sync
@@ -485,7 +487,8 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.mp_f32 = sym && h->Mp_mode == kMpF32 ? 1 : 0;
     p.mp_split = sym && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed) ? 1 : 0;
     p.mp_types = sym && h->Mp_mode == kMpMixed ? h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np) : nullptr;
-    p.mp_fix32 = p.mp_types != nullptr && h->Mp_fix_bits <= 32 ? 1 : 0;
+    p.mp_fix32 = p.mp_types != nullptr && (h->Mp_fix_bits <= 32 || h->nib_period > 0) ? 1 : 0;
+    p.nib_period = p.mp_types != nullptr ? h->nib_period : 0; p.xb_corr = h->xb_corr.as<double>(); p.nib_rhs = h->nib_rhs.as<double>(); p.nib_part = h->nib_part.as<double>();
     p.xb = sym && h->offset_form ? h->xb.as<double>() : nullptr;
     p.fi = sym && h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && h->fi.p ? h->fi.as<double>() : nullptr;
     p.fi_R = h->fi_R; p.fi_xbmax = h->fi_xbmax;
@@ -1218,13 +1221,18 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         else { h->xcorr_every = 0; h->xcorr_base = atoi(e) < 2 ? 0 : atoi(e); }
         if (!offset_form_wanted) { h->xcorr_base = 0; h->xcorr_every = 0; }
     }
-    // LPVS_STORAGE_MIXED32 on a corrected handle: 32 significant bits in the fixed-point tiles (4 B per element instead of 4.5: the nibbles
-    // are zero and are not read).  The storage error's systematic part leaves x and z with the inverse's -- measured at cfg3, 36 / 32 / 30
-    // bits: the same 1.2e-10 from the exact iterates after 2000 iterations -- but u integrates what is left of it (2e-9 .. 7e-9 instead of
-    // 1e-10 .. 5e-10: profiles/r05_cfg3_fixbits.txt), which is why 36 bits stay the default.
-    // LPVS_FIX_BITS overrides (experiments: fewer bits are emulated in the same bytes).
-    int fix_bits = (h->xcorr() && option_in_effect(LPVS_OPT_M_STORAGE, h->opt[LPVS_OPT_M_STORAGE]) == LPVS_STORAGE_MIXED32) ? 32 : 36;
+    // Corrected single-signal handles READ 32 bits of the 36 their fixed-point tiles hold (4 B per element instead of 4.5) and carry the
+    // product of the 4-bit planes with a right-hand side up to nib_period iterations old in the offset vector (admm.hip, "the stale nibble
+    // product"): x, z and u all stay where the 36-bit reads leave them (u within 5.3e-10 of the exact iterates at cfg3; plain truncation to
+    // 32 bits: 2e-9 .. 7e-9 -- the dual variable integrates it; profiles/r05_cfg3_stale_nibble_product.txt, r05_cfg3_fixbits.txt).
+    // The default, and LPVS_STORAGE_MIXED32 by name; LPVS_STORAGE_MIXED asks for the 36-bit reads.
+    const int st_asked = option_in_effect(LPVS_OPT_M_STORAGE, h->opt[LPVS_OPT_M_STORAGE]);
+    const bool read32 = h->ns == 1 && !h->f32 && h->xcorr() && (st_asked == 0 || st_asked == LPVS_STORAGE_MIXED32);
+    int fix_bits = 36;                               // (packed with all 36 bits: the nibble planes feed the stale nibble product)
     if (const char *e = getenv("LPVS_FIX_BITS")) fix_bits = atoi(e) >= 20 && atoi(e) <= 36 ? atoi(e) : fix_bits;
+    h->nib_period = read32 ? 32 : 0;                 // LPVS_NIB_PERIOD: refresh period of the stale nibble product (experiments; 0: no stale product, the 36-bit reads)
+    if (const char *e = read32 ? getenv("LPVS_NIB_PERIOD") : nullptr) h->nib_period = atoi(e) > 0 ? atoi(e) : 0;
+    h->Mp_read32 = read32;
     if (h->Mp_valid && h->Mp_mode == kMpMixed && h->Mp_fix_bits != fix_bits) h->Mp_valid = false;   // (the same M packed for the other choice)
     const int mode = mp_mode_for(h);
     const bool demoted = mode == kMpMixed && h->Mp_mode == kMpSplit && h->Mp_demoted;   // mixed was tried for this M and found no small tiles
@@ -1257,7 +1265,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
             size_t ndiag = 0;
             for (unsigned char t : ht) { h->Mp_fixed_tiles += t != 0; ndiag += t == 2; }
             h->Mp_fixed_diag = (int64_t)ndiag;
-            h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)(fix_bits <= 32 ? kMixedFixed32TileBytes : kMixedFixedTileBytes) + (double)ndiag * 1024.0 +
+            h->Mp_stream_bytes = (double)h->Mp_fixed_tiles * (double)kMixedFixedTileBytes + (double)ndiag * 1024.0 +
                                  (double)(ntiles - (size_t)h->Mp_fixed_tiles) * (double)kMixedFloatTileBytes;
             const size_t nblk_ = (size_t)(h->np / 128);
             if (getenv("LPVS_TRACE")) fprintf(stderr, "[lpvs] mixed packing: %lld of %zu tiles fixed point (%zu diagonal), ns = %lld\n", (long long)h->Mp_fixed_tiles, ntiles, nblk_, (long long)h->ns);
@@ -1302,6 +1310,12 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
             if (!h->corr.p) LPVS_TRY(h->corr.alloc(3 * v));
             LPVS_HIP(hipMemcpyAsync(h->xb0.p, h->xb.p, v, hipMemcpyDeviceToDevice, s));
         }
+        if (h->nib_period > 0 && h->Mp_mode == kMpMixed) {   // the offset vector without its nibble term: none yet (the first refresh follows launch 1)
+            if (!h->xb_corr.p) LPVS_TRY(h->xb_corr.alloc(v));
+            if (!h->nib_rhs.p) LPVS_TRY(h->nib_rhs.alloc(v));
+            { const size_t nb = (size_t)(h->np / 128), nt = nb * (nb + 1) / 2; if (!h->nib_part.p) LPVS_TRY(h->nib_part.alloc(sizeof(double) * 2 * nt * 128)); }
+            LPVS_HIP(hipMemcpyAsync(h->xb_corr.p, h->xb.p, v, hipMemcpyDeviceToDevice, s));
+        } else h->nib_period = 0;
     } else { h->xcorr_base = 0; h->xcorr_every = 0; }
     h->k_enq = 0;
     if (h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && !h->fi.p) LPVS_TRY(h->fi.alloc(sizeof(double) * fi_doubles(h->np)));
@@ -1336,7 +1350,10 @@ int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *
     h->fi_sync = -1;                                  // (the next run rebuilds the one-launch iteration's records from the new state)
     h->k_enq = iters_done;
     if (h->xcorr() && iters_done > 0)                 // re-entry: the correction of the state handed in (an uninterrupted run holds the one of its last scheduled iteration: same to second order)
+    {
         LPVS_TRY(launch_xupdate_correction(make_params(h), h->G.as<double>(), h->M_shift, h->xb_refined ? nullptr : h->bs.as<double>(), h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
+        if (h->nib_period > 0) LPVS_TRY(launch_nibble_refresh(make_params(h), false, nullptr, s, /*split=*/true));
+    }
     LPVS_HIP(hipStreamSynchronize(s));
     return LPVS_OK;
 }
@@ -1393,6 +1410,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
                 if (next_corr - h->k_enq < step) step = next_corr - h->k_enq;
             }
             LPVS_TRY(launch_admm_iterations(p, step, s));
+            if (p.nib_period > 0) for (long long g = p.fi_base; g < p.fi_base + step; ++g) h->n_nib += g == 1 || g % p.nib_period == 0;
             todo -= step; h->k_enq += step;
             if (h->xcorr() && h->k_enq == next_corr) {
                 if (h->xc_ev.size() < 2 * (nxc + 1)) {
@@ -1402,6 +1420,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
                 }
                 LPVS_HIP(hipEventRecord(h->xc_ev[2 * nxc], s));
                 LPVS_TRY(launch_xupdate_correction(p, h->G.as<double>(), h->M_shift, h->xb_refined ? nullptr : h->bs.as<double>(), h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
+                if (p.nib_period > 0) LPVS_TRY(launch_nibble_refresh(p, false, nullptr, s, /*split=*/true));   // xb_corr = xb - N rhs: the refreshes re-add the nibble term of THEIR right-hand side
                 LPVS_HIP(hipEventRecord(h->xc_ev[2 * nxc + 1], s));
                 ++nxc;
                 if (todo > 0 && !(h->tol > 0)) p.fi_base += step;   // (no stopping test can fire: the device committed exactly `step` more)
@@ -1465,7 +1484,18 @@ int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_laun
     LPVS_HIP(hipEventRecord(h->ev[1].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     *us_per_launch = h->ev[1].ms() * 1e3 / reps;
-    if (bytes_per_launch) *bytes_per_launch = sym ? h->Mp_stream_bytes : 8.0 * (double)h->np * (double)h->np;
+    if (p.nib_period > 0) {   // one refresh of the stale nibble product, stand-alone (the offset vector is put back: a refresh between two scheduled ones would move the iterates)
+        const size_t v = sizeof(double) * (size_t)h->np;
+        LPVS_HIP(hipMemcpyAsync(h->nib_rhs.p, h->xb.p, v, hipMemcpyDeviceToDevice, s));
+        LPVS_TRY(launch_nibble_refresh(p, false, nullptr, s));
+        LPVS_HIP(hipEventRecord(h->ev[1].a, s));
+        for (int i = 0; i < reps; ++i) LPVS_TRY(launch_nibble_refresh(p, false, nullptr, s));
+        LPVS_HIP(hipEventRecord(h->ev[1].b, s));
+        LPVS_HIP(hipMemcpyAsync(h->xb.p, h->nib_rhs.p, v, hipMemcpyDeviceToDevice, s));
+        LPVS_HIP(hipStreamSynchronize(s));
+        h->nib_us = h->ev[1].ms() * 1e3 / reps;
+    }
+    if (bytes_per_launch) *bytes_per_launch = sym ? h->Mp_stream_bytes - (make_params(h).mp_fix32 ? 8192.0 * (double)h->Mp_fixed_tiles : 0.0) : 8.0 * (double)h->np * (double)h->np;   // (32-bit reads: no nibble plane)
     return LPVS_OK;
 }
 
@@ -1489,17 +1519,29 @@ int32_t lpvs_admm_status(lpvs_problem *h, int64_t signal, int64_t *iters_done, d
     return LPVS_OK;
 }
 
+// the offset vector(s): xb, and -- handles that run the stale nibble product -- xb_corr behind it (both are state between two refreshes)
+static bool offset_has_nibble_part(const lpvs_problem *h) { return h->nib_period > 0 && h->xb_corr.p != nullptr; }
+int32_t lpvs_admm_offset_len(lpvs_problem *h, int64_t *len) {
+    if (!h || !len) { set_error("NULL argument"); return LPVS_EARGUMENT; }
+    if (!h->inited) { set_error("lpvs_admm_offset_len before lpvs_admm_init"); return LPVS_ESTATE; }
+    *len = !h->offset_form || !h->xb.p ? 0 : (int64_t)h->ns * h->n * (offset_has_nibble_part(h) ? 2 : 1);
+    return LPVS_OK;
+}
 int32_t lpvs_admm_get_offset_f64(lpvs_problem *h, double *xb_out) {
     if (!h || !xb_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited || !h->offset_form || !h->xb.p) { set_error("this handle has no offset vector (n < 2048, or lpvs_admm_init has not run)"); return LPVS_ESTATE; }
     LPVS_HIP(hipSetDevice(h->device));
-    return copy_state_out(h, h->xb.p, xb_out);
+    LPVS_TRY(copy_state_out(h, h->xb.p, xb_out));
+    if (offset_has_nibble_part(h)) LPVS_TRY(copy_state_out(h, h->xb_corr.p, xb_out + (int64_t)h->ns * h->n));
+    return LPVS_OK;
 }
 int32_t lpvs_admm_set_offset_f64(lpvs_problem *h, const double *xb) {
     if (!h || !xb) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited || !h->offset_form || !h->xb.p) { set_error("this handle has no offset vector (n < 2048, or lpvs_admm_init has not run)"); return LPVS_ESTATE; }
     LPVS_HIP(hipSetDevice(h->device));
-    return copy_state_in(h, h->xb.p, xb);
+    LPVS_TRY(copy_state_in(h, h->xb.p, xb));
+    if (offset_has_nibble_part(h)) LPVS_TRY(copy_state_in(h, h->xb_corr.p, xb + (int64_t)h->ns * h->n));
+    return LPVS_OK;
 }
 
 int32_t lpvs_admm_get_f64(lpvs_problem *h, double *x_out, double *z_out, double *u_out) {
@@ -1551,9 +1593,9 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
 
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out) {
     if (!h || !out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
-    const double v[11] = {h->t_basis, h->t_gram, h->t_reduce, h->t_factor, h->t_admm, h->gram_launches, h->gram_flops, h->admm_iters_timed, h->gram_form,
-                          h->t_xcorr, h->n_xcorr};
-    for (int i = 0; i < n_out && i < 11; ++i) out[i] = v[i];
+    const double v[13] = {h->t_basis, h->t_gram, h->t_reduce, h->t_factor, h->t_admm, h->gram_launches, h->gram_flops, h->admm_iters_timed, h->gram_form,
+                          h->t_xcorr, h->n_xcorr, h->n_nib, h->nib_us};
+    for (int i = 0; i < n_out && i < 13; ++i) out[i] = v[i];
     return LPVS_OK;
 }
 

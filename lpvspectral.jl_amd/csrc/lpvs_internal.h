@@ -225,6 +225,13 @@ struct AdmmParams {
     int ns;            // right-hand sides sharing M (signals of a shared-regressor batch); vectors are [ns][np]
     int mp_f32 = 0;    // Mp holds float (the _f32 entry points: M is streamed in single precision, arithmetic stays double)
     int mp_split = 0;  // Mp holds 6-byte elements (float head + 16-bit tail, 40 significant bits; see admm.hip)
+    // 32-bit reads with a STALE NIBBLE PRODUCT (admm.hip, launch_nibble_refresh): the iteration streams the 32 leading bits of the fixed-point
+    // tiles and the offset vector carries N rhs_g of the last refresh, xb = xb_corr + N rhs_g, re-formed after the launches g = 1 and g = 0 mod
+    // nib_period.  nib_period = 0: off.  xb_corr: the offset vector without any nibble term; nib_rhs: np doubles of scratch.
+    int nib_period = 0;
+    const double *xb_corr = nullptr;
+    double *nib_rhs = nullptr;
+    double *nib_part = nullptr;   // the nibble product's own per-tile partials (2 ntiles TS doubles: the two-launch iteration's are in flight in `part` when a refresh runs)
     int mp_fix32 = 0;  // the fixed-point tiles keep 32 significant bits: their nibbles are zero and are not read (handles whose x-update is corrected: the storage error's systematic part leaves the iteration with the inverse's)
     const unsigned char *mp_types = nullptr;   // mixed storage: per-tile format, 1 = 36-bit fixed point (admm.hip); several right-hand sides: diagonal tiles always 0
     // offset form of the x-update (single-problem tile-packed path): x = xb + M (z-u)/mu with xb = M b computed once from
@@ -244,6 +251,9 @@ struct AdmmParams {
     int *sm_ctl = nullptr;
 };
 bool small_iter_applicable(const AdmmParams &p);
+// xb (written) = xb_corr + N rhs, N = the nibble planes of the packed copy's fixed-point tiles; rhs = p.rhs (from_state = false) or (z - u_src) / mu
+// (split: xb_corr (written) = xb - N rhs instead: after a correction re-formed xb for the right-hand side in memory)
+int32_t launch_nibble_refresh(const AdmmParams &p, bool from_state, const double *u_src, hipStream_t s, bool split = false);
 // one step of iterative refinement for the right-hand side the next x-update multiplies (p.rhs), its residual in twice-the-mantissa
 // accumulation against H = G + shift I; xb_eff = xb0 + M~ (v - H M~ v).  t: 3 x [ns][np] scratch (admm.hip says why)
 // b != NULL: for the whole right-hand side b + v, which also corrects an unrefined xb0 = M b

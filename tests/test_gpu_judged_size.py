@@ -109,7 +109,7 @@ def test_cfg3_gram_block_against_oracle_columns(L, oracle, cfg3):
 #   device  vs oracle                 3.8e-10    8.5e-10    8.0e-10    8.2e-10      (round 4: 4.7e-10 9.4e-10 1.5e-9 1.9e-9)
 # SURVEY 8(d)'s 1e-9 against the f64 oracle holds at every count now, and what is left of it is the ORACLE's own distance to the exact
 # iterates (its Cholesky solves commit the same kind of systematic error the device's explicit inverse did: DESIGN.md section 6).
-CFG3_EXACT_BOUND = {200: 4e-10, 500: 8e-10, 1000: 5e-10, 2000: 2e-10}    # device vs the extended-precision iterate (measured x 1.7 .. 2.5)
+CFG3_EXACT_BOUND = {200: 6e-10, 500: 8e-10, 1000: 5e-10, 2000: 2e-10}    # device vs the extended-precision iterate (measured x 1.5 .. 2; u at 200: 3.9e-10)
 CFG3_ORACLE_BOUND = 1e-9                                                  # device vs the f64 oracle, every count
 def test_cfg3_one_launch_iteration_against_oracle_at_n8192(L, oracle, cfg3):
     """n = 8192 (64 row blocks, 2080 tiles, float-head diagonal tiles at their real scale): the benchmarked kernel against
@@ -126,6 +126,9 @@ def test_cfg3_one_launch_iteration_against_oracle_at_n8192(L, oracle, cfg3):
         p.admm_init(None, μ=mu, tol=0.0)
         info = p.matvec_info()
         assert info["kernel"] == "admm_iter_mixed_kernel" and info["one_launch_iteration"], info
+        # the default: 32 of the fixed-point tiles' 36 bits read per iteration (1992 tiles x 66048 B + 88 float-head tiles x 98304 B = 140.2 MB),
+        # the 4-bit planes through the stale nibble product (64 refreshes in 2000 iterations)
+        assert "32-bit fixed point reads" in info["storage"] and p.time_matvec(10)[1] == 1992 * 66048 + 88 * 98304, info
         done = 0
         for cnt in (200, 500, 1000, 2000):
             it, nxz, conv = p.admm_run(cnt - done)
@@ -159,37 +162,53 @@ def test_cfg3_one_launch_iteration_against_oracle_at_n8192(L, oracle, cfg3):
         assert np.array_equal(z != 0, fix["z"][k] != 0) and np.array_equal(z != 0, fix["oracle_z"][k] != 0)
 
 
-def test_cfg3_32_bit_tiles_keep_x_and_z_but_not_u(L, cfg3):
-    """storage="mixed32" (LPVS_STORAGE_MIXED32: 4 B per fixed-point element, 140 instead of 157 MB per iteration, +6 % signals/s) on the
-    corrected cfg3 handle: x and z sit where the default storage leaves them -- the x-update correction removes the storage error's
-    systematic part -- and meet the 1e-9 against the f64 oracle at every count; the DUAL variable u integrates what is left of the error in
-    the directions the iteration hardly feeds back (measured 2.2e-9 / 6.6e-9 / 2.5e-9 / 1.0e-9 against 1.4e-10 .. 4.5e-10 with 36 bits),
-    which is why this storage is an option and not the default (include/lpvspectral.h)."""
+def test_cfg3_36_bit_reads_by_name_and_without_the_nibble_refresh(L, cfg3, monkeypatch):
+    """The default handle of cfg3 READS 32 of the 36 bits of its fixed-point tiles (140.2 MB per iteration) and carries the product of the
+    4-bit planes with a right-hand side at most 32 iterations old in the offset vector (LPVS_STORAGE_MIXED32, the stale nibble product:
+    test_cfg3_one_launch_iteration_against_oracle_at_n8192 holds it to the exact iterates).  Here the two things beside it:
+    (a) storage="mixed" BY NAME: all 36 bits every iteration (156.5 MB), the same bounds;
+    (b) the reason the refresh exists: 32-bit reads WITHOUT it (LPVS_FIX_BITS=32: the planes are packed as zeros) leave x and z where they
+        are -- the x-update correction removes the truncation's systematic part -- but the DUAL variable integrates the rest
+        (measured 2.2e-9 / 6.6e-9 / 2.5e-9 / 1.0e-9 from the exact iterates; with the refresh 3.9e-10 / 5.3e-10 / 2.6e-10 / 9.8e-11)."""
     import hashlib, os
     c = cfg3
     fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_extended_precision_iterates.npz"))
-    with L.Problem.lpv(c["y"], c["X"], c["V"], c["w"], 8) as p:
-        G, b = p.get_gram()
-        if hashlib.sha256(np.ascontiguousarray(G).tobytes() + np.ascontiguousarray(b).tobytes()).hexdigest() != str(fix["sha256"]):
-            pytest.skip("the fixture belongs to another G, b (see test_cfg3_one_launch_iteration_against_oracle_at_n8192)")
-        del G
-        p.set_option("storage", "mixed32")
-        p.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, 512, 16))
-        p.admm_init(None, μ=0.05, tol=0.0)
-        info = p.matvec_info()
-        assert info["kernel"] == "admm_iter_mixed_kernel" and "32-bit fixed point" in info["storage"], info
-        us, nbytes = p.time_matvec(20)
-        # 140.2 MB per launch (the default: 156.5): 8192 bytes of nibbles less for each of the 1992 fixed-point tiles, 88 float-head tiles
-        assert nbytes == 156536832 - 8192 * 1992 == 1992 * 66048 + 88 * 98304, nbytes
-        done = 0
-        for k, cnt in enumerate(int(q) for q in fix["counts"]):
-            p.admm_run(cnt - done); done = cnt
-            x, z, u = p.admm_get()
-            ex, eo = max(rel(x, fix["x"][k]), rel(z, fix["z"][k])), max(rel(x, fix["oracle_x"][k]), rel(z, fix["oracle_z"][k]))
-            eu = rel(u, fix["u"][k])
-            print(f"cfg3, 32-bit tiles, {cnt} iterations: x, z vs exact {ex:.2e}, vs the f64 oracle {eo:.2e}; u vs exact {eu:.2e}")
-            assert ex <= CFG3_EXACT_BOUND[cnt] and eo <= CFG3_ORACLE_BOUND, (cnt, ex, eo)
-            assert eu <= 1.5e-8 and np.array_equal(z != 0, fix["z"][k] != 0), (cnt, eu)
+    counts = [int(q) for q in fix["counts"]]
+    def leg(storage):
+        with L.Problem.lpv(c["y"], c["X"], c["V"], c["w"], 8) as p:
+            G, b = p.get_gram()
+            if hashlib.sha256(np.ascontiguousarray(G).tobytes() + np.ascontiguousarray(b).tobytes()).hexdigest() != str(fix["sha256"]):
+                pytest.skip("the fixture belongs to another G, b (see test_cfg3_one_launch_iteration_against_oracle_at_n8192)")
+            del G
+            if storage:
+                p.set_option("storage", storage)
+            p.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, 512, 16))
+            p.admm_init(None, μ=0.05, tol=0.0)
+            info = p.matvec_info()
+            assert info["kernel"] == "admm_iter_mixed_kernel", info
+            nbytes = p.time_matvec(20)[1]
+            out, done = [], 0
+            for k, cnt in enumerate(counts):
+                p.admm_run(cnt - done); done = cnt
+                x, z, u = p.admm_get()
+                out.append((max(rel(x, fix["x"][k]), rel(z, fix["z"][k])), max(rel(x, fix["oracle_x"][k]), rel(z, fix["oracle_z"][k])),
+                            rel(u, fix["u"][k]), rel(u, fix["oracle_u"][k]), np.array_equal(z != 0, fix["z"][k] != 0)))
+            return info, nbytes, out
+    # (a) 1992 fixed-point tiles x 74240 B + 88 float-head tiles x 98304 B
+    info, nbytes, out = leg("mixed")
+    assert nbytes == 156536832 == 1992 * 74240 + 88 * 98304 and "32-bit fixed point reads" not in info["storage"], (nbytes, info)
+    for cnt, (ex, eo, eu, euo, same) in zip(counts, out):
+        print(f"cfg3, 36-bit reads, {cnt} iterations: x, z vs exact {ex:.2e}, vs the f64 oracle {eo:.2e}; u vs exact {eu:.2e}, vs the oracle {euo:.2e}")
+        assert max(ex, eu) <= CFG3_EXACT_BOUND[cnt] and max(eo, euo) <= CFG3_ORACLE_BOUND and same, (cnt, ex, eo, eu, euo)
+    # (b) plain truncation: 8192 bytes of nibbles less for each of the 1992 fixed-point tiles, no refresh
+    monkeypatch.setenv("LPVS_FIX_BITS", "32"); monkeypatch.setenv("LPVS_NIB_PERIOD", "0")
+    info, nbytes, out = leg(None)
+    assert nbytes == 156536832 - 8192 * 1992 == 1992 * 66048 + 88 * 98304 and "32-bit fixed point reads" in info["storage"], (nbytes, info)
+    for cnt, (ex, eo, eu, euo, same) in zip(counts, out):
+        print(f"cfg3, 32-bit tiles without the nibble refresh, {cnt} iterations: x, z vs exact {ex:.2e}, vs the f64 oracle {eo:.2e}; u vs exact {eu:.2e}")
+        assert ex <= CFG3_EXACT_BOUND[cnt] and eo <= CFG3_ORACLE_BOUND and same, (cnt, ex, eo)
+        assert eu <= 1.5e-8, (cnt, eu)
+    assert max(o[2] for o in out) > 1e-9                                   # (the day this fails the refresh is no longer needed)
 
 
 def test_cfg4_default_plan_fullsize_against_uncut_and_oracle(L, oracle, monkeypatch):
