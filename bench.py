@@ -1022,7 +1022,7 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         p.admm_init(None, μ=MU, tol=0.0)
         mv_us, mv_bytes = p.time_matvec(300)
         mv_info = p.matvec_info()
-        nib_us = p.timing()["nibble_refresh_us"]           # one refresh of the stale nibble product, stand-alone (0: the handle runs none)
+        nib_us = p.timing()["nibble_refresh_us"]           # one refresh of the stale nibble product where it is kernels of its own (0: none, or part of the iteration's launches)
     phase["nibble_refresh_ms"] = n_nib * nib_us * 1e-3     # (count of the timed steps' solves x that duration: inside admm_ms)
     # the same mat-vec with the inverse stored in doubles (LPVS_M_STORAGE=f64) and in uniform 6-byte elements (=split), for the
     # record: not on the timed path
@@ -1069,8 +1069,9 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         # the timed region = HIP events around the ADMM loop of every timed step / launches (the loop holds nothing else but the first
         # launch without an update and one update-only launch per 2000); mv_only_us = the same kernel without its update, back to back
         # ... minus the x-update corrections (three in 2000 iterations: two packed products and one accurate Gram product each), which are
-        # other kernels: their time is phase_xcorr_ms; likewise the refreshes of the stale nibble product (three small kernels every 32
-        # iterations: phase_nibble_refresh_ms = their count x one refresh timed stand-alone)
+        # other kernels: their time is phase_xcorr_ms.  The refreshes of the stale nibble product (103 per solve) stay IN: each is the launch
+        # it follows, which then also reads the 4-bit planes (156.5 instead of 140.2 MB), and a vector kernel of 2 us -- +0.4 us on the
+        # average (phase_nibble_refresh_ms is non-zero only where the refresh is three kernels of its own: LPVS_NIB_FUSED=0)
         mv_us = (phase["admm_ms"] - phase["xcorr_ms"] - phase["nibble_refresh_ms"]) * 1e3 / iters
     mv_share = iters * mv_us * 1e-3 / (elapsed / steps * 1e3)
     # (the one-launch kernel's instance that carries the update: <1, ...>; <0, ...> is a chunk's first launch, <2, ...> its last update)
@@ -1128,7 +1129,7 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                      "matvec_only_launch_us": mv_only_us,
                      "note": ("algorithmic bytes = %s (+ 0.2 MB of state vectors); M is read once per iteration; ONE launch per iteration: the kernel "
                               "rebuilds its right-hand-side blocks (prox + dual update) in the prologue and adds its partial sums into x with 64-bit "
-                              "fixed-point atomics; launch_us = (HIP events around the ADMM loops of the timed steps - the x-update corrections inside them, timed by events of their own, - the refreshes of the stale nibble product, count x one timed stand-alone) / launches (the two-launch scheme, "
+                              "fixed-point atomics; launch_us = (HIP events around the ADMM loops of the timed steps - the x-update corrections inside them, timed by events of their own, ; 103 of the 2000 launches also multiply the 4-bit planes of their tile and are followed by a vector kernel -- the stale nibble product, +0.4 us on this average) / launches (the two-launch scheme, "
                               "LPVS_ITERATION=two: mat-vec 24.7-25.7 us + update 5.3 us = 31.6 us per iteration); matvec_only_launch_us = that "
                               "scheme's stand-alone mat-vec kernel (the same product, no update), 300 back-to-back launches" % mv_info["bytes_formula"])
                              if mv_info.get("one_launch_iteration") else

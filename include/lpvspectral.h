@@ -95,11 +95,11 @@ int32_t lpvs_release_cached_memory(void);
 #define LPVS_STORAGE_SPLIT 2  /* float head + 16-bit tail everywhere (6 bytes, 40 significant bits) */
 #define LPVS_STORAGE_F64 3    /* doubles (8 bytes): the reference-width copy */
 #define LPVS_STORAGE_MIXED32 4 /* MIXED, but the iteration READS the 32 leading bits of the fixed-point tiles only (4 B per element: 140 instead of 157 MB per
-                                * iteration at n = 8192) and the product of the 4-bit planes is taken with a right-hand side at most 32 iterations old, carried
+                                * iteration at n = 8192) and the product of the 4-bit planes is taken with a right-hand side at most 32 iterations old (1, 2, 4, ... in the first 256), carried
                                 * in the x-update's offset vector ("stale nibble product").  THE DEFAULT of handles whose x-update is
                                 * corrected (one right-hand side, doubles, n >= 2048 -- LPVS_OPT_XUPDATE_CORRECTION); MIXED for every other handle, also when
                                 * asked for by name.  x, z and u stay where MIXED leaves them: at cfg3 after 200 .. 2000 iterations x and z are the same
-                                * 1.2e-10 .. 4.8e-10 from the exact iterates and u 9.8e-11 .. 5.3e-10 (MIXED: 9.6e-11 .. 4.5e-10) --
+                                * 1.2e-10 .. 4.8e-10 from the exact iterates and u 9.8e-11 .. 5.0e-10 (MIXED: 9.6e-11 .. 4.5e-10) --
                                 * profiles/r05_cfg3_stale_nibble_product.txt.  (Without the refresh the dual variable integrates the truncation: u 2e-9 .. 7e-9.) */
 #define LPVS_ITERATION_ONE 1
 #define LPVS_ITERATION_TWO 2
@@ -274,7 +274,9 @@ int32_t lpvs_problem_pack_params_f64(lpvs_problem *h, const double *coef, double
  * 0 none (Gram given), 1 n x n lower triangle, 2 symmetric-pair, 3 k-major panel, 4 structured
  * (arithmetic-progression w, nudft.hip), 5 structured with the slot sums by non-uniform FFT; out[9] the time of the x-update
  * corrections inside out[4] (HIP events around each), out[10] their count; out[11] the refreshes of the stale nibble product
- * enqueued inside out[4] (LPVS_STORAGE_MIXED32), out[12] the duration of one (us; measured stand-alone by lpvs_admm_time_matvec, 0 before). */
+ * enqueued inside out[4] (LPVS_STORAGE_MIXED32), out[12] the duration of one (us) where a refresh is three kernels of its own (the two-launch
+ * iteration; measured stand-alone by lpvs_admm_time_matvec) -- 0 before that call and for the one-launch iteration, whose refresh is part
+ * of the launch it follows (that launch also multiplies the 4-bit planes) plus one vector kernel. */
 int32_t lpvs_problem_get_timing(lpvs_problem *h, double *out, int32_t n_out);
 
 /* average duration (microseconds) of the ADMM mat-vec kernel of this handle over `reps` back-to-back launches, from

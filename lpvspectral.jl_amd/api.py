@@ -506,7 +506,7 @@ class Problem:
         one_launch = bool(int(k.value) & 16)
         fix32 = bool(int(k.value) & 32)            # the fixed-point tiles keep 32 significant bits (handles whose x-update is corrected)
         fixs = ("36-bit fixed point with per-row steps of which the iteration reads the 32 leading bits (4.03 B; the 4-bit planes meet a right-hand side "
-                "every 32 iterations and ride in the offset vector: 32-bit fixed point reads)" if fix32 else
+                "every 32 iterations -- more often in the first 256 -- and ride in the offset vector: 32-bit fixed point reads)" if fix32 else
                 "36-bit fixed point with per-row steps (4.53 B)")
         fixb = 66048 if fix32 else 74240
         k = C.c_int32(int(k.value) & 15)

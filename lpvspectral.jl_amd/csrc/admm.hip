@@ -3038,7 +3038,7 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     // (the stale nibble product: refresh R_g sits between the product of rhs_g and the update that adds xb to it -- where the one-launch scheme has it)
     if (p.nib_period > 0 && p.ns == 1 && p.mp_types != nullptr) {
         const long long g = p.fi_base + it;
-        if (g == 1 || g % p.nib_period == 0) (void)launch_nibble_refresh(p, false, nullptr, s);
+        if (nib_refresh_due(g, p.nib_period, p.nib_ramp)) (void)launch_nibble_refresh(p, false, nullptr, s);
     }
     if (fused_ok(p)) {
         hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0, stream_layout(p), stream_table(p));
@@ -3480,7 +3480,10 @@ extern "C" int32_t lpvs_debug_set_timeline(unsigned long long *dev_buf) {
 // prefetch_all: every tile of the batch is in the fixed format, so the diagonal tiles (and their double diagonals) are requested up
 // front like the others (cfg4: four of a window's ten tiles); otherwise diagonal tiles are loaded after the prologue (cfg3: float-head).
 // F32: the packed inverse is the plain single-precision copy of the _f32 handles (64 KB tiles, every tile requested up front; PA ignored).
-template <int MODE, int NK, bool BATCH, bool NT, bool PA, bool F32>
+// NIBR (single problems that iterate on 32-bit reads, launches after which the stale nibble product is due): the launch ALSO multiplies the
+// 4-bit planes of its fixed-point tile into the same right-hand side and adds those sums, as integers of the launch's quantum, into
+// p.nib_acc -- nib_acc_commit_kernel turns them into the offset vector of the launches that follow (see "the stale nibble product").
+template <int MODE, int NK, bool BATCH, bool NT, bool PA, bool F32, bool NIBR = false>
 __device__ __forceinline__ void
 fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
                  int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev, size_t mp_stride) {
@@ -3787,14 +3790,66 @@ fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, cons
             atomicAdd(acc_cur + voff + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
         }
     }
+    if constexpr (NIBR && !BATCH && !F32 && !PA) {
+        // ---- the nibble planes of a fixed-point tile against the same two blocks (fix_load's mode 2: heads = the bias, so an element decodes
+        // to nibble x step), reduced as above, into the second accumulator.  A rare launch (one in nib_period): the planes are requested only now.
+        if (ttype != 0) {                                              // (uniform)
+            __syncthreads();                                           // sT is read above
+            FixRaw fb;
+            fix_load(tile, wave, lane, fb, 2);
+            double vn[8], tn[8];
+            fi_fixed_product(fb, sI, sJ, wave, lane, vn, tn);
+            unsigned long long *acc_n = reinterpret_cast<unsigned long long *>(p.nib_acc);
+#pragma unroll
+            for (int m = 8, cnt = 4; m >= 2; m >>= 1, cnt >>= 1) {
+                const bool up = (c & m) != 0;
+#pragma unroll
+                for (int k = 0; k < cnt; ++k) {
+                    const double lo_ = opaque(vn[k]), hi_ = opaque(vn[k + cnt]);
+                    vn[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+                }
+            }
+            vn[0] += __shfl_xor(vn[0], 1, 64);
+            if ((c & 1) == 0) {
+                const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
+                atomicAdd(acc_n + (int64_t)I * TS + wave * 32 + 4 * rg + gq, (unsigned long long)__double2ll_rn(vn[0] * invq));
+            }
+            if (I != J) {
+#pragma unroll
+                for (int m = 32, cnt = 4; m >= 16; m >>= 1, cnt >>= 1) {
+                    const bool up = (lane & m) != 0;
+#pragma unroll
+                    for (int k = 0; k < cnt; ++k) {
+                        const double lo_ = opaque(tn[k]), hi_ = opaque(tn[k + cnt]);
+                        tn[k] = (up ? hi_ : lo_) + __shfl_xor(up ? lo_ : hi_, m, 64);
+                    }
+                }
+                const int col = ((lane & 32) ? 64 : 0) + 4 * c + ((lane & 16) ? 2 : 0);
+                sT[wave][col] = tn[0]; sT[wave][col + 1] = tn[1];
+                __syncthreads();
+                if (threadIdx.x < TS) {
+                    const double r2 = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
+                    atomicAdd(acc_n + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
+                }
+            }
+        }
+    }
     LPVS_TL_STAMP(5);
 }
 
-template <int MODE, int NK, bool BATCH, bool NT, bool PA, bool F32>
+template <int MODE, int NK, bool BATCH, bool NT, bool PA, bool F32, bool NIBR = false>
 __global__ void __launch_bounds__(256, 3)
 admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
                        int uslot, int commit_prev, size_t mp_stride, int /* PA as a run-time value: unused */) {
-    fi_one_tile_body<MODE, NK, BATCH, NT, PA, F32>(p, Mp, types, ntiles, nblk, g, aslot, uslot, commit_prev, mp_stride);
+    fi_one_tile_body<MODE, NK, BATCH, NT, PA, F32, NIBR>(p, Mp, types, ntiles, nblk, g, aslot, uslot, commit_prev, mp_stride);
+}
+// xb = xb_corr + (sums of the nibble planes' product, integers of the launch's quantum) x quantum; the accumulator is left zeroed for the next refresh
+__global__ void __launch_bounds__(256)
+nib_acc_commit_kernel(long long *__restrict__ acc, const double *__restrict__ quantum, const double *__restrict__ xb_corr, double *__restrict__ xb, int64_t np) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= np) return;
+    xb[e] = xb_corr[e] + (double)acc[e] * *quantum;
+    acc[e] = 0;
 }
 
 // constants and records of the one-launch iteration (after lpvs_admm_init / set_state; base = iterations done so far); p.ns problems
@@ -3866,6 +3921,16 @@ static FiKernel fi_kernel(int mode, bool small, bool batch, bool nt, bool pa, bo
     if (nt) return pa ? fi_kernel_mode<6, false, true, true>(mode) : fi_kernel_mode<6, false, true, false>(mode);
     return pa ? fi_kernel_mode<6, false, false, true>(mode) : fi_kernel_mode<6, false, false, false>(mode);
 }
+bool nib_fused_applies(const AdmmParams &p) {
+    const char *e = getenv("LPVS_NIB_FUSED");
+    return !(e && e[0] == '0') && p.nib_period > 0 && p.nib_acc != nullptr && p.mp_types != nullptr && p.fi_prefetch_all == 0 && fi_applicable(p);
+}
+// (the launches that also multiply the nibble planes: single problems, no prefetch of diagonal tiles; FIRST or MID)
+static FiKernel fi_kernel_nibr(int mode, bool small, bool nt) {
+    if (small) return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, 1, false, false, false, false, true> : admm_iter_mixed_kernel<FI_MID, 1, false, false, false, false, true>;
+    if (nt) return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, 6, false, true, false, false, true> : admm_iter_mixed_kernel<FI_MID, 6, false, true, false, false, true>;
+    return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, 6, false, false, false, false, true> : admm_iter_mixed_kernel<FI_MID, 6, false, false, false, false, true>;
+}
 static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, size_t mp_stride, bool prefetch_all, hipStream_t s) {
     const int nblk = (int)(p.np / TS), nprob = batch ? p.ns : 1;
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
@@ -3882,15 +3947,26 @@ static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, s
         hipLaunchKernelGGL(fi_kernel(mode, small, batch, nt, prefetch_all, p.mp_f32 != 0), dim3(grid, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot,
                            commit_prev, mp_stride, prefetch_all ? 1 : 0);
     };
-    // stale nibble product: after launch g (which multiplied rhs_g) the offset vector of the launches from g + 1 on -- g = 1 and g = 0 mod the period
-    const bool nib = !batch && p.nib_period > 0;
-    auto refresh_due = [&](long long g) { return nib && (g == 1 || g % p.nib_period == 0); };
-    launch(FI_FIRST, ntiles, base, 0, 0, 0);
-    if (refresh_due(base)) LPVS_TRY(launch_nibble_refresh(p, false, nullptr, s));              // rhs_base is the one in memory
-    for (int64_t j = 1; j < iters; ++j) {   // launch j: update u_{j-1} (reads u from slot (j-1) & 1, writes the other), mat-vec of rhs_j
-        launch(FI_MID, ntiles, base + j, (int)(j % 3), (int)((j - 1) & 1), j >= 2 ? 1 : 0);
-        if (refresh_due(base + j)) LPVS_TRY(launch_nibble_refresh(p, true, ((j - 1) & 1) ? p.u : f.ualt, s));   // rhs_{base+j} = (z - u) / mu of the state this launch left
-    }
+    // stale nibble product: launch g (which multiplies rhs_g) also multiplies the nibble planes when g = 1 or g = 0 mod the period, and the
+    // commit kernel behind it forms the offset vector of the launches from g + 1 on (LPVS_NIB_FUSED=0: the three stand-alone kernels of
+    // launch_nibble_refresh instead -- the two-launch iteration's way, for A/B runs)
+    const bool nib = !batch && !prefetch_all && nib_fused_applies(p), nib_fused = true;
+    auto refresh_due = [&](long long g) { return !batch && p.nib_period > 0 && nib_refresh_due(g, p.nib_period, p.nib_ramp); };
+    auto launch_step = [&](int mode, long long g, int aslot, int uslot, int commit_prev, const double *u_after) -> int32_t {
+        const bool due = refresh_due(g);
+        if (due && nib && nib_fused) {
+            hipLaunchKernelGGL(fi_kernel_nibr(mode, small, nt), dim3(ntiles, 1u), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot, commit_prev, mp_stride, 0);
+            hipLaunchKernelGGL(nib_acc_commit_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p.nib_acc, (const double *)(f.qbuf + (g & 1)), p.xb_corr,
+                               const_cast<double *>(p.xb), p.np);
+            return LPVS_OK;
+        }
+        launch(mode, ntiles, g, aslot, uslot, commit_prev);
+        if (due) return launch_nibble_refresh(p, u_after != nullptr, u_after, s);
+        return LPVS_OK;
+    };
+    LPVS_TRY(launch_step(FI_FIRST, base, 0, 0, 0, nullptr));                                    // rhs_base is the one in memory
+    for (int64_t j = 1; j < iters; ++j)     // launch j: update u_{j-1} (reads u from slot (j-1) & 1, writes the other), mat-vec of rhs_j = (z - u) / mu of the state it leaves
+        LPVS_TRY(launch_step(FI_MID, base + j, (int)(j % 3), (int)((j - 1) & 1), j >= 2 ? 1 : 0, ((j - 1) & 1) ? p.u : f.ualt));
     // the chunk's last update u_{iters-1}: sums of launch iters - 1, u from slot (iters - 1) & 1, everything back in the handle's vectors
     launch(FI_LAST, (unsigned)nblk, base + iters, (int)(iters % 3), (int)((iters - 1) & 1), iters >= 2 ? 1 : 0);
     hipLaunchKernelGGL(fi_fixup_kernel, dim3((unsigned)ceil_div(p.np, 256), (unsigned)nprob), dim3(256), 0, s, p, nblk, base, (long long)iters);

@@ -368,7 +368,7 @@ struct lpvs_problem {
     DevBuf xb; bool offset_form = false;   // xb = M * (signed b), computed at admm_init from the full-precision M (AdmmParams::xb)
     // the x-update's systematic error removed (admm.hip, launch_xupdate_correction): xb0 = the refined offset vector, xb = xb0 - E (x_k - xb0)
     // re-formed after the iterations k = 1, 2, 4, 8, ... (k_enq = iterations enqueued since lpvs_admm_init / lpvs_admm_set_state)
-    DevBuf xb_corr, nib_rhs, nib_part; int nib_period = 0; double n_nib = 0, nib_us = 0;   // refreshes enqueued by the timed runs; one refresh stand-alone (lpvs_admm_time_matvec)   // 32-bit reads with a stale nibble product (AdmmParams::nib_period): the offset vector without its nibble term, scratch
+    DevBuf xb_corr, nib_rhs, nib_part, nib_acc; int nib_period = 0, nib_ramp = 0; double n_nib = 0, nib_us = 0;   // refreshes enqueued by the timed runs; one refresh stand-alone (lpvs_admm_time_matvec)   // 32-bit reads with a stale nibble product (AdmmParams::nib_period): the offset vector without its nibble term, scratch
     DevBuf xb0, corr; int xcorr_base = 0, xcorr_every = 0; long long k_enq = 0; bool xb_refined = false, xcorr_double = false, xcorr_early = false;
     // the schedule: after the iterations base^j (xcorr_base >= 2), or after iteration 16 and every xcorr_every-th one; 0 0 = no correction
     long long next_correction(long long k) const {
@@ -488,7 +488,7 @@ AdmmParams make_params(const lpvs_problem *h) {
     p.mp_split = sym && (h->Mp_mode == kMpSplit || h->Mp_mode == kMpMixed) ? 1 : 0;
     p.mp_types = sym && h->Mp_mode == kMpMixed ? h->Mp.as<unsigned char>() + 6 * symv_packed_doubles(h->np) : nullptr;
     p.mp_fix32 = p.mp_types != nullptr && (h->Mp_fix_bits <= 32 || h->nib_period > 0) ? 1 : 0;
-    p.nib_period = p.mp_types != nullptr ? h->nib_period : 0; p.xb_corr = h->xb_corr.as<double>(); p.nib_rhs = h->nib_rhs.as<double>(); p.nib_part = h->nib_part.as<double>();
+    p.nib_period = p.mp_types != nullptr ? h->nib_period : 0; p.nib_ramp = h->nib_ramp; p.xb_corr = h->xb_corr.as<double>(); p.nib_rhs = h->nib_rhs.as<double>(); p.nib_part = h->nib_part.as<double>(); p.nib_acc = h->nib_acc.as<long long>();
     p.xb = sym && h->offset_form ? h->xb.as<double>() : nullptr;
     p.fi = sym && h->offset_form && h->ns == 1 && (h->Mp_mode == kMpMixed || h->Mp_mode == kMpF32) && h->fi.p ? h->fi.as<double>() : nullptr;
     p.fi_R = h->fi_R; p.fi_xbmax = h->fi_xbmax;
@@ -1223,7 +1223,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     }
     // Corrected single-signal handles READ 32 bits of the 36 their fixed-point tiles hold (4 B per element instead of 4.5) and carry the
     // product of the 4-bit planes with a right-hand side up to nib_period iterations old in the offset vector (admm.hip, "the stale nibble
-    // product"): x, z and u all stay where the 36-bit reads leave them (u within 5.3e-10 of the exact iterates at cfg3; plain truncation to
+    // product"): x, z and u all stay where the 36-bit reads leave them (u within 5.0e-10 of the exact iterates at cfg3; plain truncation to
     // 32 bits: 2e-9 .. 7e-9 -- the dual variable integrates it; profiles/r05_cfg3_stale_nibble_product.txt, r05_cfg3_fixbits.txt).
     // The default, and LPVS_STORAGE_MIXED32 by name; LPVS_STORAGE_MIXED asks for the 36-bit reads.
     const int st_asked = option_in_effect(LPVS_OPT_M_STORAGE, h->opt[LPVS_OPT_M_STORAGE]);
@@ -1232,6 +1232,10 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     if (const char *e = getenv("LPVS_FIX_BITS")) fix_bits = atoi(e) >= 20 && atoi(e) <= 36 ? atoi(e) : fix_bits;
     h->nib_period = read32 ? 32 : 0;                 // LPVS_NIB_PERIOD: refresh period of the stale nibble product (experiments; 0: no stale product, the 36-bit reads)
     if (const char *e = read32 ? getenv("LPVS_NIB_PERIOD") : nullptr) h->nib_period = atoi(e) > 0 ? atoi(e) : 0;
+    // ... denser while the right-hand side still moves fast: after every launch up to 15, every 2nd up to 31, 4th up to 63, ..., 32nd from 256 on
+    // (103 refreshes in 2000 iterations; u at cfg3 after 200 iterations 1.75e-10 from the exact iterate instead of 3.9e-10 -- 36-bit reads: 1.40e-10)
+    h->nib_ramp = read32 ? 8 : 0;
+    if (const char *e = read32 ? getenv("LPVS_NIB_RAMP") : nullptr) h->nib_ramp = atoi(e) > 0 ? atoi(e) : 0;
     h->Mp_read32 = read32;
     if (h->Mp_valid && h->Mp_mode == kMpMixed && h->Mp_fix_bits != fix_bits) h->Mp_valid = false;   // (the same M packed for the other choice)
     const int mode = mp_mode_for(h);
@@ -1313,6 +1317,8 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         if (h->nib_period > 0 && h->Mp_mode == kMpMixed) {   // the offset vector without its nibble term: none yet (the first refresh follows launch 1)
             if (!h->xb_corr.p) LPVS_TRY(h->xb_corr.alloc(v));
             if (!h->nib_rhs.p) LPVS_TRY(h->nib_rhs.alloc(v));
+            if (!h->nib_acc.p) LPVS_TRY(h->nib_acc.alloc(v));
+            LPVS_HIP(hipMemsetAsync(h->nib_acc.p, 0, v, s));
             { const size_t nb = (size_t)(h->np / 128), nt = nb * (nb + 1) / 2; if (!h->nib_part.p) LPVS_TRY(h->nib_part.alloc(sizeof(double) * 2 * nt * 128)); }
             LPVS_HIP(hipMemcpyAsync(h->xb_corr.p, h->xb.p, v, hipMemcpyDeviceToDevice, s));
         } else h->nib_period = 0;
@@ -1410,7 +1416,7 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
                 if (next_corr - h->k_enq < step) step = next_corr - h->k_enq;
             }
             LPVS_TRY(launch_admm_iterations(p, step, s));
-            if (p.nib_period > 0) for (long long g = p.fi_base; g < p.fi_base + step; ++g) h->n_nib += g == 1 || g % p.nib_period == 0;
+            if (p.nib_period > 0) for (long long g = p.fi_base; g < p.fi_base + step; ++g) h->n_nib += nib_refresh_due(g, p.nib_period, p.nib_ramp);
             todo -= step; h->k_enq += step;
             if (h->xcorr() && h->k_enq == next_corr) {
                 if (h->xc_ev.size() < 2 * (nxc + 1)) {
@@ -1484,7 +1490,8 @@ int32_t lpvs_admm_time_matvec(lpvs_problem *h, int32_t reps, double *us_per_laun
     LPVS_HIP(hipEventRecord(h->ev[1].b, s));
     LPVS_HIP(hipStreamSynchronize(s));
     *us_per_launch = h->ev[1].ms() * 1e3 / reps;
-    if (p.nib_period > 0) {   // one refresh of the stale nibble product, stand-alone (the offset vector is put back: a refresh between two scheduled ones would move the iterates)
+    h->nib_us = 0;
+    if (p.nib_period > 0 && !nib_fused_applies(p)) {   // one refresh of the stale nibble product where it is three kernels of its own (the two-launch iteration), stand-alone; the offset vector is put back
         const size_t v = sizeof(double) * (size_t)h->np;
         LPVS_HIP(hipMemcpyAsync(h->nib_rhs.p, h->xb.p, v, hipMemcpyDeviceToDevice, s));
         LPVS_TRY(launch_nibble_refresh(p, false, nullptr, s));

@@ -229,8 +229,10 @@ struct AdmmParams {
     // tiles and the offset vector carries N rhs_g of the last refresh, xb = xb_corr + N rhs_g, re-formed after the launches g = 1 and g = 0 mod
     // nib_period.  nib_period = 0: off.  xb_corr: the offset vector without any nibble term; nib_rhs: np doubles of scratch.
     int nib_period = 0;
+    int nib_ramp = 0;   // > 0: the first refreshes are denser -- the period is min(nib_period, max(1, 2^floor(log2 g) / nib_ramp)) (the right-hand side moves fastest in the first iterations)
     const double *xb_corr = nullptr;
     double *nib_rhs = nullptr;
+    long long *nib_acc = nullptr;   // np integers, zero between refreshes: the one-launch iteration's sums of the nibble planes' product (admm_iter_mixed_kernel<..., NIBR>)
     double *nib_part = nullptr;   // the nibble product's own per-tile partials (2 ntiles TS doubles: the two-launch iteration's are in flight in `part` when a refresh runs)
     int mp_fix32 = 0;  // the fixed-point tiles keep 32 significant bits: their nibbles are zero and are not read (handles whose x-update is corrected: the storage error's systematic part leaves the iteration with the inverse's)
     const unsigned char *mp_types = nullptr;   // mixed storage: per-tile format, 1 = 36-bit fixed point (admm.hip); several right-hand sides: diagonal tiles always 0
@@ -254,6 +256,19 @@ bool small_iter_applicable(const AdmmParams &p);
 // xb (written) = xb_corr + N rhs, N = the nibble planes of the packed copy's fixed-point tiles; rhs = p.rhs (from_state = false) or (z - u_src) / mu
 // (split: xb_corr (written) = xb - N rhs instead: after a correction re-formed xb for the right-hand side in memory)
 int32_t launch_nibble_refresh(const AdmmParams &p, bool from_state, const double *u_src, hipStream_t s, bool split = false);
+// is the stale nibble product refreshed after launch g?  An absolute function of g: the iterates do not depend on the chunking.
+inline bool nib_refresh_due(long long g, int period, int ramp) {
+    if (period <= 0) return false;
+    if (ramp <= 0) return g == 1 || g % period == 0;
+    long long p2 = 1;
+    while (2 * p2 <= g) p2 *= 2;                      // 2^floor(log2 g)   (g = 0: 1)
+    long long step = p2 / ramp;
+    if (step < 1) step = 1;
+    if (step > period) step = period;
+    return g % step == 0;
+}
+// the one-launch iteration multiplies the nibble planes inside the launches after which a refresh is due (otherwise: launch_nibble_refresh's three kernels)
+bool nib_fused_applies(const AdmmParams &p);
 // one step of iterative refinement for the right-hand side the next x-update multiplies (p.rhs), its residual in twice-the-mantissa
 // accumulation against H = G + shift I; xb_eff = xb0 + M~ (v - H M~ v).  t: 3 x [ns][np] scratch (admm.hip says why)
 // b != NULL: for the whole right-hand side b + v, which also corrects an unrefined xb0 = M b

@@ -99,3 +99,46 @@ def test_correction_is_an_option_of_the_interface(L, midsize):
     assert rel(zm1[:, 0], z1) <= 1e-11 and rel(zm0[:, 0], z0) <= 1e-11     # the multi-signal handle's first channel is the single-signal solve, either way
     with L.default_options(xupdate_correction="off"):
         assert count(one)[0] == 0
+
+
+@pytest.mark.parametrize("log2n,nf", [(18, 128), (20, 528)])
+def test_stale_nibble_product_inside_the_launch_and_as_kernels_of_its_own(L, monkeypatch, log2n, nf):
+    """Handles whose x-update is corrected read 32 of the 36 bits of their fixed-point tiles; the 4-bit planes meet the right-hand side of the
+    launches 0 .. 15, every 2nd up to 31, every 4th up to 63, ..., every 32nd from 256 on, and ride in the offset vector until the next refresh.  The one-launch iteration multiplies them INSIDE those
+    launches (admm_iter_mixed_kernel<..., NIBR>: integer sums of the launch's quantum, nib_acc_commit_kernel behind it); LPVS_NIB_FUSED=0 and the
+    two-launch iteration run three kernels of their own (launch_nibble_refresh) -- the same numbers up to the quantum.  n = 2048 (one load
+    per lane covers the block records) and n = 8448 (66 row blocks: the six-load instance).  36-bit reads by name differ by what the
+    stale term leaves: N (rhs_k - rhs_g), ~1e-11 of x."""
+    import bench
+    y, X, V, w = bench.synth_signal(1 << log2n, nf, 0, torch.device("cuda"))
+    def run(storage=None, iteration=None, fused=True, chunks=(70,)):
+        if fused:
+            monkeypatch.delenv("LPVS_NIB_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("LPVS_NIB_FUSED", "0")
+        with L.Problem.lpv(y, X, V, w, 8) as p:
+            if storage:
+                p.set_option("storage", storage)
+            if iteration:
+                p.set_option("iteration", iteration)
+            p.set_prox(L.SlicedSeparableSum.frequency_groups(5.0, nf, 16))
+            p.admm_init(None, μ=0.05, tol=0.0)
+            info = p.matvec_info()
+            for c in chunks:
+                p.admm_run(c)
+            return p.admm_get() + (p.admm_get_offset(), info, p.timing())
+    a = run()
+    if "32-bit fixed point reads" not in a[4]["storage"]:
+        pytest.skip("this inverse is not stored in the mixed format: " + a[4]["storage"])
+    assert a[4]["kernel"] == "admm_iter_mixed_kernel" and a[5]["nibble_refreshes"] == 16 + 8 + 8 + 1 and a[3].size == 2 * a[0].size      # launches 0 .. 15, 16 .. 30, 32 .. 60, 64
+    b = run(fused=False)
+    c = run(iteration="two")
+    d = run(chunks=(1, 31, 1, 5, 26, 6))                                     # refreshes fall on a chunk's first launch and inside chunks
+    e = run(storage="mixed")
+    assert c[4]["kernel"] != "admm_iter_mixed_kernel" and "32-bit fixed point reads" in c[4]["storage"] and e[3].size == e[0].size
+    for k in range(3):
+        assert rel(a[k], b[k]) <= 1e-13 and rel(a[k], c[k]) <= 1e-12, (k, rel(a[k], b[k]), rel(a[k], c[k]))
+        assert np.array_equal(a[k], d[k]), k
+        assert 0 < rel(a[k], e[k]) <= 5e-10, (k, rel(a[k], e[k]))         # (the dual variable: ~2e-10 after 70 iterations; x, z: ~1e-11)
+    assert np.array_equal(a[3], d[3])
+    print(f"n = {a[0].size}: inside the launch vs own kernels {rel(a[1], b[1]):.1e}, vs the two-launch iteration {rel(a[1], c[1]):.1e}, vs 36-bit reads {rel(a[1], e[1]):.1e} (z, 70 iterations)")
