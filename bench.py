@@ -1376,7 +1376,8 @@ def pmc_traffic(kernel_prefix, workload="cfg3"):
         if not meta or meta.get("admm_hip_sha16") != now or meta.get("workload", "cfg3") != workload:
             continue
         for r in rows:
-            if r.get("kernel", "").startswith(kernel_prefix):
+            # (the instance <..., true> of the one-launch iteration also multiplies the nibble planes -- 103 launches in 2000: not the dominant one)
+            if r.get("kernel", "").startswith(kernel_prefix) and not r["kernel"].endswith(", true>"):
                 return (r["fetch_corrected_bytes_per_launch"] + r["write_bytes_per_launch"],
                         f"{rel} (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, bytes per launch; collected from csrc/admm.hip sha256 {now})")
     return None, "no PMC summary of %s under profiles/ was collected from the present csrc/admm.hip (sha256 %s): not quoted" % (workload, now)

@@ -107,8 +107,9 @@ end
 
 # ---- options (include/lpvspectral.h LPVS_OPT_*) ---------------------------------------------------
 # Extensions (the reference has none of them): how a handle stores the inverse its ADMM mat-vec streams and how it iterates.
-#   storage   = :mixed (default: >= 36 significant bits per element, 1e-10 in the iterates) | :split (40 bits) | :f64 (doubles) |
-#               :mixed32 (32-bit fixed-point tiles, +6 % at n = 8192; x, z as with :mixed, the dual variable u to ~5e-9: include/lpvspectral.h)
+#   storage   = :mixed (>= 36 significant bits per element, all read every iteration; 1e-10 in the iterates) | :split (40 bits) | :f64 (doubles) |
+#               :mixed32 (the default of single-signal handles with n >= 2048: :mixed's tiles, of which the iteration reads 32 bits; the 4-bit
+#               planes ride, up to 32 iterations stale, in the x-update's offset vector -- x, z, u as with :mixed: include/lpvspectral.h)
 #   iteration = :one (default where applicable: one launch per ADMM iteration) | :two
 #   gram_form = :ap | :krs | :kr,  nt_loads = :on | :off,  slot_sums = :nufft | :direct        (`nothing` = the library's choice)
 # Estimators take them as keywords (`ls_sparse_spectral_lpv(...; storage=:f64)`); results do not depend on them beyond rounding.

@@ -10,7 +10,7 @@ mkdir -p "$R/$OUT"
 export TMPDIR=/tmp
 cd /tmp
 case $WL in
-  cfg3) ARGS="--steps 1 --warmup 0 --iters 20 --no-cpu-baseline --no-general-path --no-cfg4-strong --no-baseline-configs --no-concurrent --no-single-process --no-alt-storage" ;;
+  cfg3) ARGS="--steps 1 --warmup 0 --iters 120 --no-cpu-baseline --no-general-path --no-cfg4-strong --no-baseline-configs --no-concurrent --no-single-process --no-alt-storage" ;;
   cfg2) ARGS="--workload cfg2 --steps 1 --warmup 0 --iters 40 --no-cpu-baseline --no-concurrent" ;;
   cfg4) ARGS="--workload cfg4 --steps 1 --warmup 0 --iters 70 --no-cpu-baseline" ;;
   cfg5) ARGS="--workload cfg5 --steps 1 --warmup 0 --iters 10 --no-cpu-baseline" ;;
