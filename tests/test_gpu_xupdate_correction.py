@@ -142,3 +142,49 @@ def test_stale_nibble_product_inside_the_launch_and_as_kernels_of_its_own(L, mon
         assert 0 < rel(a[k], e[k]) <= 5e-10, (k, rel(a[k], e[k]))         # (the dual variable: ~2e-10 after 70 iterations; x, z: ~1e-11)
     assert np.array_equal(a[3], d[3])
     print(f"n = {a[0].size}: inside the launch vs own kernels {rel(a[1], b[1]):.1e}, vs the two-launch iteration {rel(a[1], c[1]):.1e}, vs 36-bit reads {rel(a[1], e[1]):.1e} (z, 70 iterations)")
+
+
+def test_stale_nibble_product_on_a_fourier_handle_whose_tiles_are_all_fixed_point(L, oracle, monkeypatch):
+    """ls_sparse_spectral's handle at n = 2048 (Nf = 1024, equidistant samples: a nearly diagonal inverse, so EVERY tile -- the diagonal ones
+    with their diagonal apart in doubles -- is fixed point and the one-launch iteration requests diagonal tiles up front: the instance the
+    window batches run).  That instance has no in-launch refresh: the stale nibble product runs as kernels of its own between the launches.
+    Against the oracle's Gram-form ADMM on the device Gram (1e-9, same support), against 36-bit reads, chunk-invariant, resumable bit for bit."""
+    monkeypatch.delenv("LPVS_NIB_FUSED", raising=False)
+    rng = np.random.default_rng(23)
+    N, Nf = 1 << 15, 1024
+    t = np.arange(N, dtype=np.float64)
+    f = (np.arange(Nf) + 0.5) / (2.0 * Nf + 1.0)
+    y = np.sin(2 * np.pi * f[100] * t) + 0.5 * np.cos(2 * np.pi * f[700] * t) + 0.2 * rng.standard_normal(N)
+    lam, mu = 30.0, 0.05
+    def run(storage=None, chunks=(90,), state=None):
+        with L.Problem.fourier(y, t, f) as p:
+            if storage:
+                p.set_option("storage", storage)
+            p.set_prox(L.NormL1(lam))
+            p.admm_init(None, μ=mu, tol=0.0)
+            if state is not None:
+                p.admm_set_state(state[0], state[1], state[2], state[3], offset=state[4])
+            info = dict(p.matvec_info(), nbytes=p.time_matvec(3)[1])
+            for c in chunks:
+                p.admm_run(c)
+            G, b = p.get_gram()
+            return p.admm_get() + (p.admm_get_offset(), info, p.timing(), G, b)
+    a = run()
+    if a[4]["kernel"] != "admm_iter_mixed_kernel" or "32-bit fixed point reads" not in a[4]["storage"]:
+        pytest.skip("this inverse is not stored in the mixed format: " + str(a[4]))
+    assert a[4]["nbytes"] == 136 * 66048 + 16 * 1024, a[4]          # all 136 tiles fixed point, 32 bits read; the 16 diagonal tiles' diagonals in doubles
+    assert a[5]["nibble_refreshes"] == 16 + 8 + 8 + 4 and a[3].size == 2 * a[0].size       # launches 0 .. 15, 16 .. 30, 32 .. 60, 64 .. 88
+    ro = oracle.admm_gram(a[6], a[7], oracle.NormL1(lam), iters=90, tol=0.0, mu=mu)
+    nz = np.count_nonzero(ro["z"])
+    assert 0 < nz < ro["z"].size and np.array_equal(a[1] != 0, ro["z"] != 0)
+    for k, name in enumerate(("x", "z", "u")):
+        assert rel(a[k], ro[name]) <= 1e-9, (name, rel(a[k], ro[name]))
+    e = run(storage="mixed")
+    d = run(chunks=(1, 15, 16, 1, 31, 26))
+    first = run(chunks=(40,))
+    r = run(chunks=(50,), state=(first[0], first[1], first[2], 40, first[3]))
+    for k in range(3):
+        assert rel(a[k], e[k]) <= 5e-10, (k, rel(a[k], e[k]))
+        assert np.array_equal(a[k], d[k]) and np.array_equal(a[k], r[k]), k
+    print(f"Fourier handle n = {a[0].size}, every tile fixed point: vs the oracle x {rel(a[0], ro['x']):.1e} z {rel(a[1], ro['z']):.1e} u {rel(a[2], ro['u']):.1e}; "
+          f"vs 36-bit reads z {rel(a[1], e[1]):.1e} u {rel(a[2], e[2]):.1e}; nnz {nz}")
