@@ -887,8 +887,9 @@ def run_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         mv_bytes = tm_mv.get("matvec_bytes_per_launch") or nmv * (8 if st == "f64" else 6) * (512 * (512 + 128) // 2)
         achieved = mv_bytes / (mv_us * 1e-6) * 1e-9
         kern = {"f64": "symv_tile_batch_kernel (8-byte elements)", "split": "symv_tile_split_batch_kernel (6-byte elements)"}.get(
-            st, ("admm_iter_mixed_kernel<batch> (the whole ADMM iteration of every window in one launch; 36-bit fixed-point tiles, tile partials "
-                 "added into x by 64-bit fixed-point atomics)") if one_launch else
+            st, ("admm_iter_mixed_kernel<batch> (the whole ADMM iteration of every window in one launch; 36-bit fixed-point tiles" +
+                 (" of which the launch reads 32 bits -- the 4-bit planes ride, up to 32 iterations stale, in the offset vectors" if tm.get("reads_32_bits") else "") +
+                 ", tile partials added into x by 64-bit fixed-point atomics)") if one_launch else
                 "symv_tile_mixed_batch_kernel (6-byte float-head tiles on the diagonal, 36-bit fixed-point tiles elsewhere)")
         roof = {"bound": "hbm", "kernel": kern + ": one tile-packed (Q + I/mu)^-1 per window, all windows of the shard per launch",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved),

@@ -365,8 +365,9 @@ int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, i
 /* phase times of the calling thread's last batched-window call (HIP events on the library's stream), out[0..9]:
  * Gram + rhs ms, inverse ms, ADMM / dense-solve ms, windows, batch mat-vec microseconds per launch (only when the environment
  * has LPVS_WINDOW_MATVEC_TIMING: 200 extra launches after the last pass), windows of that pass, passes, Gram form (0 dense, 1 structured with direct
- * slot sums, 2 structured with the slot sums by non-uniform FFT), bytes of packed inverses one of those timed launches reads, 1 if the pass ran one launch per iteration (the timed launches are then
- * the stand-alone batch mat-vec of the two-launch scheme: the same product without the update);
+ * slot sums, 2 structured with the slot sums by non-uniform FFT), bytes of packed inverses one iteration's launch reads, 1 if the pass ran one launch per iteration, 2 if that launch reads 32 of the
+ * fixed-point tiles' 36 bits (the stale nibble product, LPVS_STORAGE_MIXED32: the default) (the timed launches are then the stand-alone batch
+ * mat-vec of the two-launch scheme: the same product without the update, all 36 bits);
  * out[10..11] (when n_out >= 12): after lpvs_windows_estimate_multi_*: ranks of the RCCL communicator that gathered the
  * coefficients (0 = no collective ran: one device, or shards sharing a device), devices driven */
 int32_t lpvs_windowpsd_last_timing(double *out, int32_t n_out);

@@ -934,7 +934,7 @@ def windowpsd_last_timing():
     o = np.zeros(12)
     check(lib().lpvs_windowpsd_last_timing(out_ptr(o), 12))
     d = dict(gram_rhs_ms=o[0], inverse_ms=o[1], solve_ms=o[2], windows=int(o[3]), passes=int(o[6]), structured_gram=bool(o[7]),
-             gram_form=("dense", "ap", "ap-nufft")[int(o[7])], one_launch_iteration=bool(o[9]),
+             gram_form=("dense", "ap", "ap-nufft")[int(o[7])], one_launch_iteration=bool(o[9]), reads_32_bits=int(o[9]) == 2,
              rccl_gather_ranks=int(o[10]), multi_devices=int(o[11]))
     if o[4] > 0:
         d["matvec_us_per_iteration"] = float(o[4]); d["matvec_windows"] = int(o[5]); d["matvec_bytes_per_launch"] = float(o[8])

@@ -2610,6 +2610,8 @@ static AdmmParams batch_as_params(const AdmmBatch &p) {   // AdmmParams with ns 
                  p.scratch, p.part, p.Mp, p.nbatch};
     q.xb = p.xb; q.mp_split = p.mp_split; q.mp_types = p.mp_types; q.fi = p.fi; q.fi_base = p.fi_base; q.fi_prefetch_all = p.fi_prefetch_all;
     q.opt_iteration = p.opt_iteration; q.opt_nt_loads = p.opt_nt_loads;
+    q.nib_period = p.nib_period; q.nib_ramp = p.nib_ramp; q.xb_corr = p.xb_corr; q.nib_acc = p.nib_acc;
+    q.mp_fix32 = p.nib_period > 0 && p.nib_acc != nullptr && p.xb_corr != nullptr ? 1 : 0;
     return q;
 }
 bool fi_batch_applicable(const AdmmBatch &p) {
@@ -3790,7 +3792,7 @@ fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, cons
             atomicAdd(acc_cur + voff + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
         }
     }
-    if constexpr (NIBR && !BATCH && !F32 && !PA) {
+    if constexpr (NIBR && !F32) {
         // ---- the nibble planes of a fixed-point tile against the same two blocks (fix_load's mode 2: heads = the bias, so an element decodes
         // to nibble x step), reduced as above, into the second accumulator.  A rare launch (one in nib_period): the planes are requested only now.
         if (ttype != 0) {                                              // (uniform)
@@ -3812,7 +3814,7 @@ fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, cons
             vn[0] += __shfl_xor(vn[0], 1, 64);
             if ((c & 1) == 0) {
                 const int rg = ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
-                atomicAdd(acc_n + (int64_t)I * TS + wave * 32 + 4 * rg + gq, (unsigned long long)__double2ll_rn(vn[0] * invq));
+                atomicAdd(acc_n + voff + (int64_t)I * TS + wave * 32 + 4 * rg + gq, (unsigned long long)__double2ll_rn(vn[0] * invq));
             }
             if (I != J) {
 #pragma unroll
@@ -3829,7 +3831,7 @@ fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, cons
                 __syncthreads();
                 if (threadIdx.x < TS) {
                     const double r2 = ((sT[0][threadIdx.x] + sT[1][threadIdx.x]) + sT[2][threadIdx.x]) + sT[3][threadIdx.x];
-                    atomicAdd(acc_n + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
+                    atomicAdd(acc_n + voff + (int64_t)J * TS + threadIdx.x, (unsigned long long)__double2ll_rn(r2 * invq));
                 }
             }
         }
@@ -3844,11 +3846,13 @@ admm_iter_mixed_kernel(AdmmParams p, const unsigned char *__restrict__ Mp, const
     fi_one_tile_body<MODE, NK, BATCH, NT, PA, F32, NIBR>(p, Mp, types, ntiles, nblk, g, aslot, uslot, commit_prev, mp_stride);
 }
 // xb = xb_corr + (sums of the nibble planes' product, integers of the launch's quantum) x quantum; the accumulator is left zeroed for the next refresh
+// (blockIdx.y = problem of a batch: vectors np apart, one quantum each)
 __global__ void __launch_bounds__(256)
 nib_acc_commit_kernel(long long *__restrict__ acc, const double *__restrict__ quantum, const double *__restrict__ xb_corr, double *__restrict__ xb, int64_t np) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= np) return;
-    xb[e] = xb_corr[e] + (double)acc[e] * *quantum;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= np) return;
+    const int64_t e = (int64_t)blockIdx.y * np + i;
+    xb[e] = xb_corr[e] + (double)acc[e] * quantum[blockIdx.y];
     acc[e] = 0;
 }
 
@@ -3926,7 +3930,12 @@ bool nib_fused_applies(const AdmmParams &p) {
     return !(e && e[0] == '0') && p.nib_period > 0 && p.nib_acc != nullptr && p.mp_types != nullptr && p.fi_prefetch_all == 0 && fi_applicable(p);
 }
 // (the launches that also multiply the nibble planes: single problems, no prefetch of diagonal tiles; FIRST or MID)
-static FiKernel fi_kernel_nibr(int mode, bool small, bool nt) {
+template <bool NT, bool PA> static FiKernel fi_kernel_nibr_batch(int mode) {
+    return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, 1, true, NT, PA, false, true> : admm_iter_mixed_kernel<FI_MID, 1, true, NT, PA, false, true>;
+}
+static FiKernel fi_kernel_nibr(int mode, bool small, bool nt, bool batch = false, bool pa = false) {
+    if (batch) { if (nt) return pa ? fi_kernel_nibr_batch<true, true>(mode) : fi_kernel_nibr_batch<true, false>(mode);
+                 return pa ? fi_kernel_nibr_batch<false, true>(mode) : fi_kernel_nibr_batch<false, false>(mode); }
     if (small) return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, 1, false, false, false, false, true> : admm_iter_mixed_kernel<FI_MID, 1, false, false, false, false, true>;
     if (nt) return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, 6, false, true, false, false, true> : admm_iter_mixed_kernel<FI_MID, 6, false, true, false, false, true>;
     return mode == FI_FIRST ? admm_iter_mixed_kernel<FI_FIRST, 6, false, false, false, false, true> : admm_iter_mixed_kernel<FI_MID, 6, false, false, false, false, true>;
@@ -3950,18 +3959,20 @@ static int32_t launch_fi_chunk(const AdmmParams &p, int64_t iters, bool batch, s
     // stale nibble product: launch g (which multiplies rhs_g) also multiplies the nibble planes when g = 1 or g = 0 mod the period, and the
     // commit kernel behind it forms the offset vector of the launches from g + 1 on (LPVS_NIB_FUSED=0: the three stand-alone kernels of
     // launch_nibble_refresh instead -- the two-launch iteration's way, for A/B runs)
-    const bool nib = !batch && !prefetch_all && nib_fused_applies(p), nib_fused = true;
-    auto refresh_due = [&](long long g) { return !batch && p.nib_period > 0 && nib_refresh_due(g, p.nib_period, p.nib_ramp); };
+    // (a batch: only inside the launch -- launch_nibble_refresh is a single-problem routine; the engine enables the stale product only then)
+    const bool nib = batch ? (p.nib_period > 0 && p.nib_acc != nullptr && p.xb_corr != nullptr && p.mp_types != nullptr) : (!prefetch_all && nib_fused_applies(p));
+    auto refresh_due = [&](long long g) { return p.nib_period > 0 && nib_refresh_due(g, p.nib_period, p.nib_ramp); };
     auto launch_step = [&](int mode, long long g, int aslot, int uslot, int commit_prev, const double *u_after) -> int32_t {
         const bool due = refresh_due(g);
-        if (due && nib && nib_fused) {
-            hipLaunchKernelGGL(fi_kernel_nibr(mode, small, nt), dim3(ntiles, 1u), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot, commit_prev, mp_stride, 0);
-            hipLaunchKernelGGL(nib_acc_commit_kernel, dim3((unsigned)ceil_div(p.np, 256)), dim3(256), 0, s, p.nib_acc, (const double *)(f.qbuf + (g & 1)), p.xb_corr,
+        if (due && nib) {
+            hipLaunchKernelGGL(fi_kernel_nibr(mode, small, nt, batch, prefetch_all), dim3(ntiles, (unsigned)nprob), dim3(256), 0, s, p, Mp, p.mp_types, (int)ntiles, nblk, g, aslot, uslot, commit_prev,
+                               mp_stride, prefetch_all ? 1 : 0);
+            hipLaunchKernelGGL(nib_acc_commit_kernel, dim3((unsigned)ceil_div(p.np, 256), (unsigned)nprob), dim3(256), 0, s, p.nib_acc, (const double *)(f.qbuf + (g & 1) * nprob), p.xb_corr,
                                const_cast<double *>(p.xb), p.np);
             return LPVS_OK;
         }
         launch(mode, ntiles, g, aslot, uslot, commit_prev);
-        if (due) return launch_nibble_refresh(p, u_after != nullptr, u_after, s);
+        if (due && !batch) return launch_nibble_refresh(p, u_after != nullptr, u_after, s);
         return LPVS_OK;
     };
     LPVS_TRY(launch_step(FI_FIRST, base, 0, 0, 0, nullptr));                                    // rhs_base is the one in memory

@@ -1789,7 +1789,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         Wdev = Wp.as<double>();
     }
     PhaseTrace tr(s);
-    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, xb, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb, fibuf, Q0, M0, b0, x0buf, ballscr;
+    DevBuf P, slab, M, Q, bvec, x, z, u, rhs, xb, status, work, istat, offs, scr, part, Mp, seg, npart, tab, tabb, fibuf, Q0, M0, b0, x0buf, ballscr, xbc, nibacc;
     ApSlotsDev sd;
     DrainOnExit drain(s);
     const int64_t nprob_max = bw * ns;
@@ -2002,6 +2002,20 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
                     ab.fi_prefetch_all = allfix ? 1 : 0;
                 } else ab.fi = nullptr;
             }
+            // 32-bit reads of the fixed-point tiles + the stale nibble product (admm.hip) where the batch iterates in one launch: the
+            // default, and LPVS_STORAGE_MIXED32 by name; LPVS_STORAGE_MIXED reads all 36 bits.  (The refresh of a batch exists only inside the launch.)
+            if (ab.fi != nullptr && (storage_opt == 0 || storage_opt == LPVS_STORAGE_MIXED32) && !(getenv("LPVS_NIB_FUSED") && getenv("LPVS_NIB_FUSED")[0] == '0')) {
+                int period = 32, ramp = 8;
+                if (const char *e = getenv("LPVS_NIB_PERIOD")) period = atoi(e) > 0 ? atoi(e) : 0;
+                if (const char *e = getenv("LPVS_NIB_RAMP")) ramp = atoi(e) > 0 ? atoi(e) : 0;
+                if (period > 0) {
+                    if (!xbc.p) LPVS_TRY(xbc.alloc(vb));
+                    if (!nibacc.p) LPVS_TRY(nibacc.alloc(vb));
+                    LPVS_HIP(hipMemcpyAsync(xbc.p, xb.p, sizeof(double) * (size_t)np * (size_t)nprob, hipMemcpyDeviceToDevice, s));
+                    LPVS_HIP(hipMemsetAsync(nibacc.p, 0, sizeof(double) * (size_t)np * (size_t)nprob, s));
+                    ab.nib_period = period; ab.nib_ramp = ramp; ab.xb_corr = xbc.as<double>(); ab.nib_acc = nibacc.as<long long>();
+                }
+            }
             LPVS_HIP(hipEventRecord(ev[2].a, s));
             LPVS_TRY(launch_admm_batch_init(ab, s));
             if (ab.fi) LPVS_TRY(launch_fi_batch_setup(ab, s));
@@ -2021,7 +2035,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
                 LPVS_HIP(hipStreamSynchronize(s));
             }
             LPVS_HIP(hipEventRecord(ev[2].b, s));
-            g_win_timing[9] = ab.fi != nullptr ? 1 : 0;   // the pass ran one launch per iteration
+            g_win_timing[9] = ab.fi != nullptr ? (ab.nib_period > 0 ? 2 : 1) : 0;   // the pass ran one launch per iteration (2: reading 32 of the fixed-point tiles' 36 bits, stale nibble product)
             if (want_mv && w0 + nb_ >= nwin) {
                 LPVS_TRY(launch_admm_batch_matvec_only(ab, 3, s));
                 LPVS_HIP(hipEventRecord(ev[3].a, s));
@@ -2037,7 +2051,7 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
                     LPVS_HIP(hipStreamSynchronize(s));
                     size_t nfix = 0, ndiag = 0;
                     for (unsigned char t : ht) { nfix += t != 0; ndiag += t == 2; }
-                    bytes = (double)nfix * (double)kMixedFixedTileBytes + (double)ndiag * 1024.0 + (double)(ht.size() - nfix) * (double)kMixedFloatTileBytes;
+                    bytes = (double)nfix * (double)(ab.nib_period > 0 ? kMixedFixed32TileBytes : kMixedFixedTileBytes) + (double)ndiag * 1024.0 + (double)(ht.size() - nfix) * (double)kMixedFloatTileBytes;   // (32-bit reads: no nibble planes)
                 }
                 g_win_timing[8] = bytes;
             }

@@ -319,6 +319,11 @@ struct AdmmBatch {
     int opt_iteration = 0, opt_nt_loads = 0;   // LPVS_OPT_ITERATION / LPVS_OPT_NT_LOADS of the call (0: thread default / environment)
     double *scratch = nullptr;                 // IndBallL0 with n > 8192: 2 * np doubles per problem (selection keys), else unused
     const double *x0 = nullptr;                // init = true: the starting point of every problem ([nbatch][np]); nullptr: zeros
+    // 32-bit reads of the fixed-point tiles with the stale nibble product (AdmmParams: nib_period, nib_ramp, xb_corr, nib_acc), one-launch batches only:
+    // xb is then written by the refreshes (xb = xb_corr + N rhs_g per problem), xb_corr keeps M b
+    int nib_period = 0, nib_ramp = 0;
+    const double *xb_corr = nullptr;           // [nbatch][np]
+    long long *nib_acc = nullptr;              // [nbatch][np], zero between refreshes
 };
 bool fi_batch_applicable(const AdmmBatch &p);
 int32_t launch_fi_batch_setup(const AdmmBatch &p, hipStream_t s);   // constants and the records of iteration 0 (after launch_admm_batch_init)

@@ -192,6 +192,43 @@ def test_mixed_vs_split_windows(L, monkeypatch):
         assert rel(out[st][0], out["f64"][0]) <= 1e-9, (st, rel(out[st][0], out["f64"][0]))
 
 
+def test_window_batches_read_32_bits_with_the_stale_nibble_product(L, monkeypatch):
+    """Round 5: where a window batch iterates in one launch, that launch reads 32 of the 36 bits of the fixed-point tiles and the product of
+    the 4-bit planes rides, up to 32 iterations stale, in every window's offset vector (the launches after which a refresh is due multiply
+    the planes too: admm_iter_mixed_kernel<..., BATCH, NIBR>).  An irregular grid (the inverses are NOT nearly diagonal), three row blocks per
+    window: the default against 36-bit reads (storage "mixed" by name) and doubles; LPVS_NIB_PERIOD=0 switches it off; bit-reproducible."""
+    from lpvspectral_jl_amd import api
+    rng = np.random.default_rng(44)
+    n, nwin, Nf = 1500, 8, 160
+    t = np.cumsum(0.5 + rng.random(n * nwin))
+    f = (np.arange(Nf) + 1.0) / (2.6 * Nf)
+    y = np.sin(2 * np.pi * f[11] * t) + 0.6 * np.cos(2 * np.pi * f[90] * t) + 0.3 * rng.standard_normal(n * nwin)
+    eng = dict(estimator=1, lam=0.0, prox=(1, 1.5, 0), μ=0.05, tol=0.0, iters=600, sign=-1)
+    monkeypatch.delenv("LPVS_ITERATION", raising=False)
+    out, flags = {}, {}
+    for name, st, env in (("default", None, {}), ("again", None, {}), ("mixed32", "mixed32", {}), ("mixed", "mixed", {}), ("f64", "f64", {}), ("period 0", None, {"LPVS_NIB_PERIOD": "0"})):
+        if st is None:
+            monkeypatch.delenv("LPVS_M_STORAGE", raising=False)
+        else:
+            monkeypatch.setenv("LPVS_M_STORAGE", st)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out[name] = api.windows_estimate([y], t, f, n, 0, None, eng)[0]
+        flags[name] = api.windowpsd_last_timing()
+        for k in env:
+            monkeypatch.delenv(k)
+    if not flags["mixed"]["one_launch_iteration"]:
+        pytest.skip("this batch does not iterate in one launch: " + str(flags["mixed"]))
+    assert flags["default"]["reads_32_bits"] and flags["mixed32"]["reads_32_bits"]
+    assert not flags["mixed"]["reads_32_bits"] and not flags["period 0"]["reads_32_bits"] and not flags["f64"]["one_launch_iteration"]
+    assert np.array_equal(out["default"], out["again"]) and np.array_equal(out["default"], out["mixed32"]) and np.array_equal(out["mixed"], out["period 0"])
+    assert 0 < np.count_nonzero(out["f64"]) < out["f64"].size
+    e32, e36, d = rel(out["default"], out["f64"]), rel(out["mixed"], out["f64"]), rel(out["default"], out["mixed"])
+    print(f"8 windows, np = 384, irregular grid, 600 iterations: 32-bit reads + stale nibble product vs doubles {e32:.2e}, 36-bit reads vs doubles {e36:.2e}, between them {d:.2e}")
+    assert e32 <= 1e-9 and e36 <= 1e-9 and d <= 1e-10
+    assert np.array_equal(out["default"] != 0, out["f64"] != 0)
+
+
 @pytest.mark.parametrize("zero", [True, False])
 def test_indball_and_init_through_the_engine_vs_oracle(L, oracle, zero):
     """The two estimator options that used to fall back to the sequential loop now run in the batch: proxg = IndBallL0(r)
