@@ -101,13 +101,14 @@ def test_correction_is_an_option_of_the_interface(L, midsize):
         assert count(one)[0] == 0
 
 
-@pytest.mark.parametrize("log2n,nf", [(18, 128), (20, 528)])
+@pytest.mark.parametrize("log2n,nf", [(18, 128), (20, 528), (20, 768)])
 def test_stale_nibble_product_inside_the_launch_and_as_kernels_of_its_own(L, monkeypatch, log2n, nf):
     """Handles whose x-update is corrected read 32 of the 36 bits of their fixed-point tiles; the 4-bit planes meet the right-hand side of the
     launches 0 .. 15, every 2nd up to 31, every 4th up to 63, ..., every 32nd from 256 on, and ride in the offset vector until the next refresh.  The one-launch iteration multiplies them INSIDE those
     launches (admm_iter_mixed_kernel<..., NIBR>: integer sums of the launch's quantum, nib_acc_commit_kernel behind it); LPVS_NIB_FUSED=0 and the
     two-launch iteration run three kernels of their own (launch_nibble_refresh) -- the same numbers up to the quantum.  n = 2048 (one load
-    per lane covers the block records) and n = 8448 (66 row blocks: the six-load instance).  36-bit reads by name differ by what the
+    per lane covers the block records), n = 8448 (66 row blocks: the six-load instance) and n = 12288 (a packed inverse beyond the Infinity
+    Cache: that instance with non-temporal loads).  36-bit reads by name differ by what the
     stale term leaves: N (rhs_k - rhs_g), ~1e-11 of x."""
     import bench
     y, X, V, w = bench.synth_signal(1 << log2n, nf, 0, torch.device("cuda"))
