@@ -1075,6 +1075,10 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         # average (phase_nibble_refresh_ms is non-zero only where the refresh is three kernels of its own: LPVS_NIB_FUSED=0)
         mv_us = (phase["admm_ms"] - phase["xcorr_ms"] - phase["nibble_refresh_ms"]) * 1e3 / iters
     mv_share = iters * mv_us * 1e-3 / (elapsed / steps * 1e3)
+    # fixed-point tiles of the packed inverse (from the byte count: 66 048 B per fixed-point tile read at 32 bits, 98 304 B per float-head tile)
+    _np = -(-(2 * NF * NV) // 128) * 128
+    _nt = (_np // 128) * (_np // 128 + 1) // 2
+    n_fixed_tiles = int(round((_nt * 98304 - mv_bytes) / (98304 - 66048))) if n_nib > 0 else 0
     # (the one-launch kernel's instance that carries the update: <1, ...>; <0, ...> is a chunk's first launch, <2, ...> its last update)
     # (the PMC summary is collected from the f64 bench: the _f32 handles run another instance of the kernel on other bytes)
     traffic, traffic_src = pmc_traffic(mv_info["kernel"] + ("<1" if mv_info.get("one_launch_iteration") else "")) if args.log2n == LOG2N and args.dtype == "f64" else (None, None)
@@ -1127,6 +1131,9 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved),
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": mv_bytes,
                      "launch_us": mv_us, "launches_per_step": iters, "share_of_step": mv_share, "same_matvec_with_8_byte_storage": alt, "same_matvec_with_uniform_6_byte_storage": alt6,
+                     # (for comparisons across rounds: the same launch priced with the bytes round 4's iteration read -- all 36 bits of the fixed-point
+                     # tiles -- and with the doubles SURVEY 8(d) counts; neither is `frac`, which counts the bytes the launch reads now)
+                     **({"frac_if_priced_with_36_bit_bytes": (mv_bytes + 8192.0 * n_fixed_tiles) / (mv_us * 1e-6) * 1e-9 / HBM_PEAK_GBS} if n_nib > 0 and n_fixed_tiles else {}),
                      "matvec_only_launch_us": mv_only_us,
                      "note": ("algorithmic bytes = %s (+ 0.2 MB of state vectors); M is read once per iteration; ONE launch per iteration: the kernel "
                               "rebuilds its right-hand-side blocks (prox + dual update) in the prologue and adds its partial sums into x with 64-bit "
