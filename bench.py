@@ -75,88 +75,90 @@ def guarded(fn, what):
         return {"error": ("%s: %s" % (type(e).__name__, e))[:600]}
 
 
-def flatten_for_the_driver(o):
-    """The driver's parser keeps the SCALAR entries of `config`, `roofline` and `cpu_baseline` (keys up to 40 characters, strings up to
-    ~140) and drops everything else: unknown top-level keys and nested records (BENCH_r04.json: `extra_keys`).  So that the whole metric
-    (iterations/s beside signals/s), the MFMA-Gram fraction and every BASELINE configuration are driver-witnessed, the figures of the
-    nested records are repeated here as flat scalars; the nested records stay on the line for readers."""
-    cfg, roof = o.setdefault("config", {}), o.get("roofline") or {}
-    num = lambda v: float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else None
+DRIVER_MAX_KEYS, DRIVER_MAX_STR = 20, 120
 
-    def put(dst, key, v):
-        assert len(key) <= 40, key
-        if isinstance(v, str):
-            dst[key] = v[:136]
-        elif isinstance(v, bool) or v is None:
-            dst[key] = v
-        elif num(v) is not None:
-            dst[key] = num(v)
 
-    if "admm_iters_per_sec" in o:
-        put(cfg, "admm_iters_per_sec", o["admm_iters_per_sec"])
-    for k, v in (o.get("phase_ms") or {}).items():
-        put(cfg, "phase_" + k, v)
-    f = o.get("factorisation") or {}
-    if "frac" in f:
-        put(roof, "factorisation_frac_of_f64_mfma_peak", f["frac"]); put(roof, "factorisation_ms", f["ms"]); put(roof, "factorisation_TFLOPs", f["achieved"])
-    g = o.get("gram_general_path") or {}
-    if "error" in g:
-        put(roof, "gram_mfma_error", g["error"])
-    elif g:
-        put(roof, "gram_mfma_frac_of_f64_mfma_peak", g["frac"]); put(roof, "gram_mfma_TFLOPs_issued", g["achieved"])
-        put(roof, "gram_mfma_TFLOPs_algorithmic", g["achieved_algorithmic"]); put(roof, "gram_mfma_launch_ms", g["launch_ms"])
-        put(roof, "gram_mfma_kernel", g["kernel"])
+def _scalar(v):
+    """A value the driver's parser keeps: bool / None / number (rounded to 6 significant digits: the record has a length budget too) / short string."""
+    if isinstance(v, bool) or v is None:
+        return True, v
+    if isinstance(v, (int, np.integer)):
+        return True, int(v)
+    if isinstance(v, (float, np.floating)):
+        if not np.isfinite(v):
+            return True, None
+        return True, int(v) if (float(v).is_integer() and abs(v) < 2 ** 53) else float("%.6g" % float(v))   # (byte / launch counts stay exact)
+    if isinstance(v, str):
+        return True, v[:DRIVER_MAX_STR]
+    return False, None
 
-    def sub(name, rec, unit_key):
-        if rec is None:
-            return
-        if "error" in rec:
-            put(cfg, name + "_error", rec["error"]); return
-        put(cfg, name + "_" + unit_key, rec.get("value")); put(cfg, name + "_ms_per_step", rec.get("ms_per_step")); put(cfg, name + "_steps", rec.get("steps"))
-        put(cfg, name + "_admm_iters_per_sec", rec.get("admm_iters_per_sec"))
-        r = rec.get("roofline") or {}
-        put(cfg, name + "_roofline_frac", r.get("frac")); put(cfg, name + "_roofline_GBps", r.get("achieved")); put(cfg, name + "_launch_us", r.get("launch_us"))
-        if r.get("kernel"):
-            put(cfg, name + "_kernel", r["kernel"].split(" ")[0])
-        c = rec.get("cpu_baseline") or {}
-        if "error" in c:
-            put(cfg, name + "_cpu_baseline_error", c["error"])
-        elif c:
-            put(cfg, name + "_cpu_baseline", c.get("value")); put(cfg, name + "_cpu_cores", c.get("cores"))
-        for k in ("iteration_ms_all_channels", "n_gpus", "scaling"):
-            if k in rec:
-                put(cfg, name + "_" + k, rec[k])
-        fz = rec.get("factorisation") or {}
-        put(cfg, name + "_factor_frac_of_mfma_peak", fz.get("frac_of_f64_mfma_peak"))
-    sub("cfg2", o.get("cfg2"), "signals_per_s")
-    sub("cfg4", o.get("cfg4_strong"), "windows_per_s")
-    sub("cfg5", o.get("cfg5"), "signals_per_s")
-    sub("rowsharded", o.get("cfg3_row_sharded"), "signals_per_s")
-    c4 = o.get("cfg4_strong") or {}
-    if "phase_ms_rank0" in c4:
-        put(cfg, "cfg4_solve_ms_rank0", c4["phase_ms_rank0"].get("solve_ms"))
-    sp = o.get("single_process") or {}
-    for k in ("cfg3", "cfg4", "cfg5"):
-        r = sp.get("single_process_" + k) or {}
-        if "error" in r:
-            put(cfg, "one_process_%s_error" % k, r["error"])
-        elif r:
-            put(cfg, "one_process_%s_%s" % (k, r.get("unit", "").replace("/", "_per_")), r.get("value"))
-    two = cfg.get("two_solves_in_flight") or {}
-    if "value" in two:
-        put(cfg, "two_in_flight_signals_per_s", two["value"])
-    a8 = cfg.get("whole_step_with_8_byte_storage") or {}
-    if "signals_per_s_per_gpu" in a8:
-        put(cfg, "signals_per_s_with_8_byte_M", a8["signals_per_s_per_gpu"])
-    a36 = cfg.get("whole_step_with_36_bit_reads") or {}
-    if "signals_per_s_per_gpu" in a36:
-        put(cfg, "signals_per_s_with_36_bit_reads", a36["signals_per_s_per_gpu"])
-    m8 = roof.get("same_matvec_with_8_byte_storage") or {}
-    if "frac_of_hbm_peak" in m8:
-        put(roof, "matvec_8_byte_frac", m8["frac_of_hbm_peak"]); put(roof, "matvec_8_byte_launch_us", m8["launch_us"])
-    for k in ("rccl_ranks", "collective_ranks", "backend"):
-        if k in o:
-            put(cfg, k, o[k])
+
+def _take(priority, rest):
+    """The first DRIVER_MAX_KEYS scalar items: the priority list first (entries that are None or not scalars are skipped), then whatever scalars of
+    the full record still fit, in its own order."""
+    out = {}
+    for k, v in list(priority) + [(k, v) for k, v in (rest or {}).items()]:
+        ok, val = _scalar(v)
+        if not ok or val is None or k in out or len(out) >= DRIVER_MAX_KEYS or len(k) > 36:
+            continue
+        out[k] = val
+    return out
+
+
+def driver_record(o):
+    """Make the JSON line fit the driver's parser (BENCH_r05.json: of `config`, `roofline` and `cpu_baseline` it kept the first ~21 SCALAR entries -- about 1100
+    characters each --, dropped nested records and unknown top-level keys; round 5's 70 flattened keys lost cfg4, cfg5 and the 8-byte figure that way).
+    So: `config`, `roofline`, `cpu_baseline` become at most 20 scalars each, numbers first, short names, no prose -- every BASELINE configuration's value and
+    roofline fraction, the iteration rate, the phase times, the like-for-like figures (8-byte M, host arrays, two solves in flight), the MFMA fractions --
+    and the FULL records (nested sub-records, notes, formulas) move to `detail`, which the driver drops and a reader keeps."""
+    cfg, roof, cpu = o.get("config") or {}, o.get("roofline") or {}, o.get("cpu_baseline")
+    o["detail"] = {"config": cfg, "roofline": roof, **({"cpu_baseline": cpu} if cpu is not None else {})}
+    g = lambda d, *ks: (g(d.get(ks[0]) or {}, *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    ph = o.get("phase_ms") or {}
+    errs = [k for k in ("cfg2", "cfg4_strong", "cfg5", "cfg3_row_sharded", "gram_general_path") if isinstance(o.get(k), dict) and "error" in o[k]]
+    errs += ["single_process_" + k for k in ("cfg3", "cfg4", "cfg5") if "error" in (g(o, "single_process", "single_process_" + k) or {})]
+    errs += [k for k in ("two_solves_in_flight", "whole_step_with_8_byte_storage", "from_host_arrays") if "error" in (cfg.get(k) or {})]
+    gram_ms = sum(ph[k] for k in ("basis_ms", "gram_ms", "reduce_rhs_ms")) if all(k in ph for k in ("basis_ms", "gram_ms", "reduce_rhs_ms")) else None
+    one4 = g(o, "single_process", "single_process_cfg4")
+    prio_cfg = [
+        ("workload", cfg.get("workload")),
+        ("admm_iters_per_sec", o.get("admm_iters_per_sec")),
+        ("phase_factor_ms", ph.get("factor_ms")), ("phase_admm_ms", ph.get("admm_ms")), ("phase_gram_rhs_ms", gram_ms),
+        ("cfg4_windows_per_s", g(o, "cfg4_strong", "value")), ("cfg4_roofline_frac", g(o, "cfg4_strong", "roofline", "frac")),
+        ("cfg4_iteration_us", g(o, "cfg4_strong", "roofline", "launch_us")),
+        ("cfg5_signals_per_s", g(o, "cfg5", "value")), ("cfg5_roofline_frac", g(o, "cfg5", "roofline", "frac")),
+        ("cfg5_iteration_ms", g(o, "cfg5", "iteration_ms_all_channels")),
+        ("cfg2_signals_per_s", g(o, "cfg2", "value")), ("cfg2_iteration_us", g(o, "cfg2", "roofline", "launch_us")),
+        ("signals_per_s_8_byte_M", g(cfg, "whole_step_with_8_byte_storage", "signals_per_s_per_gpu")),
+        ("signals_per_s_host_arrays", g(cfg, "from_host_arrays", "signals_per_s_per_gpu")),
+        ("two_in_flight_signals_per_s", g(cfg, "two_solves_in_flight", "value")),
+        ("sub_record_errors", len(errs)),
+        ("first_error", (errs[0] + ": " + str((o.get(errs[0]) or g(o, "single_process", errs[0]) or cfg.get(errs[0]) or {}).get("error"))) if errs else None),
+        ("rccl_ranks", o.get("rccl_ranks")), ("xcorr_per_solve", cfg.get("xupdate_corrections_per_solve")),
+        ("rowsharded_signals_per_s", g(o, "cfg3_row_sharded", "value")),
+        ("one_process_cfg4_windows_per_s", (one4 or {}).get("value") if "error" not in (one4 or {}) else None),
+        ("nibble_refreshes_per_solve", cfg.get("nibble_refreshes_per_solve")),
+    ]
+    # the workloads' own lines (--workload cfg2 | cfg4 | cfg5): their few scalars follow in the record's own order
+    o["config"] = _take(prio_cfg, cfg)
+    if roof:
+        m8 = roof.get("same_matvec_with_8_byte_storage") or {}
+        fz, gg = o.get("factorisation") or {}, o.get("gram_general_path") or {}
+        prio_roof = [
+            ("bound", roof.get("bound")), ("kernel", (roof.get("kernel") or "").split(" ")[0] or None), ("achieved", roof.get("achieved")), ("peak", roof.get("peak")),
+            ("unit", roof.get("unit")), ("frac", roof.get("frac")), ("traffic", roof.get("traffic")),
+            ("bytes_per_launch", roof.get("algorithmic_bytes_per_launch")), ("launch_us", roof.get("launch_us")),
+            ("launch_us_all_of_admm", roof.get("launch_us_all_of_admm")), ("launches_per_step", roof.get("launches_per_step")), ("share_of_step", roof.get("share_of_step")),
+            ("frac_of_stream_6290_GBps", roof.get("frac_of_measured_stream_6290_GBps")),
+            ("matvec_8_byte_frac", m8.get("frac_of_hbm_peak")), ("frac_with_36_bit_bytes", roof.get("frac_if_priced_with_36_bit_bytes")),
+            ("factor_frac_of_f64_mfma", fz.get("frac", fz.get("frac_of_f64_mfma_peak"))), ("factor_ms", fz.get("ms")),
+            ("gram_mfma_frac_of_f64_peak", gg.get("frac")), ("gram_mfma_TFLOPs_issued", gg.get("achieved")), ("gram_mfma_ms", gg.get("launch_ms")),
+        ]
+        o["roofline"] = _take(prio_roof, {k: v for k, v in roof.items() if k not in ("note", "traffic_source", "kernel")})
+    if isinstance(cpu, dict):
+        prio_cpu = [(k, cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "admm_iters_per_sec", "cpus_visible", "threads_used", "error")]
+        prio_cpu.append(("gemv_stream_GBps", cpu.get("achieved_gemv_stream_GBps")))
+        o["cpu_baseline"] = _take(prio_cpu, None)
 
 
 def synth_signal(N, Nf, seed, device):
@@ -533,7 +535,7 @@ def main():
             o["backend"] = "none (single process)" if dist is None else ("rccl (torch.distributed nccl)" if args.backend == "nccl" else args.backend)
             o["rccl_ranks"] = world if (dist is not None and args.backend == "nccl") else 0
             o["collective_ranks"] = world
-            guarded(lambda: flatten_for_the_driver(o), "flatten_for_the_driver")
+            driver_record(o)
             print(json.dumps(o), flush=True)
             state["printed"] = True
 
@@ -671,6 +673,25 @@ def measure_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ra
     elapsed = max_over_ranks(time.perf_counter() - t0)
     anyfail = max_over_ranks(1.0 if failed else 0.0) > 0      # (an all-reduce MAX: every rank learns of any rank's failure)
     tm = L.windowpsd_last_timing() if not failed else {}
+    # the dominant kernel's bytes per iteration of this rank's shard (one untimed call of 8 iterations that appends 200 stand-alone batch mat-vec
+    # launches and reports the bytes of packed inverses a launch of the iteration reads); local, no collective
+    roof = None
+    if rank == 0 and not failed and tm.get("one_launch_iteration") and iters > 0:
+        def _roof():
+            os.environ["LPVS_WINDOW_MATVEC_TIMING"] = "1"
+            try:
+                L.windowpsd_sparse_batched(y, t, f, n, 0, None, λ=CFG4["lam"], μ=CFG4["mu"], tol=0.0, iters=8, win_lo=lo, win_hi=hi, device=local)
+                tm_mv = L.windowpsd_last_timing()
+            finally:
+                del os.environ["LPVS_WINDOW_MATVEC_TIMING"]
+            it_us = tm["solve_ms"] * 1e3 / iters              # HIP events around the ADMM loops of the last timed step / iterations: all windows of the shard
+            ach = tm_mv["matvec_bytes_per_launch"] / (it_us * 1e-6) * 1e-9
+            return {"bound": "hbm", "kernel": "admm_iter_mixed_kernel<batch>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(ach),
+                    "algorithmic_bytes_per_launch": tm_mv["matvec_bytes_per_launch"], "launch_us": it_us, "windows_per_launch": hi - lo, "launches_per_step": iters,
+                    "reads_32_bits": bool(tm.get("reads_32_bits")),
+                    "note": "launch_us = one ADMM iteration of ALL the shard's windows (cache-sized chunks, two halves in flight: DESIGN 4.5.3); the chunks' "
+                            "inverses are re-read from the Infinity Cache, so `achieved` may exceed the HBM stream rate"}
+        roof = guarded(_roof, "cfg4_strong.roofline")
     del y, t
     torch.cuda.empty_cache()
     L._lib.lib().lpvs_release_cached_memory()
@@ -685,7 +706,7 @@ def measure_cfg4(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ra
             "final_gather": "none" if world == 1 else ("rccl" if args.backend == "nccl" else args.backend) + " all_gather of per-window coefficients, PSD summed in window order",
             "one_launch_iteration": bool(tm.get("one_launch_iteration")), "gram_form": tm.get("gram_form"),
             "phase_ms_rank0": {k: v for k, v in tm.items() if k.endswith("_ms")}, "psd_argmax": int(np.argmax(S)),
-            "iters_min_max": [int(its.min()), int(its.max())]}
+            "iters_min_max": [int(its.min()), int(its.max())], "roofline": roof}
 
 
 def measure_rowsharded(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks, steps, warmup, iters, log2n):
@@ -1064,7 +1085,21 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
             ms36 = (time.perf_counter() - t1) / 3 * 1e3
             return {"ms_per_step": ms36, "signals_per_s_per_gpu": 1e3 / ms36, "steps": 3}
     alt36_step = guarded(_alt36_step, "whole_step_with_36_bit_reads") if (alt is not None and "error" not in alt and not rowsh and n_nib > 0) else None
+    # ... and from HOST arrays to the host result (SURVEY 8(d) defines signals/s that way; `value` starts from HBM-resident inputs as the bench contract
+    # asks): the same solve with numpy inputs -- 3 x 8 MB uploaded by the constructor inside the timed call
+    def _host_step():
+        yh, Xh, Vh, wh = (a.cpu().numpy() for a in (y, X, V, w))
+        solve(L, yh, Xh, Vh, wh, NV, iters, local)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            solve(L, yh, Xh, Vh, wh, NV, iters, local)
+        torch.cuda.synchronize(dev)
+        msh = (time.perf_counter() - t1) / 3 * 1e3
+        return {"ms_per_step": msh, "signals_per_s_per_gpu": 1e3 / msh, "steps": 3, "uploaded_bytes_per_step": int(3 * yh.nbytes + wh.nbytes)}
+    host_step = guarded(_host_step, "from_host_arrays") if (not rowsh and not args.no_alt_storage) else None
     mv_only_us = mv_us
+    all_us = phase["admm_ms"] * 1e3 / iters                # everything inside the ADMM loops' events / iterations: corrections and refreshes included (rounds <= 4 priced this)
     if mv_info.get("one_launch_iteration"):
         # the iteration IS one launch of this kernel (update in its prologue, fixed-point accumulation at its end): its duration inside
         # the timed region = HIP events around the ADMM loop of every timed step / launches (the loop holds nothing else but the first
@@ -1108,14 +1143,14 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         "value": (1 if rowsh else world) * steps / elapsed, "unit": "signals/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if rowsh else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "cfg3: ls_sparse_spectral_lpv group-lasso N=2^%d Nf=%d Nv=%d n=%d lambda=%g mu=%g iters=%d tol=0, one signal per GPU"
+        "config": {"workload": "cfg3 ls_sparse_spectral_lpv group lasso N=2^%d Nf=%d Nv=%d n=%d lam=%g mu=%g iters=%d tol=0; 1 signal/GPU"
                                % (args.log2n, NF, NV, 2 * NF * NV, LAMBDA, MU, iters),
                    "signals_per_step_per_gpu": 1.0 / world if rowsh else 1, "gram_form": form,
                    "gram": ("structured, slot sums by a non-uniform FFT (nufft.hip); MFMA path not taken" if form == "ap-nufft" else
                             "structured (VALU f64, nudft.hip); MFMA path not taken" if form == "ap" else "dense f64 MFMA (%s)" % form),
                    "matvec_storage": mv_info["storage"], "xupdate_corrections_per_solve": n_xcorr, "nibble_refreshes_per_solve": n_nib, "nibble_refresh_us": nib_us,
-                   "xupdate_correction": "after iterations 16, 512, 1024, ...: one step of iterative refinement of the x-update's offset vector, residual in twice the mantissa (DESIGN 6.1)",
-                   "whole_step_with_8_byte_storage": alt_step, "whole_step_with_36_bit_reads": alt36_step, "concurrent_solves_per_gpu": args.streams, "two_solves_in_flight": two_in_flight,
+                   "xupdate_correction": "after iterations 16, 128, 256, 512, 1024, ...: one step of iterative refinement of the x-update's offset vector, residual in twice the mantissa (DESIGN 6.1)",
+                   "whole_step_with_8_byte_storage": alt_step, "whole_step_with_36_bit_reads": alt36_step, "from_host_arrays": host_step, "concurrent_solves_per_gpu": args.streams, "two_solves_in_flight": two_in_flight,
                    "sharding": "sample rows of one signal over the ranks, one all-reduce of the Gram (SURVEY 8(e)(2))" if rowsh else "independent signals",
                    "final_gather": "none" if (world == 1 or rowsh) else ("rccl" if args.backend == "nccl" else args.backend) + " all_gather"},
         "admm_iters_per_sec": iters / (phase["admm_ms"] * 1e-3),
@@ -1130,7 +1165,7 @@ def run_cfg3(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks)
         "roofline": {"bound": "hbm", "kernel": mv_info["kernel"] + " (ADMM mat-vec with the tile-packed lower triangle of (G + I/mu)^-1)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", **roof_fracs(achieved),
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": mv_bytes,
-                     "launch_us": mv_us, "launches_per_step": iters, "share_of_step": mv_share, "same_matvec_with_8_byte_storage": alt, "same_matvec_with_uniform_6_byte_storage": alt6,
+                     "launch_us": mv_us, "launch_us_all_of_admm": all_us, "launches_per_step": iters, "share_of_step": mv_share, "same_matvec_with_8_byte_storage": alt, "same_matvec_with_uniform_6_byte_storage": alt6,
                      # (for comparisons across rounds: the same launch priced with the bytes round 4's iteration read -- all 36 bits of the fixed-point
                      # tiles -- and with the doubles SURVEY 8(d) counts; neither is `frac`, which counts the bytes the launch reads now)
                      **({"frac_if_priced_with_36_bit_bytes": (mv_bytes + 8192.0 * n_fixed_tiles) / (mv_us * 1e-6) * 1e-9 / HBM_PEAK_GBS} if n_nib > 0 and n_fixed_tiles else {}),

@@ -114,10 +114,11 @@ int32_t lpvs_release_cached_memory(void);
                                        * -> 285 MB) */
 #define LPVS_OPT_WINDOWS_IN_FLIGHT 7 /* parts of a chunk solved concurrently on streams of their own: 1 .. 4 (default 2) */
 #define LPVS_OPT_RESERVE_CUS 8       /* CUs the factorisation's trailing updates leave to its pivot chain: > 0, or LPVS_RESERVE_NONE (default 8) */
-#define LPVS_OPT_XUPDATE_CORRECTION 9 /* LPVS_XCORR_*: re-form the x-update's offset vector after the iterations 16, 512, 1024, 2048, ... by one step of iterative
-                                       * refinement, residual accumulated in twice the mantissa (handles of n >= 2048).  Default: ON for handles with
-                                       * one right-hand side, OFF for several (a correction costs an accurate product over the f64 Gram per signal).  Per handle
-                                       * (before lpvs_admm_init) or as a thread default. */
+#define LPVS_OPT_XUPDATE_CORRECTION 9 /* LPVS_XCORR_*: re-form the x-update's offset vector after the iterations 16, 128, 256, 512, 1024, ... (several right-hand sides: 16, 512, 1024, ...) by one step of iterative
+                                       * refinement, residual accumulated in twice the mantissa (handles of n >= 2048).  Default: ON -- since
+                                       * round 6 also for handles with several right-hand sides (cfg5: 4e-10 of drift in x, z after 2000 iterations without it;
+                                       * a correction there is one accurate pass over the f64 Gram for all channels, 1.9 % of the run).  Per handle (before
+                                       * lpvs_admm_init) or as a thread default. */
 #define LPVS_XCORR_ON 1
 #define LPVS_XCORR_OFF 2
 #define LPVS_SLOTS_NUFFT 1
@@ -236,21 +237,26 @@ int32_t lpvs_admm_run(lpvs_problem *h, int64_t max_iters, int64_t *iters_done, d
                       int32_t *converged);
 /* resume (checkpoint / re-entry): after lpvs_admm_init (same mu, tol, prox, linear_sign) install iterates
  * saved with lpvs_admm_get_f64 from an earlier run -- possibly of another process -- together with the number of
- * iterations they represent; lpvs_admm_run then continues exactly as the uninterrupted run would (the x-update of
- * src/lasso.jl:150-151 only needs z and u).  Arrays are n (x ns) in the solver's own order, as lpvs_admm_get_f64 returns. */
+ * iterations they represent; lpvs_admm_run then continues as the uninterrupted run would (the x-update of src/lasso.jl:150-151 only
+ * needs z and u) -- BIT FOR BIT for handles of n < 2048; handles of n >= 2048 also carry the x-update's offset vector between two
+ * scheduled iterations (below): with it (lpvs_admm_set_offset_f64) the continuation is bit-exact, without it the vector is re-formed from
+ * the state handed in and the continuation agrees to second order (~1e-12).  iters_done = 0 restarts: the offset vector of a fresh
+ * lpvs_admm_init is put back.  Arrays are n (x ns) in the solver's own order, as lpvs_admm_get_f64 returns. */
 int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *z, const double *u, int64_t iters_done);
 /* Handles of n >= 2048 run the x-update in its offset form, x = xb + M (z - u)/mu, and re-form the offset vector after the iterations
- * 16, 512, 1024, 2048, ... so that the systematic error of the explicit inverse leaves the iteration (one step of iterative refinement
+ * 16, 128, 256, 512, 1024, ... (handles with several right-hand sides: 16, 512, 1024, ...) so that the systematic error of the explicit inverse leaves the iteration (one step of iterative refinement
  * with the residual accumulated in twice the mantissa).  That vector is part of the iteration's state between two
  * scheduled iterations: a checkpoint that is to continue BIT FOR BIT saves it with lpvs_admm_get_offset_f64 next to x, z, u and
  * installs it with lpvs_admm_set_offset_f64 after lpvs_admm_set_state_f64 (which, without it, re-forms the vector from the state it is
  * given -- the same to second order).  Always doubles (also for handles made by the _f32 constructors).
  * lpvs_admm_offset_len: how many -- n x ns, or 2 n for a handle that iterates on LPVS_STORAGE_MIXED32 reads (the vector with and without
  * the nibble term of the last refresh: both are state); 0 when the handle has no offset vector (n < 2048).  The buffer is opaque: hand
- * back what lpvs_admm_get_offset_f64 wrote.  get / set: LPVS_ESTATE when the handle has no offset vector, or before lpvs_admm_init. */
+ * back what lpvs_admm_get_offset_f64 wrote.  `len` = the number of doubles the caller's buffer holds and must EQUAL lpvs_admm_offset_len
+ * (LPVS_EARGUMENT otherwise: a checkpoint written by a 36-bit handle does not go into a handle that reads 32 bits, or the reverse -- nothing
+ * is read or written past a buffer of the wrong size).  get / set: LPVS_ESTATE when the handle has no offset vector, or before lpvs_admm_init. */
 int32_t lpvs_admm_offset_len(lpvs_problem *h, int64_t *len);
-int32_t lpvs_admm_get_offset_f64(lpvs_problem *h, double *xb_out);
-int32_t lpvs_admm_set_offset_f64(lpvs_problem *h, const double *xb);
+int32_t lpvs_admm_get_offset_f64(lpvs_problem *h, double *xb_out, int64_t len);
+int32_t lpvs_admm_set_offset_f64(lpvs_problem *h, const double *xb, int64_t len);
 /* per-signal state of a multi-signal handle (lpvs_admm_run reports the slowest signal / the largest ||x-z||) */
 int32_t lpvs_admm_status(lpvs_problem *h, int64_t signal, int64_t *iters_done, double *nxz, int32_t *converged);
 /* iterates in the solver's own (regressor-column) order; any pointer may be NULL */
@@ -392,6 +398,18 @@ int32_t lpvs_windows_estimate_f64(const double *Y, int64_t ns, const double *t, 
                                   int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
                                   int32_t linear_sign, int64_t win_lo, int64_t win_hi, int32_t device, double *x_re,
                                   double *x_im, int64_t *iters_out);
+
+/* The same call returning the raw ADMM state of every problem instead of the packed coefficients: the (x, z) that ADMM returns
+ * (src/lasso.jl:170) and the scaled dual variable u (:147,:155), each ns x (win_hi - win_lo) x Nreg, signal-major then window-major,
+ * Nreg = 2 Nf (2 Nf - 1 with the zero frequency first) in the reference's ordering [re; im] (src/lasso.jl:93-97).  Sparse estimators
+ * only.  x_out / z_out / u_out are HOST arrays; any of them (and iters_out) may be NULL.  What the parity tests hold the window
+ * batches' iteration to the oracle with (x, z AND u at the bench's own iteration count); fourier2complex(z) is what
+ * lpvs_windows_estimate_f64 returns for the same arguments. */
+int32_t lpvs_windows_estimate_state_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap,
+                                        const double *W, const double *freqs, int64_t Nf, int32_t estimator, double lam,
+                                        int32_t prox_kind, double prox_param, int64_t group_len, double mu, double tol, int64_t iters,
+                                        int32_t linear_sign, int64_t win_lo, int64_t win_hi, int32_t device, double *x_out,
+                                        double *z_out, double *u_out, int64_t *iters_out);
 
 /* ---- the same engine driven over several devices by ONE host process (SURVEY.md section 8(e) "Process model") --------
  * The k windows are split into contiguous ranges over `ngpus` devices (devices[r], or 0..ngpus-1 when devices == NULL;

@@ -257,7 +257,7 @@ function set_state!(p::Problem, x, z, u, iters_done::Integer; offset=nothing)
         Int64(iters_done)::Int64)::Int32)
     if offset !== nothing          # the offset vector saved with the iterates (`offset_vector`): the run continues bit for bit
         ov = dense(Float64, offset)
-        GC.@preserve ov check(@ccall LIB.lpvs_admm_set_offset_f64(p.h::Ptr{Cvoid}, ov::Ptr{Float64})::Int32)
+        GC.@preserve ov check(@ccall LIB.lpvs_admm_set_offset_f64(p.h::Ptr{Cvoid}, ov::Ptr{Float64}, Int64(length(ov))::Int64)::Int32)
     end
 end
 # the x-update's offset vector currently in effect (handles of n >= 2048; `nothing` otherwise): part of a checkpoint next to `iterates`.
@@ -267,7 +267,7 @@ function offset_vector(p::Problem)
     check(@ccall LIB.lpvs_admm_offset_len(p.h::Ptr{Cvoid}, k::Ref{Int64})::Int32)
     k[] == 0 && return nothing
     xb = zeros(k[])
-    GC.@preserve xb check(@ccall LIB.lpvs_admm_get_offset_f64(p.h::Ptr{Cvoid}, xb::Ptr{Float64})::Int32)
+    GC.@preserve xb check(@ccall LIB.lpvs_admm_get_offset_f64(p.h::Ptr{Cvoid}, xb::Ptr{Float64}, Int64(length(xb))::Int64)::Int32)
     (p.ns == 1 || k[] != p.n * p.ns) ? xb : reshape(xb, p.n, p.ns)
 end
 

@@ -104,12 +104,14 @@ SIGNATURES = {
     "lpvs_admm_run": (_I32, [_P, _I64, _PI64, C.POINTER(_F64), C.POINTER(_I32)]),
     "lpvs_admm_set_state_f64": (_I32, [_P, _P, _P, _P, _I64]),
     "lpvs_admm_offset_len": (_I32, [_P, _PI64]),
-    "lpvs_admm_get_offset_f64": (_I32, [_P, _P]),
-    "lpvs_admm_set_offset_f64": (_I32, [_P, _P]),
+    "lpvs_admm_get_offset_f64": (_I32, [_P, _P, _I64]),
+    "lpvs_admm_set_offset_f64": (_I32, [_P, _P, _I64]),
     "lpvs_admm_matvec_kind": (_I32, [_P, C.POINTER(_I32)]),
     "lpvs_windowpsd_last_timing": (_I32, [_P, _I32]),
     "lpvs_windows_estimate_f64": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
                                           _I64, _I64, _I32, _P, _P, _P]),
+    "lpvs_windows_estimate_state_f64": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
+                                                _I64, _I64, _I32, _P, _P, _P, _P]),
     "lpvs_windows_estimate_multi_f64": (_I32, [_P, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I32, _F64, _I32, _F64, _I64, _F64, _F64, _I64, _I32,
                                                 _P, _I32, _P, _P, _P]),
     "lpvs_lpv_batch_multi_f64": (_I32, [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _F64, _I64, _F64, _F64, _I64, _P, _I32, _P, _P, _P]),

@@ -466,8 +466,7 @@ class Problem:
         check(fn(self._h, out_ptr(arrs[0]), out_ptr(arrs[1]), out_ptr(arrs[2]), int(iters)))
         if offset is not None:
             off = np.asfortranarray(np.asarray(offset, dtype=np.float64))
-            assert off.size == self._offset_len(), "offset has the wrong length"
-            check(lib().lpvs_admm_set_offset_f64(self._h, out_ptr(off)))
+            check(lib().lpvs_admm_set_offset_f64(self._h, out_ptr(off), int(off.size)))   # (a wrong length is the library's LPVS_EARGUMENT -> ValueError)
 
     def _offset_len(self):
         k = C.c_int64(0)
@@ -482,7 +481,7 @@ class Problem:
         if k == 0:
             return None
         xb = np.zeros(k if k != self.n * self.ns or self.ns == 1 else (self.n, self.ns), order="F")
-        check(lib().lpvs_admm_get_offset_f64(self._h, out_ptr(xb)))
+        check(lib().lpvs_admm_get_offset_f64(self._h, out_ptr(xb), int(xb.size)))
         return xb
 
     def admm_get(self):
@@ -1020,6 +1019,44 @@ def windows_estimate(Y, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None, de
                                           int(kind), float(param), int(glen), float(eng["μ"]), float(eng["tol"]), int(eng["iters"]),
                                           int(eng["sign"]), int(win_lo), win_hi, int(device), out_ptr(xre), out_ptr(xim), out_ptr(its)))
     return (xre + 1j * xim)[:, :nwin], its[:, :nwin]
+
+
+def windows_estimate_state(Y, t, freqs, n, noverlap, W, eng, win_lo=0, win_hi=None, device=0):
+    """``lpvs_windows_estimate_state_f64``: the engine of :func:`windows_estimate`, returning the raw ADMM state ``x, z, u`` of every
+    problem (each ``[ns][nwin][Nreg]`` in the reference's ordering ``[re; im]``: the ``(x, z)`` of src/lasso.jl:170 and the dual variable) and
+    the iteration counts ``[ns][nwin]``.  Sparse estimators, Float64."""
+    Ys = [as_f64(y) for y in Y]
+    ns, Ly = len(Ys), Ys[0][2]
+    assert all(e[2] == Ly for e in Ys), "signals must have the same length"
+    kt, pt, Lt = as_f64(t)
+    kf, pf, Nf = as_f64(freqs)
+    kw, pw, nW = as_f64(W)
+    assert Ly == Lt, "y and t has to be the same length"
+    assert W is None or nW == n, "W must have one weight per window sample"
+    k = C.c_int64(0)
+    check(lib().lpvs_window_count(Ly, int(n), int(noverlap), C.byref(k)))
+    win_hi = int(k.value) if win_hi is None else int(win_hi)
+    nwin = win_hi - int(win_lo)
+    if ns == 1:
+        keep, pY = Ys[0][0], Ys[0][1]
+    elif all(_lib.is_device_array(y) for y in Y):
+        import torch
+        keep = torch.stack([y.reshape(-1) for y in Y]).contiguous()
+        pY = C.c_void_p(keep.data_ptr())
+    else:
+        keep = np.ascontiguousarray(np.stack([_host(y) for y in Y]))
+        pY = out_ptr(keep)
+    zf = C.c_int64(0)
+    fh = np.ascontiguousarray(np.asarray(_host(freqs), dtype=np.float64))
+    check(lib().lpvs_check_freq_f64(out_ptr(fh), Nf, C.byref(zf)))
+    nreg = 2 * Nf - 1 if zf.value else 2 * Nf
+    x, z, u = (np.zeros((ns, max(nwin, 1), nreg)) for _ in range(3))
+    its = np.zeros((ns, max(nwin, 1)), dtype=np.int64)
+    kind, param, glen = eng["prox"]
+    check(lib().lpvs_windows_estimate_state_f64(pY, ns, pt, Ly, int(n), int(noverlap), pw, pf, Nf, int(eng["estimator"]), float(eng["lam"]),
+                                                int(kind), float(param), int(glen), float(eng["μ"]), float(eng["tol"]), int(eng["iters"]),
+                                                int(eng["sign"]), int(win_lo), win_hi, int(device), out_ptr(x), out_ptr(z), out_ptr(u), out_ptr(its)))
+    return x[:, :nwin], z[:, :nwin], u[:, :nwin], its[:, :nwin]
 
 
 def windows_estimate_multi(Y, t, freqs, n, noverlap, W, eng, ngpus=0, devices=None):

@@ -2875,10 +2875,21 @@ static int stream_runs(const AdmmParams &p);
 // The panel walk's plan (symv_tile_mfma_ws_kernel<.., PANEL>): the unit list (row I of panel k; kPanelC tile columns per panel) cut into G
 // ranges of equal tile counts.  Device table (ints), cached per (device, nblk, G):  [0] = G;  then G rows {u0, u1, k0, I0, f0};  then
 // F0[npanel + 1], the first flush index of every panel (a workgroup flushes the panel's column sums once per panel it walks in).
-struct PanelPlan { const int *dev = nullptr; int G = 0, nflush = 0; };
+struct PanelPlan { const int *dev = nullptr; int G = 0, nflush = 0, nunits = 0; };
+static std::mutex g_panel_mu;
+static std::map<std::tuple<int, int, int>, PanelPlan> g_panel_cache;
+// (lpvs_release_cached_memory: the plans' device tables are caches like the pool's blocks)
+void release_panel_plans() {
+    std::lock_guard<std::mutex> lk(g_panel_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : g_panel_cache) { (void)hipSetDevice(std::get<0>(kv.first)); (void)hipFree(const_cast<int *>(kv.second.dev)); }
+    (void)hipSetDevice(cur);
+    g_panel_cache.clear();
+}
 static PanelPlan panel_plan(int nblk, int G) {
-    static std::mutex mu;
-    static std::map<std::tuple<int, int, int>, PanelPlan> cache;
+    std::mutex &mu = g_panel_mu;
+    auto &cache = g_panel_cache;
     int device = 0;
     (void)hipGetDevice(&device);
     std::lock_guard<std::mutex> lk(mu);
@@ -2919,7 +2930,7 @@ static PanelPlan panel_plan(int nblk, int G) {
         (void)hipGetLastError();
         return pl;                                              // (not cached: the caller falls back to the run walk)
     }
-    pl.dev = dev; pl.G = G; pl.nflush = f;
+    pl.dev = dev; pl.G = G; pl.nflush = f; pl.nunits = (int)units.size();
     cache[key] = pl;
     return pl;
 }
@@ -2977,7 +2988,12 @@ static bool stream_panel(const AdmmParams &p) {
     const bool off = [] { const char *e = getenv("LPVS_MULTI_WALK"); return !(e && std::string(e) == "panel"); }();   // (read per call: tests switch it)
     const bool q4_off = [] { const char *e = getenv("LPVS_MULTI_MFMA"); return e && std::string(e) == "16"; }();
     if (off || q4_off || stream_runs(p) == 0 || p.ns > 8 || !p.mp_split) return false;
-    return panel_plan((int)(p.np / TS), (int)stream_cus()).dev != nullptr;
+    // the P1 records (one per unit) and the P2 records (ids (flush index) * kPanelC + c) live in the per-tile record areas, ntiles records per
+    // signal each: a plan that would index past them (short triangles: ~45 row blocks with LPVS_MULTI_RUNS=2) takes the run walk instead
+    const int nblk = (int)(p.np / TS);
+    const long long ntiles = (long long)nblk * (nblk + 1) / 2;
+    const PanelPlan pl = panel_plan(nblk, (int)stream_cus());
+    return pl.dev != nullptr && (long long)pl.nflush * kPanelC <= ntiles && (long long)pl.nunits <= ntiles;
 }
 static int stream_layout(const AdmmParams &p) { return stream_panel(p) ? -kPanelC : stream_runs(p); }
 static const int *stream_table(const AdmmParams &p) { return stream_panel(p) ? panel_plan((int)(p.np / TS), (int)stream_cus()).dev : nullptr; }
@@ -3030,7 +3046,7 @@ static void launch_sym_matvec(const AdmmParams &p, const AdmmStatus *status, hip
 }
 
 // one ADMM iteration on the packed symmetric form
-static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
+static int32_t launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     const int nblk = (int)(p.np / TS);
     const unsigned ntiles = (unsigned)(nblk * (nblk + 1) / 2);
     const unsigned ns = (unsigned)p.ns;
@@ -3040,7 +3056,7 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
     // (the stale nibble product: refresh R_g sits between the product of rhs_g and the update that adds xb to it -- where the one-launch scheme has it)
     if (p.nib_period > 0 && p.ns == 1 && p.mp_types != nullptr) {
         const long long g = p.fi_base + it;
-        if (nib_refresh_due(g, p.nib_period, p.nib_ramp)) (void)launch_nibble_refresh(p, false, nullptr, s);
+        if (nib_refresh_due(g, p.nib_period, p.nib_ramp)) LPVS_TRY(launch_nibble_refresh(p, false, nullptr, s));   // (LPVS_ESTATE without its buffers: not a stale offset vector)
     }
     if (fused_ok(p)) {
         hipLaunchKernelGGL(admm_fused_update2_kernel, dim3((unsigned)nblk, ns), dim3(512), 0, s, p, part1, part2, nblk, (int)ntiles, blocknorm, it & 1, it > 0 ? 1 : 0, stream_layout(p), stream_table(p));
@@ -3051,6 +3067,7 @@ static void launch_iteration_sym(const AdmmParams &p, hipStream_t s, int it) {
             hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)nblk, ns), dim3(256), 0, s, part1, part2, nblk, (int)ntiles, p.np, p.x, p.status, p.xb, 0);
         hipLaunchKernelGGL(admm_prox_kernel, dim3(ns), dim3(1024), 0, s, p);
     }
+    return LPVS_OK;
 }
 
 static void launch_symv_raw(const double *M, int64_t np, const double *rhs, double *x, const AdmmStatus *st, int ns,
@@ -4192,7 +4209,7 @@ int32_t launch_admm_iterations(const AdmmParams &p, int64_t iters, hipStream_t s
     }
     for (int64_t i = 0; i < iters; ++i) {
         if (sym) {
-            launch_iteration_sym(p, s, (int)i);
+            LPVS_TRY(launch_iteration_sym(p, s, (int)i));
         } else {
             launch_symv_raw(p.M, p.np, p.rhs, p.x, p.status, p.ns, s);
             if (p.prox_kind != LPVS_PROX_BALL_L0 && p.n <= 4096) {

@@ -590,6 +590,7 @@ int32_t lpvs_release_cached_memory(void) {
     std::vector<StreamBundle *> idle;
     { std::lock_guard<std::mutex> g(g_bundle_mu); idle.swap(g_bundles); }
     for (StreamBundle *b : idle) delete b;           // idle streams / events of destroyed handles
+    release_panel_plans();                           // the panel walk's cached device tables (admm.hip)
     return LPVS_OK;
 }
 
@@ -1205,21 +1206,31 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     h->drop_graph();
     LPVS_TRY(factorize(h, 1.0 / mu));            // no-op when M is cached for this shift; clears Mp_valid otherwise
     // ---- the x-update correction (admm.hip, launch_xupdate_correction): decided first, the packing below depends on it.
-    // Default: single-signal handles of n >= 2048, after the iterations 16, 512, 1024, 2048, ... (three corrections in 2000 iterations).
-    // Handles with several right-hand sides run without it unless asked: a correction is an accurate product over the f64 Gram per signal
-    // (7 ms for the 8 channels of n = 32768), where one signal at n = 8192 pays 0.1 ms.
+    // Default: every handle of n >= 2048, after the iterations 16, 512, 1024, 2048, ... (three corrections in 2000 iterations).
+    // Round 6: handles with several right-hand sides too -- at cfg5's judged size (n = 32768, 8 channels) the uncorrected run drifts 4.1e-10
+    // in x, z (1.4e-10 in u) from the corrected one after 2000 iterations (profiles/r06_cfg5_xcorr_fullsize.txt), the same constant forcing
+    // E w as at cfg3; a correction there is an accurate product over the 8.6-GB f64 Gram for all channels in one pass: 8.6 ms, three of them
+    // 1.9 % of a 2000-iteration run.  LPVS_XCORR_OFF switches it off per handle.
     // LPVS_XUPDATE_CORRECTION (A/B measurements): "0" none; "B" after B^j; "eN" after 16 and every N-th; "dN" after 16, N, 2N, 4N, ...
     const bool offset_form_wanted = h->np >= kSymmetricMinNp && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
     const int xc_opt = option_in_effect(LPVS_OPT_XUPDATE_CORRECTION, h->opt[LPVS_OPT_XUPDATE_CORRECTION]);   // explicit, thread default, or environment ("0" = off)
-    const bool xc_on = offset_form_wanted && (xc_opt == LPVS_XCORR_ON || (xc_opt == 0 && h->ns == 1));
-    h->xcorr_base = 0; h->xcorr_every = xc_on ? 512 : 0; h->xcorr_double = true;
+    const bool xc_on = offset_form_wanted && xc_opt != LPVS_XCORR_OFF;
+    // Schedule (round 6): after 16, then 128 and its doublings for one right-hand side (five corrections in 2000 iterations: +0.4 ms at cfg3) --
+    // the off-family sweep (tests/test_gpu_offfamily.py, profiles/r06_offfamily_probe*.txt) has cases at cond(G + I/mu) ~ 2e4 where 16, 512, ...
+    // leaves x, z 8e-10 from the exact iterates after 600 iterations and this schedule 1.5e-10; 512 and its doublings for several right-hand sides
+    // (a correction there is a pass over the whole f64 Gram for all channels: 8.6 ms at cfg5; measured 2.6e-10 from the oracle at n = 8192).
+    h->xcorr_base = 0; h->xcorr_every = xc_on ? (h->ns == 1 ? 128 : 512) : 0; h->xcorr_double = true;
     const char *xc_env = xc_on ? getenv("LPVS_XUPDATE_CORRECTION") : nullptr;
     if (xc_env != nullptr && xc_env[0] == '0' && xc_env[1] == 0) xc_env = nullptr;   // ("0" only says off, and only as the option's last fallback)
     if (const char *e = xc_env) {                                                    // schedule experiments: "B", "eN", "dN", "qN"
-        h->xcorr_double = e[0] == 'd' || e[0] == 'q'; h->xcorr_early = e[0] == 'q';   // "qN": after 1, 2, 4, 8, 16, N, 2N, 4N, ...
-        if (e[0] == 'e' || e[0] == 'd' || e[0] == 'q') { h->xcorr_base = 0; h->xcorr_every = atoi(e + 1) > 0 ? atoi(e + 1) : 0; }
-        else { h->xcorr_every = 0; h->xcorr_base = atoi(e) < 2 ? 0 : atoi(e); }
-        if (!offset_form_wanted) { h->xcorr_base = 0; h->xcorr_every = 0; }
+        const bool sched = (e[0] == 'e' || e[0] == 'd' || e[0] == 'q') && atoi(e + 1) > 0;
+        const bool base = e[0] >= '0' && e[0] <= '9' && atoi(e) >= 2;
+        if (sched) {
+            h->xcorr_double = e[0] == 'd' || e[0] == 'q'; h->xcorr_early = e[0] == 'q';   // "qN": after 1, 2, 4, 8, 16, N, 2N, 4N, ...
+            h->xcorr_base = 0; h->xcorr_every = atoi(e + 1);
+        } else if (base) { h->xcorr_every = 0; h->xcorr_base = atoi(e); }
+        // anything else ("1", "on", "true", ...) only says ON: the default schedule set above stays (it used to fall through
+        // to base = 0, i.e. silently OFF, and took the 32-bit reads with it)
     }
     // Corrected single-signal handles READ 32 bits of the 36 their fixed-point tiles hold (4 B per element instead of 4.5) and carry the
     // product of the 4-bit planes with a right-hand side up to nib_period iterations old in the offset vector (admm.hip, "the stale nibble
@@ -1300,11 +1311,13 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     h->offset_form = h->np >= kSymmetricMinNp && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
     if (h->offset_form) {
         if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
-        // every signal's M b.  Corrected handles leave its forward error to the first correction (which refines the whole right-hand side
-        // b + v: sixteen iterations with an offset vector good to ~1e-12 do not show); the others refine it here against the Gram the handle
-        // still holds, residual in twice the mantissa (admm.hip).  rhs and scratch are free until launch_admm_init below writes the state.
-        // LPVS_XB_REFINE = rounds (A/B measurements)
-        int steps = h->xcorr() ? 0 : 1;
+        // every signal's M b, refined once against the Gram the handle still holds, residual in twice the mantissa (admm.hip).  Round 5 left
+        // that to the first correction for corrected handles ("sixteen iterations with an offset vector good to ~1e-12 do not show") -- they do
+        // show off the benchmark's input family: at cond(G + I/mu) = 2.8e5 (mu = 1, unnormalised basis) the sixteen x-updates with E b in them
+        // are integrated by the dual variable and stay there (decay 1 - 1/(mu g) per iteration): u 9.0e-9 from the exact iterates after 600
+        // iterations against 3.0e-10 with the offset vector refined here (profiles/r06_offfamily_probe_refine.txt).  One accurate product: 0.2 ms
+        // at n = 8192.  rhs and scratch are free until launch_admm_init below writes the state.  LPVS_XB_REFINE = rounds (A/B measurements)
+        int steps = 1;
         if (const char *e = getenv("LPVS_XB_REFINE")) steps = atoi(e) < 0 ? 0 : atoi(e);
         h->xb_refined = steps > 0;
         LPVS_TRY(launch_offset_vector_refined(h->G.as<double>(), h->M.as<double>(), h->np, h->n, (int)h->ns, h->bs.as<double>(), h->M_shift, steps,
@@ -1355,6 +1368,14 @@ int32_t lpvs_admm_set_state_f64(lpvs_problem *h, const double *x, const double *
     LPVS_TRY(launch_admm_restate(p, iters_done, s));
     h->fi_sync = -1;                                  // (the next run rebuilds the one-launch iteration's records from the new state)
     h->k_enq = iters_done;
+    if (h->xcorr() && iters_done == 0) {              // a restart from iteration 0: the offset vector of a fresh lpvs_admm_init (no correction, no nibble term yet),
+        const size_t v = sizeof(double) * (size_t)h->np * (size_t)h->ns;   // not the one the previous run's last scheduled iteration left behind
+        LPVS_HIP(hipMemcpyAsync(h->xb.p, h->xb0.p, v, hipMemcpyDeviceToDevice, s));
+        if (h->nib_period > 0 && h->xb_corr.p) {
+            LPVS_HIP(hipMemcpyAsync(h->xb_corr.p, h->xb0.p, v, hipMemcpyDeviceToDevice, s));
+            LPVS_HIP(hipMemsetAsync(h->nib_acc.p, 0, v, s));
+        }
+    }
     if (h->xcorr() && iters_done > 0)                 // re-entry: the correction of the state handed in (an uninterrupted run holds the one of its last scheduled iteration: same to second order)
     {
         LPVS_TRY(launch_xupdate_correction(make_params(h), h->G.as<double>(), h->M_shift, h->xb_refined ? nullptr : h->bs.as<double>(), h->xb0.as<double>(), h->xb.as<double>(), h->corr.as<double>(), s));
@@ -1534,17 +1555,28 @@ int32_t lpvs_admm_offset_len(lpvs_problem *h, int64_t *len) {
     *len = !h->offset_form || !h->xb.p ? 0 : (int64_t)h->ns * h->n * (offset_has_nibble_part(h) ? 2 : 1);
     return LPVS_OK;
 }
-int32_t lpvs_admm_get_offset_f64(lpvs_problem *h, double *xb_out) {
+static int32_t offset_len_matches(const lpvs_problem *h, int64_t len) {
+    const int64_t want = (offset_has_nibble_part(h) ? 2 : 1) * (int64_t)h->ns * h->n;
+    if (len != want) {
+        set_error("offset buffer of %lld doubles, this handle's offset vector has %lld (lpvs_admm_offset_len: n x ns, or 2 n for a handle that iterates on "
+                  "LPVS_STORAGE_MIXED32 reads -- a checkpoint goes back into a handle with the same storage option)", (long long)len, (long long)want);
+        return LPVS_EARGUMENT;
+    }
+    return LPVS_OK;
+}
+int32_t lpvs_admm_get_offset_f64(lpvs_problem *h, double *xb_out, int64_t len) {
     if (!h || !xb_out) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited || !h->offset_form || !h->xb.p) { set_error("this handle has no offset vector (n < 2048, or lpvs_admm_init has not run)"); return LPVS_ESTATE; }
+    LPVS_TRY(offset_len_matches(h, len));
     LPVS_HIP(hipSetDevice(h->device));
     LPVS_TRY(copy_state_out(h, h->xb.p, xb_out));
     if (offset_has_nibble_part(h)) LPVS_TRY(copy_state_out(h, h->xb_corr.p, xb_out + (int64_t)h->ns * h->n));
     return LPVS_OK;
 }
-int32_t lpvs_admm_set_offset_f64(lpvs_problem *h, const double *xb) {
+int32_t lpvs_admm_set_offset_f64(lpvs_problem *h, const double *xb, int64_t len) {
     if (!h || !xb) { set_error("NULL argument"); return LPVS_EARGUMENT; }
     if (!h->inited || !h->offset_form || !h->xb.p) { set_error("this handle has no offset vector (n < 2048, or lpvs_admm_init has not run)"); return LPVS_ESTATE; }
+    LPVS_TRY(offset_len_matches(h, len));           // (no length, no way to tell a 36-bit handle's n-vector from a 32-bit handle's 2n: a host out-of-bounds read)
     LPVS_HIP(hipSetDevice(h->device));
     LPVS_TRY(copy_state_in(h, h->xb.p, xb));
     if (offset_has_nibble_part(h)) LPVS_TRY(copy_state_in(h, h->xb_corr.p, xb + (int64_t)h->ns * h->n));
@@ -2071,6 +2103,19 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
         LPVS_HIP(hipMemcpyAsync(zh.data(), sol, sizeof(double) * (size_t)np * (size_t)nprob, hipMemcpyDeviceToHost, s));
         LPVS_HIP(hipStreamSynchronize(s));
         g_win_timing[0] += ev[0].ms(); g_win_timing[1] += ev[1].ms(); g_win_timing[2] += ev[2].ms(); g_win_timing[6] += 1;
+        if (sparse && (a.st_x || a.st_z || a.st_u)) {   // the raw state of this pass's problems (lpvs_windows_estimate_state_f64)
+            std::vector<double> sh((size_t)np * (size_t)nprob);
+            const struct { const double *dev; double *out; } legs[3] = {{x.as<double>(), a.st_x}, {z.as<double>(), a.st_z}, {u.as<double>(), a.st_u}};
+            for (const auto &lg : legs) {
+                if (!lg.out) continue;
+                LPVS_HIP(hipMemcpyAsync(sh.data(), lg.dev, sizeof(double) * sh.size(), hipMemcpyDeviceToHost, s));
+                LPVS_HIP(hipStreamSynchronize(s));
+                for (int q = 0; q < nb_; ++q)
+                    for (int64_t sg = 0; sg < ns; ++sg)
+                        std::memcpy(lg.out + ((size_t)sg * (size_t)a.st_nwin + (size_t)(win_lo + w0 + q - a.st_base)) * (size_t)nreg,
+                                    sh.data() + ((size_t)q * (size_t)ns + (size_t)sg) * (size_t)np, sizeof(double) * (size_t)nreg);
+            }
+        }
         for (int q = 0; q < nb_; ++q)
             for (int64_t sg = 0; sg < ns; ++sg) {
                 const double *c = zh.data() + ((size_t)q * (size_t)ns + (size_t)sg) * (size_t)np;   // fourier2complex, src/utilities.jl:62-73
@@ -2213,6 +2258,26 @@ int32_t lpvs_windows_estimate_f64(const double *Y, int64_t ns, const double *t, 
     }));
     LPVS_TRY(ore.finish());
     return oim.finish();
+}
+
+int32_t lpvs_windows_estimate_state_f64(const double *Y, int64_t ns, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,
+                                        const double *freqs, int64_t Nf, int32_t estimator, double lam, int32_t prox_kind, double prox_param,
+                                        int64_t group_len, double mu, double tol, int64_t iters, int32_t linear_sign, int64_t win_lo,
+                                        int64_t win_hi, int32_t device, double *x_out, double *z_out, double *u_out, int64_t *iters_out) {
+    if (!Y || !t || !freqs || ns < 1) { set_error("NULL argument or ns < 1"); return LPVS_EARGUMENT; }
+    if (estimator != LPVS_EST_SPARSE && estimator != LPVS_EST_SPARSE_INIT) { set_error("only the sparse estimators have an ADMM state"); return LPVS_EARGUMENT; }
+    for (const double *p : {x_out, z_out, u_out})
+        if (p && is_device_ptr(p)) { set_error("the state outputs are HOST arrays"); return LPVS_EARGUMENT; }
+    std::vector<const double *> ys((size_t)ns);
+    for (int64_t q = 0; q < ns; ++q) ys[(size_t)q] = Y + q * L;
+    WinJob job{ys.data(), ns, t, L, n, noverlap, W, freqs, Nf, estimator, lam, prox_kind, prox_param, group_len, mu, tol, iters, linear_sign,
+               win_lo, win_hi, device};
+    const int64_t nwin = win_hi > win_lo ? win_hi - win_lo : 0;
+    job.st_x = x_out; job.st_z = z_out; job.st_u = u_out; job.st_base = win_lo; job.st_nwin = nwin;
+    LPVS_TRY(windows_engine_chunked(job, [&](int64_t w, int64_t sg, const double *, const double *, int64_t its) {
+        if (iters_out) iters_out[(size_t)sg * (size_t)nwin + (size_t)w] = its;
+    }));
+    return LPVS_OK;
 }
 
 int32_t lpvs_windowpsd_sparse_f64(const double *y, const double *t, int64_t L, int64_t n, int64_t noverlap, const double *W,

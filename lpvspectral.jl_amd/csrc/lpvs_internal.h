@@ -285,6 +285,7 @@ int32_t launch_pack_tiles_split(const double *M, int64_t np, unsigned char *Mp, 
 int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s,
                                 bool diag_float = false, double *abs_part = nullptr, int64_t n_valid = 0, double *rows_scratch = nullptr, int fix_bits = 36);   // diag_float: diagonal tiles always in the float-head format (multi-signal handles); abs_part: also the largest absolute row sum -> absmax[1]
 bool multi_signal_fixed_tiles_ok(int64_t np);               // the multi-signal tile product in use reads fixed-point off-diagonal tiles
+void release_panel_plans();                                 // admm.hip: frees the cached device tables of the panel walk
 int32_t launch_pack_tiles_mixed_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, unsigned char *types, unsigned long long *absmax,
                                       hipStream_t s, bool diag_float = false, double *abs_part = nullptr, int64_t n_valid = 0, double *rows_scratch = nullptr, int fix_bits = 36);
 constexpr size_t kMixedFixedTileBytes = 128 * 128 * 4 + 128 * 128 / 2 + 128 * 4, kMixedFloatTileBytes = 128 * 128 * 6;
@@ -365,6 +366,9 @@ struct WinJob {
     bool f32_grid = false;                        // the frequency grid was widened from floats: snap it to the progression it was rounded from
     int opt[kOptCount] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // the caller's default options (captured on ITS thread: multi.hip runs the job on workers)
     bool opt_captured = false;
+    // lpvs_windows_estimate_state_f64: the raw ADMM state (x, z, u of src/lasso.jl:146-155, reference ordering [re; im]) of every problem, written by the
+    // pass that solved it into HOST arrays [ns][st_nwin][nreg] indexed by (window - st_base); any of the three may be null
+    double *st_x = nullptr, *st_z = nullptr, *st_u = nullptr; int64_t st_base = 0, st_nwin = 0;
 };
 // sink(window index relative to win_lo, signal, re[Nf], im[Nf], iterations): window order, signals innermost
 typedef std::function<void(int64_t, int64_t, const double *, const double *, int64_t)> WinSink;

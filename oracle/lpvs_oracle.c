@@ -472,6 +472,45 @@ int64_t lpvo_admm_gram(const double *G, int64_t n, const double *b, double *x, d
     return it;
 }
 
+/* The same iteration for `nrhs` right-hand sides B (n x nrhs, column-major) sharing G -- hence ONE Cholesky factor --, without a
+ * stopping test (tol = 0), the iterates after the ascending counts snaps[0..nsnap) written to xs / zs / us ([nrhs][nsnap][n]).
+ * Per right-hand side the arithmetic is lpvo_admm_gram's, operation for operation (the channels only run side by side on
+ * OpenMP threads): what the tests hold a multi-channel device handle to at a long horizon without one factorisation per channel. */
+int64_t lpvo_admm_gram_multi(const double *G, int64_t n, const double *B, int64_t nrhs, int prox_kind, double prox_param,
+                             int64_t glen, double mu, const int64_t *snaps, int64_t nsnap, double *xs, double *zs, double *us) {
+    if (!(mu >= 0 && mu <= 1)) return LPVO_EASSERT;
+    if (nsnap < 1 || nrhs < 1) return LPVO_EDOMAIN;
+    double *L = (double *)malloc(sizeof(double) * n * n), *Lt = (double *)malloc(sizeof(double) * n * n);
+    if (!L || !Lt) { free(L); free(Lt); return LPVO_ENOMEM; }
+    memcpy(L, G, sizeof(double) * n * n);
+    for (int64_t i = 0; i < n; ++i) L[i * n + i] += 1.0 / mu;
+    if (chol_lower(L, n)) { free(L); free(Lt); return LPVO_EDOMAIN; }
+    for (int64_t i = 0; i < n; ++i) for (int64_t k = 0; k < n; ++k) Lt[i * n + k] = L[k * n + i];
+    const int64_t iters = snaps[nsnap - 1];
+#pragma omp parallel for schedule(static, 1)
+    for (int64_t c = 0; c < nrhs; ++c) {
+        const double *b = B + c * n;
+        double *x = (double *)calloc(n, sizeof(double)), *z = (double *)calloc(n, sizeof(double));
+        double *u = (double *)calloc(n, sizeof(double)), *tmp = (double *)malloc(sizeof(double) * n);
+        int64_t next = 0;
+        for (int64_t i = 1; i <= iters; ++i) {
+            for (int64_t k = 0; k < n; ++k) x[k] = b[k] + (z[k] - u[k]) / mu;
+            chol_solve(L, Lt, n, x);
+            for (int64_t k = 0; k < n; ++k) tmp[k] = x[k] + u[k];
+            lpvo_prox(prox_kind, z, tmp, n, prox_param, glen, mu);
+            for (int64_t k = 0; k < n; ++k) { tmp[k] = x[k] - z[k]; u[k] += tmp[k]; }
+            while (next < nsnap && snaps[next] == i) {
+                const size_t o = ((size_t)c * (size_t)nsnap + (size_t)next) * (size_t)n;
+                memcpy(xs + o, x, sizeof(double) * n); memcpy(zs + o, z, sizeof(double) * n); memcpy(us + o, u, sizeof(double) * n);
+                ++next;
+            }
+        }
+        free(x); free(z); free(u); free(tmp);
+    }
+    free(L); free(Lt);
+    return iters;
+}
+
 /* G = A' diag(W) A (n x n, full), b = A' diag(W) y ; W may be NULL.  (src/lasso.jl:119-120) */
 int lpvo_gram(const double *A, int64_t m, int64_t n, const double *y, const double *W, double *G,
               double *b) {

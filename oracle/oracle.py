@@ -234,6 +234,25 @@ def admm_gram(G, b, proxg, x0=None, iters=10000, tol=1e-5, mu=0.05, history=Fals
     return dict(x=x, z=z, u=u, iters=int(it), nxz=hist[:it] if history else None)
 
 
+def admm_gram_multi(G, B, proxg, snaps, mu=0.05):
+    """admm_gram for the columns of ``B`` (n x nrhs) sharing ``G`` -- one Cholesky factor --, tol = 0, started from zero: returns
+    ``{count: (x, z, u)}`` with arrays ``[n][nrhs]`` for the ascending iteration counts in ``snaps``.  Per column the arithmetic is
+    admm_gram's operation for operation (tests/test_oracle_golden.py holds the two to bit equality)."""
+    G = np.asfortranarray(G, dtype=np.float64)
+    B = np.asfortranarray(np.asarray(B, dtype=np.float64).reshape(G.shape[0], -1))
+    n, nrhs = B.shape
+    snaps = np.ascontiguousarray(sorted(int(s) for s in snaps), dtype=np.int64)
+    xs, zs, us = (np.zeros((nrhs, len(snaps), n)) for _ in range(3))
+    f = lib().lpvo_admm_gram_multi
+    f.restype = C.c_int64
+    it = f(_p(G), C.c_int64(n), _p(B), C.c_int64(nrhs), C.c_int(proxg.kind), C.c_double(proxg.param), C.c_int64(proxg.glen), C.c_double(mu),
+           _p(snaps), C.c_int64(len(snaps)), _p(xs), _p(zs), _p(us))
+    if it == -2:
+        raise AssertionError("μ should be ≤ 1")
+    assert it == snaps[-1], it
+    return {int(s): (xs[:, k].T.copy(), zs[:, k].T.copy(), us[:, k].T.copy()) for k, s in enumerate(snaps)}
+
+
 _LIB_LD = None
 
 

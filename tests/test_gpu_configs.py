@@ -203,6 +203,56 @@ def test_cfg5_indball_multichannel_vs_oracle(L, oracle, Nf):
     assert all(np.array_equal(ses[q].x, P[:, q]) for q in range(ns))
 
 
+def test_cfg5_kernel_chain_long_horizon_vs_oracle(L, oracle):
+    """cfg5's kernel chain at the BENCH'S OWN HORIZON where the CPU oracle can follow (VERDICT round 5, next #1c): 8 channels sharing (X, V),
+    Nf = 256, Nv = 16 -> n = 8192 (N = 2^20, so that the mixed storage cfg5 streams holds: 36-bit fixed-point tiles below the diagonal),
+    IndBallL0(32), 2000 iterations of symv_tile_mfma_ws_kernel (4x4x4 MFMA, partials per run of tiles) -> symv_reduce_runs_kernel ->
+    admm_prox_kernel (one-pass top-32), with the x-update correction that is the default of multi-channel handles since round 6.
+    Channels 0 and 5 against oracle.admm_gram_multi (src/lasso.jl:136-171 on the Gram form, one Cholesky factor for both; README.md:79-83 for the
+    estimator) on the device's own Gram: live for the first 200 iterations, from the fixture tests/golden/cfg5_n8192_oracle_iterates.npz
+    (tools/cfg5_midsize_vs_oracle.py --save; keyed by the sha256 of G, B; a live run checks the stored iterates bit for bit) at 500, 1000 and
+    2000 -- rel-L2 of x, z, u <= 1e-9, identical support (32 of 8192) at every count.  Measured 2.6e-10 at 2000 (uncorrected: 4.1e-10)."""
+    import bench, hashlib
+    from _guards import precondition_not_met
+    N, Nf, Nv, ns, r, mu = 1 << 20, 256, 16, 8, 32, 0.05
+    Y, X, V, w = bench.synth_channels(N, Nf, ns, torch.device("cuda"))
+    dev = {}
+    with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
+        assert p.n == 8192
+        p.set_prox(L.IndBallL0(r))
+        p.admm_init(None, μ=mu, tol=0.0)
+        info = p.matvec_info()
+        assert info["kernel"] == "symv_tile_mfma_ws_kernel" and "36-bit fixed point" in info["storage"] and info["signals_per_pass"] == 8, info
+        done = 0
+        for cnt in (200, 500, 1000, 2000):
+            it, _, conv = p.admm_run(cnt - done); done = cnt
+            assert it == cnt and not conv
+            dev[cnt] = p.admm_get()
+        assert p.timing()["xcorr_count"] == 3                                          # after 16, 512, 1024: several right-hand sides
+        G, _ = p.get_gram(); B = p.get_rhs()
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg5_n8192_oracle_iterates.npz"))
+    fp = hashlib.sha256(np.ascontiguousarray(G).tobytes() + np.ascontiguousarray(B).tobytes()).hexdigest()
+    if str(fix["sha256"]) != fp:
+        precondition_not_met("tests/golden/cfg5_n8192_oracle_iterates.npz belongs to another G, B (%s..., now %s...): regenerate it with "
+                             "tools/cfg5_midsize_vs_oracle.py --save" % (str(fix["sha256"])[:12], fp[:12]))
+    chans, counts = [int(c) for c in fix["channels"]], [int(c) for c in fix["counts"]]
+    assert counts == [200, 500, 1000, 2000]
+    live = oracle.admm_gram_multi(G, B[:, chans], oracle.IndBallL0(r), [200], mu=mu)[200]
+    for i, name in enumerate(("oracle_x", "oracle_z", "oracle_u")):
+        assert np.array_equal(live[i], fix[name][0]), name                             # the stored oracle iterates ARE the oracle's
+    worst = {}
+    for k, cnt in enumerate(counts):
+        x, z, u = dev[cnt]
+        for j, ch in enumerate(chans):
+            ox, oz, ou = fix["oracle_x"][k][:, j], fix["oracle_z"][k][:, j], fix["oracle_u"][k][:, j]
+            e = dict(x=rel(x[:, ch], ox), z=rel(z[:, ch], oz), u=rel(u[:, ch], ou))
+            worst[cnt] = max(worst.get(cnt, 0.0), *e.values())
+            assert max(e.values()) <= 1e-9, (cnt, ch, e)
+            assert np.array_equal(z[:, ch] != 0, oz != 0) and np.count_nonzero(oz) == r, (cnt, ch)
+    print("cfg5 chain n=8192, 8 channels, IndBallL0(32): channels %s vs oracle.admm_gram_multi, worst rel-L2 of x, z, u after %s" %
+          (chans, ", ".join(f"{c}: {worst[c]:.2e}" for c in counts)))
+
+
 def _ball_prox_host(v, r):
     """IndBallL0(r): keep the r largest |v| (lowest index first on ties), zero the rest."""
     idx = np.argsort(-np.abs(v), kind="stable")[:r]

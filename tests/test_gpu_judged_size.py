@@ -8,9 +8,10 @@
       ``admm_iter_mixed_kernel`` (name asserted): rel-L2 of x, z, u <= 1e-9 with identical support after 200, 500, 1000 and the
       bench's own 2000 iterations (SURVEY 8(d)'s tolerance, met at every count since round 5's x-update correction), and against
       the EXACT iterates -- the same algorithm in extended precision, a committed fixture -- to 2e-10 at 2000.
-  cfg4 (1024 windows x 2^16, Nf = 256 with the zero frequency, L1, mu = 1e-4)
-    * the DEFAULT execution plan (cache-sized chunks, two parts in flight) against the uncut single launch sequence bit for bit,
-      and four spot windows against ``oracle.admm_quadratic`` / the oracle's whole host pipeline.
+  cfg4 (1024 windows x 2^16, Nf = 256 with the zero frequency, L1, mu = 1e-4), 2000 iterations per window as bench.py runs it
+    * the DEFAULT execution plan (cache-sized chunks, two parts in flight, 32-bit reads + stale nibble product) against the uncut
+      single launch sequence bit for bit, and the raw state x, z, u of four spot windows against ``oracle.admm_quadratic`` /
+      ``oracle.admm_gram`` / the oracle's whole host pipeline.
 
 Tolerances.  Dense form vs oracle: 1e-12 of max|G| (same rounded phases fl(w x) as the reference, only the summation order differs).
 Structured form vs oracle: the reference rounds the phase w*x to a double BEFORE cos/sin (src/lasso.jl:42), an error of up to
@@ -20,6 +21,8 @@ Structured form vs oracle: the reference rounds the phase w*x to a double BEFORE
 import numpy as np
 import pytest
 import torch
+
+from _guards import precondition_not_met
 
 pytestmark = pytest.mark.gpu
 
@@ -148,7 +151,7 @@ def test_cfg3_one_launch_iteration_against_oracle_at_n8192(L, oracle, cfg3):
     fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_extended_precision_iterates.npz"))
     fp = hashlib.sha256(np.ascontiguousarray(G).tobytes() + np.ascontiguousarray(b).tobytes()).hexdigest()
     if str(fix["sha256"]) != fp:
-        pytest.skip("tests/golden/cfg3_extended_precision_iterates.npz belongs to another G, b (%s..., now %s...): the Gram's bits changed -- "
+        precondition_not_met("tests/golden/cfg3_extended_precision_iterates.npz belongs to another G, b (%s..., now %s...): the Gram's bits changed -- "
                     "regenerate it with tools/cfg3_vs_oracle.py --longdouble --save, then --reuse-ld --save" % (str(fix["sha256"])[:12], fp[:12]))
     assert np.array_equal(ro["z"], fix["oracle_z"][0]) and np.array_equal(ro["x"], fix["oracle_x"][0])   # the stored oracle iterates ARE the oracle's
     for k, cnt in enumerate(int(q) for q in fix["counts"]):
@@ -178,7 +181,7 @@ def test_cfg3_36_bit_reads_by_name_and_without_the_nibble_refresh(L, cfg3, monke
         with L.Problem.lpv(c["y"], c["X"], c["V"], c["w"], 8) as p:
             G, b = p.get_gram()
             if hashlib.sha256(np.ascontiguousarray(G).tobytes() + np.ascontiguousarray(b).tobytes()).hexdigest() != str(fix["sha256"]):
-                pytest.skip("the fixture belongs to another G, b (see test_cfg3_one_launch_iteration_against_oracle_at_n8192)")
+                precondition_not_met("the fixture belongs to another G, b (see test_cfg3_one_launch_iteration_against_oracle_at_n8192)")
             del G
             if storage:
                 p.set_option("storage", storage)
@@ -212,38 +215,52 @@ def test_cfg3_36_bit_reads_by_name_and_without_the_nibble_refresh(L, cfg3, monke
 
 
 def test_cfg4_default_plan_fullsize_against_uncut_and_oracle(L, oracle, monkeypatch):
-    """1024 windows x 2^16 under the engine's DEFAULT plan (what bench.py's cfg4 record times) vs one uncut launch sequence, bit for
-    bit; windows 0, 341, 342 (a chunk boundary of the default plan) and 1023 against the oracle."""
+    """1024 windows x 2^16 under the engine's DEFAULT plan (what bench.py's cfg4 record times: cache-sized chunks, two parts in flight, 32 of
+    the fixed-point tiles' 36 bits read + the stale nibble product with its period ramped to 32 from launch 256 on) AT THE BENCH'S OWN
+    2000 ITERATIONS PER WINDOW (src/lsfft.jl:112-126 -> src/lasso.jl:105-126; VERDICT round 5, next #1a):
+      * bit for bit against one uncut launch sequence;
+      * windows 0, 341, 342 (a chunk boundary of the default plan) and 1023: the raw state x, z AND u (lpvs_windows_estimate_state_f64)
+        against the oracle's ADMM on the window's device Gram -- oracle.admm_quadratic (Quadratic(Q, +q) with its CG x-update, as written)
+        and oracle.admm_gram (the same iteration with the exact Cholesky x-update) -- rel-L2 <= 1e-9, identical support; and the packed
+        coefficients against the oracle's whole host pipeline (1e-8: its Gram is formed on the host)."""
     import bench
     from lpvspectral_jl_amd import _lib, api
-    n, nwin, Nf, iters = 1 << 16, 1024, 256, 80          # (the chunked plan needs >= 64 iterations, api.hip windows_engine_chunked)
+    n, nwin, Nf, iters = 1 << 16, 1024, 256, 2000
     y, t, f = bench.synth_windows(nwin, n, Nf, torch.device("cuda"))
     eng = dict(estimator=_lib.EST_SPARSE, lam=0.0, prox=(_lib.PROX_L1, 0.2, 0), μ=1e-4, tol=0.0, iters=iters, sign=_lib.LINEAR_QUADRATIC_AS_WRITTEN)
-    for v in ("LPVS_WINDOW_CHUNK_MB", "LPVS_WINDOWS_IN_FLIGHT", "LPVS_ITERATION", "LPVS_NT_LOADS"):
+    for v in ("LPVS_WINDOW_CHUNK_MB", "LPVS_WINDOWS_IN_FLIGHT", "LPVS_ITERATION", "LPVS_NT_LOADS", "LPVS_NIB_PERIOD", "LPVS_NIB_RAMP", "LPVS_NIB_FUSED", "LPVS_M_STORAGE"):
         monkeypatch.delenv(v, raising=False)
     x1, its1 = api.windows_estimate([y], t, f, n, 0, None, eng)
     tm = api.windowpsd_last_timing()
-    assert tm["one_launch_iteration"] and tm["windows"] == nwin, tm
+    assert tm["one_launch_iteration"] and tm["reads_32_bits"] and tm["windows"] == nwin, tm
+    xs, zs, us, its_s = api.windows_estimate_state([y], t, f, n, 0, None, eng)          # the default plan again, raw state out
     monkeypatch.setenv("LPVS_WINDOW_CHUNK_MB", "0"); monkeypatch.setenv("LPVS_WINDOWS_IN_FLIGHT", "1")
     x0, its0 = api.windows_estimate([y], t, f, n, 0, None, eng)
     monkeypatch.delenv("LPVS_WINDOW_CHUNK_MB"); monkeypatch.delenv("LPVS_WINDOWS_IN_FLIGHT")
     assert x1.shape == (1, nwin, Nf) and np.all(its1 == iters)
-    assert np.array_equal(x1, x0) and np.array_equal(its1, its0)
+    assert np.array_equal(x1, x0) and np.array_equal(its1, its0) and np.array_equal(its1, its_s)
+    assert zs.shape == (1, nwin, 2 * Nf - 1)
+    assert all(np.array_equal(oracle.fourier2complex(zs[0, i], 1), x1[0, i]) for i in range(nwin))    # the state call IS the same run
     S = (np.abs(x1[0]) ** 2).sum(0)
     assert int(np.argmax(S)) == 33
     yh, th = y.cpu().numpy(), t.cpu().numpy()
     W = np.ones(n)
-    worst = 0.0
+    worst = {"cg": 0.0, "chol": 0.0}
     for i in (0, 341, 342, 1023):
         yi, ti = yh[i * n:(i + 1) * n], th[i * n:(i + 1) * n]
         with L.Problem.fourier(yi, ti, f, W) as p:
             Q, q = p.get_gram()
-        ro = oracle.admm_quadratic(Q, q, oracle.NormL1(0.2), iters=iters, tol=0.0, mu=1e-4)
-        zo = oracle.fourier2complex(ro["z"], 1)
-        e = rel(x1[0, i], zo); worst = max(worst, e)
-        assert e <= 1e-9, (i, e)
-        assert np.array_equal(x1[0, i] != 0, zo != 0), i
+        dev = {"x": xs[0, i], "z": zs[0, i], "u": us[0, i]}
+        assert np.count_nonzero(dev["u"]) > 0
+        for name, ro in (("cg", oracle.admm_quadratic(Q, q, oracle.NormL1(0.2), iters=iters, tol=0.0, mu=1e-4)),
+                         ("chol", oracle.admm_gram(Q, -q, oracle.NormL1(0.2), iters=iters, tol=0.0, mu=1e-4))):
+            assert ro["iters"] == iters
+            e = {k: rel(dev[k], ro[k]) for k in ("x", "z", "u")}
+            worst[name] = max(worst[name], *e.values())
+            assert max(e.values()) <= 1e-9, (i, name, e)
+            assert np.array_equal(dev["z"] != 0, ro["z"] != 0) and 0 < np.count_nonzero(ro["z"]) < ro["z"].size, (i, name)
         xo = oracle.ls_sparse_spectral(yi, ti, f, W, proxg=oracle.NormL1(0.2), iters=iters, tol=0.0, mu=1e-4)[0]   # the whole host pipeline
         assert rel(x1[0, i], xo) <= 1e-8, (i, rel(x1[0, i], xo))
         assert np.array_equal(x1[0, i] != 0, xo != 0), i
-    print(f"cfg4 1024 x 2^16, default plan: bit-identical to the uncut call; spot windows vs oracle.admm_quadratic worst rel-L2 {worst:.2e}")
+    print(f"cfg4 1024 x 2^16, default plan, {iters} iterations per window: bit-identical to the uncut call; spot windows' x, z, u vs "
+          f"oracle.admm_quadratic worst rel-L2 {worst['cg']:.2e}, vs oracle.admm_gram (Cholesky x-update) {worst['chol']:.2e}")

@@ -87,10 +87,12 @@ def test_ridge_solves_on_ill_conditioned_lpv_bases(L, oracle):
 
 
 def test_resume_from_saved_state_continues_bit_for_bit(L):
-    """SURVEY section 5 (checkpoint / resume): x, z, u, the x-update's offset vector (round 5: it is re-formed after the iterations
-    1, 2, 4, ... and so part of the state between two of them -- iteration 60 sits between 32 and 64) and the iteration count read
+    """SURVEY section 5 (checkpoint / resume): x, z, u, the x-update's offset vector (it is re-formed after the iterations
+    16, 128, 256, 512, ... and so part of the state between two of them -- iteration 60 sits between 16 and 128) and the iteration count read
     back from one handle and installed into a fresh one continue the run bit for bit, including the stopping iteration.  Without the
-    offset vector the library re-forms it from the x it is given: the same run to second order (1e-10 here), same stopping iteration."""
+    offset vector the library re-forms it from the x it is given: the same run to second order (1e-10 here), same stopping iteration.
+    ADVICE round 5: the offset buffer travels WITH ITS LENGTH (a buffer of another handle kind's size is LPVS_EARGUMENT, nothing is read
+    past it), and lpvs_admm_set_state with iters_done = 0 on a handle that has already run restarts it as a fresh init does."""
     n, mu = 2304, 0.05
     G, b = _spd_problem(n, 9)
     with L.Problem.gram(G, b) as p:
@@ -118,6 +120,25 @@ def test_resume_from_saved_state_continues_bit_for_bit(L):
         xr, zr, ur = q.admm_get()
     assert (it, conv) == (it_full, conv_full) and abs(nxz - nxz_full) <= 1e-8 * nxz_full
     assert np.linalg.norm(zr - zf) <= 1e-10 * np.linalg.norm(zf) and np.array_equal(zr != 0, zf != 0)
+    # a buffer of the wrong size is refused in both directions (this handle: n doubles; a handle on 32-bit reads: 2 n)
+    from lpvspectral_jl_amd._lib import lib, out_ptr
+    with L.Problem.gram(G, b) as q:
+        q.set_prox(L.NormL1(0.3))
+        q.admm_init(None, μ=mu, tol=1e-7)
+        k = q._offset_len()
+        assert k == n
+        for bad in (np.zeros(2 * n), np.zeros(n - 1)):
+            with pytest.raises(ValueError, match="offset buffer"):
+                q.admm_set_state(x1, z1, u1, iters=60, offset=bad)
+            assert lib().lpvs_admm_get_offset_f64(q._h, out_ptr(bad), int(bad.size)) != 0
+        # restart: run, then set_state(zeros, iters = 0) -- the same iterates as the first 60 of a fresh handle, bit for bit
+        q.admm_run(100)
+        z0 = np.zeros(n)
+        q.admm_set_state(z0, z0, z0, iters=0)
+        it, _, _ = q.admm_run(60)
+        xs, zs, us = q.admm_get()
+        assert it == 60 and np.array_equal(xs, x1) and np.array_equal(zs, z1) and np.array_equal(us, u1)
+        assert np.array_equal(q.admm_get_offset(), off1)
     with L.Problem.gram(G[:512, :512].copy(), b[:512].copy()) as q:           # (n < 2048: the plain x-update, no offset vector)
         q.set_prox(L.NormL1(0.3)); q.admm_init(None, μ=mu, tol=1e-7)
         assert q.admm_get_offset() is None

@@ -6,6 +6,8 @@ rel <= 1e-6 (CG's own tolerance), identical support and stopping iterations vs t
 import numpy as np
 import pytest
 
+from _guards import precondition_not_met
+
 pytestmark = pytest.mark.gpu
 
 
@@ -218,7 +220,7 @@ def test_window_batches_read_32_bits_with_the_stale_nibble_product(L, monkeypatc
         for k in env:
             monkeypatch.delenv(k)
     if not flags["mixed"]["one_launch_iteration"]:
-        pytest.skip("this batch does not iterate in one launch: " + str(flags["mixed"]))
+        precondition_not_met("this batch does not iterate in one launch: " + str(flags["mixed"]))
     assert flags["default"]["reads_32_bits"] and flags["mixed32"]["reads_32_bits"]
     assert not flags["mixed"]["reads_32_bits"] and not flags["period 0"]["reads_32_bits"] and not flags["f64"]["one_launch_iteration"]
     assert np.array_equal(out["default"], out["again"]) and np.array_equal(out["default"], out["mixed32"]) and np.array_equal(out["mixed"], out["period 0"])

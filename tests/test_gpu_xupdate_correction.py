@@ -2,7 +2,7 @@
 seconds.  GPU only.
 
 An explicit inverse applies (I + E) H^-1; E w is a constant forcing of the ADMM map, which its slow modes integrate.  lpvs_admm_run removes it
-with one step of iterative refinement of the offset vector after the iterations 16, 512, 1024, ... (residual accumulated in twice the
+with one step of iterative refinement of the offset vector after the iterations 16, 128, 256, 512, 1024, ... (residual accumulated in twice the
 mantissa).  Here: n = 2048 (LPV group lasso, N = 2^16 -- the two-launch iteration on 6-byte tiles: the correction is not tied to the
 one-launch kernel), device iterates with and without the correction against oracle.admm_gram_ld (src/lasso.jl:136-171 on the Gram form,
 x87 extended precision) and the f64 oracle on the device's own Gram.  Measured (tools/xcorr_midsize.py): uncorrected 2.5e-11 / 3.0e-11
@@ -12,6 +12,8 @@ import os
 
 import numpy as np
 import pytest
+
+from _guards import precondition_not_met
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -48,7 +50,7 @@ def test_correction_brings_the_iterates_to_the_exact_ones(L, oracle, midsize):
     ctypes.CDLL("libgomp.so.1").omp_set_num_threads(min(8, os.cpu_count() or 1))     # (the oracle's row-block loops do not scale to a 128-thread team)
     G, b, corr, tm = _solve(L, midsize, [375, 375])
     _, _, plain, tm0 = _solve(L, midsize, [375, 375], correction="off")
-    assert tm["xcorr_count"] == 2 and tm0["xcorr_count"] == 0 and 0 < tm["xcorr_ms"] < 0.2 * tm["admm_ms"]      # after iterations 16 and 512
+    assert tm["xcorr_count"] == 4 and tm0["xcorr_count"] == 0 and 0 < tm["xcorr_ms"] < 0.2 * tm["admm_ms"]      # after iterations 16, 128, 256 and 512
     ld = oracle.admm_gram_ld(G, b, oracle.GroupL2(5.0, 16), [375, 750], mu=0.05)
     ro = oracle.admm_gram(G, b, oracle.GroupL2(5.0, 16), iters=750, tol=0.0, mu=0.05)
     e_or = rel(ro["z"], ld[750][1])
@@ -63,26 +65,28 @@ def test_correction_brings_the_iterates_to_the_exact_ones(L, oracle, midsize):
 
 
 def test_correction_schedule_is_absolute_and_the_offset_is_state(L, midsize):
-    """The corrections cut the launch sequence at absolute iteration indices (16, 512, ...): the iterates do not depend on how the caller
+    """The corrections cut the launch sequence at absolute iteration indices (16, 128, 256, 512, ...): the iterates do not depend on how the caller
     chunks lpvs_admm_run; the offset vector changes exactly there and is the fourth vector of a checkpoint."""
     _, _, whole, _ = _solve(L, midsize, [600])
-    _, _, parts, _ = _solve(L, midsize, [10, 6, 1, 300, 195, 88])        # 16 and 512 fall on and inside chunk boundaries
+    _, _, parts, _ = _solve(L, midsize, [10, 6, 1, 110, 1, 127, 1, 200, 144])        # 16, 128, 256 fall on chunk boundaries, 512 inside a chunk
     for a, b in zip(whole[0][:3], parts[-1][:3]):
         assert np.array_equal(a, b)
     # (a handle that iterates on 32-bit reads hands out 2n values: the offset with the nibble term of the last refresh -- it moves every 32
     # iterations -- and, behind it, the one without, which only the corrections write)
     n = whole[0][0].size
-    off = [q[3][-n:] for q in parts]                                      # after iterations 10, 16, 17, 317, 512, 600
+    off = [q[3][-n:] for q in parts]                                      # after iterations 10, 16, 17, 127, 128, 255, 256, 456, 600
     assert not np.array_equal(off[0], off[1])                             # re-formed after iteration 16 ...
-    assert np.array_equal(off[1], off[2]) and np.array_equal(off[2], off[3])   # ... constant from there to 511 ...
-    assert not np.array_equal(off[3], off[4])                             # ... re-formed after iteration 512 ...
-    assert np.array_equal(off[4], off[5]) and np.array_equal(parts[-1][3], whole[0][3])
-    assert 0 < rel(off[5], off[0]) < 1e-8                                 # (it moves by ~1e-12 of itself; the nibble term taken out: ~1e-10)
+    assert np.array_equal(off[1], off[2]) and np.array_equal(off[2], off[3])   # ... constant from there to 127 ...
+    assert not np.array_equal(off[3], off[4]) and np.array_equal(off[4], off[5])   # ... re-formed after 128, constant to 255 ...
+    assert not np.array_equal(off[5], off[6]) and np.array_equal(off[6], off[7])   # ... after 256, constant to 511 ...
+    assert not np.array_equal(off[7], off[8])                             # ... and after 512, inside the last chunk
+    assert np.array_equal(parts[-1][3], whole[0][3])
+    assert 0 < rel(off[8], off[0]) < 1e-8                                 # (it moves by ~1e-12 of itself; the nibble term taken out: ~1e-10)
 
 
 def test_correction_is_an_option_of_the_interface(L, midsize):
-    """LPVS_OPT_XUPDATE_CORRECTION: default on for one right-hand side and off for several; explicit values win; thread defaults reach the
-    constructor-created handle."""
+    """LPVS_OPT_XUPDATE_CORRECTION: default on -- for one right-hand side and, since round 6, for several (cfg5 drifts 4e-10 without it:
+    profiles/r06_cfg5_xcorr_fullsize.txt); explicit values win; thread defaults reach the constructor-created handle."""
     y, X, V, w = midsize
     Y2 = torch.stack([y, 0.5 * y], dim=1).contiguous()
     prox = L.SlicedSeparableSum.frequency_groups(5.0, 128, 16)
@@ -94,8 +98,8 @@ def test_correction_is_an_option_of_the_interface(L, midsize):
             return p.timing()["xcorr_count"], p.admm_get()[1]
     one = lambda: L.Problem.lpv(y, X, V, w, 8)
     two = lambda: L.Problem.lpv_multi(Y2, X, V, w, 8)
-    c1, z1 = count(one); c0, z0 = count(one, "off"); m0, zm0 = count(two); m1, zm1 = count(two, "on")
-    assert (c1, c0, m0, m1) == (1, 0, 0, 1)                                # after iteration 16
+    c1, z1 = count(one); c0, z0 = count(one, "off"); m0, zm0 = count(two, "off"); m1, zm1 = count(two); m2, _ = count(two, "on")
+    assert (c1, c0, m0, m1, m2) == (1, 0, 0, 1, 1)                         # after iteration 16
     assert rel(zm1[:, 0], z1) <= 1e-11 and rel(zm0[:, 0], z0) <= 1e-11     # the multi-signal handle's first channel is the single-signal solve, either way
     with L.default_options(xupdate_correction="off"):
         assert count(one)[0] == 0
@@ -130,7 +134,7 @@ def test_stale_nibble_product_inside_the_launch_and_as_kernels_of_its_own(L, mon
             return p.admm_get() + (p.admm_get_offset(), info, p.timing())
     a = run()
     if "32-bit fixed point reads" not in a[4]["storage"]:
-        pytest.skip("this inverse is not stored in the mixed format: " + a[4]["storage"])
+        precondition_not_met("this inverse is not stored in the mixed format: " + a[4]["storage"])
     assert a[4]["kernel"] == "admm_iter_mixed_kernel" and a[5]["nibble_refreshes"] == 16 + 8 + 8 + 1 and a[3].size == 2 * a[0].size      # launches 0 .. 15, 16 .. 30, 32 .. 60, 64
     b = run(fused=False)
     c = run(iteration="two")
@@ -172,7 +176,7 @@ def test_stale_nibble_product_on_a_fourier_handle_whose_tiles_are_all_fixed_poin
             return p.admm_get() + (p.admm_get_offset(), info, p.timing(), G, b)
     a = run()
     if a[4]["kernel"] != "admm_iter_mixed_kernel" or "32-bit fixed point reads" not in a[4]["storage"]:
-        pytest.skip("this inverse is not stored in the mixed format: " + str(a[4]))
+        precondition_not_met("this inverse is not stored in the mixed format: " + str(a[4]))
     assert a[4]["nbytes"] == 136 * 66048 + 16 * 1024, a[4]          # all 136 tiles fixed point, 32 bits read; the 16 diagonal tiles' diagonals in doubles
     assert a[5]["nibble_refreshes"] == 16 + 8 + 8 + 4 and a[3].size == 2 * a[0].size       # launches 0 .. 15, 16 .. 30, 32 .. 60, 64 .. 88
     ro = oracle.admm_gram(a[6], a[7], oracle.NormL1(lam), iters=90, tol=0.0, mu=mu)

@@ -170,6 +170,19 @@ def test_prox_operators(oracle):
     assert np.all(oracle.prox(oracle.GroupL2(100.0, 3), v, 0.25) == 0)
 
 
+def test_shared_factor_form_equals_the_single_runs(oracle):
+    """oracle.admm_gram_multi (several right-hand sides, ONE Cholesky factor, snapshots: what a multi-channel device handle is held to at
+    a long horizon) is admm_gram per column, bit for bit, for every prox operator and at every snapshot."""
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((300, 64)); G = A.T @ A; B = A.T @ rng.standard_normal((300, 3))
+    for g in (oracle.IndBallL0(5), oracle.GroupL2(2.0, 8), oracle.NormL1(1.0), oracle.NormL0(0.5)):
+        out = oracle.admm_gram_multi(G, B, g, [7, 40, 90], mu=0.05)
+        for c in range(3):
+            for cnt in (7, 40, 90):
+                r = oracle.admm_gram(G, B[:, c], g, iters=cnt, tol=0.0, mu=0.05)
+                assert all(np.array_equal(out[cnt][k][:, c], r[name]) for k, name in enumerate("xzu")), (g.kind, c, cnt)
+
+
 def test_admm_mu_assert(oracle):
     with pytest.raises(AssertionError):
         oracle.admm_gram(np.eye(3), np.ones(3), oracle.NormL1(1.0), mu=1.5)
