@@ -1532,6 +1532,40 @@ __device__ __forceinline__ void store_f64(double v, __amdgpu_buffer_rsrc_t rsrc,
 //   270 MB of per-tile column sums of a launch (and their re-read by the reduction) become 10 MB.
 constexpr int kPanelC = 4;
 constexpr size_t kPanelLds = 0;                                       // (the column sums live in registers)
+#if defined(LPVS_TIMELINE) && LPVS_TIMELINE == 3
+// Debug build only (make timeline3 -> liblpvspectral_timeline3.so; tools/ws_timeline.py): where a launch of the wave-specialised kernel spends its
+// time, BY ROLE.  One wave of each role (wave 0: P1, wave 2: P2, wave 4: loader) keeps the 100-MHz wall clock (s_memrealtime) at entry and end and
+// the SUM of the time it spent waiting at the stage barriers (stamp before / after every barrier); the loader also the sum of the time inside `put`
+// (waiting for the stage's bytes + decoding them into the LDS image).  The role that waits least at the barriers is the one the others wait for.
+// 32 words per workgroup: role r at [8 r ..]: {entry, -, end, barrier-wait ticks, barriers, put ticks (loader)}; [24] XCC_ID, [25] HW_ID.
+__device__ unsigned long long *g_lpvs_tl_ws = nullptr;
+extern "C" int32_t lpvs_debug_set_timeline_ws(unsigned long long *dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lpvs_tl_ws), &dev_buf, sizeof(dev_buf)) == hipSuccess ? LPVS_OK : LPVS_EDEVICE;
+}
+// (32-bit tick arithmetic in VECTOR registers: the kernel has no scalar register to spare -- 102 used, any more spill --, and six vector
+// instructions per stage cost the matrix pipe ~40 of a stage's ~2800 cycles)
+__device__ __forceinline__ unsigned int ws_tl_now() {
+    unsigned int v;
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"((unsigned int)t));
+    return v;
+}
+#define WS_TL_DECL unsigned int tl_pre = ws_tl_now(), tl_post = tl_pre, tl_wait, tl_put, tl_t = tl_pre, tl_nbar; \
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0" : "=v"(tl_wait), "=v"(tl_put), "=v"(tl_nbar)); (void)tl_t; (void)tl_put; \
+    if (g_lpvs_tl_ws != nullptr && lane == 0 && (wave == 0 || wave == 2 || wave == 4)) g_lpvs_tl_ws[(size_t)blockIdx.x * 32 + 8 * (wave >> 1)] = __builtin_amdgcn_s_memrealtime();
+#define WS_BARRIER() do { tl_wait += tl_post - tl_pre; tl_pre = ws_tl_now(); __syncthreads(); tl_post = ws_tl_now(); ++tl_nbar; } while (0)
+#define WS_TL_PUT_BEGIN() do { tl_t = ws_tl_now(); } while (0)
+#define WS_TL_PUT_END() do { tl_put += ws_tl_now() - tl_t; } while (0)
+#define WS_TL_FINISH(role) do { if (g_lpvs_tl_ws != nullptr && lane == 0) { unsigned long long *r_ = g_lpvs_tl_ws + (size_t)blockIdx.x * 32 + 8 * (role); \
+        r_[2] = __builtin_amdgcn_s_memrealtime(); r_[3] = tl_wait + (tl_post - tl_pre); r_[4] = tl_nbar; r_[5] = tl_put; \
+        if ((role) == 0) { r_[24] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20); r_[25] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4); } } } while (0)
+#else
+#define WS_TL_DECL
+#define WS_BARRIER() __syncthreads()
+#define WS_TL_PUT_BEGIN() do { } while (0)
+#define WS_TL_PUT_END() do { } while (0)
+#define WS_TL_FINISH(role) do { } while (0)
+#endif
 template <bool SPLIT, bool Q4, bool RUNS, bool FIX, bool PANEL = false>
 __global__ void __launch_bounds__(512, 1)
 symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__restrict__ rhs_all, int64_t np, int ns, int ntiles,
@@ -1609,6 +1643,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
         cv.I = __builtin_amdgcn_readfirstlane(cv.I); cv.J = __builtin_amdgcn_readfirstlane(cv.J);
     }
     int tp = 0;                                      // parity of the visit count
+    WS_TL_DECL
 
     if (wave >= 4) {
         // ---- loader waves.  Thread (r = ltid >> 4, c = ltid & 15) owns rows r and r + 16 of a stage:
@@ -1745,9 +1780,9 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
         fetch(integral_constant<int, 1>{}, cv, tyc);
         fetch(integral_constant<int, 2>{}, cv, tyc);
         fetch(integral_constant<int, 3>{}, cv, tyc);
-        put(integral_constant<int, 0>{}, 0, tyc != 0);
+        WS_TL_PUT_BEGIN(); put(integral_constant<int, 0>{}, 0, tyc != 0); WS_TL_PUT_END();
         fetch(integral_constant<int, 0>{}, v1.t < tend ? v1 : cv, v1.t < tend ? ty1 : tyc);
-        __syncthreads();
+        WS_BARRIER();
 #pragma unroll 1
         for (;;) {
             // while the MFMA waves multiply step q of the current visit, stage step q + 1 and refill its slot from the next visit
@@ -1756,15 +1791,16 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             const StreamVisit src = v1.t < tend ? v1 : cv;
             const unsigned tys = v1.t < tend ? ty1 : tyc;
             const bool fxc = tyc != 0;
-            put(integral_constant<int, 1>{}, tp, fxc); fetch(integral_constant<int, 1>{}, src, tys); __syncthreads();
-            put(integral_constant<int, 2>{}, tp, fxc); fetch(integral_constant<int, 2>{}, src, tys); __syncthreads();
-            put(integral_constant<int, 3>{}, tp, fxc); fetch(integral_constant<int, 3>{}, src, tys); __syncthreads();
-            if (v1.t < tend) put(integral_constant<int, 0>{}, tp ^ 1, ty1 != 0);
+            WS_TL_PUT_BEGIN(); put(integral_constant<int, 1>{}, tp, fxc); WS_TL_PUT_END(); fetch(integral_constant<int, 1>{}, src, tys); WS_BARRIER();
+            WS_TL_PUT_BEGIN(); put(integral_constant<int, 2>{}, tp, fxc); WS_TL_PUT_END(); fetch(integral_constant<int, 2>{}, src, tys); WS_BARRIER();
+            WS_TL_PUT_BEGIN(); put(integral_constant<int, 3>{}, tp, fxc); WS_TL_PUT_END(); fetch(integral_constant<int, 3>{}, src, tys); WS_BARRIER();
+            WS_TL_PUT_BEGIN(); if (v1.t < tend) put(integral_constant<int, 0>{}, tp ^ 1, ty1 != 0); WS_TL_PUT_END();
             fetch(integral_constant<int, 0>{}, v2.t < tend ? v2 : cv, v2.t < tend ? ty2 : tyc);
-            __syncthreads();
+            WS_BARRIER();
             if (v1.t >= tend) break;
             cv = v1; v1 = v2; tyc = ty1; ty1 = ty2; tp ^= 1;
         }
+        if (wave == 4) WS_TL_FINISH(2);
         return;
     }
 
@@ -1783,7 +1819,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
     const int64_t pass_bytes = (int64_t)nvalid * ntiles * TS * 8;
     const int part_records = (int)(pass_bytes < 0x7fffffff ? pass_bytes : 0x7fffffff);
     f64x4 acc2[4];                                   // waves 2-3: P2 blocks, columns 64*(wave-2) + 16*u .., over the tile's stages
-    __syncthreads();                                 // step 0 of the first visit staged
+    WS_BARRIER();                                    // step 0 of the first visit staged
     // One continuous software pipeline over the steps: a step's 32 MFMAs run as four groups of eight, each group's operands
     // read from LDS while the previous group multiplies.  The step's barrier sits BEFORE its last group (whose operands are in
     // registers by then: nobody reads the step's LDS images after it), and the next step's first operands are requested
@@ -1844,7 +1880,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             load(integral_constant<int, 1>{}, par, tp, 1, first); __builtin_amdgcn_sched_barrier(0); mul(0, integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0);
             load(integral_constant<int, 2>{}, par, tp, 0, first); __builtin_amdgcn_sched_barrier(0); mul(1, integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0);
             load(integral_constant<int, 3>{}, par, tp, 1, first); __builtin_amdgcn_sched_barrier(0); mul(0, integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                         // the next step is staged; this step's images are free
+            WS_BARRIER();                            // the next step is staged; this step's images are free
             load(integral_constant<int, 0>{}, par ^ 1, next_tp, 0, last); __builtin_amdgcn_sched_barrier(0); mul(1, integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0);
             if constexpr (!RUNS) store1(a0, a1, (cv.t * TS + MT_ROWS * ((Q + q0) & (NQ - 1))) * 8);
         };
@@ -1867,6 +1903,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             if (cv.t >= tend) break;
             tp ^= 1;
         }
+        if (wave == 0) WS_TL_FINISH(0);
     } else {
         // P2: columns 64*(wave-2) + 16*u .., the 32 rows of a stage.  A[s = li][k = lk], B[k = lk][j = c = li]
         using AT = std::conditional_t<Q4, f64x2, double>;
@@ -1905,7 +1942,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             load(integral_constant<int, 1>{}, par, 1); __builtin_amdgcn_sched_barrier(0); mul(0, Q == 0); __builtin_amdgcn_sched_barrier(0);
             load(integral_constant<int, 2>{}, par, 0); __builtin_amdgcn_sched_barrier(0); mul(1, false); __builtin_amdgcn_sched_barrier(0);
             load(integral_constant<int, 3>{}, par, 1); __builtin_amdgcn_sched_barrier(0); mul(0, false); __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                         // the next step is staged; this step's images are free
+            WS_BARRIER();                            // the next step is staged; this step's images are free
             load(integral_constant<int, 0>{}, par ^ 1, 0); __builtin_amdgcn_sched_barrier(0); mul(1, false); __builtin_amdgcn_sched_barrier(0);
             if constexpr (Q == NQ - 1 && !PANEL) {   // P2 of the tile is complete: D row = s = lk + 4*reg, col = li
                 if (cv.I != cv.J) {
@@ -1970,6 +2007,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             cv = nv;
             if (cv.t >= tend) break;
         }
+        if (wave == 2) WS_TL_FINISH(1);
     }
 }
 
@@ -3477,7 +3515,7 @@ __device__ __forceinline__ void fi_fixed_product(const FixRaw &fr, const double 
 }
 
 
-#ifdef LPVS_TIMELINE
+#if defined(LPVS_TIMELINE) && LPVS_TIMELINE < 3
 // Debug build only (make timeline -> liblpvspectral_timeline.so; tools/iter_timeline.py): every workgroup of the single-problem one-launch
 // iteration leaves wall-clock stamps (s_memrealtime, 100 MHz) of its phases, 8 words per workgroup and launch parity:
 //   {g, entry, update done, prologue barrier passed, tile consumed, last atomic issued, XCC_ID, HW_ID}
@@ -3507,7 +3545,7 @@ __device__ __forceinline__ void
 fi_one_tile_body(const AdmmParams &p, const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ types, int ntiles, int nblk, long long g, int aslot,
                  int uslot /* u is read from: 0 = p.u, 1 = the alternate buffer */, int commit_prev, size_t mp_stride) {
     constexpr bool prefetch_all = PA;               // (a template parameter: the two cases need different register sets, together they spill)
-#ifdef LPVS_TIMELINE
+#if defined(LPVS_TIMELINE) && LPVS_TIMELINE < 3
     const bool tl_on = MODE == FI_MID && !BATCH && !F32 && g_lpvs_tl != nullptr;
     unsigned long long *tl_rec = tl_on ? g_lpvs_tl + ((size_t)(g & 1) * (size_t)ntiles + blockIdx.x) * 8 : nullptr;
     if (tl_on && threadIdx.x == 0) {
