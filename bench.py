@@ -1396,16 +1396,23 @@ def run_cfg5(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks,
     return out
 
 
-def source_sha16(rel="lpvspectral.jl_amd/csrc/admm.hip"):
+KERNEL_SOURCES = ("admm_device.h", "admm.hip", "admm_one_launch.hip", "admm_multi.hip", "admm_small.hip")   # (the same list in tools/pmc_summary.py)
+
+
+def source_sha16():
+    """sha256 (16 hex digits) over the sources of the kernels the bench's rooflines are about: what a PMC summary is stamped with."""
     import hashlib
-    with open(os.path.join(ROOT, rel), "rb") as fh:
-        return hashlib.sha256(fh.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "lpvspectral.jl_amd", "csrc", rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel_prefix, workload="cfg3"):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of `workload`
     (PMC passes cannot run inside the timed bench).  tools/pmc_summary.py stamps a summary with the sha256 of the kernel source
-    it was collected from; a summary whose stamp is missing or differs from the present csrc/admm.hip is NOT quoted (a stale
+    it was collected from (KERNEL_SOURCES); a summary whose stamp is missing or differs from the present sources is NOT quoted (a stale
     figure is worse than none)."""
     import glob
     now = source_sha16()
@@ -1416,14 +1423,14 @@ def pmc_traffic(kernel_prefix, workload="cfg3"):
             continue
         meta = next((r for r in rows if r.get("kernel") == "__meta__"), None)
         rel = os.path.relpath(path, ROOT)
-        if not meta or meta.get("admm_hip_sha16") != now or meta.get("workload", "cfg3") != workload:
+        if not meta or meta.get("kernel_sources_sha16") != now or meta.get("workload", "cfg3") != workload:
             continue
         for r in rows:
             # (the instance <..., true> of the one-launch iteration also multiplies the nibble planes -- 103 launches in 2000: not the dominant one)
             if r.get("kernel", "").startswith(kernel_prefix) and not r["kernel"].endswith(", true>"):
                 return (r["fetch_corrected_bytes_per_launch"] + r["write_bytes_per_launch"],
-                        f"{rel} (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, bytes per launch; collected from csrc/admm.hip sha256 {now})")
-    return None, "no PMC summary of %s under profiles/ was collected from the present csrc/admm.hip (sha256 %s): not quoted" % (workload, now)
+                        f"{rel} (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, bytes per launch; kernel sources sha256 {now})")
+    return None, "no PMC summary of %s under profiles/ was collected from the present kernel sources (sha256 %s): not quoted" % (workload, now)
 
 
 if __name__ == "__main__":

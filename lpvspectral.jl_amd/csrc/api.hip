@@ -756,8 +756,7 @@ static ApSlots make_ap_slots(const std::vector<double> &hw, double xam) {
     sl.omr_hi.resize((size_t)sl.nf8); sl.omr_lo.resize((size_t)sl.nf8);
     sl.s0 = sl.nf8;
     bool merged = false;
-    static const bool merge_on = [] { const char *e = getenv("LPVS_AP_SLOTS"); return !(e && std::string(e) == "split"); }();
-    if (merge_on && Nf > 1 && D != 0.0L) {
+    if (Nf > 1 && D != 0.0L) {
         const long double j0r = 2.0L * a0 / D;
         const long long j0 = llroundl(j0r);
         const long double delta = 2.0L * a0 - (long double)j0 * D;
@@ -1212,15 +1211,15 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     // E w as at cfg3; a correction there is an accurate product over the 8.6-GB f64 Gram for all channels in one pass: 8.6 ms, three of them
     // 1.9 % of a 2000-iteration run.  LPVS_XCORR_OFF switches it off per handle.
     // LPVS_XUPDATE_CORRECTION (A/B measurements): "0" none; "B" after B^j; "eN" after 16 and every N-th; "dN" after 16, N, 2N, 4N, ...
-    const bool offset_form_wanted = h->np >= kSymmetricMinNp && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
+    const bool offset_form_wanted = h->np >= kSymmetricMinNp;
     const int xc_opt = option_in_effect(LPVS_OPT_XUPDATE_CORRECTION, h->opt[LPVS_OPT_XUPDATE_CORRECTION]);   // explicit, thread default, or environment ("0" = off)
     const bool xc_on = offset_form_wanted && xc_opt != LPVS_XCORR_OFF;
     // Schedule (round 6): after 16, then 128 and its doublings for one right-hand side (five corrections in 2000 iterations: +0.4 ms at cfg3) --
     // the off-family sweep (tests/test_gpu_offfamily.py, profiles/r06_offfamily_probe*.txt) has cases at cond(G + I/mu) ~ 2e4 where 16, 512, ...
     // leaves x, z 8e-10 from the exact iterates after 600 iterations and this schedule 1.5e-10; 512 and its doublings for several right-hand sides
-    // (a correction there is a pass over the whole f64 Gram for all channels: 8.6 ms at cfg5; measured 2.6e-10 from the oracle at n = 8192).
+    // (a correction there is a pass over the whole f64 Gram for all channels: 8.6 ms at cfg5; measured 2.6e-10 from the CPU reference iterates at n = 8192: tests/test_gpu_configs.py).
     h->xcorr_base = 0; h->xcorr_every = xc_on ? (h->ns == 1 ? 128 : 512) : 0; h->xcorr_double = true;
-    const char *xc_env = xc_on ? getenv("LPVS_XUPDATE_CORRECTION") : nullptr;
+    const char *xc_env = xc_on ? experiment_env("LPVS_XUPDATE_CORRECTION") : nullptr;   // (schedules: an experiment knob; "0" = off is the option's plain fallback, option_from_env)
     if (xc_env != nullptr && xc_env[0] == '0' && xc_env[1] == 0) xc_env = nullptr;   // ("0" only says off, and only as the option's last fallback)
     if (const char *e = xc_env) {                                                    // schedule experiments: "B", "eN", "dN", "qN"
         const bool sched = (e[0] == 'e' || e[0] == 'd' || e[0] == 'q') && atoi(e + 1) > 0;
@@ -1240,13 +1239,13 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     const int st_asked = option_in_effect(LPVS_OPT_M_STORAGE, h->opt[LPVS_OPT_M_STORAGE]);
     const bool read32 = h->ns == 1 && !h->f32 && h->xcorr() && (st_asked == 0 || st_asked == LPVS_STORAGE_MIXED32);
     int fix_bits = 36;                               // (packed with all 36 bits: the nibble planes feed the stale nibble product)
-    if (const char *e = getenv("LPVS_FIX_BITS")) fix_bits = atoi(e) >= 20 && atoi(e) <= 36 ? atoi(e) : fix_bits;
+    if (const char *e = experiment_env("LPVS_FIX_BITS")) fix_bits = atoi(e) >= 20 && atoi(e) <= 36 ? atoi(e) : fix_bits;
     h->nib_period = read32 ? 32 : 0;                 // LPVS_NIB_PERIOD: refresh period of the stale nibble product (experiments; 0: no stale product, the 36-bit reads)
-    if (const char *e = read32 ? getenv("LPVS_NIB_PERIOD") : nullptr) h->nib_period = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = read32 ? experiment_env("LPVS_NIB_PERIOD") : nullptr) h->nib_period = atoi(e) > 0 ? atoi(e) : 0;
     // ... denser while the right-hand side still moves fast: after every launch up to 15, every 2nd up to 31, 4th up to 63, ..., 32nd from 256 on
     // (103 refreshes in 2000 iterations; u at cfg3 after 200 iterations 1.75e-10 from the exact iterate instead of 3.9e-10 -- 36-bit reads: 1.40e-10)
     h->nib_ramp = read32 ? 8 : 0;
-    if (const char *e = read32 ? getenv("LPVS_NIB_RAMP") : nullptr) h->nib_ramp = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = read32 ? experiment_env("LPVS_NIB_RAMP") : nullptr) h->nib_ramp = atoi(e) > 0 ? atoi(e) : 0;
     h->Mp_read32 = read32;
     if (h->Mp_valid && h->Mp_mode == kMpMixed && h->Mp_fix_bits != fix_bits) h->Mp_valid = false;   // (the same M packed for the other choice)
     const int mode = mp_mode_for(h);
@@ -1308,7 +1307,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
     LPVS_TRY(copy_to_device(h->bs.p, hb.data(), v, s));
     // reduced-precision copies of M (split, f32) are only ever applied to (z-u)/mu: x = xb + M~ (z-u)/mu, xb = M b in full precision
     // (round 5: the 8-byte storage too -- the offset vector is refined against a double-double residual, which the in-loop product M (b + v) cannot be)
-    h->offset_form = h->np >= kSymmetricMinNp && getenv("LPVS_NO_OFFSET_FORM") == nullptr;
+    h->offset_form = h->np >= kSymmetricMinNp;
     if (h->offset_form) {
         if (!h->xb.p) LPVS_TRY(h->xb.alloc(v));
         // every signal's M b, refined once against the Gram the handle still holds, residual in twice the mantissa (admm.hip).  Round 5 left
@@ -1318,7 +1317,7 @@ int32_t lpvs_admm_init_f64(lpvs_problem *h, const double *x0, double mu, double 
         // iterations against 3.0e-10 with the offset vector refined here (profiles/r06_offfamily_probe_refine.txt).  One accurate product: 0.2 ms
         // at n = 8192.  rhs and scratch are free until launch_admm_init below writes the state.  LPVS_XB_REFINE = rounds (A/B measurements)
         int steps = 1;
-        if (const char *e = getenv("LPVS_XB_REFINE")) steps = atoi(e) < 0 ? 0 : atoi(e);
+        if (const char *e = experiment_env("LPVS_XB_REFINE")) steps = atoi(e) < 0 ? 0 : atoi(e);
         h->xb_refined = steps > 0;
         LPVS_TRY(launch_offset_vector_refined(h->G.as<double>(), h->M.as<double>(), h->np, h->n, (int)h->ns, h->bs.as<double>(), h->M_shift, steps,
                                               h->xb.as<double>(), h->rhs.as<double>(), h->scratch.as<double>(), s));
@@ -2036,10 +2035,10 @@ int32_t windows_engine(const WinJob &a, Sink sink) {
             }
             // 32-bit reads of the fixed-point tiles + the stale nibble product (admm.hip) where the batch iterates in one launch: the
             // default, and LPVS_STORAGE_MIXED32 by name; LPVS_STORAGE_MIXED reads all 36 bits.  (The refresh of a batch exists only inside the launch.)
-            if (ab.fi != nullptr && (storage_opt == 0 || storage_opt == LPVS_STORAGE_MIXED32) && !(getenv("LPVS_NIB_FUSED") && getenv("LPVS_NIB_FUSED")[0] == '0')) {
+            if (ab.fi != nullptr && (storage_opt == 0 || storage_opt == LPVS_STORAGE_MIXED32) && !(experiment_env("LPVS_NIB_FUSED") && experiment_env("LPVS_NIB_FUSED")[0] == '0')) {
                 int period = 32, ramp = 8;
-                if (const char *e = getenv("LPVS_NIB_PERIOD")) period = atoi(e) > 0 ? atoi(e) : 0;
-                if (const char *e = getenv("LPVS_NIB_RAMP")) ramp = atoi(e) > 0 ? atoi(e) : 0;
+                if (const char *e = experiment_env("LPVS_NIB_PERIOD")) period = atoi(e) > 0 ? atoi(e) : 0;
+                if (const char *e = experiment_env("LPVS_NIB_RAMP")) ramp = atoi(e) > 0 ? atoi(e) : 0;
                 if (period > 0) {
                     if (!xbc.p) LPVS_TRY(xbc.alloc(vb));
                     if (!nibacc.p) LPVS_TRY(nibacc.alloc(vb));

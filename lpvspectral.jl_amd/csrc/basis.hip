@@ -269,7 +269,7 @@ int32_t launch_window_panels(const double *t, const int64_t *toff_dev, int nbatc
 int32_t launch_trig_table(const double *X, int64_t N, const double *w, int64_t Nf, double2 *T,
                           hipStream_t s) {
     if (N == 0 || Nf == 0) return LPVS_OK;
-    const char *e = getenv("LPVS_PHASE");            // diagnostic (read per call): "exact" = phases of the unrounded products w x
+    const char *e = experiment_env("LPVS_PHASE");            // diagnostic (read per call): "exact" = phases of the unrounded products w x
     if (e != nullptr && std::string(e) == "exact")
         hipLaunchKernelGGL(trig_table_kernel<true>, dim3((unsigned)ceil_div(N * Nf, 256)), dim3(256), 0, s, X, N, w, Nf, T);
     else

@@ -1165,14 +1165,14 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     const std::vector<int2> &ht = ru_tiles(np);   // persistent host copy: the async upload may outlive this call
     LPVS_HIP(hipMemcpyAsync(tiles, ht.data(), sizeof(int2) * ht.size(), hipMemcpyHostToDevice, s));
     const size_t lds = sizeof(double) * 2 * RU_BK * (RU_TM + RU_TN);
-    const bool single_wg_pivot = [] { const char *e = getenv("LPVS_PIVOT"); return !(e && std::string(e) == "sweep64"); }();
-    const bool lookahead_on = [] { const char *e = getenv("LPVS_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+    const bool single_wg_pivot = [] { const char *e = experiment_env("LPVS_PIVOT"); return !(e && std::string(e) == "sweep64"); }();
+    const bool lookahead_on = [] { const char *e = experiment_env("LPVS_LOOKAHEAD"); return !(e && e[0] == '0'); }();
     LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rank_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // 128-wide pivot blocks (one-workgroup inverse) up to np ~ 12k; beyond, the bulk update is long enough to hide the
     // 256-wide chain (pivot block by the 64-wide sweep) and the deeper update runs closer to the MFMA peak
-    const int kw_env = [] { const char *e = getenv("LPVS_KW"); return e ? atoi(e) : 0; }();
+    const int kw_env = [] { const char *e = experiment_env("LPVS_KW"); return e ? atoi(e) : 0; }();
     // (the group schedule below runs 128-wide steps: 39.9 ms against 47.5 with 256-wide steps at np = 12288, 89.5 / 93.5 at 16384, equal at 32768)
-    const bool steps_scheme = [] { const char *e = getenv("LPVS_FACTOR_SCHEME"); return e && std::string(e) == "steps"; }();
+    const bool steps_scheme = [] { const char *e = experiment_env("LPVS_FACTOR_SCHEME"); return e && std::string(e) == "steps"; }();
     const int kw_outer = kw_env == 128 || kw_env == 256 ? kw_env : ((steps_scheme && np >= 12288) ? 256 : 128);
     const bool la = lookahead_on && aux != nullptr && np > kw_outer;
     if (la) LPVS_TRY(aux->ensure());
@@ -1215,7 +1215,7 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     // disjoint from the rest launch's; the priority tiles were last written by the previous group's rest launch (hence the wait).
     // Panels live in 2 x kMaxGroup slots (slot = pivot block mod 8): chain nb0 and the next group's chains write the other half
     // while this group's launches still read theirs; a half is rewritten two groups later, behind the events above.
-    const int group_env = [] { const char *e = getenv("LPVS_FACTOR_GROUP"); return e ? atoi(e) : 0; }();   // 1 .. 4 panels per pass (diagnostic)
+    const int group_env = [] { const char *e = experiment_env("LPVS_FACTOR_GROUP"); return e ? atoi(e) : 0; }();   // 1 .. 4 panels per pass (diagnostic)
     // Measured at np = 8192 (tools/factor_ab3.sh): 1 panel per pass 16.2 ms, 2: 14.0, 3: 15.0, 4: 15.4 (round 2's schedule: 17.8).  Deeper
     // passes amortise the per-tile overhead further, but the side stream's share of the matrix work grows with the group (bands of
     // depth 128 .. 128 (mg - 1) and a priority launch of mg bands: 15 % of the flops at mg = 2, 30 % at mg = 4) and its workgroups
@@ -1223,14 +1223,14 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     // From np = 12288 the main pass is long enough to cover a four-step side chain: 84.5 ms with groups of four (and the 8-pivot
     // stages below) against 89.6 with pairs at np = 16384 (tools/factor_ab4.sh).
     const int mgmax = group_env >= 1 && group_env <= kMaxGroup ? group_env : (np >= 12288 ? 4 : 2);
-    const bool groups_on = [] { const char *e = getenv("LPVS_FACTOR_SCHEME"); return !(e && std::string(e) == "steps"); }();
-    const bool fused_chain = [] { const char *e = getenv("LPVS_CHAIN"); return !(e && std::string(e) == "split"); }();
-    const bool mfma_pivot = [] { const char *e = getenv("LPVS_PIVOT"); return !(e && std::string(e) == "regs"); }();   // regs: the register kernel
+    const bool groups_on = [] { const char *e = experiment_env("LPVS_FACTOR_SCHEME"); return !(e && std::string(e) == "steps"); }();
+    const bool fused_chain = [] { const char *e = experiment_env("LPVS_CHAIN"); return !(e && std::string(e) == "split"); }();
+    const bool mfma_pivot = [] { const char *e = experiment_env("LPVS_PIVOT"); return !(e && std::string(e) == "regs"); }();   // regs: the register kernel
     if (la && groups_on && single_wg_pivot && kw_outer == 128 && np >= 2048 && np % 128 == 0 && ldp == np) {
         hipStream_t side = aux->side;
         // LPVS_RU_STAGE=8: 8-pivot LDS stages (32 KB per workgroup) and a register budget for three workgroups per CU
         // (np = 8192: 14.65 ms against 13.3 with 16-pivot stages and two workgroups per CU; np = 16384: 84.5 against 86.5 -- default from 12288)
-        const int stage_env = [] { const char *e = getenv("LPVS_RU_STAGE"); return e ? atoi(e) : 0; }();
+        const int stage_env = [] { const char *e = experiment_env("LPVS_RU_STAGE"); return e ? atoi(e) : 0; }();
         const bool bk8 = stage_env == 8 || (stage_env != 16 && np >= 12288);
         const size_t ldsm = bk8 ? lds / 2 : lds;
         auto ru_kernel = bk8 ? rank_updatem_kernel<8, 3> : rank_updatem_kernel<16, 2>;
@@ -1241,7 +1241,7 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
         // The one-workgroup pivot inverse asks for the rest of a CU's LDS (unused): it can then only be placed on a CU that holds no other
         // workgroup -- one of those the deep passes' CU mask leaves out -- and nothing joins it there (np = 8192: 13.5 -> 13.2 ms; with three
         // update workgroups per CU, from np = 12288, it waits too long for an empty CU: 84.5 -> 86.3 ms at 16384).  LPVS_PIVOT_ALONE=0/1.
-        const int alone_env = [] { const char *e = getenv("LPVS_PIVOT_ALONE"); return e ? atoi(e) : -1; }();
+        const int alone_env = [] { const char *e = experiment_env("LPVS_PIVOT_ALONE"); return e ? atoi(e) : -1; }();
         const bool pivot_alone = alone_env >= 0 ? alone_env != 0 : np < 12288;
         const size_t pivot_pad = (pivot_alone && aux->bulk) ? (size_t)(160 * 1024 - 40 * 1024) : 0;
         if (pivot_pad) LPVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pivot_inverse_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pivot_pad));
@@ -1266,7 +1266,7 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
         // band launches on 64 x 64 tiles (rank_updateb_kernel) below np = 8192: 4.31 -> 3.98 ms at 4096; from 8192 the deep pass is the
         // critical path either way (side chain 445 -> 390 us per pair against a 393-us deep pass; 12.9-13.1 ms with 128 x 128 band tiles,
         // 13.1-13.3 with 64 x 64).  LPVS_BAND_TILE=64|128 forces one.
-        const int band_env = [] { const char *e = getenv("LPVS_BAND_TILE"); return e ? atoi(e) : 0; }();
+        const int band_env = [] { const char *e = experiment_env("LPVS_BAND_TILE"); return e ? atoi(e) : 0; }();
         const bool band64 = band_env == 64 || (band_env != 128 && np < 8192);
         auto launch_bands = [&](hipStream_t st, const RuGroup &g, int e0, int nsl, int band) {   // the tiles of bands e0 .. e0 + nsl - 1
             if (band64)
@@ -1327,7 +1327,7 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
     chain(0, panelbuf[0], panelbuf[0] + KW * ldp, side);
     LPVS_HIP(hipEventRecord(aux->panel, side));
     // measured at np = 8192: 18.4 -> 17.8 ms; neutral at 16384, slightly slower at 4096 (5.6 -> 5.8 ms): used from np = 6144
-    const bool depth2 = np >= 6144 && [] { const char *e = getenv("LPVS_LOOKAHEAD"); return !(e && e[0] == '1'); }();   // LPVS_LOOKAHEAD=1: depth one
+    const bool depth2 = np >= 6144 && [] { const char *e = experiment_env("LPVS_LOOKAHEAD"); return !(e && e[0] == '1'); }();   // LPVS_LOOKAHEAD=1: depth one
     if (depth2) {
         // Depth-2 look-ahead.  With depth one the main stream alternates  band_k | bulk_k  (the band of step k, which the next
         // pivot chain waits for, runs alone on the chip and two event hand-overs sit between consecutive bulks: 57 of 286 us
@@ -1388,7 +1388,7 @@ static int32_t spd_inverse_two_level(double *A, int64_t np, double *work, int *s
 static int32_t spd_inverse_impl(double *A, int64_t np, int nbatch, double *work, int *status_dev, hipStream_t s, SweepAux *aux) {
     if (np % 128 != 0) { set_error("spd_inverse: np=%lld not a multiple of 128", (long long)np); return LPVS_ESTATE; }
     LPVS_HIP(hipMemsetAsync(status_dev, 0, sizeof(int) * (size_t)nbatch, s));
-    const bool two_level_on = [] { const char *e = getenv("LPVS_FACTOR"); return !(e && std::string(e) == "sweep64"); }();
+    const bool two_level_on = [] { const char *e = experiment_env("LPVS_FACTOR"); return !(e && std::string(e) == "sweep64"); }();
     if (nbatch == 1 && np >= kTwoLevelMinNp && two_level_on) {
         LPVS_TRY(spd_inverse_two_level(A, np, work, status_dev, s, aux));
     } else {

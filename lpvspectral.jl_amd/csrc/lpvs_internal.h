@@ -12,6 +12,25 @@
 
 namespace lpvs {
 
+// ---- environment knobs ------------------------------------------------------------------------------------------------------------
+// Three kinds.  (1) Fallbacks of the OPTIONS of the interface (include/lpvspectral.h: LPVS_M_STORAGE, LPVS_ITERATION, LPVS_GRAM_FORM,
+// LPVS_NT_LOADS, LPVS_NUDFT, LPVS_WINDOW_CHUNK_MB, LPVS_WINDOWS_IN_FLIGHT, LPVS_RESERVE_CUS, LPVS_XUPDATE_CORRECTION=0) and (2) operational
+// ones that change no result (LPVS_POOL_GIB, LPVS_BATCH_PANEL_GIB, LPVS_TRACE, LPVS_NO_GRAPH, LPVS_WINDOW_MATVEC_TIMING, LPVS_MULTI_FORCE_RCCL,
+// LPVS_MULTI_ALLOW_SHARED_DEVICE): plain getenv.  (3) EXPERIMENT knobs -- schedules and kernel variants kept for the A/B measurements the
+// design documents quote, and the numerics studies (LPVS_FIX_BITS, LPVS_NIB_*, LPVS_XB_REFINE, LPVS_XUPDATE_CORRECTION schedules, LPVS_PHASE,
+// LPVS_FACTOR*, LPVS_PIVOT*, LPVS_KW, LPVS_LOOKAHEAD, LPVS_CHAIN, LPVS_BAND_TILE, LPVS_RU_STAGE, LPVS_MULTI_*): read through experiment_env, which
+// answers nullptr unless the process ALSO has LPVS_EXPERIMENTS=1 (the test-suite and tools/ set it; a production process that inherits a
+// stray LPVS_FIX_BITS does not change its results), and is compiled out altogether with -DLPVS_NO_EXPERIMENTS.
+inline const char *experiment_env(const char *name) {
+#ifdef LPVS_NO_EXPERIMENTS
+    (void)name;
+    return nullptr;
+#else
+    const char *on = getenv("LPVS_EXPERIMENTS");
+    return (on && on[0] == '1') ? getenv(name) : nullptr;
+#endif
+}
+
 // ---- error plumbing ---------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 #define LPVS_HIP(call)                                                                       \
@@ -201,7 +220,7 @@ int32_t spd_inverse_inplace_batch(double *A, int64_t np, int nbatch, double *wor
 // C (m x m, ld) = A * B for symmetric np x np operands (test/diagnostic helper)
 int32_t launch_symm_matmul(const double *A, const double *B, double *C, int64_t np, hipStream_t s);
 
-// ---- ADMM (admm.hip) --------------------------------------------------------------------
+// ---- ADMM (admm*.hip: the family map is at the head of admm.hip) --------------------------------------------------------------------
 struct AdmmStatus {  // lives in device memory, copied back after each run
     long long iters;
     int converged;
@@ -285,7 +304,7 @@ int32_t launch_pack_tiles_split(const double *M, int64_t np, unsigned char *Mp, 
 int32_t launch_pack_tiles_mixed(const double *M, int64_t np, unsigned char *Mp, unsigned char *types, unsigned long long *absmax, hipStream_t s,
                                 bool diag_float = false, double *abs_part = nullptr, int64_t n_valid = 0, double *rows_scratch = nullptr, int fix_bits = 36);   // diag_float: diagonal tiles always in the float-head format (multi-signal handles); abs_part: also the largest absolute row sum -> absmax[1]
 bool multi_signal_fixed_tiles_ok(int64_t np);               // the multi-signal tile product in use reads fixed-point off-diagonal tiles
-void release_panel_plans();                                 // admm.hip: frees the cached device tables of the panel walk
+void release_panel_plans();                                 // admm_multi.hip: frees the cached device tables of the panel walk
 int32_t launch_pack_tiles_mixed_batch(const double *M, int64_t np, int nbatch, unsigned char *Mp, unsigned char *types, unsigned long long *absmax,
                                       hipStream_t s, bool diag_float = false, double *abs_part = nullptr, int64_t n_valid = 0, double *rows_scratch = nullptr, int fix_bits = 36);
 constexpr size_t kMixedFixedTileBytes = 128 * 128 * 4 + 128 * 128 / 2 + 128 * 4, kMixedFloatTileBytes = 128 * 128 * 6;

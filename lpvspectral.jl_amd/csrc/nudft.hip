@@ -378,13 +378,11 @@ static int32_t nudft_impl(const double *x, const double *y, int64_t N, const dou
     if (nslots % 8 != 0) { set_error("nudft: slot count %d is not a multiple of 8", nslots); return LPVS_ESTATE; }
     const unsigned nchunks = seg ? nseg : (unsigned)nudft_chunks(N, nslots);
     const int64_t rpc = seg ? 0 : nudft_rows_per_chunk(N, nslots);
-    static const int slots_per_thread = [] { const char *e = getenv("LPVS_NUDFT_S"); return (e && atoi(e) == 1) ? 1 : 2; }();
     if (nq == 1) {
         dim3 grid((unsigned)ceil_div(nslots, 128), nchunks, 1);
         hipLaunchKernelGGL(nudft_single_kernel<2>, grid, dim3(256), 0, s, x, y, N, Wt, ldw, om_hi, om_lo, nslots, step, partial, seg, rpc);
     } else if (nq <= 8) launch_accumulate<2, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
     else if (nq <= 16) launch_accumulate<4, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
-    else if (slots_per_thread == 1) launch_accumulate<9, 1>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
     else launch_accumulate<9, 2>(nchunks, s, x, y, N, Wt, ldw, nq, om_hi, om_lo, nslots, step, partial, seg, rpc);
     LPVS_HIP(hipGetLastError());
     const int64_t count = (int64_t)nslots * nq * 4;

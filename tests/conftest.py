@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# Several tests select kernel / schedule variants and numerics experiments through the library's EXPERIMENT knobs (LPVS_FIX_BITS, LPVS_NIB_*,
+# LPVS_FACTOR_SCHEME, LPVS_MULTI_*, ...): those are inert unless the process has this master switch (csrc/lpvs_internal.h: experiment_env).
+os.environ.setdefault("LPVS_EXPERIMENTS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

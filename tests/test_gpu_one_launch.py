@@ -1,4 +1,4 @@
-"""The one-launch ADMM iteration (csrc/admm.hip: fixed-point accumulation of the tile partials, update in the next launch's
+"""The one-launch ADMM iteration (csrc/admm_one_launch.hip: fixed-point accumulation of the tile partials, update in the next launch's
 prologue; the default for single-signal handles with the mixed storage) against the two-launch iteration (LPVS_ITERATION=two):
 same iterates to rounding, same stopping iteration, invariant under chunking, re-entry from a saved state, all fusable prox
 operators.  GPU only."""

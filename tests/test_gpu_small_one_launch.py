@@ -1,4 +1,4 @@
-"""One launch per ADMM iteration below np = 2048 (``admm_small_iter_kernel``, csrc/admm.hip): the full-matrix path of cfg2-sized problems
+"""One launch per ADMM iteration below np = 2048 (``admm_small_iter_kernel``, csrc/admm_small.hip): the full-matrix path of cfg2-sized problems
 (n = 1024 / 1023) -- every workgroup redoes the update and takes the stopping decision itself, x and u double-buffered by launch
 parity.  Against ``oracle.admm_gram`` (src/lasso.jl:136-171 on the Gram form of :98) with the kernel name asserted; the reference's
 stopping rule in the iteration it belongs to (both parities of the stopping launch, inside and at the end of a chunk); any chunking

@@ -1,5 +1,5 @@
 # cfg2 iteration time: rows of M per workgroup of the one-launch iteration, graph replay vs direct launches, two-launch iteration
-for env in "LPVS_SMALL_ROWS=4" "LPVS_SMALL_ROWS=8" "LPVS_NO_GRAPH=1" "LPVS_ITERATION=two"; do
+for env in "LPVS_NO_GRAPH=0" "LPVS_NO_GRAPH=1" "LPVS_ITERATION=two"; do
   echo "== $env"
   env $env python bench.py --workload cfg2 --no-cpu-baseline --no-concurrent --steps 5 2>/dev/null | python -c "
 import json,sys

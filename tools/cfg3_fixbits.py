@@ -3,6 +3,7 @@
 removes the storage error's systematic part (LPVS_FIX_BITS zeroes low bits of the 36 in the SAME format: accuracy only, the bytes do not
 change), for several correction schedules -- against the extended-precision iterates of the fixture (same G, b by sha256).
 usage: cfg3_fixbits.py [bits,...] [schedules,...]"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

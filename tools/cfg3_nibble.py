@@ -4,6 +4,7 @@ this handle, P = 32; LPVS_NIB_PERIOD = P) against 36-bit reads (storage = "mixed
 extended-precision iterates of the fixture (same G, b by sha256), the f64 oracle's, and the time of the 2000 iterations.  A leg "Ps" runs
 the refresh as three kernels of its own (LPVS_NIB_FUSED=0) instead of inside the iteration's launch.
 usage: cfg3_nibble.py [legs,...]      default: 36,32,32s,16,64"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

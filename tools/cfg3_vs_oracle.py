@@ -14,6 +14,7 @@ holds the device to: tests/golden/cfg3_extended_precision_iterates.npz).
 --perturb        the f64 oracle once more on G (1 + d), b (1 + d), |d| <= 2^-52 elementwise (symmetric): what a one-ulp uncertainty of
                  the INPUTS does to the iterate -- the conditioning of the problem itself, whatever computes it.
 usage: cfg3_vs_oracle.py [--longdouble | --reuse-ld FILE] [--save FILE] [--refine 0,2] [--variants] [--perturb] [--no-f64-oracle] [iteration counts ...]"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import argparse, os, sys, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

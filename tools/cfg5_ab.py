@@ -3,6 +3,7 @@
 segments of ~8 tiles, per-tile column-sum records; default: column panels with the column sums in LDS) and the x-update correction on / off --
 product launch time (HIP events, 30 back-to-back launches), iteration time over 300 iterations, and the iterates of the two walks against each other.
 usage: cfg5_ab.py [iters]"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

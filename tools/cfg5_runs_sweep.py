@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """cfg5's multi-signal product against the segment length of the run walk (LPVS_MULTI_RUNS = tiles per segment: a workgroup's contiguous
 stretch of the packed inverse and the length of a P1 run) -- one process, one handle; 30 back-to-back launches each (HIP events)."""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

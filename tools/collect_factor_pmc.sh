@@ -1,4 +1,5 @@
 #!/bin/bash
+export LPVS_EXPERIMENTS=1   # the schedule knobs below are experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 # Matrix-pipe utilisation of the factorisation's kernels from SQ counters (own pass, kernel-trace only), for the round-2 schedule
 # (LPVS_FACTOR_SCHEME=steps) and the default group schedule.  Run on the GPU box:  bash tools/collect_factor_pmc.sh <outdir> [n]
 OUT=${1:-gpurun_out/pmc_factor}

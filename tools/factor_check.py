@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Accuracy and time of M = (G + I/mu)^-1 against torch.linalg.inv (fp64) for several sizes.
 usage: factor_check.py [n ...]   (LPVS_FACTOR=sweep64 selects the single-level sweep)"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

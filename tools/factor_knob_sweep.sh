@@ -1,4 +1,5 @@
 #!/bin/bash
+export LPVS_EXPERIMENTS=1   # the schedule knobs below are experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 # The factorisation of an 8192 x 8192 SPD matrix (tools/factor_time.py: best / all of 5) under every schedule knob of linalg.hip, one
 # process per setting (the knobs are read once per process).  Run on the GPU box:  bash tools/factor_knob_sweep.sh > gpurun_out/r05/factor_knob_sweep.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Factorisation time only (no accuracy check): factor_time.py n [reps]"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch time of the multi-signal ADMM mat-vec (ns right-hand sides sharing M) at the cfg5 matrix size.
 usage: matvec_multi.py [Nf] [Nv] [ns ...]     env: LPVS_MULTI_MATVEC=stream|dma|valu, LPVS_M_STORAGE=f64"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

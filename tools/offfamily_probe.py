@@ -4,6 +4,7 @@ variants (36-bit reads, uniform 6-byte elements, doubles, no x-update correction
 device Gram -- the f64 oracle (Cholesky) and the same algorithm in x87 extended precision, which says which f64 side carries a difference.
 Prints max over x, z of rel-L2, and u, per leg; cond(G + I/mu) from the extreme eigenvalues.
 usage: offfamily_probe.py [--iters 600] [--variants] [case-id substrings ...]"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

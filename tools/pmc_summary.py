@@ -24,8 +24,11 @@ for k, d in sorted(res.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WR
                  "write_bytes_per_launch": d["WRITE_SIZE"] * 1024 / nw})
 import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-stamp = hashlib.sha256(open(os.path.join(root, "lpvspectral.jl_amd", "csrc", "admm.hip"), "rb").read()).hexdigest()[:16]
-rows.insert(0, {"kernel": "__meta__", "admm_hip_sha16": stamp, "workload": workload, "command": "bench.py, workload %s, one step of a few iterations (tools/collect_pmc.sh)" % workload})
+h = hashlib.sha256()
+for rel in ("admm_device.h", "admm.hip", "admm_one_launch.hip", "admm_multi.hip", "admm_small.hip"):     # bench.KERNEL_SOURCES
+    h.update(open(os.path.join(root, "lpvspectral.jl_amd", "csrc", rel), "rb").read())
+stamp = h.hexdigest()[:16]
+rows.insert(0, {"kernel": "__meta__", "kernel_sources_sha16": stamp, "workload": workload, "command": "bench.py, workload %s, one step of a few iterations (tools/collect_pmc.sh)" % workload})
 json.dump(rows, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 rows = rows[1:]
 for r in rows[:12]:

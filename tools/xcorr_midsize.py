@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The x-update correction at a size the extended-precision oracle runs in seconds (n = 2048): device iterates with and without it against
 oracle.admm_gram_ld and oracle.admm_gram on the device Gram.  usage: xcorr_midsize.py [log2N] [Nf] [iters]"""
+import os; os.environ.setdefault("LPVS_EXPERIMENTS", "1")   # this tool flips experiment knobs of the library (csrc/lpvs_internal.h: experiment_env)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
