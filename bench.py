@@ -1396,14 +1396,15 @@ def run_cfg5(L, args, world, rank, local, dev, cdev, dist, sync, max_over_ranks,
     return out
 
 
-KERNEL_SOURCES = ("admm_device.h", "admm.hip", "admm_one_launch.hip", "admm_multi.hip", "admm_small.hip")   # (the same list in tools/pmc_summary.py)
+# sources of the kernel a workload's roofline is about (the same table in tools/pmc_summary.py): a PMC summary is stamped with their sha256
+KERNEL_SOURCES = {"cfg3": ("admm_device.h", "admm_one_launch.hip"), "cfg4": ("admm_device.h", "admm_one_launch.hip"),
+                  "cfg2": ("admm_device.h", "admm_small.hip"), "cfg5": ("admm_device.h", "admm_multi.hip")}
 
 
-def source_sha16():
-    """sha256 (16 hex digits) over the sources of the kernels the bench's rooflines are about: what a PMC summary is stamped with."""
+def source_sha16(workload="cfg3"):
     import hashlib
     h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
+    for rel in KERNEL_SOURCES[workload]:
         with open(os.path.join(ROOT, "lpvspectral.jl_amd", "csrc", rel), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -1415,7 +1416,7 @@ def pmc_traffic(kernel_prefix, workload="cfg3"):
     it was collected from (KERNEL_SOURCES); a summary whose stamp is missing or differs from the present sources is NOT quoted (a stale
     figure is worse than none)."""
     import glob
-    now = source_sha16()
+    now = source_sha16(workload)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_traffic*.json")), reverse=True):
         try:
             rows = json.load(open(path))

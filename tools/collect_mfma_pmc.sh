@@ -1,5 +1,6 @@
 #!/bin/bash
-# MFMA utilisation of the Gram kernel from SQ counters (own pass, kernel-trace only).  Run on the GPU box:
+# MFMA utilisation of the dense Gram kernel (gram_kernel<KRS>: the general-w path, bench.py's `gram_general_path` -- NOT skipped here) from SQ
+# counters (own pass, kernel-trace only).  Run on the GPU box:
 #   bash tools/collect_mfma_pmc.sh <outdir>
 OUT=${1:-gpurun_out/pmc_mfma}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -7,7 +8,7 @@ mkdir -p "$R/$OUT"
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv \
-    -d "$R/$OUT/sq" -o bench -- python3 "$R/bench.py" --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --no-general-path --no-cfg4-strong --no-concurrent > "$R/$OUT/sq.log" 2>&1
+    -d "$R/$OUT/sq" -o bench -- python3 "$R/bench.py" --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --no-cfg4-strong --no-baseline-configs --no-concurrent --no-single-process --no-alt-storage > "$R/$OUT/sq.log" 2>&1
 echo "rc=$?"
 cd "$R"
 python3 - "$OUT" <<'PY'

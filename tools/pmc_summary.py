@@ -25,7 +25,9 @@ for k, d in sorted(res.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WR
 import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
-for rel in ("admm_device.h", "admm.hip", "admm_one_launch.hip", "admm_multi.hip", "admm_small.hip"):     # bench.KERNEL_SOURCES
+SOURCES = {"cfg3": ("admm_device.h", "admm_one_launch.hip"), "cfg4": ("admm_device.h", "admm_one_launch.hip"),
+           "cfg2": ("admm_device.h", "admm_small.hip"), "cfg5": ("admm_device.h", "admm_multi.hip")}     # bench.KERNEL_SOURCES
+for rel in SOURCES[workload]:
     h.update(open(os.path.join(root, "lpvspectral.jl_amd", "csrc", rel), "rb").read())
 stamp = h.hexdigest()[:16]
 rows.insert(0, {"kernel": "__meta__", "kernel_sources_sha16": stamp, "workload": workload, "command": "bench.py, workload %s, one step of a few iterations (tools/collect_pmc.sh)" % workload})

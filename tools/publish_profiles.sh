@@ -11,4 +11,6 @@ for k in 4 5 2; do [ -s $P/k${k}_kernel_stats.csv ] && cp $P/k${k}_kernel_stats.
 for w in cfg2 cfg4 cfg5; do [ -s $P/pmc_$w/pmc_summary.json ] && cp $P/pmc_$w/pmc_summary.json profiles/${R}_pmc_traffic_$w.json; done
 [ -s $P/iteration_timeline.txt ] && cp $P/iteration_timeline.txt profiles/${R}_iteration_timeline.txt
 [ -s $P/pmc_factor/factor_mfma_summary.json ] && cp $P/pmc_factor/factor_mfma_summary.json profiles/${R}_factor_mfma_pmc.json
+[ -s $P/kg_kernel_stats.csv ] && cp $P/kg_kernel_stats.csv profiles/${R}_bench_cfg3_with_dense_gram_kernel_stats.csv
+[ -s $P/pmc_gram/mfma_summary.json ] && cp $P/pmc_gram/mfma_summary.json profiles/${R}_gram_mfma_counters.json
 ls -la profiles | grep "${R}_"
