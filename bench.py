@@ -154,7 +154,7 @@ def driver_record(o):
             ("factor_frac_of_f64_mfma", fz.get("frac", fz.get("frac_of_f64_mfma_peak"))), ("factor_ms", fz.get("ms")),
             ("gram_mfma_frac_of_f64_peak", gg.get("frac")), ("gram_mfma_TFLOPs_issued", gg.get("achieved")), ("gram_mfma_ms", gg.get("launch_ms")),
         ]
-        o["roofline"] = _take(prio_roof, {k: v for k, v in roof.items() if k not in ("note", "traffic_source", "kernel", "frac_of_measured_stream_6290_GBps", "algorithmic_bytes_per_launch")})
+        o["roofline"] = _take(prio_roof, {k: v for k, v in roof.items() if k not in ("note", "traffic_source", "kernel", "frac_of_measured_stream_6290_GBps", "algorithmic_bytes_per_launch", "frac_if_priced_with_36_bit_bytes")})
     if isinstance(cpu, dict):
         prio_cpu = [(k, cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "admm_iters_per_sec", "cpus_visible", "threads_used", "error")]
         prio_cpu.append(("gemv_stream_GBps", cpu.get("achieved_gemv_stream_GBps")))

@@ -557,6 +557,26 @@ function windows_estimate(Ys::Vector, t, freqs, n::Int, noverlap::Int, W, eng; n
     complex.(re, im_), its
 end
 
+# The raw ADMM state of every window instead of the packed coefficients: (x, z) as `ADMM` returns them (src/lasso.jl:170) and the scaled dual
+# variable u, each Nreg x k x ns (Nreg = 2Nf, or 2Nf - 1 with the zero frequency first; the reference's ordering [re; im], src/lasso.jl:93-97),
+# and the iteration counts.  Sparse estimators, one device.  (What the parity tests hold the window batches' iteration to the CPU reference with.)
+function windows_estimate_state(Ys::Vector, t, freqs, n::Int, noverlap::Int, W, eng; device::Int=0)
+    L = length(Ys[1]); ns = length(Ys)
+    Ym = Matrix{Float64}(undef, L, ns)
+    for (s, y) in enumerate(Ys); Ym[:, s] .= y; end
+    tv, fv, Wv = dense(Float64, t), dense(Float64, freqs), dense(Float64, W)
+    k = length(_offsets(L, n, noverlap)); Nf = length(fv)
+    nreg = check_freq(fv) === nothing ? 2Nf : 2Nf - 1
+    x, z, u = zeros(nreg, k, ns), zeros(nreg, k, ns), zeros(nreg, k, ns)     # column-major (Nreg, k, ns) == the ABI's ns x k x Nreg
+    its = zeros(Int64, k, ns)
+    GC.@preserve Ym tv fv Wv x z u its check(@ccall LIB.lpvs_windows_estimate_state_f64(Ym::Ptr{Float64}, Int64(ns)::Int64, tv::Ptr{Float64},
+        Int64(L)::Int64, Int64(n)::Int64, Int64(noverlap)::Int64, Wv::Ptr{Float64}, fv::Ptr{Float64}, Int64(Nf)::Int64, eng.est::Int32,
+        eng.lam::Float64, eng.prox[1]::Int32, eng.prox[2]::Float64, eng.prox[3]::Int64, eng.μ::Float64, eng.tol::Float64,
+        Int64(eng.iters)::Int64, eng.sign::Int32, Int64(0)::Int64, Int64(k)::Int64, Int32(device)::Int32, x::Ptr{Float64}, z::Ptr{Float64},
+        u::Ptr{Float64}, its::Ptr{Int64})::Int32)
+    x, z, u, its
+end
+
 function ls_windowpsd(y, t, freqs=nothing; nw=8, noverlap=-1, window_func=rect, estimator=ls_spectral, ngpus=1, kwargs...)
     n = length(y) ÷ nw                                                               # src/lsfft.jl:112-126
     freqs === nothing && (freqs = default_freqs(t, n))

@@ -192,14 +192,51 @@ static void launch_residual_dd(const double *A, int64_t np, int64_t n, int ns, c
 // ---- the offset vector xb = (G + shift I)^-1 b of the x-update's offset form: xb = M b, then `steps` rounds  xb += M (b - (G + shift I) xb)
 // with the residual accumulated as above -- the forward error of the explicit inverse (|M H - I| ~ 2e-13 at n = 8192) leaves xb, whatever
 // it multiplies in the iteration.  G, b are the problem's data, exact as given.  t1, t2: [ns][np] scratch.
+// x_q = M rhs_q for up to 8 right-hand sides in ONE pass over the full symmetric matrix (one wave per row; launch_symv_raw's kernels re-read M for
+// every signal: 8 x 8.6 GB = 11 ms per product at cfg5, two products per lpvs_admm_init since round 6 -- 1.4 ms each this way).  Per signal the
+// arithmetic is symv_kernel's, operation for operation (lane j takes the column pairs j, j + 64, ... in order, then the wave's fixed shuffle sum).
+template <int NSB>
+__global__ void __launch_bounds__(256)
+symv_rows_multi_kernel(const double *__restrict__ M, int64_t np, const double *__restrict__ rhs_all, double *__restrict__ x_all, int ns) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= np) return;
+    const double2 *m2 = reinterpret_cast<const double2 *>(M + row * np);
+    const double2 *r2 = reinterpret_cast<const double2 *>(rhs_all);
+    const int64_t nv = np / 2;
+    double acc[NSB];
+#pragma unroll
+    for (int q = 0; q < NSB; ++q) acc[q] = 0.0;
+    for (int64_t j = lane; j < nv; j += 64) {
+        const double2 m = m2[j];
+#pragma unroll
+        for (int q = 0; q < NSB; ++q)
+            if (q < ns) {
+                const double2 v = r2[(int64_t)q * nv + j];
+                acc[q] = fma(m.x, v.x, acc[q]);
+                acc[q] = fma(m.y, v.y, acc[q]);
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < NSB; ++q) {
+        const double sum = wave_sum(acc[q]);
+        if (lane == 0 && q < ns) x_all[(int64_t)q * np + row] = sum;
+    }
+}
+static void launch_symv_all_signals(const double *M, int64_t np, const double *rhs, double *x, int ns, hipStream_t s) {
+    if (ns == 1) { launch_symv_raw(M, np, rhs, x, nullptr, 1, s); return; }
+    for (int q0 = 0; q0 < ns; q0 += 8)
+        hipLaunchKernelGGL(symv_rows_multi_kernel<8>, dim3((unsigned)ceil_div(np, 4)), dim3(256), 0, s, M, np, rhs + (int64_t)q0 * np, x + (int64_t)q0 * np, std::min(8, ns - q0));
+}
+
 int32_t launch_offset_vector_refined(const double *G, const double *M, int64_t np, int64_t n, int ns, const double *b, double shift, int steps,
                                      double *xb, double *t1, double *t2, hipStream_t s) {
-    launch_symv_raw(M, np, b, xb, nullptr, ns, s);
+    launch_symv_all_signals(M, np, b, xb, ns, s);
     const int64_t total = np * (int64_t)ns;
     const unsigned nb = (unsigned)ceil_div(total, 256);
     for (int k = 0; k < steps; ++k) {
         launch_residual_dd(G, np, n, ns, b, 1.0, xb, shift, t2, s);                                              // t2 = b - H xb
-        launch_symv_raw(M, np, t2, t1, nullptr, ns, s);                                                          // t1 = M r
+        launch_symv_all_signals(M, np, t2, t1, ns, s);                                                           // t1 = M r
         hipLaunchKernelGGL(vec_add_kernel, dim3(nb), dim3(256), 0, s, xb, t1, total);
     }
     LPVS_HIP(hipGetLastError());

@@ -14,7 +14,7 @@ cd "$R"
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys, json
 out = sys.argv[1]
-vals, dur = {}, None
+vals, dur, launches = {}, 0.0, 0
 for f in glob.glob(os.path.join(out, "sq", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if "gram_kernel" in r.get("Kernel_Name", ""):
@@ -22,9 +22,10 @@ for f in glob.glob(os.path.join(out, "sq", "**", "*counter_collection.csv"), rec
 for f in glob.glob(os.path.join(out, "sq", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if "gram_kernel" in r.get("Kernel_Name", ""):
-            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+            dur += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9; launches += 1     # (the counters are summed over the launches too)
 cyc = vals.get("GRBM_GUI_ACTIVE", 0) / 8.0            # rocprofv3 sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
-res = {"raw": vals, "gram_seconds_profiled": dur, "gpu_cycles": cyc,
+res = {"raw": vals, "gram_kernel_launches": launches, "gram_seconds_profiled": dur, "gpu_cycles": cyc,
+       "achieved_TFLOPs_issued_while_profiled": vals.get("SQ_INSTS_VALU_MFMA_F64", 0) * 2048 / dur * 1e-12 if dur else None,   # 16x16x4: 2048 flop per instruction
        "effective_clock_GHz": cyc / dur * 1e-9 if dur else None,
        "mfma_busy_fraction": vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024) if cyc else None,
        "mfma_f64_instructions": vals.get("SQ_INSTS_VALU_MFMA_F64"),
