@@ -790,3 +790,32 @@ def test_multi_signal_tile_product_variants_agree(L, oracle, ns, prox, monkeypat
             ro = oracle.admm_gram(G, B[:, c], oracle.IndBallL0(6), iters=300, tol=1e-6, mu=0.05)
             assert ro["iters"] == per[c][0], (c, ro["iters"], per[c])
             assert np.array_equal(ro["z"] != 0, z[:, c] != 0) and rel(z[:, c], ro["z"]) <= 1e-9, (c, rel(z[:, c], ro["z"]))
+
+
+def test_panel_walk_falls_back_where_its_records_do_not_fit(L, monkeypatch):
+    """the opt-in column-panel walk of the multi-signal product indexes its P2 records as (flush index) * 4 + c into the ntiles records
+    a signal owns; with LPVS_MULTI_RUNS=2 a short triangle (45 row blocks: ntiles = 1035 < (256 + 12) * 4 flush records) would overrun them.  The plan
+    is now checked against the record area and the run walk taken instead: at the smallest sizes around the limit the panel request gives the run
+    walk's iterates (bit for bit where it falls back, to summation order where the panel walk still applies)."""
+    rng = np.random.default_rng(41)
+    N, Nv, ns = 3000, 16, 8
+    for Nf in (180, 192):                                            # n = 5760 (45 row blocks: falls back), 6144 (48: the panel walk runs)
+        X = np.sort(10 * rng.random(N)); V = np.linspace(0, 1, N)
+        w = 2 * np.pi * (np.arange(Nf) + 1.0) * 25 / Nf
+        Y = np.stack([np.cos(w[(3 * q + 1) % Nf] * X) * (1 + q * V) + 0.3 * np.sin(w[(5 * q + 2) % Nf] * X) + 0.05 * rng.standard_normal(N) for q in range(ns)], axis=1)
+        out = {}
+        for name, env in (("runs", {"LPVS_MULTI_RUNS": "2"}), ("panel", {"LPVS_MULTI_RUNS": "2", "LPVS_MULTI_WALK": "panel"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            with L.Problem.lpv_multi(Y, X, V, w, Nv) as p:
+                p.set_prox(L.IndBallL0(6))
+                p.admm_init(None, μ=0.05, tol=0.0)
+                assert p.matvec_info()["kernel"] == "symv_tile_mfma_ws_kernel"
+                p.admm_run(120)
+                out[name] = p.admm_get()
+            for k in env:
+                monkeypatch.delenv(k)
+        for a, b in zip(out["panel"], out["runs"]):
+            assert np.all(np.isfinite(a)) and rel(a, b) <= 1e-12, (Nf, rel(a, b))
+        if Nf == 180:
+            assert all(np.array_equal(a, b) for a, b in zip(out["panel"], out["runs"]))      # the fall-back IS the run walk

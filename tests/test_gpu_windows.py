@@ -299,3 +299,46 @@ def test_chunked_engine_is_bit_identical_to_the_uncut_one(L, knobs, monkeypatch)
     assert np.array_equal(x1, x0) and np.array_equal(S1, S0) and np.array_equal(its1, its0)
     for a, b in zip(acc1, acc0):
         assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_window_state_entry_point(L, oracle, monkeypatch):
+    """lpvs_windows_estimate_state_f64 (round 6): the raw ADMM state x, z, u of every problem of a window batch -- two signals sharing every window's
+    factorisation, a window SUB-range, ragged chunks with two parts in flight -- is (a) the same run as lpvs_windows_estimate_f64 (fourier2complex(z)
+    equals its coefficients bit for bit, same iteration counts), (b) the single-window handle's state of the same problem to summation order, with
+    u += x - z holding between them, and (c) refused for the dense estimator and for device output pointers."""
+    import ctypes as C
+    from lpvspectral_jl_amd import _lib, api
+    rng = np.random.default_rng(21)
+    n, nwin, Nf = 1 << 10, 41, 96
+    t = np.arange(nwin * n, dtype=np.float64)
+    f = np.arange(0, Nf) / 250.0                                   # zero frequency first: Nreg = 2 Nf - 1
+    y = np.sin(2 * np.pi * f[20] * t) + 0.3 * rng.standard_normal(nwin * n) + 0.2
+    v = 0.7 * np.cos(2 * np.pi * f[55] * t) + 0.3 * rng.standard_normal(nwin * n)
+    eng = dict(estimator=_lib.EST_SPARSE, lam=0.0, prox=(_lib.PROX_L1, 0.3, 0), μ=1e-3, tol=0.0, iters=150, sign=_lib.LINEAR_QUADRATIC_AS_WRITTEN)
+    monkeypatch.setenv("LPVS_WINDOW_CHUNK_MB", "3"); monkeypatch.setenv("LPVS_WINDOWS_IN_FLIGHT", "2")
+    lo, hi = 5, 38
+    xc, its = api.windows_estimate([y, v], t, f, n, 0, None, eng, win_lo=lo, win_hi=hi)
+    x, z, u, its_s = api.windows_estimate_state([y, v], t, f, n, 0, None, eng, win_lo=lo, win_hi=hi)
+    assert x.shape == z.shape == u.shape == (2, hi - lo, 2 * Nf - 1) and np.array_equal(its, its_s) and np.all(its == 150)
+    for q in range(2):
+        for i in range(hi - lo):
+            assert np.array_equal(oracle.fourier2complex(z[q, i], 1), xc[q, i]), (q, i)
+    for q, sig in enumerate((y, v)):
+        for i in (0, 16, hi - lo - 1):                               # first window of the range, a chunk boundary's neighbourhood, the last
+            w = lo + i
+            with L.Problem.fourier(sig[w * n:(w + 1) * n], t[w * n:(w + 1) * n], f, np.ones(n)) as p:
+                p.set_prox(L.NormL1(0.3))
+                p.admm_init(None, μ=1e-3, tol=0.0, linear_sign=-1)
+                p.admm_run(150)
+                xs, zs, us = p.admm_get()
+            assert rel(x[q, i], xs) <= 1e-9 and rel(z[q, i], zs) <= 1e-9 and rel(u[q, i], us) <= 1e-9, (q, i)
+            assert np.array_equal(z[q, i] != 0, zs != 0) and np.count_nonzero(u[q, i]) > 0
+    # (c) misuse
+    with pytest.raises(ValueError, match="sparse estimators"):
+        api.windows_estimate_state([y], t, f, n, 0, None, dict(eng, estimator=_lib.EST_DENSE))
+    import torch
+    dz = torch.zeros(nwin * (2 * Nf - 1), dtype=torch.float64, device="cuda")
+    yk, ty, fy = (np.ascontiguousarray(a) for a in (y, t, f))
+    rc = _lib.lib().lpvs_windows_estimate_state_f64(_lib.out_ptr(yk), 1, _lib.out_ptr(ty), len(yk), n, 0, None, _lib.out_ptr(fy), Nf, _lib.EST_SPARSE, 0.0,
+                                                    _lib.PROX_L1, 0.3, 0, 1e-3, 0.0, 10, -1, 0, nwin, 0, None, C.c_void_p(dz.data_ptr()), None, None)
+    assert rc != 0 and b"HOST arrays" in _lib.lib().lpvs_last_error()
