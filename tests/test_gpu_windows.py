@@ -342,3 +342,45 @@ def test_window_state_entry_point(L, oracle, monkeypatch):
     rc = _lib.lib().lpvs_windows_estimate_state_f64(_lib.out_ptr(yk), 1, _lib.out_ptr(ty), len(yk), n, 0, None, _lib.out_ptr(fy), Nf, _lib.EST_SPARSE, 0.0,
                                                     _lib.PROX_L1, 0.3, 0, 1e-3, 0.0, 10, -1, 0, nwin, 0, None, C.c_void_p(dz.data_ptr()), None, None)
     assert rc != 0 and b"HOST arrays" in _lib.lib().lpvs_last_error()
+
+
+@pytest.mark.parametrize("grid,window,mu,prox", [("irregular", "rect", 0.05, "l1"), ("irregular", "hanning", 1e-4, "l0"), ("irregular", "hanning", 1.0, "group"),
+                                                 ("equidistant", "hanning", 0.05, "group"), ("equidistant", "rect", 1.0, "l1")])
+def test_window_batches_off_family_against_oracle(L, oracle, grid, window, mu, prox):
+    """The window batches' default numerics (mixed storage, one launch per iteration, 32-bit reads + stale nibble product) OFF cfg4's input family
+    (BASELINE's equidistant record with mu = 1e-4 has nearly diagonal inverses: tools/cfg4_tile_magnitudes.py), held to the ORACLE -- not to another HIP
+    path -- through the raw state: irregular sampling (dense inverses), a window function, mu from 1e-4 to 1, all three fusable prox operators, 600
+    iterations (past launch 256, where the refresh period has ramped to 32); x, z AND u of every window against oracle.admm_gram on the window's
+    device Gram (Quadratic(Q, +q) as written: b = -q), rel-L2 <= 1e-9, identical support.  Which iteration ran is asserted."""
+    from lpvspectral_jl_amd import _lib, api
+    rng = np.random.default_rng(7)
+    n, nwin, Nf = 3000, 6, 256                                      # Nreg = 512: four row blocks, ten tiles per window -- cfg4's tile shape
+    t = np.cumsum(0.5 + rng.random(n * nwin)) if grid == "irregular" else np.arange(n * nwin, dtype=np.float64)
+    f = (np.arange(Nf) + 1.0) / (2.6 * Nf)
+    y = np.sin(2 * np.pi * f[11] * t) + 0.6 * np.cos(2 * np.pi * f[90] * t + 0.3) + 0.3 * rng.standard_normal(n * nwin)
+    W = L.hanning(n) if window == "hanning" else None
+    Wh = np.asarray(W) if W is not None else np.ones(n)
+    with L.Problem.fourier(y[:n], t[:n], f, Wh) as p0:
+        Q0, q0 = p0.get_gram()
+    # a penalty that leaves a non-trivial support: from the first window's own correlations
+    lam = {"l1": float(np.quantile(np.abs(q0), 0.8)), "group": float(np.quantile(np.abs(q0), 0.8)) * 1.5,
+           "l0": float(np.quantile(np.abs(np.linalg.solve(Q0 + np.eye(len(q0)) / mu, q0)), 0.8)) ** 2 / (2 * mu)}[prox]
+    kind, glen, oprox = {"l1": (_lib.PROX_L1, 0, oracle.NormL1(lam)), "l0": (_lib.PROX_L0, 0, oracle.NormL0(lam)),
+                         "group": (_lib.PROX_GROUP_L2, 4, oracle.GroupL2(lam, 4))}[prox]
+    eng = dict(estimator=_lib.EST_SPARSE, lam=0.0, prox=(kind, lam, glen), μ=mu, tol=0.0, iters=600, sign=_lib.LINEAR_QUADRATIC_AS_WRITTEN)
+    x, z, u, its = api.windows_estimate_state([y], t, f, n, 0, W, eng)
+    tm = api.windowpsd_last_timing()
+    assert np.all(its == 600) and x.shape == (1, nwin, 2 * Nf)
+    worst = 0.0
+    for i in range(nwin):
+        with L.Problem.fourier(y[i * n:(i + 1) * n], t[i * n:(i + 1) * n], f, Wh) as p:
+            Q, q = p.get_gram()
+        ro = oracle.admm_gram(Q, -q, oprox, iters=600, tol=0.0, mu=mu)
+        e = {k: rel(v[0, i], ro[k]) for k, v in (("x", x), ("z", z), ("u", u))}
+        worst = max(worst, *e.values())
+        assert max(e.values()) <= 1e-9, (i, e, tm)
+        assert np.array_equal(z[0, i] != 0, ro["z"] != 0) and 0 < np.count_nonzero(ro["z"]) < ro["z"].size, i
+    print(f"window batch, {grid} grid, {window} window, mu = {mu:g}, {prox}: x, z, u of {nwin} windows vs oracle.admm_gram worst rel-L2 {worst:.2e}; "
+          f"one launch per iteration {tm['one_launch_iteration']}, 32-bit reads {tm['reads_32_bits']}")
+    if grid == "equidistant":
+        assert tm["one_launch_iteration"] and tm["reads_32_bits"], tm        # (nearly diagonal inverses: every tile fixed point)
