@@ -193,7 +193,7 @@ static void launch_residual_dd(const double *A, int64_t np, int64_t n, int ns, c
 // with the residual accumulated as above -- the forward error of the explicit inverse (|M H - I| ~ 2e-13 at n = 8192) leaves xb, whatever
 // it multiplies in the iteration.  G, b are the problem's data, exact as given.  t1, t2: [ns][np] scratch.
 // x_q = M rhs_q for up to 8 right-hand sides in ONE pass over the full symmetric matrix (one wave per row; launch_symv_raw's kernels re-read M for
-// every signal: 8 x 8.6 GB = 11 ms per product at cfg5, two products per lpvs_admm_init since round 6 -- 1.4 ms each this way).  Per signal the
+// every signal: 8 x 8.6 GB = 11 ms per product at cfg5, two products per lpvs_admm_init since round 6 -- 3.6 ms each this way: 8.66 GB fetched, the right-hand sides re-read from the L2 per row).  Per signal the
 // arithmetic is symv_kernel's, operation for operation (lane j takes the column pairs j, j + 64, ... in order, then the wave's fixed shuffle sum).
 template <int NSB>
 __global__ void __launch_bounds__(256)
