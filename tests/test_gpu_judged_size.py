@@ -105,14 +105,15 @@ def test_cfg3_gram_block_against_oracle_columns(L, oracle, cfg3):
 #   oracle.admm_gram_ld     the same algorithm in x87 extended precision (64-bit mantissa): the ADJUDICATOR between two f64 paths.
 # Fixture: tests/golden/cfg3_extended_precision_iterates.npz (tools/cfg3_vs_oracle.py --longdouble --save, then --reuse-ld --save: 9 + 3
 # CPU-minutes), keyed by the sha256 of G, b -- the device Gram is bit-reproducible (fixed-point accumulation, fixed summation orders).
-# Measured, rel-L2(z) (profiles/r05_cfg3_vs_oracle_with_correction.txt; without the x-update correction: r05_cfg3_vs_oracle_and_extended_precision.txt):
+# Measured (round 6: offset vector refined at lpvs_admm_init, corrections after 16, 128, 256, 512, 1024; max over x, z, u of rel-L2):
 #   iterations                        200        500        1000       2000
-#   device  vs exact                  1.9e-10    4.8e-10    2.6e-10    1.2e-10      (round 4's iteration: 2.4e-10 5.4e-10 8.8e-10 1.22e-9)
-#   oracle  vs exact                  2.0e-10    3.7e-10    5.6e-10    7.2e-10
-#   device  vs oracle                 3.8e-10    8.5e-10    8.0e-10    8.2e-10      (round 4: 4.7e-10 9.4e-10 1.5e-9 1.9e-9)
-# SURVEY 8(d)'s 1e-9 against the f64 oracle holds at every count now, and what is left of it is the ORACLE's own distance to the exact
-# iterates (its Cholesky solves commit the same kind of systematic error the device's explicit inverse did: DESIGN.md section 6).
-CFG3_EXACT_BOUND = {200: 4e-10, 500: 8e-10, 1000: 5e-10, 2000: 2e-10}    # device vs the extended-precision iterate (measured x 1.6 .. 2.1)
+#   device  vs exact                  1.2e-10    2.4e-10    1.9e-10    9.7e-11      (round 5's schedule 16, 512, 1024: 1.9e-10 4.8e-10 2.6e-10 1.2e-10;
+#                                                                                    round 4, uncorrected: 2.4e-10 5.4e-10 8.8e-10 1.22e-9)
+#   oracle  vs exact (z)              2.0e-10    3.7e-10    5.6e-10    7.2e-10
+#   device  vs oracle                 2.8e-10    5.1e-10    7.1e-10    8.0e-10      (round 4: 4.7e-10 9.4e-10 1.5e-9 1.9e-9)
+# SURVEY 8(d)'s 1e-9 against the f64 oracle holds at every count, and what is left of it is the ORACLE's own distance to the exact
+# iterates (its Cholesky solves commit the same kind of systematic error the device's explicit inverse did: DESIGN.md section 6.1).
+CFG3_EXACT_BOUND = {200: 2.5e-10, 500: 4e-10, 1000: 3.5e-10, 2000: 2e-10}   # device vs the extended-precision iterate (measured x 1.6 .. 2.1)
 CFG3_ORACLE_BOUND = 1e-9                                                  # device vs the f64 oracle, every count
 def test_cfg3_one_launch_iteration_against_oracle_at_n8192(L, oracle, cfg3):
     """n = 8192 (64 row blocks, 2080 tiles, float-head diagonal tiles at their real scale): the benchmarked kernel against
