@@ -157,13 +157,23 @@ shifted_residual_dd_kernel(const double *__restrict__ A, int64_t np, int64_t n, 
     dot2_t acc[kDdSignals];
 #pragma unroll
     for (int q = 0; q < kDdSignals; ++q) acc[q] = {0.0, 0.0};
-    if (row < n)
-        for (int64_t j = lane; j < np; j += 64) {
-            const double m = -a[j];
+    if (row < n) {
+        // 16-byte loads, four in flight per lane (round 6: scalar 8-byte loads one at a time left the pass latency-bound, 129 us for the 512 MB of cfg3's
+        // Gram); a lane takes the column pairs 2 lane + 128 t.  The sums are carried in twice the mantissa: their order is immaterial to the rounded result.
+        const double2 *a2 = reinterpret_cast<const double2 *>(a);
+        const int64_t nv = np / 2;                                   // (np is a multiple of 128)
+#pragma unroll 4
+        for (int64_t j = lane; j < nv; j += 64) {
+            const double2 m = a2[j];
 #pragma unroll
             for (int q = 0; q < kDdSignals; ++q)
-                if (q < nsg) dot2_fma(acc[q], m, x_all[(int64_t)(sg0 + q) * np + j]);
+                if (q < nsg) {
+                    const double2 xv = reinterpret_cast<const double2 *>(x_all + (int64_t)(sg0 + q) * np)[j];
+                    dot2_fma(acc[q], -m.x, xv.x);
+                    dot2_fma(acc[q], -m.y, xv.y);
+                }
         }
+    }
 #pragma unroll
     for (int q = 0; q < kDdSignals; ++q) {
         if (q >= nsg) break;
