@@ -6,6 +6,7 @@
 #   bash tools/collect_round.sh pmc      FETCH_SIZE / WRITE_SIZE of every workload, matrix-pipe counters of the factorisation
 #   bash tools/collect_round.sh gram     the dense MFMA Gram (general-w path; judge's row N1): kernel stats of a bench run WITH gram_general_path, SQ counters of gram_kernel
 set -x
+set -e   # a step that fails or is killed at its limit ends the call: no further GPU step behind it
 PART=${1:-bench}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/gpurun_out/prof"
