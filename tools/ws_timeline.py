@@ -68,6 +68,10 @@ for r, name in ((0, "P1 wave (row sums; keeps the B operand in registers)"), (1,
         describe("time inside put (wait for the stage's bytes + decode + LDS stores)", put)
         print(f"{'  ... as a fraction of the lifetime':64s} median {pct(put / life, 50):7.3f};   the rest (issuing the next stage's loads, scalar bookkeeping): median {pct((life - put - wait) / life, 50):7.3f}")
         describe("  ... per stage", put / np.maximum(nbar, 1))
+        arr = rec[:, 8 * r + 6].astype(np.int64)
+        describe("  of which waiting for the stage's bytes (until its youngest load returned)", arr)
+        describe("  ... per stage", arr / np.maximum(nbar, 1))
+        describe("  decode + LDS stores per stage", (put - arr) / np.maximum(nbar, 1))
 xcc = rec[:, 24] & 0xF
 end0 = rec[:, 2] - t0
 print("\nper XCD: workgroups / median end / last end (us): " + "  ".join(f"x{int(k)}: {int((xcc == k).sum())} / {np.median(end0[xcc == k]) * TICK_US:.1f} / {end0[xcc == k].max() * TICK_US:.1f}" for k in np.unique(xcc)))
