@@ -342,36 +342,34 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             const int t = v.t < tend ? v.t : tend - 1;
             return (reinterpret_cast<const unsigned int *>(types)[t >> 2] >> (8 * (t & 3))) & 255u;
         };
-        // fetch = the loads of a step; put = its registers -> the LDS images.  Both are written as HALVES (k = 0 / 1: the thread's row r / r + 16 of the
-        // stage), so that put_fetch below can refill a half's registers right behind their decode (round 6).
-        auto fetch_half = [&](auto qc, auto kc, const StreamVisit &v, unsigned ty) {
-            constexpr int Q = decltype(qc)::value, k = decltype(kc)::value;
+        auto fetch = [&](auto qc, const StreamVisit &v, unsigned ty) {
+            constexpr int Q = decltype(qc)::value;
             const int qp = (Q + q0) & (NQ - 1);
             const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Mp + (size_t)v.t * kTileBytes), 0, (int)kTileBytes, 0x00020000);
             if constexpr (SPLIT) {
-                const int oh = qp * (MT_ROWS * TS * 4) + k * (16 * TS * 4), ot = TS * TS * 4 + qp * (MT_ROWS * TS * 2) + k * (16 * TS * 2);
+                const int oh = qp * (MT_ROWS * TS * 4), ot = TS * TS * 4 + qp * (MT_ROWS * TS * 2);
                 // (FIX: the tails exist in a diagonal tile only, nibbles and steps below the diagonal only -- descriptors of size zero drop the rest)
                 const bool fx = FIX && ty != 0;
                 const __amdgpu_buffer_rsrc_t tails = FIX ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Mp + (size_t)v.t * kTileBytes), 0, fx ? 0 : (int)kTileBytes, 0x00020000) : tile;
-                raw[Q][3 * k] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a, oh, 0);
-                raw[Q][3 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + 256, oh, 0);
-                raw[Q][3 * k + 2] = __builtin_amdgcn_raw_buffer_load_b128(tails, lo_t, ot, 0);
+                raw[Q][0] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a, oh, 0);
+                raw[Q][1] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + 256, oh, 0);
+                raw[Q][2] = __builtin_amdgcn_raw_buffer_load_b128(tails, lo_t, ot, 0);
+                raw[Q][3] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a, oh + 16 * TS * 4, 0);
+                raw[Q][4] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + 256, oh + 16 * TS * 4, 0);
+                raw[Q][5] = __builtin_amdgcn_raw_buffer_load_b128(tails, lo_t, ot + 16 * TS * 2, 0);
+                if constexpr (FIX) {
+                    const __amdgpu_buffer_rsrc_t aux = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Mp + (size_t)v.t * kTileBytes), 0, fx ? (int)kMixedFixedTileBytes : 0, 0x00020000);
+                    raw[Q][6][0] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_nib, qp * (64 * 8 * 4), 0);
+                    raw[Q][6][1] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_nib + 16, qp * (64 * 8 * 4), 0);
+                    raw[Q][6][2] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_stp, qp * (4 * 8 * 4), 0);
+                    raw[Q][6][3] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_stp + 16, qp * (4 * 8 * 4), 0);
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    raw[Q][4 * k + j] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + j * 256, qp * (MT_ROWS * TS * 8) + k * (16 * TS * 8), 0);
-            }
-        };
-        auto fetch_rest = [&](auto qc, const StreamVisit &v, unsigned ty) {
-            constexpr int Q = decltype(qc)::value;
-            const int qp = (Q + q0) & (NQ - 1);
-            if constexpr (FIX) {
-                const bool fx = ty != 0;
-                const __amdgpu_buffer_rsrc_t aux = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Mp + (size_t)v.t * kTileBytes), 0, fx ? (int)kMixedFixedTileBytes : 0, 0x00020000);
-                raw[Q][6][0] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_nib, qp * (64 * 8 * 4), 0);
-                raw[Q][6][1] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_nib + 16, qp * (64 * 8 * 4), 0);
-                raw[Q][6][2] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_stp, qp * (4 * 8 * 4), 0);
-                raw[Q][6][3] = __builtin_amdgcn_raw_buffer_load_b32(aux, lo_stp + 16, qp * (4 * 8 * 4), 0);
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        raw[Q][4 * k + j] = __builtin_amdgcn_raw_buffer_load_b128(tile, lo_a + j * 256, qp * (MT_ROWS * TS * 8) + k * (16 * TS * 8), 0);
             }
             const int s0 = s0_of(v);
             const int64_t left = (int64_t)(ns - s0) * np * 8;
@@ -386,46 +384,45 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
                 for (int k = 0; k < RJ; ++k) prj[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, go_rj[k], oJ, 0));
             }
         };
-        using std::integral_constant;
-        auto fetch = [&](auto qc, const StreamVisit &v, unsigned ty) {
-            fetch_half(qc, integral_constant<int, 0>{}, v, ty);
-            fetch_half(qc, integral_constant<int, 1>{}, v, ty);
-            fetch_rest(qc, v, ty);
-        };
-        auto put_half = [&](auto qc, auto kc, bool fx) {   // row half k of the step's registers -> the stage image of parity Q & 1; fx: a fixed-point tile
-            constexpr int Q = decltype(qc)::value, k = decltype(kc)::value;
-            constexpr unsigned par = Q & 1;
-            unsigned char *sp = stg + par * kStgB + wo_stg;
-            if (FIX && fx) {                         // (uniform)
-                const u32x4 ha = raw[Q][3 * k], hb = raw[Q][3 * k + 1];
-                const unsigned int nw = raw[Q][FIX ? 6 : 0][k];
-                const double step = (double)__uint_as_float(raw[Q][FIX ? 6 : 0][2 + k]), off = -(0x1p52 + 0x1p35) * step;
-                auto dec = [&](unsigned int hi, int j) -> double {      // (2^52 + q) * step - (2^52 + 2^35) * step, exact
-                    const unsigned int top = __builtin_amdgcn_alignbit(0x04330000u, hi, 28);
-                    unsigned int lo = (nw >> (4 * j)) & 15u;
-                    asm("v_lshl_or_b32 %0, %1, 4, %0" : "+v"(lo) : "v"(hi));
-                    return fma(__hiloint2double((int)top, (int)lo), step, off);
-                };
-                f64x2 *row = reinterpret_cast<f64x2 *>(sp + k * (16 * MT_RS * 8));
-                row[0] = (f64x2){dec(ha.x, 0), dec(ha.y, 1)};
-                row[1] = (f64x2){dec(ha.z, 2), dec(ha.w, 3)};
-                row[32] = (f64x2){dec(hb.x, 4), dec(hb.y, 5)};
-                row[33] = (f64x2){dec(hb.z, 6), dec(hb.w, 7)};
-            } else if constexpr (SPLIT) {
-                const u32x4 ha = raw[Q][3 * k], hb = raw[Q][3 * k + 1], lq = raw[Q][3 * k + 2];
-                f64x2 *row = reinterpret_cast<f64x2 *>(sp + k * (16 * MT_RS * 8));
-                row[0] = (f64x2){split_decode_lo(__uint_as_float(ha.x), lq.x), split_decode_hi(__uint_as_float(ha.y), lq.x)};
-                row[1] = (f64x2){split_decode_lo(__uint_as_float(ha.z), lq.y), split_decode_hi(__uint_as_float(ha.w), lq.y)};
-                row[32] = (f64x2){split_decode_lo(__uint_as_float(hb.x), lq.z), split_decode_hi(__uint_as_float(hb.y), lq.z)};
-                row[33] = (f64x2){split_decode_lo(__uint_as_float(hb.z), lq.w), split_decode_hi(__uint_as_float(hb.w), lq.w)};
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4 *>(sp + k * (16 * MT_RS * 8) + j * 256) = raw[Q][4 * k + j];
-            }
-        };
-        auto put_rest = [&](auto qc, int vtp) {       // the right-hand-side slices that travel with the step (J slice: visit parity)
+        auto put = [&](auto qc, int vtp, bool fx) {  // step's registers -> the LDS images of parity Q & 1 (J slice: visit parity); fx: a fixed-point tile
             constexpr int Q = decltype(qc)::value;
             constexpr unsigned par = Q & 1;
+            unsigned char *sp = stg + par * kStgB + wo_stg;
+            WS_TL_ARRIVED(pri[Q][RI - 1]);
+            if (FIX && fx) {                         // (uniform)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const u32x4 ha = raw[Q][3 * k], hb = raw[Q][3 * k + 1];
+                    const unsigned int nw = raw[Q][FIX ? 6 : 0][k];
+                    const double step = (double)__uint_as_float(raw[Q][FIX ? 6 : 0][2 + k]), off = -(0x1p52 + 0x1p35) * step;
+                    auto dec = [&](unsigned int hi, int j) -> double {      // (2^52 + q) * step - (2^52 + 2^35) * step, exact
+                        const unsigned int top = __builtin_amdgcn_alignbit(0x04330000u, hi, 28);
+                        unsigned int lo = (nw >> (4 * j)) & 15u;
+                        asm("v_lshl_or_b32 %0, %1, 4, %0" : "+v"(lo) : "v"(hi));
+                        return fma(__hiloint2double((int)top, (int)lo), step, off);
+                    };
+                    f64x2 *row = reinterpret_cast<f64x2 *>(sp + k * (16 * MT_RS * 8));
+                    row[0] = (f64x2){dec(ha.x, 0), dec(ha.y, 1)};
+                    row[1] = (f64x2){dec(ha.z, 2), dec(ha.w, 3)};
+                    row[32] = (f64x2){dec(hb.x, 4), dec(hb.y, 5)};
+                    row[33] = (f64x2){dec(hb.z, 6), dec(hb.w, 7)};
+                }
+            } else if constexpr (SPLIT) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const u32x4 ha = raw[Q][3 * k], hb = raw[Q][3 * k + 1], lq = raw[Q][3 * k + 2];
+                    f64x2 *row = reinterpret_cast<f64x2 *>(sp + k * (16 * MT_RS * 8));
+                    row[0] = (f64x2){split_decode_lo(__uint_as_float(ha.x), lq.x), split_decode_hi(__uint_as_float(ha.y), lq.x)};
+                    row[1] = (f64x2){split_decode_lo(__uint_as_float(ha.z), lq.y), split_decode_hi(__uint_as_float(ha.w), lq.y)};
+                    row[32] = (f64x2){split_decode_lo(__uint_as_float(hb.x), lq.z), split_decode_hi(__uint_as_float(hb.y), lq.z)};
+                    row[33] = (f64x2){split_decode_lo(__uint_as_float(hb.z), lq.w), split_decode_hi(__uint_as_float(hb.w), lq.w)};
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4 *>(sp + k * (16 * MT_RS * 8) + j * 256) = raw[Q][4 * k + j];
+            }
 #pragma unroll
             for (int k = 0; k < RI; ++k) *reinterpret_cast<double *>(ri + par * kRiB + wo_ri[k]) = pri[Q][k];
             if constexpr (Q == 0) {
@@ -434,26 +431,7 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
                 for (int k = 0; k < RJ; ++k) *reinterpret_cast<double *>(rjp + wo_rj[k]) = prj[k];
             }
         };
-        auto put = [&](auto qc, int vtp, bool fx) {
-            WS_TL_ARRIVED(pri[decltype(qc)::value][RI - 1]);
-            put_half(qc, integral_constant<int, 0>{}, fx);
-            put_half(qc, integral_constant<int, 1>{}, fx);
-            put_rest(qc, vtp);
-        };
-        // A step's decode and the refill of its ring slot, interleaved: the registers of a row half are requested again right behind the instructions
-        // that consumed them, so that the address path works on the next loads WHILE the wave decodes (as put(); fetch() the 11-15 loads of a step left
-        // in one burst after ~55 vector instructions that the matrix pipe lets through one per MFMA: 0.8 + 0.4 us of a 1.47-us stage at cfg5).
-        auto put_fetch = [&](auto qc, int vtp, bool fx, bool staged, const StreamVisit &v, unsigned ty) {
-            WS_TL_ARRIVED(pri[decltype(qc)::value][RI - 1]);
-            if (staged) put_half(qc, integral_constant<int, 0>{}, fx);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_half(qc, integral_constant<int, 0>{}, v, ty);
-            __builtin_amdgcn_sched_barrier(0);
-            if (staged) { put_half(qc, integral_constant<int, 1>{}, fx); put_rest(qc, vtp); }
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_half(qc, integral_constant<int, 1>{}, v, ty);
-            fetch_rest(qc, v, ty);
-        };
+        using std::integral_constant;
         StreamVisit v1 = next(cv);                   // the visit after the current one; `src` = the visit the ring is refilled from
         unsigned tyc = type_of(cv), ty1 = type_of(v1);   // formats of the current and the next visit's tiles (scalar)
         // prologue: the first visit's four steps in flight, step 0 staged, slot 0 refilled from the next visit
@@ -472,10 +450,11 @@ symv_tile_mfma_ws_kernel(const unsigned char *__restrict__ Mp, const double *__r
             const StreamVisit src = v1.t < tend ? v1 : cv;
             const unsigned tys = v1.t < tend ? ty1 : tyc;
             const bool fxc = tyc != 0;
-            WS_TL_PUT_BEGIN(); put_fetch(integral_constant<int, 1>{}, tp, fxc, true, src, tys); WS_TL_PUT_END(); WS_BARRIER();
-            WS_TL_PUT_BEGIN(); put_fetch(integral_constant<int, 2>{}, tp, fxc, true, src, tys); WS_TL_PUT_END(); WS_BARRIER();
-            WS_TL_PUT_BEGIN(); put_fetch(integral_constant<int, 3>{}, tp, fxc, true, src, tys); WS_TL_PUT_END(); WS_BARRIER();
-            WS_TL_PUT_BEGIN(); put_fetch(integral_constant<int, 0>{}, tp ^ 1, ty1 != 0, v1.t < tend, v2.t < tend ? v2 : cv, v2.t < tend ? ty2 : tyc); WS_TL_PUT_END();
+            WS_TL_PUT_BEGIN(); put(integral_constant<int, 1>{}, tp, fxc); WS_TL_PUT_END(); fetch(integral_constant<int, 1>{}, src, tys); WS_BARRIER();
+            WS_TL_PUT_BEGIN(); put(integral_constant<int, 2>{}, tp, fxc); WS_TL_PUT_END(); fetch(integral_constant<int, 2>{}, src, tys); WS_BARRIER();
+            WS_TL_PUT_BEGIN(); put(integral_constant<int, 3>{}, tp, fxc); WS_TL_PUT_END(); fetch(integral_constant<int, 3>{}, src, tys); WS_BARRIER();
+            WS_TL_PUT_BEGIN(); if (v1.t < tend) put(integral_constant<int, 0>{}, tp ^ 1, ty1 != 0); WS_TL_PUT_END();
+            fetch(integral_constant<int, 0>{}, v2.t < tend ? v2 : cv, v2.t < tend ? ty2 : tyc);
             WS_BARRIER();
             if (v1.t >= tend) break;
             cv = v1; v1 = v2; tyc = ty1; ty1 = ty2; tp ^= 1;
